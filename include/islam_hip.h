@@ -1,0 +1,156 @@
+/* islam_hip.h -- C ABI of libislam_hip.so: the MI355X (gfx950) implementation of iSLAM's bilevel
+ * hot path.
+ *
+ * The reference (sair-lab/iSLAM @ 2024_10_08) has no FFI of its own: its hot path is Python on
+ * PyTorch/PyPose plus four CuPy RawKernels.  Each entry point below therefore names the reference
+ * Python/CUDA code it replaces (file:line under /root/reference); INTEGRATION.md shows the ctypes
+ * stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch tensors' data_ptr()),
+ *     contiguous, row-major / NCHW; the library never frees or retains them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it;
+ *     only islam_pvgo_run_chain() synchronises (it reads one 128-byte status block per LM trial);
+ *   - return 0 on success, <0 on error: -1 bad argument, -2 HIP runtime error, -3 non-positive
+ *     pivot in the block Cholesky (PyPose: "Linear solver failed. Breaking optimization step"),
+ *     -4 unsupported graph topology;  islam_last_error() returns a thread-local message;
+ *   - dtype codes: 0 = float32, 1 = float64.
+ */
+#ifndef ISLAM_HIP_H
+#define ISLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISLAM_OK 0
+#define ISLAM_EARG (-1)
+#define ISLAM_EHIP (-2)
+#define ISLAM_ENOTPD (-3)
+#define ISLAM_ETOPO (-4)
+#define ISLAM_F32 0
+#define ISLAM_F64 1
+
+const char* islam_last_error(void);
+int islam_abi_version(void);
+
+/* ---------------------------------------------------------------- PWC-Net front-end kernels */
+
+/* 81-channel local correlation, forward.
+ * Replaces Network/PWC/correlation.py:281-331 (_FunctionCorrelation.forward) and its two CUDA
+ * kernels kernel_Correlation_rearrange (:8-33) + kernel_Correlation_updateOutput (:35-103):
+ *   out[b,(dy+4)*9+(dx+4),y,x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c,y+dy,x+dx],  dy,dx in [-4,4], zero pad.
+ * f1,f2: (B,C,H,W) float32; out: (B,81,H,W) float32. */
+int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* stream);
+
+/* Correlation backward.  Replaces correlation.py:334-383 with kernels updateGradFirst (:105-167) and
+ * updateGradSecond (:169-233).  g1 and/or g2 may be NULL (needs_input_grad false). */
+int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2,
+                     int B, int C, int H, int W, void* stream);
+
+/* Backward warp + validity mask.  Replaces Network/PWC/PWCNet.py:170-206 (PWCDCNet.warp):
+ * out = grid_sample(x, grid + flow*scale, bilinear, zeros, align_corners=True) * (grid_sample(1,..) >= 0.9999).
+ * x,out: (B,C,H,W); flow: (B,2,H,W) float32.  `scale` is the per-level factor of PWCNet.py:259-268. */
+int islam_warp_mask(const float* x, const float* flow, float scale, float* out, int B, int C, int H, int W,
+                    void* stream);
+
+/* ---------------------------------------------------------------- stereo scale recovery */
+
+/* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176
+ * (scale_from_disp_flow, disparity branch) for a whole batch in one launch.
+ * disp (B,1,H,W), flow (B,2,H,W) in pixels at 1/4 res; pose7 (B,7) = the ENU motion [t,q];
+ * intr4 (B,4) = fx,fy,cx,cy at 1/4 res; baseline (B); edge (B,H,W) uint8 or NULL; disp_th (B).
+ * Outputs: scale (B) = (M^T w)/(M^T M); z (B,H,W); mask, dmask (B,H,W) uint8;
+ * sums (B,18) float64: [0] M^T M, [1] M^T w, [2..16] the first-order sums the backward pass of
+ * `scale` w.r.t. the pose needs (layout in scale_ls.hip), [17] number of masked pixels;
+ * partial: scratch of B*ISLAM_SCALE_NBLK*18 doubles. */
+#define ISLAM_SCALE_NBLK 16
+#define ISLAM_SCALE_NSUM 18
+int islam_scale_ls(const float* disp, const float* flow, const float* pose7, const float* intr4,
+                   const float* baseline, const uint8_t* edge, const float* disp_th,
+                   float* scale, float* z, uint8_t* mask, uint8_t* dmask, double* sums, double* partial,
+                   int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- IMU pre-integration */
+
+/* Replaces the frame loop of imu_integrator.py:116-158 and pp.module.IMUPreintegrator.forward
+ * (integrate + predict; covariance propagation is discarded by the reference and not computed).
+ * dt (S), gyro (S,3), acc (S,3): the batch slice (already bias-corrected / denoised);
+ * seg (nframes+1) int64: sample offset of each frame boundary inside the slice;
+ * init_pos(3), init_rot(4), init_vel(3); motion_mode as imu_integrator.py:69-80.
+ * max_frame_samples = max_i (seg[i+1]-seg[i]) (known on the host from rgb2imu_sync).
+ * Outputs: world mode nframes+1 rows (row 0 = init), motion mode nframes rows.
+ * scratch: at least islam_imu_scratch_bytes(S, nframes, dtype) bytes. */
+size_t islam_imu_scratch_bytes(int64_t S, int nframes, int dtype);
+int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes,
+                     int64_t S, int max_frame_samples, const void* init_pos, const void* init_rot,
+                     const void* init_vel, double gravity, int motion_mode, void* out_pos, void* out_rot,
+                     void* out_vel, void* scratch, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- PVGO (pose-velocity graph optimisation) */
+
+typedef struct {
+    double w[4];          /* information scalars: lw0^2 (VO), lw1^2 (dvel), lw2^2 (IMU rot), lw3^2 (transvel); pvgo.py:125-129 */
+    double radius;        /* TrustRegion(radius=..), pvgo.py:170 */
+    double vmin, vmax;    /* LM(min=1e-4), max=1e32 default: diagonal clamp */
+    double high, low, up, down, factor, rmin, rmax;   /* ppost.TrustRegion defaults 0.5,1e-3,2,0.5,0.5,1e-6,1e16 */
+    int reject;           /* LM reject=16 default */
+    int max_steps;        /* StopOnPlateau(steps=10) */
+    int patience;         /* StopOnPlateau(patience=3) */
+    double decreasing;    /* StopOnPlateau(decreasing=1e-3) */
+    int seg_len[2];       /* partitioned block-Cholesky: interior nodes per segment at level 0 / 1 (0 = auto) */
+} islam_pvgo_params;
+
+typedef struct {
+    int steps;            /* optimizer.step() calls made */
+    int trials;           /* damped solves (inner while-loop iterations) over all steps */
+    int status;           /* ISLAM_OK or ISLAM_ENOTPD (step broken like PyPose) */
+    double loss;          /* final unweighted loss */
+    double damping;       /* final damping */
+} islam_pvgo_result;
+
+void islam_pvgo_default_params(islam_pvgo_params* p);
+size_t islam_pvgo_workspace_bytes(int N);
+
+/* Whole LM loop on a canonical chain graph (links[k] = [k, k+1], E = N-1), float64.
+ * Replaces pvgo.py:168-180: PoseVelGraph + pp.optim.LM(Cholesky, TrustRegion) + StopOnPlateau.
+ * nodes (N,7), vels (N,3): in = initial values, out = optimised (NOT yet aligned, see islam_pvgo_align);
+ * poses (N-1,7) VO motions; drots (N-1,4), dtrans (N-1,3), dvels (N-1,3), dts (N-1).
+ * trace: optional HOST buffer of 3*trace_cap doubles receiving (loss, damping, accepted) per trial. */
+int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const double* drots,
+                         const double* dtrans, const double* dvels, const double* dts, int N,
+                         const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes,
+                         islam_pvgo_result* result, double* trace, int trace_cap, void* stream);
+
+/* Stage-level entry points (same kernels the loop above launches; exported for parity tests/profiling). */
+/* residuals + Jacobian blocks per link -> lin (42 x M, component-major), loss_part (nblocks) */
+int islam_pvgo_linearize(const double* nodes, const double* vels, const double* poses, const double* drots,
+                         const double* dtrans, const double* dvels, const double* dts, int N,
+                         double* lin, double* loss_part, void* stream);
+/* block-tridiagonal normal equations: Hd (N,9,9), Ho (N-1,9,9) [rows k, cols k+1], rhs (N,9) = -J^T W r, diag clamped */
+int islam_pvgo_build_normal(const double* lin, const double* dts, int N, const double w[4], double vmin, double vmax,
+                            double* Hd, double* Ho, double* rhs, void* stream);
+/* Hd.diag += Hd.diag*damping (in place, cumulative), then solve -> dx (N,9).  status (device int[4]). */
+int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, double damping, int N,
+                           const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
+/* X <- Exp(sign*dx[:, :6]) * X ; v += sign*dx[:, 6:]  (LieTensor.add_) */
+int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N,
+                       double* nodes_out, double* vels_out, void* stream);
+
+/* vo_loss forward/backward (pvgo.py:67-78 with PyPose's left-tangent gradient convention).
+ * fwd: e (E,6) = Log(P^-1 Xi^-1 Xj); trans_loss, rot_loss (E).  bwd: grad_poses (E,7), last column 0. */
+int islam_pvgo_vo_loss_fwd(const double* nodes, const int64_t* edges, const double* poses, int E,
+                           double* err6, double* trans_loss, double* rot_loss, void* stream);
+int islam_pvgo_vo_loss_bwd(const double* poses, const double* err6, const double* g_trans, const double* g_rot,
+                           int E, double* grad_poses, void* stream);
+/* align_to (pvgo.py:114-119): nodes <- target * nodes[0]^-1 * nodes ; vels <- R(target) R(nodes[0])^-1 vels */
+int islam_pvgo_align(const double* nodes, const double* vels, const double* target7, int N,
+                     double* nodes_out, double* vels_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISLAM_HIP_H */

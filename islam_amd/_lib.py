@@ -1,0 +1,107 @@
+"""ctypes binding of libislam_hip.so (the C ABI declared in include/islam_hip.h).
+
+The library is built in-tree by ``islam_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There
+is no CPU fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libislam_hip.so')
+_lib = None
+
+c_void_p, c_int, c_int64, c_double, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                         ctypes.c_double, ctypes.c_float, ctypes.c_size_t)
+
+SCALE_NBLK, SCALE_NSUM = 16, 18
+
+
+class PvgoParams(ctypes.Structure):
+    _fields_ = [('w', c_double * 4), ('radius', c_double), ('vmin', c_double), ('vmax', c_double),
+                ('high', c_double), ('low', c_double), ('up', c_double), ('down', c_double), ('factor', c_double),
+                ('rmin', c_double), ('rmax', c_double), ('reject', c_int), ('max_steps', c_int), ('patience', c_int),
+                ('decreasing', c_double), ('seg_len', c_int * 2)]
+
+
+class PvgoResult(ctypes.Structure):
+    _fields_ = [('steps', c_int), ('trials', c_int), ('status', c_int), ('loss', c_double), ('damping', c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/islam_hip.h declares
+SIGNATURES = {
+    'islam_last_error': (ctypes.c_char_p, []),
+    'islam_abi_version': (c_int, []),
+    'islam_corr81_fwd': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    'islam_corr81_bwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    'islam_warp_mask': (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 4 + [c_void_p]),
+    'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
+    'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +
+                         [c_void_p] * 4 + [c_int, c_void_p]),
+    'islam_pvgo_default_params': (None, [ctypes.POINTER(PvgoParams)]),
+    'islam_pvgo_workspace_bytes': (c_size_t, [c_int]),
+    'islam_pvgo_run_chain': (c_int, [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p, c_size_t,
+                                                      ctypes.POINTER(PvgoResult), c_void_p, c_int, c_void_p]),
+    'islam_pvgo_linearize': (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 3),
+    'islam_pvgo_build_normal': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_double), c_double, c_double] +
+                                [c_void_p] * 4),
+    'islam_pvgo_solve_chain': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
+                                                        c_void_p, c_void_p]),
+    'islam_pvgo_retract': (c_int, [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 3),
+    'islam_pvgo_vo_loss_fwd': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4),
+    'islam_pvgo_vo_loss_bwd': (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 2),
+    'islam_pvgo_align': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3),
+}
+
+
+class IslamHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libislam_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j4']
+    if not verbose:
+        cmd.insert(1, '-s')
+    subprocess.check_call(cmd)
+
+
+def lib():
+    """Load libislam_hip.so; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(islam_amd has no CPU fallback)' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IslamHipError(rc, lib().islam_last_error().decode('utf-8', 'replace'))
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('islam_amd kernels need device tensors (got a %s tensor); there is no CPU path' % t.device)

@@ -1,0 +1,235 @@
+// PWC-Net cost-volume kernels for gfx950: 81-channel local correlation (forward + both gradients)
+// and the backward warp with validity mask.
+//
+// Replaces (reference file:line under /root/reference):
+//   Network/PWC/correlation.py:8-33    kernel_Correlation_rearrange   (NCHW -> zero-padded NHWC copy in HBM)
+//   Network/PWC/correlation.py:35-103  kernel_Correlation_updateOutput (1 block of 32 threads per pixel,
+//                                       81 serial __syncthreads rounds)
+//   Network/PWC/correlation.py:105-233 kernel_Correlation_updateGradFirst / updateGradSecond
+//   Network/PWC/PWCNet.py:170-206      PWCDCNet.warp (CPU meshgrid + H2D + 2 grid_samples + masking)
+//
+// MI355X design: no padded copy ever touches HBM.  A workgroup owns a 32x4 pixel tile of one image;
+// it streams the channels in chunks of 16 through LDS (f1 tile and the (4+8)x(32+8) halo tile of f2,
+// zero filled outside the image, coalesced 128-byte row reads of the NCHW tensors).  The nine waves
+// of the workgroup each own one vertical displacement dy; a lane owns two horizontally adjacent
+// pixels and keeps their 2x9 horizontal displacements in registers, so every f2 value fetched from
+// LDS (five 8-byte reads per channel) feeds up to four FMAs.  Writes are 128-byte row segments.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+using namespace islam;
+
+namespace {
+
+constexpr int TW = 32, TH = 4;          // pixel tile
+constexpr int CC = 16;                  // channels per LDS chunk
+constexpr int F2W = TW + 8, F2H = TH + 8;
+constexpr int F2RS = F2W;               // row stride (floats), even -> 8-byte aligned pairs
+
+__global__ __launch_bounds__(576) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          float* __restrict__ out, int C, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float s1[CC * TH * TW];
+    __shared__ __attribute__((aligned(16))) float s2[CC * F2H * F2RS];
+    const int tx = threadIdx.x, ty = threadIdx.y, dyi = threadIdx.z;      // 16 x 4 x 9
+    const int tid = tx + 16 * ty + 64 * dyi;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t plane = (size_t)H * W;
+    const float* f1b = f1 + (size_t)b * C * plane;
+    const float* f2b = f2 + (size_t)b * C * plane;
+
+    float acc0[9], acc1[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    for (int cb = 0; cb < C; cb += CC) {
+        const int nc = min(CC, C - cb);
+        __syncthreads();
+        for (int i = tid; i < nc * F2H * F2W; i += 576) {
+            const int c = i / (F2H * F2W), rem = i - c * (F2H * F2W);
+            const int ly = rem / F2W, lx = rem - ly * F2W;
+            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = f2b[(size_t)(cb + c) * plane + (size_t)gy * W + gx];
+            s2[(c * F2H + ly) * F2RS + lx] = v;
+        }
+        for (int i = tid; i < nc * TH * TW; i += 576) {
+            const int c = i / (TH * TW), rem = i - c * (TH * TW);
+            const int ly = rem / TW, lx = rem - ly * TW;
+            const int gy = y0 + ly, gx = x0 + lx;
+            float v = 0.f;
+            if (gy < H && gx < W) v = f1b[(size_t)(cb + c) * plane + (size_t)gy * W + gx];
+            s1[(c * TH + ly) * TW + lx] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const float2 a = *reinterpret_cast<const float2*>(&s1[(c * TH + ty) * TW + 2 * tx]);
+            const float* row = &s2[(c * F2H + ty + dyi) * F2RS + 2 * tx];
+            float r[10];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float2 v = *reinterpret_cast<const float2*>(row + 2 * q);
+                r[2 * q] = v.x;
+                r[2 * q + 1] = v.y;
+            }
+#pragma unroll
+            for (int dx = 0; dx < 9; ++dx) {
+                acc0[dx] = fmaf(a.x, r[dx], acc0[dx]);
+                acc1[dx] = fmaf(a.y, r[dx + 1], acc1[dx]);
+            }
+        }
+    }
+    const int gy = y0 + ty, gx = x0 + 2 * tx;
+    if (gy < H) {
+        const float fc = (float)C;
+        float* ob = out + ((size_t)b * 81 + (size_t)dyi * 9) * plane + (size_t)gy * W + gx;
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+            if (gx < W) ob[(size_t)dx * plane] = acc0[dx] / fc;
+            if (gx + 1 < W) ob[(size_t)dx * plane + 1] = acc1[dx] / fc;
+        }
+    }
+}
+
+// gradient w.r.t. the first input:  g1[b,c,y,x] = (1/C) sum_{p,o} gout[b,(p+4)*9+(o+4),y,x] * f2[b,c,y+p,x+o]
+// gradient w.r.t. the second input: g2[b,c,y,x] = (1/C) sum_{p,o} gout[b,op,y-p,x-o]    * f1[b,c,y-p,x-o]
+// A workgroup owns a 32x8 pixel tile and 8 channels; the 81 gout planes of the tile (with halo for g2)
+// are staged through LDS nine at a time (one dy row of displacements per pass).
+constexpr int BW = 32, BH = 8, BC = 8;
+
+template <bool SECOND>
+__global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict__ fin, const float* __restrict__ gout,
+                                                          float* __restrict__ gin, int C, int H, int W) {
+    // FIRST : needs gout at the pixel itself (no halo) and f2 with halo
+    // SECOND: needs gout*f1 at (y-p, x-o): stage the product plane with halo
+    __shared__ float sg[9][BH + 8][BW + 8];      // one dy row of gout planes (SECOND: with halo)
+    __shared__ float sf[BC][BH + 8][BW + 8];     // input feature tile with halo
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int b = blockIdx.z / ((C + BC - 1) / BC);
+    const int cb = (blockIdx.z % ((C + BC - 1) / BC)) * BC;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    const size_t plane = (size_t)H * W;
+    const int nc = min(BC, C - cb);
+    for (int i = threadIdx.x; i < nc * (BH + 8) * (BW + 8); i += 256) {
+        const int c = i / ((BH + 8) * (BW + 8)), rem = i - c * ((BH + 8) * (BW + 8));
+        const int ly = rem / (BW + 8), lx = rem - ly * (BW + 8);
+        const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = fin[((size_t)b * C + cb + c) * plane + (size_t)gy * W + gx];
+        sf[c][ly][lx] = v;
+    }
+    float acc[BC];
+#pragma unroll
+    for (int c = 0; c < BC; ++c) acc[c] = 0.f;
+    for (int p = 0; p < 9; ++p) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * (BH + 8) * (BW + 8); i += 256) {
+            const int o = i / ((BH + 8) * (BW + 8)), rem = i - o * ((BH + 8) * (BW + 8));
+            const int ly = rem / (BW + 8), lx = rem - ly * (BW + 8);
+            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = gout[((size_t)b * 81 + p * 9 + o) * plane + (size_t)gy * W + gx];
+            sg[o][ly][lx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+            if (!SECOND) {
+                const float g = sg[o][ty + 4][tx + 4];
+#pragma unroll
+                for (int c = 0; c < BC; ++c) acc[c] = fmaf(g, sf[c][ty + p][tx + o], acc[c]);
+            } else {
+                // source pixel (y - (p-4), x - (o-4)) -> local (ty + 4 - (p-4), tx + 4 - (o-4)) = (ty + 8 - p, tx + 8 - o)
+                const float g = sg[o][ty + 8 - p][tx + 8 - o];
+#pragma unroll
+                for (int c = 0; c < BC; ++c) acc[c] = fmaf(g, sf[c][ty + 8 - p][tx + 8 - o], acc[c]);
+            }
+        }
+    }
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy < H && gx < W) {
+        const float fc = (float)C;
+        for (int c = 0; c < nc; ++c) gin[((size_t)b * C + cb + c) * plane + (size_t)gy * W + gx] = acc[c] / fc;
+    }
+}
+
+// PWCDCNet.warp.  The coordinate pipeline restates torch's grid_sample(align_corners=True) in the
+// same float32 operation order (normalise to [-1,1], un-normalise, floor, corner weights
+// nw=(x1-ix)(y1-iy) ...), so fused multiply-add contraction is disabled here.
+__global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                         float scale, float* __restrict__ out, int C, int H, int W) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const float fx = flow[((size_t)b * 2 + 0) * plane + pix] * scale;
+    const float fy = flow[((size_t)b * 2 + 1) * plane + pix] * scale;
+    const float vx = (float)px + fx, vy = (float)py + fy;
+    const float gx = 2.0f * vx / (float)(W > 1 ? W - 1 : 1) - 1.0f;
+    const float gy = 2.0f * vy / (float)(H > 1 ? H - 1 : 1) - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float nw = (x1f - ix) * (y1f - iy), ne = (ix - x0f) * (y1f - iy);
+    const float sw = (x1f - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    // NaN/inf coordinates fail every comparison -> no valid corner -> output 0 like grid_sample's bounds test
+    const bool vx0 = x0f >= 0.f && x0f <= (float)(W - 1), vx1 = x1f >= 0.f && x1f <= (float)(W - 1);
+    const bool vy0 = y0f >= 0.f && y0f <= (float)(H - 1), vy1 = y1f >= 0.f && y1f <= (float)(H - 1);
+    const bool v00 = vx0 && vy0, v01 = vx1 && vy0, v10 = vx0 && vy1, v11 = vx1 && vy1;
+    const int xi0 = vx0 ? (int)x0f : 0, xi1 = vx1 ? (int)x1f : 0, yi0 = vy0 ? (int)y0f : 0, yi1 = vy1 ? (int)y1f : 0;
+    float m = 0.f;
+    if (v00) m += nw;
+    if (v01) m += ne;
+    if (v10) m += sw;
+    if (v11) m += se;
+    const float mask = (m < 0.9999f) ? 0.f : 1.f;      // PWCNet.py:203-204 (NaN m: both tests false in torch -> stays NaN*...; treated as 1)
+    const size_t o00 = (size_t)yi0 * W + xi0, o01 = (size_t)yi0 * W + xi1, o10 = (size_t)yi1 * W + xi0, o11 = (size_t)yi1 * W + xi1;
+    const float* xb = x + (size_t)b * C * plane;
+    float* ob = out + (size_t)b * C * plane + pix;
+    for (int c = 0; c < C; ++c) {
+        const float* p = xb + (size_t)c * plane;
+        float s = 0.f;
+        if (v00) s += p[o00] * nw;
+        if (v01) s += p[o01] * ne;
+        if (v10) s += p[o10] * sw;
+        if (v11) s += p[o11] * se;
+        ob[(size_t)c * plane] = s * mask;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_corr81_fwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B), block(16, 4, 9);
+    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, C, H, W);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
+                     void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_corr81_bwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
+    dim3 grid((W + BW - 1) / BW, (H + BH - 1) / BH, B * ((C + BC - 1) / BC)), block(256);
+    if (g1) hipLaunchKernelGGL(corr81_bwd_kernel<false>, grid, block, 0, as_stream(stream), f2, gout, g1, C, H, W);
+    if (g2) hipLaunchKernelGGL(corr81_bwd_kernel<true>, grid, block, 0, as_stream(stream), f1, gout, g2, C, H, W);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_warp_mask(const float* x, const float* flow, float scale, float* out, int B, int C, int H, int W, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask: bad shape (%d,%d,%d,%d)", B, C, H, W);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B), block(256);
+    hipLaunchKernelGGL(warp_mask_kernel, grid, block, 0, as_stream(stream), x, flow, scale, out, C, H, W);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// IMU pre-integration on gfx950, float64 / float32.
+//
+// Replaces (reference file:line under /root/reference):
+//   imu_integrator.py:116-158  the per-frame Python loop of IMUModule.integrate
+//                              (each iteration ~60 tiny kernels + 3 D2H syncs)
+//   pp.module.IMUPreintegrator.forward = integrate + predict (PyPose, external);
+//   its covariance propagation is discarded by the reference and is not computed.
+//
+// Floating-point contract: the results are defined to be bit-identical to the plain-C restatement
+// in oracle/imu_preint.c.  Every operation is one IEEE operation in the working precision in the
+// order written there (FMA contraction is disabled for this translation unit), the doubling scan of
+// pp.cumprod keeps its Hillis-Steele association order, cumsum and the frame-to-frame state chain
+// are sequential, sqrt/divide are correctly rounded, and sin/cos come from the fdlibm k_sin/k_cos
+// polynomials evaluated in double.
+//
+// Kernels (data stays in HBM/L2 between them; sizes are tiny, the path is launch-latency bound):
+//   A  scan_kernel   one wave per frame: dr_j = Exp(gyro_j dt_j), doubling scan in LDS -> incre_r
+//   B  chain_kernel  one lane: R0_{i+1} = R0_i * incre_r_i[F]   (strictly sequential, like the reference)
+//   C  frame_kernel  one lane per frame: a_j, cumsum of dv / dp / dt, rotate by R0_i
+//   D  (world mode, inside chain_kernel's second pass) p/v chain
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+using namespace islam;
+
+namespace {
+
+__device__ __forceinline__ double ksin(double x) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double v = z * x;
+    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+__device__ __forceinline__ double kcos(double x) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double ax = fabs(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - z * r);
+    double qx = (ax > 0.78125) ? 0.28125 : 0.25 * ax;
+    double hz = 0.5 * z - qx;
+    double a = 1.0 - qx;
+    return a - (hz - z * r);
+}
+__device__ __forceinline__ void sincos_contract(double x, double* s, double* c) {
+    const double pio4 = 7.85398163397448278999e-01, invpio2 = 6.36619772367581382433e-01,
+                 pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    double y = x;
+    int q = 0;
+    if (fabs(x) > pio4) {
+        double fn = rint(x * invpio2);
+        y = (x - fn * pio2_1) - fn * pio2_1t;
+        q = (int)((long long)fn & 3);
+    }
+    double sy = ksin(y), cy = kcos(y);
+    switch (q) {
+        case 0: *s = sy; *c = cy; break;
+        case 1: *s = cy; *c = -sy; break;
+        case 2: *s = -sy; *c = -cy; break;
+        default: *s = -cy; *c = sy; break;
+    }
+}
+
+template <class T> struct Eps;
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+template <> struct Eps<float> { static constexpr float v = 1.1920928955078125e-07f; };
+
+template <class T> __device__ __forceinline__ T sqrt_rn(T x);
+template <> __device__ __forceinline__ double sqrt_rn<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float sqrt_rn<float>(float x) { return sqrtf(x); }
+
+template <class T> struct Q { T x, y, z, w; };
+
+template <class T> __device__ __forceinline__ Q<T> qmul(Q<T> a, Q<T> b) {
+    Q<T> o;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return o;
+}
+template <class T> __device__ __forceinline__ void qact(Q<T> q, const T* p, T* o) {
+    T cx = (T)2 * (q.y * p[2] - q.z * p[1]);
+    T cy = (T)2 * (q.z * p[0] - q.x * p[2]);
+    T cz = (T)2 * (q.x * p[1] - q.y * p[0]);
+    T ox = p[0] + q.w * cx + (q.y * cz - q.z * cy);
+    T oy = p[1] + q.w * cy + (q.z * cx - q.x * cz);
+    T oz = p[2] + q.w * cz + (q.x * cy - q.y * cx);
+    o[0] = ox; o[1] = oy; o[2] = oz;
+}
+template <class T> __device__ __forceinline__ Q<T> so3exp(T px, T py, T pz) {
+    T th2 = px * px + py * py + pz * pz;
+    T th = sqrt_rn<T>(th2);
+    T imag, real;
+    if (th > Eps<T>::v) {
+        double s, c;
+        sincos_contract((double)((T)0.5 * th), &s, &c);
+        imag = (T)s / th;
+        real = (T)c;
+    } else {
+        T th4 = th2 * th2;
+        imag = (T)0.5 - (T)(1.0 / 48.0) * th2 + (T)(1.0 / 3840.0) * th4;
+        real = (T)1.0 - (T)(1.0 / 8.0) * th2 + (T)(1.0 / 384.0) * th4;
+    }
+    return {px * imag, py * imag, pz * imag, real};
+}
+template <class T> __device__ __forceinline__ Q<T> ldq(const T* p) { return {p[0], p[1], p[2], p[3]}; }
+template <class T> __device__ __forceinline__ void stq(Q<T> q, T* p) { p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w; }
+
+// A: per frame i, incre_r (F_i + 1 quaternions) -> ir[(seg[i] + i) .. ]   (frame i owns F_i + 1 slots)
+template <class T>
+__global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, const T* __restrict__ gyro,
+                                                   const int64_t* __restrict__ seg, T* __restrict__ ir) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* buf0 = reinterpret_cast<T*>(smem_raw);
+    const int i = blockIdx.x;
+    const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+    const int L = F + 1;
+    T* buf1 = buf0 + 4 * L;
+    for (int j = threadIdx.x; j < L; j += 64) {
+        Q<T> q{0, 0, 0, 1};
+        if (j > 0) {
+            const int sidx = a + j - 1;
+            const T d = dt[sidx];
+            q = so3exp<T>(gyro[3 * sidx] * d, gyro[3 * sidx + 1] * d, gyro[3 * sidx + 2] * d);
+        }
+        stq(q, buf0 + 4 * j);
+    }
+    __syncthreads();
+    T* cur = buf0;
+    T* nxt = buf1;
+    for (int s = 1; s < L; s *= 2) {             // pp.cumprod(left=False): x[i] <- x[i-s] * x[i] for all i >= s at once
+        for (int j = threadIdx.x; j < L; j += 64) {
+            Q<T> v = ldq(cur + 4 * j);
+            if (j >= s) v = qmul(ldq(cur + 4 * (j - s)), v);
+            stq(v, nxt + 4 * j);
+        }
+        __syncthreads();
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    T* o = ir + 4 * ((size_t)a + i);
+    for (int j = threadIdx.x; j < L; j += 64) stq(ldq(cur + 4 * j), o + 4 * j);
+}
+
+// B: sequential rotation chain over frames.  R0[i] = rotation at the start of frame i, R0[nframes] = final.
+template <class T>
+__global__ void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                 const T* __restrict__ init_rot, T* __restrict__ R0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Q<T> r = ldq(init_rot);
+    stq(r, R0);
+    for (int i = 0; i < nframes; ++i) {
+        const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+        if (F > 0) r = qmul(r, ldq(ir + 4 * ((size_t)a + i + F)));
+        stq(r, R0 + 4 * (size_t)(i + 1));
+    }
+}
+
+// C: per frame (one lane each): local integration, rotated into the frame's start orientation.
+//    loc[i] = { R0_i incre_v[F] (3), R0_i incre_p[F] (3), incre_t (1) }
+template <class T>
+__global__ __launch_bounds__(64) void frame_kernel(const T* __restrict__ dt, const T* __restrict__ acc,
+                                                    const int64_t* __restrict__ seg, int nframes,
+                                                    const T* __restrict__ ir, const T* __restrict__ R0, T gravity,
+                                                    T* __restrict__ loc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nframes) return;
+    const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+    const Q<T> r0 = ldq(R0 + 4 * (size_t)i);
+    const T* irf = ir + 4 * ((size_t)a + i);
+    const T g[3] = {0, 0, gravity};
+    T iv[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, it = 0;
+    for (int j = 0; j < F; ++j) {
+        Q<T> q = qmul(r0, ldq(irf + 4 * (j + 1)));
+        Q<T> qi{-q.x, -q.y, -q.z, q.w};
+        T gb[3], av[3], ra[3];
+        qact(qi, g, gb);
+        av[0] = acc[3 * (a + j)] - gb[0];
+        av[1] = acc[3 * (a + j) + 1] - gb[1];
+        av[2] = acc[3 * (a + j) + 2] - gb[2];
+        qact(ldq(irf + 4 * j), av, ra);
+        const T d = dt[a + j];
+        const T d2 = d * d;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            T dp = iv[c] * d + ra[c] * (T)0.5 * d2;
+            ip[c] = ip[c] + dp;
+            iv[c] = iv[c] + ra[c] * d;
+        }
+        it = it + d;
+    }
+    T rv[3], rp[3];
+    qact(r0, iv, rv);
+    qact(r0, ip, rp);
+    T* o = loc + 7 * (size_t)i;
+    o[0] = rv[0]; o[1] = rv[1]; o[2] = rv[2]; o[3] = rp[0]; o[4] = rp[1]; o[5] = rp[2]; o[6] = it;
+}
+
+// D: outputs.  world mode: sequential p/v chain (row 0 = init).  motion mode: every frame starts from p = v = 0.
+template <class T>
+__global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
+                              const T* __restrict__ loc, const T* __restrict__ init_pos, const T* __restrict__ init_vel,
+                              int motion_mode, T* __restrict__ out_pos, T* __restrict__ out_rot, T* __restrict__ out_vel) {
+    if (motion_mode) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= nframes) return;
+        const int F = (int)(seg[i + 1] - seg[i]);
+        const T* l = loc + 7 * (size_t)i;
+        const T zero = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // predict with p0 = v0 = 0:  vel = 0 + R0 iv ; pos = (0 + R0 ip) + 0 * t
+            out_vel[3 * (size_t)i + c] = (F > 0) ? (zero + l[c]) : zero;
+            out_pos[3 * (size_t)i + c] = (F > 0) ? ((zero + l[3 + c]) + zero * l[6]) : zero;
+        }
+        Q<T> a = ldq(R0 + 4 * (size_t)i), b = ldq(R0 + 4 * (size_t)(i + 1));
+        Q<T> ai{-a.x, -a.y, -a.z, a.w};
+        stq(qmul(ai, b), out_rot + 4 * (size_t)i);
+        return;
+    }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T p[3] = {init_pos[0], init_pos[1], init_pos[2]}, v[3] = {init_vel[0], init_vel[1], init_vel[2]};
+    for (int c = 0; c < 3; ++c) { out_pos[c] = p[c]; out_vel[c] = v[c]; }
+    stq(ldq(R0), out_rot);
+    T sp[3] = {p[0], p[1], p[2]};
+    for (int i = 0; i < nframes; ++i) {
+        const int F = (int)(seg[i + 1] - seg[i]);
+        const T* l = loc + 7 * (size_t)i;
+        T sv[3];
+        if (F == 0) {                               // imu_integrator.py:134-140: vel zeroed, pos / rot held
+            sv[0] = sv[1] = sv[2] = 0;
+        } else {
+            for (int c = 0; c < 3; ++c) {
+                sv[c] = v[c] + l[c];
+                sp[c] = p[c] + l[3 + c] + v[c] * l[6];
+            }
+        }
+        const size_t row = (size_t)i + 1;
+        for (int c = 0; c < 3; ++c) { out_pos[3 * row + c] = sp[c]; out_vel[3 * row + c] = sv[c]; p[c] = sp[c]; v[c] = sv[c]; }
+        stq(ldq(R0 + 4 * row), out_rot + 4 * row);
+    }
+}
+
+template <class T>
+int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframes, int64_t S, const T* ip, const T* ir0,
+        const T* iv, double gravity, int motion_mode, T* opos, T* orot, T* ovel, void* scratch, int maxF, hipStream_t s) {
+    T* ir = reinterpret_cast<T*>(scratch);                 // 4 * (S + nframes)
+    T* R0 = ir + 4 * ((size_t)S + nframes);                // 4 * (nframes + 1)
+    T* loc = R0 + 4 * ((size_t)nframes + 1);               // 7 * nframes
+    const size_t lds = 2 * 4 * (size_t)(maxF + 1) * sizeof(T);
+    if (lds > 64 * 1024) return fail(ISLAM_EARG, "islam_imu_preint: %d IMU samples in one frame interval exceed the LDS scan buffer", maxF);
+    hipLaunchKernelGGL(scan_kernel<T>, dim3(nframes), dim3(64), lds, s, dt, gyro, seg, ir);
+    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(64), 0, s, seg, nframes, ir, ir0, R0);
+    hipLaunchKernelGGL(frame_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, dt, acc, seg, nframes, ir, R0, (T)gravity, loc);
+    if (motion_mode)
+        hipLaunchKernelGGL(finish_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 1, opos, orot, ovel);
+    else
+        hipLaunchKernelGGL(finish_kernel<T>, dim3(1), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 0, opos, orot, ovel);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t islam_imu_scratch_bytes(int64_t S, int nframes, int dtype) {
+    const size_t es = dtype == ISLAM_F64 ? 8 : 4;
+    return es * (4 * ((size_t)S + nframes) + 4 * ((size_t)nframes + 1) + 7 * (size_t)nframes) + 256;
+}
+
+// max_frame_samples: the largest seg[i+1]-seg[i]; the caller knows it (host-side rgb2imu_sync), passing it
+// avoids a device->host read.
+int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes, int64_t S,
+                     int max_frame_samples, const void* init_pos, const void* init_rot, const void* init_vel,
+                     double gravity, int motion_mode, void* out_pos, void* out_rot, void* out_vel, void* scratch,
+                     int dtype, void* stream) {
+    if (nframes < 1 || S < 0) return fail(ISLAM_EARG, "islam_imu_preint: nframes=%d S=%lld", nframes, (long long)S);
+    const int flag = motion_mode ? 1 : 0, maxF = max_frame_samples;
+    if (maxF < 0 || maxF > S) return fail(ISLAM_EARG, "islam_imu_preint: max frame samples %d out of range", maxF);
+    hipStream_t s = as_stream(stream);
+    if (dtype == ISLAM_F64)
+        return run<double>((const double*)dt, (const double*)gyro, (const double*)acc, seg, nframes, S, (const double*)init_pos,
+                           (const double*)init_rot, (const double*)init_vel, gravity, flag, (double*)out_pos, (double*)out_rot,
+                           (double*)out_vel, scratch, maxF, s);
+    if (dtype == ISLAM_F32)
+        return run<float>((const float*)dt, (const float*)gyro, (const float*)acc, seg, nframes, S, (const float*)init_pos,
+                          (const float*)init_rot, (const float*)init_vel, gravity, flag, (float*)out_pos, (float*)out_rot,
+                          (float*)out_vel, scratch, maxF, s);
+    return fail(ISLAM_EARG, "islam_imu_preint: dtype %d", dtype);
+}
+
+}  // extern "C"

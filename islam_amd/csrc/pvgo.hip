@@ -1,0 +1,896 @@
+// PVGO back-end on gfx950: SE(3) Levenberg-Marquardt over VO / IMU factors on a chain graph, fp64.
+//
+// Replaces (reference file:line under /root/reference):
+//   pvgo.py:26-64    PoseVelGraph.forward        -> linearize_kernel / trial_kernel (residuals)
+//   pvgo.py:168-180  pp.optim.LM + TrustRegion + StopOnPlateau loop -> islam_pvgo_run_chain
+//   pvgo.py:67-78    vo_loss (+ PyPose backward)  -> vo_loss_{fwd,bwd}_kernel
+//   pvgo.py:114-119  align_to                     -> align_kernel
+//   PyPose (external, un-vendored): modjac/jacrev Jacobian, J^T W J, cholesky_ex/cholesky_solve,
+//   LieTensor.add_ -- restated from its published algorithm (SURVEY.md section 8a box).
+//
+// Design: the reference materialises a dense (rows x 10N) Jacobian, a dense
+// block_diag weight and a dense 10N x 10N normal matrix.  The graph is a chain, so the normal
+// matrix is block-tridiagonal with 9x9 blocks [rho phi v] per node.  We
+//   1. linearise per link (one lane per link, everything in registers),
+//   2. build the 9x9 diagonal / coupling blocks per node (gather from the two adjacent links,
+//      no atomics, deterministic),
+//   3. factor with a partitioned ("spike") block Cholesky: the chain is cut into segments, one
+//      wavefront eliminates each segment's interior onto its two separator nodes, the separators
+//      form a ~20x smaller chain that is reduced the same way, the last level is solved by one
+//      wavefront, and two back-substitution sweeps expand the solution.  Inside a wavefront one
+//      lane owns one column of the augmented 9 x 28 matrix [S | U | F^T | g]; pivots are broadcast
+//      with v_readlane, the 19x19 Schur update runs over all 64 lanes from an LDS copy,
+//   4. apply the step on a trial copy, re-evaluate the loss and the trust-region ratio per link,
+//   5. take the accept/reject decision in a one-wave control kernel; the host reads back one
+//      128-byte status block per trial.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "lie_dev.h"
+
+using namespace islam;
+
+namespace {
+
+constexpr int LIN_C = 42;   // doubles per link record (component-major: lin[c*M + k])
+constexpr int FAC = 252;    // 28 columns x 9 rows stored per eliminated node
+constexpr int XS = 10;      // padded column stride of the LDS copies (16-byte aligned columns)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double bcast(double v, int src) {   // src must be wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------
+// residuals of one link (pvgo.py:36-51); also returns what the Jacobian needs
+struct LinkRes {
+    V3<double> erho, ephi, er, rv, rt;
+    SE3<double> pre;      // P^-1 * Xi^-1
+    Q4<double> rpre;      // dR^-1 * Ri^-1
+};
+
+__device__ __forceinline__ LinkRes link_residuals(SE3<double> Xi, SE3<double> Xj, V3<double> vi, V3<double> vj,
+                                                  SE3<double> P, Q4<double> dR, V3<double> dp, V3<double> dv,
+                                                  double dt) {
+    LinkRes o;
+    o.pre = se3_mul(se3_inv(P), se3_inv(Xi));
+    se3_log(se3_mul(o.pre, Xj), o.erho, o.ephi);
+    o.rv = dv - (vj - vi);
+    o.rpre = qmul(qinv(dR), qinv(Xi.q));
+    o.er = so3_log(qmul(o.rpre, Xj.q));
+    o.rt = (Xj.t - Xi.t) - (dt * vi + dp);
+    return o;
+}
+
+__device__ __forceinline__ V3<double> ld3(const double* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ Q4<double> ld4(const double* p) { return {p[0], p[1], p[2], p[3]}; }
+
+// one lane per link: residuals + Jacobian blocks G, C (A = [[G, C],[0, G]]) and B
+__global__ __launch_bounds__(64) void linearize_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                        const double* __restrict__ poses, const double* __restrict__ drots,
+                                                        const double* __restrict__ dtrans, const double* __restrict__ dvels,
+                                                        const double* __restrict__ dts, int M, double* __restrict__ lin,
+                                                        double* __restrict__ loss_part) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    double sq = 0.0;
+    if (k < M) {
+        SE3<double> Xi = se3_load(nodes + 7 * k), Xj = se3_load(nodes + 7 * (k + 1));
+        LinkRes r = link_residuals(Xi, Xj, ld3(vels + 3 * k), ld3(vels + 3 * (k + 1)), se3_load(poses + 7 * k),
+                                   ld4(drots + 4 * k), ld3(dtrans + 3 * k), ld3(dvels + 3 * k), dts[k]);
+        // d pgerr / d delta_j = Jl^-1(e) Ad(pre) = [[Ji R, Ji([t]x R - Q Ji R)],[0, Ji R]]
+        M3<double> Ji = so3_Jl_inv(r.ephi);
+        M3<double> R = qmat(r.pre.q);
+        M3<double> G = Ji * R;
+        M3<double> C = Ji * (skew(r.pre.t) * R - se3_Q(r.erho, r.ephi) * G);
+        M3<double> B = so3_Jl_inv(r.er) * qmat(r.rpre);
+        double rec[LIN_C];
+        rec[0] = r.erho.x; rec[1] = r.erho.y; rec[2] = r.erho.z;
+        rec[3] = r.ephi.x; rec[4] = r.ephi.y; rec[5] = r.ephi.z;
+        m3_store(G, rec + 6);
+        m3_store(C, rec + 15);
+        rec[24] = r.er.x; rec[25] = r.er.y; rec[26] = r.er.z;
+        m3_store(B, rec + 27);
+        rec[36] = r.rv.x; rec[37] = r.rv.y; rec[38] = r.rv.z;
+        rec[39] = r.rt.x; rec[40] = r.rt.y; rec[41] = r.rt.z;
+#pragma unroll
+        for (int c = 0; c < LIN_C; ++c) lin[(size_t)c * M + k] = rec[c];
+        sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+    }
+    sq = wave_sum(sq);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = sq;
+}
+
+struct LinkNormal {       // weighted per-link normal-equation pieces
+    M3<double> Srr, Srp, Spp;   // pose-pose block S = [[Srr, Srp],[Srp^T, Spp]]
+    V3<double> gr, gp;          // J_j^T W r, pose part
+    V3<double> rv, rt;
+};
+
+__device__ __forceinline__ LinkNormal link_normal(const double* __restrict__ lin, int M, int k, double w0, double w1,
+                                                  double w2, double w3) {
+    double rec[LIN_C];
+#pragma unroll
+    for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + k];
+    V3<double> er{rec[0], rec[1], rec[2]}, ep{rec[3], rec[4], rec[5]}, eR{rec[24], rec[25], rec[26]};
+    M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+    M3<double> Gt = transpose(G), Ct = transpose(C), Bt = transpose(B);
+    M3<double> GtG = Gt * G;
+    LinkNormal o;
+    o.rv = {rec[36], rec[37], rec[38]};
+    o.rt = {rec[39], rec[40], rec[41]};
+    o.Srr = w0 * GtG + w3 * m3_identity<double>();
+    o.Srp = w0 * (Gt * C);
+    o.Spp = w0 * (Ct * C + GtG) + w2 * (Bt * B);
+    o.gr = w0 * (Gt * er) + w3 * o.rt;
+    o.gp = w0 * (Ct * er + Gt * ep) + w2 * (Bt * eR);
+    return o;
+}
+
+__device__ __forceinline__ void put3x3(double* H, int r0, int c0, M3<double> a) {
+    H[(r0 + 0) * 9 + c0 + 0] = a.a00; H[(r0 + 0) * 9 + c0 + 1] = a.a01; H[(r0 + 0) * 9 + c0 + 2] = a.a02;
+    H[(r0 + 1) * 9 + c0 + 0] = a.a10; H[(r0 + 1) * 9 + c0 + 1] = a.a11; H[(r0 + 1) * 9 + c0 + 2] = a.a12;
+    H[(r0 + 2) * 9 + c0 + 0] = a.a20; H[(r0 + 2) * 9 + c0 + 1] = a.a21; H[(r0 + 2) * 9 + c0 + 2] = a.a22;
+}
+
+// one lane per node: gather the two adjacent links into Hd[k], Ho[k] (coupling k -> k+1), rhs[k] = -J^T W r
+__global__ __launch_bounds__(64) void build_normal_kernel(const double* __restrict__ lin, const double* __restrict__ dts,
+                                                           int N, double w0, double w1, double w2, double w3, double vmin,
+                                                           double vmax, double* __restrict__ Hd, double* __restrict__ Ho,
+                                                           double* __restrict__ rhs) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= N) return;
+    const int M = N - 1;
+    const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const M3<double> I = m3_identity<double>();
+    M3<double> Hrr = Z, Hrp = Z, Hpp = Z;
+    V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
+    double hvv = 0.0, hrv = 0.0;
+    if (k > 0) {                       // link k-1, this node is its "j" end
+        LinkNormal L = link_normal(lin, M, k - 1, w0, w1, w2, w3);
+        Hrr = Hrr + L.Srr; Hrp = Hrp + L.Srp; Hpp = Hpp + L.Spp;
+        gr = gr + L.gr; gp = gp + L.gp;
+        gv = gv - w1 * L.rv;
+        hvv += w1;
+    }
+    double* o = Ho + (size_t)k * 81;
+    if (k < M) {                       // link k, this node is its "i" end
+        LinkNormal L = link_normal(lin, M, k, w0, w1, w2, w3);
+        double dt = dts[k];
+        Hrr = Hrr + L.Srr; Hrp = Hrp + L.Srp; Hpp = Hpp + L.Spp;
+        gr = gr - L.gr; gp = gp - L.gp;
+        gv = gv + w1 * L.rv - (w3 * dt) * L.rt;
+        hvv += w1 + w3 * dt * dt;
+        hrv = w3 * dt;
+        put3x3(o, 0, 0, -1.0 * L.Srr); put3x3(o, 0, 3, -1.0 * L.Srp); put3x3(o, 0, 6, Z);
+        put3x3(o, 3, 0, -1.0 * transpose(L.Srp)); put3x3(o, 3, 3, -1.0 * L.Spp); put3x3(o, 3, 6, Z);
+        put3x3(o, 6, 0, (-w3 * dt) * I); put3x3(o, 6, 3, Z); put3x3(o, 6, 6, (-w1) * I);
+    }
+    double* h = Hd + (size_t)k * 81;
+    put3x3(h, 0, 0, Hrr); put3x3(h, 0, 3, Hrp); put3x3(h, 0, 6, hrv * I);
+    put3x3(h, 3, 0, transpose(Hrp)); put3x3(h, 3, 3, Hpp); put3x3(h, 3, 6, Z);
+    put3x3(h, 6, 0, hrv * I); put3x3(h, 6, 3, Z); put3x3(h, 6, 6, hvv * I);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) h[d * 10] = fmin(fmax(h[d * 10], vmin), vmax);   // A.diagonal().clamp_(min, max)
+    double* b = rhs + (size_t)k * 9;
+    b[0] = -gr.x; b[1] = -gr.y; b[2] = -gr.z; b[3] = -gp.x; b[4] = -gp.y; b[5] = -gp.z;
+    b[6] = -gv.x; b[7] = -gv.y; b[8] = -gv.z;
+}
+
+// ------------------------------------------------------------------------------------------
+// partitioned block-tridiagonal Cholesky
+struct LevelSrc {
+    int level0;                  // 1: read Hd/Ho/rhs0 (+ cumulative damping), 0: compose from the previous level
+    double* Hd;
+    const double* Ho;
+    const double* rhs0;
+    const double* state;         // state[2] = damping
+    double damping_override;     // used when state == nullptr
+    const double *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill;
+    int Pprev;                   // number of segments of the previous level
+};
+struct LevelDst {
+    double *fac, *inv;           // n x 252, n x 9
+    double *Dsep, *rsep;         // (n / stride) x 81, x 9
+    double *cL, *cR, *cgL, *cgR, *fill;   // P x 81 / P x 9
+    double* x;                   // n x 9, written when the level consists of one segment
+};
+
+// column `lane` of the augmented matrix [S | U | F^T | g] of node k (F^T columns come from elsewhere)
+__device__ __forceinline__ void load_cols(const LevelSrc& s, int k, int n, int lane, double damping, double (&m)[9]) {
+#pragma unroll
+    for (int r = 0; r < 9; ++r) m[r] = 0.0;
+    if (lane < 9) {
+        if (s.level0) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) m[r] = s.Hd[(size_t)k * 81 + r * 9 + lane];
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                if (r == lane) {
+                    m[r] = m[r] + m[r] * damping;            // A.diagonal().add_(A.diagonal()*damping), kept for retries
+                    s.Hd[(size_t)k * 81 + r * 10] = m[r];
+                }
+        } else {
+            const bool hasL = (k + 1) < s.Pprev;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double v = s.Dsep[(size_t)k * 81 + r * 9 + lane] - s.cR[(size_t)k * 81 + r * 9 + lane];
+                if (hasL) v -= s.cL[(size_t)(k + 1) * 81 + r * 9 + lane];
+                m[r] = v;
+            }
+        }
+    } else if (lane < 18) {
+        if (k + 1 < n) {
+            const int c = lane - 9;
+            const double* O = s.level0 ? (s.Ho + (size_t)k * 81) : (s.fill + (size_t)(k + 1) * 81);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) m[r] = O[r * 9 + c];
+        }
+    } else if (lane == 27) {
+        if (s.level0) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) m[r] = s.rhs0[(size_t)k * 9 + r];
+        } else {
+            const bool hasL = (k + 1) < s.Pprev;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double v = s.rsep[(size_t)k * 9 + r] - s.cgR[(size_t)k * 9 + r];
+                if (hasL) v -= s.cgL[(size_t)(k + 1) * 9 + r];
+                m[r] = v;
+            }
+        }
+    }
+}
+
+// pairs (a <= b) of the symmetric 9x9 accumulation F~^T F~ handled by lanes 0..44
+__constant__ unsigned char kPairA[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2,
+                                         2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8};
+__constant__ unsigned char kPairB[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7,
+                                         8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
+
+__device__ __forceinline__ double dot9(const double* a, const double* b) {
+    double s = a[0] * b[0];
+#pragma unroll
+    for (int q = 1; q < 9; ++q) s = fma(a[q], b[q], s);
+    return s;
+}
+
+// Back-substitution through one segment (nodes c0 .. c0+cnt-1), right to left.
+// xn = solution of the node right of the segment (0 if none), xL = solution of the left separator (0 if none).
+__device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, const double* __restrict__ inv,
+                                                double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
+                                                const double (&xL)[9]) {
+    const int r = lane < 9 ? lane : 8;
+    for (int c = c0 + cnt - 1; c >= c0; --c) {
+        const double* f = fac + (size_t)c * FAC;
+        double lt[9], w = f[27 * 9 + r];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lt[i] = f[i * 9 + r];              // row r of L^T
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w = fma(-f[(9 + q) * 9 + r], xn[q], w);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w = fma(-f[(18 + q) * 9 + r], xL[q], w);
+        const double iv = inv[(size_t)c * 9 + r];
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            double xi = bcast(w * iv, i);
+            xn[i] = xi;
+            w = fma(-lt[i], xi, w);      // only rows r < i matter; rows >= i are never read again
+        }
+        if (lane < 9) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i == lane) mine = xn[i];
+            x[(size_t)c * 9 + lane] = mine;
+        }
+    }
+}
+
+// One wavefront per segment: eliminate the segment's interior nodes onto its two separators.
+__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags) {
+    __shared__ __attribute__((aligned(16))) double Xs[19 * XS];
+    __shared__ __attribute__((aligned(16))) double Tn[19 * XS];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    const int stride = m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(m, n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + m;
+    const bool has_right = sR < n;
+    const double damping = src.state ? src.state[2] : src.damping_override;
+
+    double mcol[9], nb[9];
+    load_cols(src, c0, n, lane, damping, mcol);
+    if (has_left && lane >= 18 && lane < 27) {          // spike F^T: coupling (left separator rows, c0 cols) transposed
+        const int jj = lane - 18;
+        const double* O = src.level0 ? (src.Ho + (size_t)(c0 - 1) * 81) : (src.fill + (size_t)c0 * 81);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) mcol[r] = O[jj * 9 + r];
+    }
+    double accL = 0.0;
+    int bad = 0;
+
+    for (int t = 0; t < cnt; ++t) {
+        const int c = c0 + t;
+        const bool last = (t == cnt - 1);
+        if (c + 1 < n) load_cols(src, c + 1, n, lane, damping, nb);
+        else {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) nb[r] = 0.0;
+        }
+        // ---- Cholesky elimination of the 9 unknowns of node c, applied to all 28 columns
+        double myinv = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            double piv = bcast(mcol[i], i);
+            if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+            double rs = rsqrt(piv);
+            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);   // one Newton step: full double accuracy
+            if (lane == i) myinv = rs;
+            double li[9];
+#pragma unroll
+            for (int r = i + 1; r < 9; ++r) li[r] = bcast(mcol[r], i) * rs;
+            mcol[i] *= rs;
+#pragma unroll
+            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-li[r], mcol[i], mcol[r]);
+        }
+        if (lane < 28) {
+            double* f = dst.fac + (size_t)c * FAC + lane * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) f[r] = mcol[r];
+        }
+        if (lane < 9) dst.inv[(size_t)c * 9 + lane] = myinv;
+        if (lane >= 9 && lane < 28) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Xs[(lane - 9) * XS + r] = mcol[r];
+        }
+        __syncthreads();
+        // ---- Schur update T = X^T X, X = [U~ | F~ | y~]:  entries (r, cb), r < 9, cb < 19
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = q * 64 + lane;
+            if (e < 171) {
+                const int cb = e / 9, r = e - cb * 9;
+                Tn[cb * XS + r] = dot9(Xs + r * XS, Xs + cb * XS);
+            }
+        }
+        if (has_left && lane < 54) {                    // F~^T F~ (45 pairs) and F~^T y~ (9), kept in registers
+            const int a = lane < 45 ? kPairA[lane] : lane - 45;
+            const int b = lane < 45 ? kPairB[lane] : 9;
+            accL += dot9(Xs + (9 + a) * XS, Xs + (9 + b) * XS);
+        }
+        __syncthreads();
+        if (!last) {
+            if (lane < 9) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) mcol[r] = nb[r] - Tn[lane * XS + r];
+            } else if (lane < 18) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) mcol[r] = nb[r];
+            } else if (lane < 27) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) mcol[r] = has_left ? -Tn[(lane - 9) * XS + r] : 0.0;
+            } else if (lane == 27) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) mcol[r] = nb[r] - Tn[18 * XS + r];
+            }
+        } else if (has_right) {
+            // contributions to the right separator (reduced node p) and the separator's own blocks
+            for (int e = lane; e < 81; e += 64) {
+                const int r = e / 9, cc = e - r * 9;
+                dst.cR[(size_t)p * 81 + e] = Tn[cc * XS + r];
+                dst.fill[(size_t)p * 81 + e] = has_left ? -Tn[(9 + r) * XS + cc] : 0.0;   // rows: left sep, cols: right sep
+            }
+            if (lane < 9) {
+                dst.cgR[(size_t)p * 9 + lane] = Tn[18 * XS + lane];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst.Dsep[(size_t)p * 81 + r * 9 + lane] = nb[r];
+            }
+            if (lane == 27) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (has_left) {
+        if (lane < 45) {
+            const int a = kPairA[lane], b = kPairB[lane];
+            dst.cL[(size_t)p * 81 + a * 9 + b] = accL;
+            dst.cL[(size_t)p * 81 + b * 9 + a] = accL;
+        } else if (lane < 54) {
+            dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
+        }
+    }
+    if (bad && lane == 0) atomicOr(flags, 1);
+
+    if (gridDim.x == 1) {          // single segment: the whole level is factored, solve it here
+        __syncthreads();
+        double xn[9], xL[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
+        backsub_segment(dst.fac, dst.inv, dst.x, 0, n, lane, xn, xL);
+    }
+}
+
+// expand the solution of the separators (xsep, from the next level) into this level's interior nodes
+__global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
+                                                         const double* __restrict__ xsep, double* __restrict__ x, int n,
+                                                         int m) {
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    const int stride = m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(m, n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + m;
+    const bool has_right = sR < n;
+    double xn[9], xL[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        xL[q] = has_left ? xsep[(size_t)(p - 1) * 9 + q] : 0.0;
+        xn[q] = has_right ? xsep[(size_t)p * 9 + q] : 0.0;
+    }
+    if (has_right && lane < 9) x[(size_t)sR * 9 + lane] = xsep[(size_t)p * 9 + lane];
+    backsub_segment(fac, inv, x, c0, cnt, lane, xn, xL);
+}
+
+// ------------------------------------------------------------------------------------------
+// trial step: retract on a copy, new residuals, loss and trust-region denominator partials
+__global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                    const double* __restrict__ dx, const double* __restrict__ poses,
+                                                    const double* __restrict__ drots, const double* __restrict__ dtrans,
+                                                    const double* __restrict__ dvels, const double* __restrict__ dts,
+                                                    const double* __restrict__ lin, int M, double* __restrict__ nodes_t,
+                                                    double* __restrict__ vels_t, double* __restrict__ part) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    double sq = 0.0, qd = 0.0;
+    if (k < M) {
+        const double* di = dx + (size_t)k * 9;
+        const double* dj = dx + (size_t)(k + 1) * 9;
+        V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+        V3<double> drj = ld3(dj), dpj = ld3(dj + 3), dvj = ld3(dj + 6);
+        SE3<double> Xi = se3_mul(se3_exp(dri, dpi), se3_load(nodes + 7 * k));             // LieTensor.add_
+        SE3<double> Xj = se3_mul(se3_exp(drj, dpj), se3_load(nodes + 7 * (k + 1)));
+        V3<double> vi = ld3(vels + 3 * k) + dvi, vj = ld3(vels + 3 * (k + 1)) + dvj;
+        double dt = dts[k];
+        LinkRes r = link_residuals(Xi, Xj, vi, vj, se3_load(poses + 7 * k), ld4(drots + 4 * k), ld3(dtrans + 3 * k),
+                                   ld3(dvels + 3 * k), dt);
+        sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+        se3_store(Xi, nodes_t + 7 * k);
+        vels_t[3 * k] = vi.x; vels_t[3 * k + 1] = vi.y; vels_t[3 * k + 2] = vi.z;
+        if (k == M - 1) {
+            se3_store(Xj, nodes_t + 7 * (k + 1));
+            vels_t[3 * k + 3] = vj.x; vels_t[3 * k + 4] = vj.y; vels_t[3 * k + 5] = vj.z;
+        }
+        // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
+        double rec[LIN_C];
+#pragma unroll
+        for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + k];
+        M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+        V3<double> ddr = drj - dri, ddp = dpj - dpi;
+        V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dt * dvi;
+        V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+            R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+        qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+             dot(j4, 2.0 * R4 + j4);
+    }
+    sq = wave_sum(sq);
+    qd = wave_sum(qd);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sq; part[2 * blockIdx.x + 1] = qd; }
+}
+
+// state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
+//        [8] reject_count [9] accepted [10] error [11] has_loss
+struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; };
+
+__global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
+                                                            double* __restrict__ st, int* flags) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += loss_part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        if (st[11] == 0.0) { st[0] = s; st[11] = 1.0; }   // self.loss only computed on the very first step
+        st[1] = st[0];                                     // self.last = self.loss
+        st[8] = 0.0;
+        st[9] = 0.0;
+        st[10] = 0.0;
+        flags[0] = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void control_trial_kernel(const double* __restrict__ part, int nblk,
+                                                            double* __restrict__ st, int* flags, TRParams tr) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { s += part[2 * i]; q += part[2 * i + 1]; }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        if (flags[0] != 0) { st[10] = 1.0; st[9] = 0.0; return; }     // solver failed: PyPose breaks the step
+        const double last = st[1];
+        st[6] = s;
+        st[7] = -q;
+        const double quality = (last - s) / (-q);
+        st[5] = quality;
+        double radius = 1.0 / st[2], down = st[4];
+        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
+        else if (quality > tr.low) { down = tr.down; }
+        else { radius = radius * down; down = down * tr.factor; }
+        down = fmax(tr.rmin, fmin(down, tr.rmax));
+        radius = fmax(tr.rmin, fmin(radius, tr.rmax));
+        st[3] = radius; st[4] = down; st[2] = 1.0 / radius;
+        if (last < s && st[8] < (double)tr.reject) {       // reject: undo, loss = last
+            st[0] = last;
+            st[8] += 1.0;
+            st[9] = 0.0;
+        } else {
+            st[0] = s;
+            st[9] = 1.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void retract_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                      const double* __restrict__ dx, double sign, int N,
+                                                      double* __restrict__ nodes_o, double* __restrict__ vels_o) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= N) return;
+    const double* d = dx + (size_t)k * 9;
+    SE3<double> X = se3_mul(se3_exp(sign * ld3(d), sign * ld3(d + 3)), se3_load(nodes + 7 * k));
+    se3_store(X, nodes_o + 7 * k);
+    V3<double> v = ld3(vels + 3 * k) + sign * ld3(d + 6);
+    vels_o[3 * k] = v.x; vels_o[3 * k + 1] = v.y; vels_o[3 * k + 2] = v.z;
+}
+
+__global__ __launch_bounds__(64) void vo_loss_fwd_kernel(const double* __restrict__ nodes, const int64_t* __restrict__ edges,
+                                                          const double* __restrict__ poses, int E, double* __restrict__ err6,
+                                                          double* __restrict__ tl, double* __restrict__ rl) {
+    int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    SE3<double> Xi = se3_load(nodes + 7 * edges[2 * e]), Xj = se3_load(nodes + 7 * edges[2 * e + 1]);
+    SE3<double> P = se3_load(poses + 7 * e);
+    V3<double> rho, phi;
+    se3_log(se3_mul(se3_mul(se3_inv(P), se3_inv(Xi)), Xj), rho, phi);
+    double* o = err6 + 6 * (size_t)e;
+    o[0] = rho.x; o[1] = rho.y; o[2] = rho.z; o[3] = phi.x; o[4] = phi.y; o[5] = phi.z;
+    tl[e] = dot(rho, rho);
+    rl[e] = dot(phi, phi);
+}
+
+// PyPose autograd: g_E = g_e Jl^-1(e) ; g_P = -g_E Ad(P^-1), stored as a 7-vector with a trailing 0
+__global__ __launch_bounds__(64) void vo_loss_bwd_kernel(const double* __restrict__ poses, const double* __restrict__ err6,
+                                                          const double* __restrict__ g_trans, const double* __restrict__ g_rot,
+                                                          int E, double* __restrict__ grad) {
+    int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    const double* er = err6 + 6 * (size_t)e;
+    V3<double> rho = ld3(er), phi = ld3(er + 3);
+    V3<double> gr = (2.0 * g_trans[e]) * rho, gp = (2.0 * g_rot[e]) * phi;
+    M3<double> Ji = so3_Jl_inv(phi);
+    M3<double> Q = se3_Q(rho, phi);
+    // row-vector times Jl^-1 = [[Ji, -Ji Q Ji],[0, Ji]]
+    V3<double> a = tmul(Ji, gr);
+    V3<double> b = tmul(Ji, gp) - tmul(Ji, tmul(Q, a));
+    SE3<double> Pi = se3_inv(se3_load(poses + 7 * e));
+    M3<double> R = qmat(Pi.q);
+    // row-vector times Ad(Pi) = [[R, [t]x R],[0, R]]
+    V3<double> o0 = tmul(R, a);
+    V3<double> o1 = tmul(R, tmul(skew(Pi.t), a)) + tmul(R, b);
+    double* g = grad + 7 * (size_t)e;
+    g[0] = -o0.x; g[1] = -o0.y; g[2] = -o0.z; g[3] = -o1.x; g[4] = -o1.y; g[5] = -o1.z; g[6] = 0.0;
+}
+
+__global__ __launch_bounds__(64) void align_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                    const double* __restrict__ target, int N, double* __restrict__ nodes_o,
+                                                    double* __restrict__ vels_o) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= N) return;
+    SE3<double> T = se3_load(target), S = se3_load(nodes);
+    SE3<double> rel = se3_mul(T, se3_inv(S));
+    Q4<double> rq = qmul(T.q, qinv(S.q));
+    se3_store(se3_mul(rel, se3_load(nodes + 7 * k)), nodes_o + 7 * k);
+    V3<double> v = qact(rq, ld3(vels + 3 * k));
+    vels_o[3 * k] = v.x; vels_o[3 * k + 1] = v.y; vels_o[3 * k + 2] = v.z;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+struct LevelPlan { int n, m, P, nsep; };
+
+int plan_levels(int N, const int seg_len[2], LevelPlan out[3]) {
+    // level sizes: a level with n <= 40 nodes (or the third level) is solved by a single wavefront
+    int nl = 0;
+    int n = N;
+    for (int l = 0; l < 3; ++l) {
+        LevelPlan L;
+        L.n = n;
+        bool single = (l == 2) || n <= 40;
+        if (!single) {
+            int m = (seg_len && seg_len[l] > 0) ? seg_len[l] : 0;
+            if (m <= 0) {
+                // balance the dependent chains: m_l + (rest) ; ~cube root split for two cuts, sqrt for the last
+                if (l == 0) m = std::max(4, (int)std::lround(std::cbrt((double)n) * 1.15));
+                else m = std::max(4, (int)std::lround(std::sqrt((double)n)));
+            }
+            if (m + 1 >= n) single = true;
+            else { L.m = m; L.P = (n + m) / (m + 1); L.nsep = n / (m + 1); }
+        }
+        if (single) { L.m = n; L.P = 1; L.nsep = 0; out[nl++] = L; break; }
+        out[nl++] = L;
+        n = L.nsep;
+    }
+    return nl;
+}
+
+struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x; };
+
+struct Workspace {
+    double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
+    int* flags;
+    LevelBufs lv[3];
+    size_t bytes;
+};
+
+// carve the workspace; sizes use worst-case level shapes (level l has at most N / 5^l nodes)
+Workspace carve(void* base, int N) {
+    Workspace w;
+    char* p = (char*)base;
+    auto take = [&](size_t nd) { double* r = (double*)p; p += align_up(nd * sizeof(double)); return r; };
+    const int M = std::max(N - 1, 1);
+    const int nblk = (M + 63) / 64;
+    w.lin = take((size_t)LIN_C * M);
+    w.loss_part = take(nblk);
+    w.part = take(2 * (size_t)nblk);
+    w.Hd = take((size_t)N * 81);
+    w.Ho = take((size_t)N * 81);
+    w.rhs = take((size_t)N * 9);
+    w.dx = take((size_t)N * 9);
+    w.nodes_t = take((size_t)N * 7);
+    w.vels_t = take((size_t)N * 3);
+    w.state = take(16);
+    w.flags = (int*)take(2);
+    int n = N;
+    for (int l = 0; l < 3; ++l) {
+        LevelBufs& b = w.lv[l];
+        int segs = n / 5 + 2;     // m >= 4 -> stride >= 5
+        b.fac = take((size_t)n * FAC);
+        b.inv = take((size_t)n * 9);
+        b.x = take((size_t)n * 9);
+        b.Dsep = take((size_t)segs * 81);
+        b.rsep = take((size_t)segs * 9);
+        b.cL = take((size_t)segs * 81);
+        b.cR = take((size_t)segs * 81);
+        b.fill = take((size_t)segs * 81);
+        b.cgL = take((size_t)segs * 9);
+        b.cgR = take((size_t)segs * 9);
+        n = segs;
+    }
+    w.bytes = (size_t)(p - (char*)base);
+    return w;
+}
+
+// enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
+int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
+                  double damping, int N, const int seg_len[2], double* dx, hipStream_t s) {
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    for (int l = 0; l < nl; ++l) {
+        LevelSrc src{};
+        LevelDst dst{};
+        if (l == 0) {
+            src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = state; src.damping_override = damping;
+        } else {
+            const LevelBufs& pb = w.lv[l - 1];
+            src.level0 = 0; src.Dsep = pb.Dsep; src.rsep = pb.rsep; src.cL = pb.cL; src.cR = pb.cR; src.cgL = pb.cgL;
+            src.cgR = pb.cgR; src.fill = pb.fill; src.Pprev = plan[l - 1].P;
+        }
+        const LevelBufs& b = w.lv[l];
+        dst.fac = b.fac; dst.inv = b.inv; dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR;
+        dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
+        dst.x = (l == 0) ? dx : b.x;
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, w.flags);
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        const LevelBufs& b = w.lv[l];
+        double* x = (l == 0) ? dx : b.x;
+        hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
+                           plan[l].m);
+    }
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void islam_pvgo_default_params(islam_pvgo_params* p) {
+    p->w[0] = p->w[1] = p->w[2] = p->w[3] = 1.0;
+    p->radius = 1e4;
+    p->vmin = 1e-4;
+    p->vmax = 1e32;
+    p->high = 0.5; p->low = 1e-3; p->up = 2.0; p->down = 0.5; p->factor = 0.5; p->rmin = 1e-6; p->rmax = 1e16;
+    p->reject = 16;
+    p->max_steps = 10;
+    p->patience = 3;
+    p->decreasing = 1e-3;
+    p->seg_len[0] = p->seg_len[1] = 0;
+}
+
+size_t islam_pvgo_workspace_bytes(int N) {
+    if (N < 1) return 0;
+    return carve(nullptr, N).bytes + 256;
+}
+
+int islam_pvgo_linearize(const double* nodes, const double* vels, const double* poses, const double* drots,
+                         const double* dtrans, const double* dvels, const double* dts, int N, double* lin,
+                         double* loss_part, void* stream) {
+    if (N < 2) return fail(ISLAM_EARG, "islam_pvgo_linearize: N=%d < 2", N);
+    const int M = N - 1, nblk = (M + 63) / 64;
+    hipLaunchKernelGGL(linearize_kernel, dim3(nblk), dim3(64), 0, as_stream(stream), nodes, vels, poses, drots, dtrans,
+                       dvels, dts, M, lin, loss_part);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_build_normal(const double* lin, const double* dts, int N, const double w[4], double vmin, double vmax,
+                            double* Hd, double* Ho, double* rhs, void* stream) {
+    if (N < 2) return fail(ISLAM_EARG, "islam_pvgo_build_normal: N=%d < 2", N);
+    hipLaunchKernelGGL(build_normal_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), lin, dts, N, w[0], w[1],
+                       w[2], w[3], vmin, vmax, Hd, Ho, rhs);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
+                           void* workspace, size_t workspace_bytes, double* dx, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_solve_chain: N=%d < 1", N);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N))
+        return fail(ISLAM_EARG, "islam_pvgo_solve_chain: workspace %zu < %zu bytes", workspace_bytes,
+                    islam_pvgo_workspace_bytes(N));
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    int rc = enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, s);
+    if (rc != ISLAM_OK) return rc;
+    int flag = 0;
+    ISLAM_HIP_CHECK(hipMemcpyAsync(&flag, w.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (flag) return fail(ISLAM_ENOTPD, "islam_pvgo_solve_chain: non-positive pivot (matrix not positive definite)");
+    return ISLAM_OK;
+}
+
+int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N, double* nodes_out,
+                       double* vels_out, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_retract: N=%d < 1", N);
+    hipLaunchKernelGGL(retract_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, dx, sign, N,
+                       nodes_out, vels_out);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_vo_loss_fwd(const double* nodes, const int64_t* edges, const double* poses, int E, double* err6,
+                           double* trans_loss, double* rot_loss, void* stream) {
+    if (E < 1) return fail(ISLAM_EARG, "islam_pvgo_vo_loss_fwd: E=%d < 1", E);
+    hipLaunchKernelGGL(vo_loss_fwd_kernel, dim3((E + 63) / 64), dim3(64), 0, as_stream(stream), nodes, edges, poses, E,
+                       err6, trans_loss, rot_loss);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_vo_loss_bwd(const double* poses, const double* err6, const double* g_trans, const double* g_rot, int E,
+                           double* grad_poses, void* stream) {
+    if (E < 1) return fail(ISLAM_EARG, "islam_pvgo_vo_loss_bwd: E=%d < 1", E);
+    hipLaunchKernelGGL(vo_loss_bwd_kernel, dim3((E + 63) / 64), dim3(64), 0, as_stream(stream), poses, err6, g_trans,
+                       g_rot, E, grad_poses);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_align(const double* nodes, const double* vels, const double* target7, int N, double* nodes_out,
+                     double* vels_out, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_align: N=%d < 1", N);
+    hipLaunchKernelGGL(align_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, target7, N,
+                       nodes_out, vels_out);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
+                         const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, void* workspace,
+                         size_t workspace_bytes, islam_pvgo_result* result, double* trace, int trace_cap, void* stream) {
+    if (N < 2) return fail(ISLAM_EARG, "islam_pvgo_run_chain: N=%d < 2", N);
+    if (!prm || !result) return fail(ISLAM_EARG, "islam_pvgo_run_chain: null params/result");
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N))
+        return fail(ISLAM_EARG, "islam_pvgo_run_chain: workspace %zu < %zu bytes", workspace_bytes,
+                    islam_pvgo_workspace_bytes(N));
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    const int M = N - 1, nblk = (M + 63) / 64;
+    static thread_local double* host_state = nullptr;
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 16 * sizeof(double), hipHostMallocDefault));
+
+    double init[16] = {0};
+    init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
+    init[3] = prm->radius;
+    init[4] = prm->down;
+    ISLAM_HIP_CHECK(hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, s));
+    TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject};
+
+    double* cur_n = nodes;  double* cur_v = vels;      // current iterate (caller's buffers)
+    double* tri_n = w.nodes_t; double* tri_v = w.vels_t;
+    int steps = 0, trials = 0, patience_count = 0, status = ISLAM_OK;
+    bool continual = true;
+    double loss = 0.0, damping = init[2];
+    while (continual) {
+        // ---- optimizer.step()
+        hipLaunchKernelGGL(linearize_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, poses, drots, dtrans, dvels, dts, M,
+                           w.lin, w.loss_part);
+        hipLaunchKernelGGL(build_normal_kernel, dim3((N + 63) / 64), dim3(64), 0, s, w.lin, dts, N, prm->w[0], prm->w[1],
+                           prm->w[2], prm->w[3], prm->vmin, prm->vmax, w.Hd, w.Ho, w.rhs);
+        hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nblk, w.state, w.flags);
+        int reject_count = 0;
+        double last = 0.0;
+        bool broke = false;
+        for (;;) {           // while self.last <= self.loss
+            int rc = enqueue_solve(w, w.Hd, w.Ho, w.rhs, w.state, 0.0, N, prm->seg_len, w.dx, s);
+            if (rc != ISLAM_OK) return rc;
+            hipLaunchKernelGGL(trial_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
+                               dts, w.lin, M, tri_n, tri_v, w.part);
+            hipLaunchKernelGGL(control_trial_kernel, dim3(1), dim3(64), 0, s, w.part, nblk, w.state, w.flags, tr);
+            ISLAM_LAUNCH_CHECK();
+            ISLAM_HIP_CHECK(hipMemcpyAsync(host_state, w.state, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
+            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+            ++trials;
+            last = host_state[1];
+            damping = host_state[2];
+            if (host_state[10] != 0.0) {      // "Linear solver failed. Breaking optimization step..."
+                status = ISLAM_ENOTPD;
+                loss = host_state[0];
+                broke = true;
+                break;
+            }
+            const bool accepted = host_state[9] != 0.0;
+            if (trace && trials <= trace_cap) {
+                trace[3 * (trials - 1)] = host_state[6];
+                trace[3 * (trials - 1) + 1] = damping;
+                trace[3 * (trials - 1) + 2] = accepted ? 1.0 : 0.0;
+            }
+            loss = host_state[0];
+            reject_count = (int)host_state[8];
+            if (accepted) { std::swap(cur_n, tri_n); std::swap(cur_v, tri_v); break; }
+        }
+        ++steps;
+        // ---- scheduler.step(loss)   (StopOnPlateau)
+        if (steps >= prm->max_steps) continual = false;
+        if ((last - loss) < prm->decreasing) ++patience_count; else patience_count = 0;
+        if (patience_count >= prm->patience) continual = false;
+        if (reject_count >= prm->reject) continual = false;
+        if (broke) { /* PyPose keeps looping through the scheduler; the plateau counter stops it */ }
+    }
+    if (cur_n != nodes) {
+        ISLAM_HIP_CHECK(hipMemcpyAsync(nodes, cur_n, (size_t)N * 7 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        ISLAM_HIP_CHECK(hipMemcpyAsync(vels, cur_v, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    result->steps = steps;
+    result->trials = trials;
+    result->status = status;
+    result->loss = loss;
+    result->damping = damping;
+    return ISLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/islam_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only.  All functions raise when given
+CPU tensors: the product path has no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_double, c_float, c_int, c_int64, c_size_t, c_void_p, check, lib, ptr, require_cuda, stream_ptr
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+# --------------------------------------------------------------------------- correlation / warp
+def corr81_forward(first, second):
+    """Network/PWC/correlation.py:281-331.  (B,C,H,W) x2 float32 -> (B,81,H,W)."""
+    require_cuda(first, second)
+    assert first.is_contiguous() and second.is_contiguous(), 'inputs must be contiguous NCHW (correlation.py:287-288)'
+    assert first.dtype == torch.float32 and second.dtype == torch.float32 and first.shape == second.shape
+    B, C, H, W = first.shape
+    out = torch.empty((B, 81, H, W), dtype=torch.float32, device=first.device)
+    check(lib().islam_corr81_fwd(ptr(first), ptr(second), ptr(out), B, C, H, W, stream_ptr(first.device)))
+    return out
+
+
+def corr81_backward(first, second, grad_out, need_first=True, need_second=True):
+    """Network/PWC/correlation.py:334-383."""
+    require_cuda(first, second, grad_out)
+    assert grad_out.is_contiguous(), 'gradOutput must be contiguous (correlation.py:337)'
+    B, C, H, W = first.shape
+    g1 = torch.empty_like(first) if need_first else None
+    g2 = torch.empty_like(second) if need_second else None
+    check(lib().islam_corr81_bwd(ptr(first), ptr(second), ptr(grad_out), ptr(g1), ptr(g2), B, C, H, W,
+                                 stream_ptr(first.device)))
+    return g1, g2
+
+
+class _Correlation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second):
+        ctx.save_for_backward(first, second)
+        return corr81_forward(first, second)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        first, second = ctx.saved_tensors
+        return corr81_backward(first, second, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+def FunctionCorrelation(tenFirst, tenSecond):
+    """Drop-in for Network.PWC.correlation.FunctionCorrelation (correlation.py:386-388)."""
+    return _Correlation.apply(tenFirst, tenSecond)
+
+
+def warp_mask(x, flow, scale=1.0):
+    """PWCDCNet.warp(x, flow*scale) (Network/PWC/PWCNet.py:170-206), forward only (flow net is frozen, F5)."""
+    require_cuda(x, flow)
+    x, flow = _f32c(x), _f32c(flow)
+    B, C, H, W = x.shape
+    assert flow.shape == (B, 2, H, W)
+    out = torch.empty_like(x)
+    check(lib().islam_warp_mask(ptr(x), ptr(flow), c_float(scale), ptr(out), B, C, H, W, stream_ptr(x.device)))
+    return out
+
+
+# --------------------------------------------------------------------------- scale recovery
+def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th):
+    """Batched dense_ba.scale_from_disp_flow (dense_ba.py:88-176).  Returns scale (B), z (B,H,W),
+    mask, depth_mask (B,H,W) bool, sums (B,18) float64."""
+    require_cuda(disp, flow, pose7)
+    dev = disp.device
+    disp, flow = _f32c(disp), _f32c(flow)
+    B, _, H, W = flow.shape
+    pose7 = _f32c(pose7.detach())
+    intr4 = _f32c(intr4.to(dev))
+    baseline = _f32c(baseline.to(dev))
+    disp_th = _f32c(disp_th.to(dev))
+    if edge is not None:
+        edge = edge.to(dev).to(torch.uint8).contiguous()
+    scale = torch.empty(B, dtype=torch.float32, device=dev)
+    z = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    dmask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    sums = torch.empty((B, _lib.SCALE_NSUM), dtype=torch.float64, device=dev)
+    partial = torch.empty((B, _lib.SCALE_NBLK, _lib.SCALE_NSUM), dtype=torch.float64, device=dev)
+    check(lib().islam_scale_ls(ptr(disp), ptr(flow), ptr(pose7), ptr(intr4), ptr(baseline), ptr(edge), ptr(disp_th),
+                               ptr(scale), ptr(z), ptr(mask), ptr(dmask), ptr(sums), ptr(partial), B, H, W,
+                               stream_ptr(dev)))
+    return scale, z, mask.bool(), dmask.bool(), sums
+
+
+# --------------------------------------------------------------------------- IMU
+def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
+    """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,
+    float32 or float64; seg int64 device tensor (nframes+1), seg_host the same on the host."""
+    require_cuda(dt, gyro, acc, seg)
+    dtype = dt.dtype
+    code = {torch.float32: 0, torch.float64: 1}[dtype]
+    dev = dt.device
+    nframes = int(seg_host.shape[0]) - 1
+    S = int(dt.shape[0])
+    maxF = int(np.max(np.diff(seg_host))) if nframes > 0 else 0
+    rows = nframes if motion_mode else nframes + 1
+    pos = torch.empty((rows, 3), dtype=dtype, device=dev)
+    rot = torch.empty((rows, 4), dtype=dtype, device=dev)
+    vel = torch.empty((rows, 3), dtype=dtype, device=dev)
+    nbytes = lib().islam_imu_scratch_bytes(S, nframes, code)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().islam_imu_preint(ptr(dt), ptr(gyro), ptr(acc), ptr(seg), nframes, S, maxF, ptr(init_pos), ptr(init_rot),
+                                 ptr(init_vel), c_double(gravity), 1 if motion_mode else 0, ptr(pos), ptr(rot), ptr(vel),
+                                 ptr(scratch), code, stream_ptr(dev)))
+    return pos, rot, vel
+
+
+# --------------------------------------------------------------------------- PVGO
+def pvgo_default_params(loss_weight=(1, 1, 1, 1), radius=1e4, seg_len=(0, 0)):
+    p = _lib.PvgoParams()
+    lib().islam_pvgo_default_params(ctypes.byref(p))
+    for i in range(4):
+        p.w[i] = float(loss_weight[i]) ** 2            # pvgo.py:125-129
+    p.radius = float(radius)
+    p.seg_len[0], p.seg_len[1] = int(seg_len[0]), int(seg_len[1])
+    return p
+
+
+def pvgo_workspace(N, device):
+    nbytes = lib().islam_pvgo_workspace_bytes(N)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, params, workspace=None, trace_cap=0):
+    """In-place LM on float64 device tensors.  Returns (PvgoResult, trace ndarray (trials,3) or None)."""
+    require_cuda(nodes, vels, poses, drots, dtrans, dvels, dts)
+    for t in (nodes, vels, poses, drots, dtrans, dvels, dts):
+        assert t.dtype == torch.float64 and t.is_contiguous()
+    N = nodes.shape[0]
+    if workspace is None:
+        workspace = pvgo_workspace(N, nodes.device)
+    ws, nbytes = workspace
+    res = _lib.PvgoResult()
+    trace = np.zeros((trace_cap, 3), dtype=np.float64) if trace_cap > 0 else None
+    tp = trace.ctypes.data_as(c_void_p) if trace is not None else c_void_p(0)
+    check(lib().islam_pvgo_run_chain(ptr(nodes), ptr(vels), ptr(poses), ptr(drots), ptr(dtrans), ptr(dvels), ptr(dts), N,
+                                     ctypes.byref(params), ptr(ws), c_size_t(nbytes), ctypes.byref(res), tp, trace_cap,
+                                     stream_ptr(nodes.device)))
+    if trace is not None:
+        trace = trace[:min(res.trials, trace_cap)]
+    return res, trace
+
+
+def pvgo_linearize(nodes, vels, poses, drots, dtrans, dvels, dts):
+    N = nodes.shape[0]
+    M = N - 1
+    lin = torch.empty((42, M), dtype=torch.float64, device=nodes.device)
+    part = torch.empty(((M + 63) // 64,), dtype=torch.float64, device=nodes.device)
+    check(lib().islam_pvgo_linearize(ptr(nodes), ptr(vels), ptr(poses), ptr(drots), ptr(dtrans), ptr(dvels), ptr(dts), N,
+                                     ptr(lin), ptr(part), stream_ptr(nodes.device)))
+    return lin, part
+
+
+def pvgo_build_normal(lin, dts, N, w4, vmin=1e-4, vmax=1e32):
+    dev = lin.device
+    Hd = torch.zeros((N, 9, 9), dtype=torch.float64, device=dev)
+    Ho = torch.zeros((N, 9, 9), dtype=torch.float64, device=dev)
+    rhs = torch.zeros((N, 9), dtype=torch.float64, device=dev)
+    w = (c_double * 4)(*[float(x) for x in w4])
+    check(lib().islam_pvgo_build_normal(ptr(lin), ptr(dts), N, w, c_double(vmin), c_double(vmax), ptr(Hd), ptr(Ho),
+                                        ptr(rhs), stream_ptr(dev)))
+    return Hd, Ho, rhs
+
+
+def pvgo_solve_chain(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
+    N = Hd.shape[0]
+    if workspace is None:
+        workspace = pvgo_workspace(N, Hd.device)
+    ws, nbytes = workspace
+    dx = torch.empty((N, 9), dtype=torch.float64, device=Hd.device)
+    sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+    check(lib().islam_pvgo_solve_chain(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, ptr(ws), c_size_t(nbytes),
+                                       ptr(dx), stream_ptr(Hd.device)))
+    return dx
+
+
+def pvgo_retract(nodes, vels, dx, sign=1.0):
+    N = nodes.shape[0]
+    no, vo = torch.empty_like(nodes), torch.empty_like(vels)
+    check(lib().islam_pvgo_retract(ptr(nodes), ptr(vels), ptr(dx), c_double(sign), N, ptr(no), ptr(vo),
+                                   stream_ptr(nodes.device)))
+    return no, vo
+
+
+def pvgo_align(nodes, vels, target7):
+    N = nodes.shape[0]
+    no, vo = torch.empty_like(nodes), torch.empty_like(vels)
+    check(lib().islam_pvgo_align(ptr(nodes), ptr(vels), ptr(target7), N, ptr(no), ptr(vo), stream_ptr(nodes.device)))
+    return no, vo
+
+
+class _VoLoss(torch.autograd.Function):
+    """graph.vo_loss(edges, poses) (pvgo.py:67-78): nodes detached, gradient to ``poses`` only, in PyPose's
+    convention (left-tangent 6-vector stored in a 7-vector with a trailing 0)."""
+
+    @staticmethod
+    def forward(ctx, nodes, edges, poses):
+        E = edges.shape[0]
+        p64 = poses.detach().to(torch.float64).contiguous()
+        err = torch.empty((E, 6), dtype=torch.float64, device=nodes.device)
+        tl = torch.empty(E, dtype=torch.float64, device=nodes.device)
+        rl = torch.empty(E, dtype=torch.float64, device=nodes.device)
+        check(lib().islam_pvgo_vo_loss_fwd(ptr(nodes), ptr(edges), ptr(p64), E, ptr(err), ptr(tl), ptr(rl),
+                                           stream_ptr(nodes.device)))
+        ctx.save_for_backward(p64, err)
+        ctx.out_dtype = poses.dtype
+        return tl.to(poses.dtype), rl.to(poses.dtype)
+
+    @staticmethod
+    def backward(ctx, g_tl, g_rl):
+        p64, err = ctx.saved_tensors
+        E = p64.shape[0]
+        grad = torch.empty((E, 7), dtype=torch.float64, device=p64.device)
+        gt = g_tl.to(torch.float64).contiguous()
+        gr = g_rl.to(torch.float64).contiguous()
+        check(lib().islam_pvgo_vo_loss_bwd(ptr(p64), ptr(err), ptr(gt), ptr(gr), E, ptr(grad), stream_ptr(p64.device)))
+        return None, None, grad.to(ctx.out_dtype)
+
+
+def pvgo_vo_loss(nodes64, edges, poses):
+    return _VoLoss.apply(nodes64, edges, poses)

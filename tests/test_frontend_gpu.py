@@ -1,0 +1,123 @@
+"""GPU parity of the front-end kernels (correlation, warp, scale recovery) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cwrap, scale as oscale
+
+pytestmark = pytest.mark.gpu
+
+# the five (C,H,W) shapes PWC-Net calls the correlation with at 448x640 + ragged edge cases
+PWC_SHAPES = [(196, 7, 10), (128, 14, 20), (96, 28, 40), (64, 56, 80), (32, 112, 160)]
+EDGE_SHAPES = [(1, 1, 1), (3, 5, 7), (17, 9, 33), (33, 4, 65), (5, 13, 31)]
+
+
+@pytest.mark.parametrize('C,H,W', PWC_SHAPES + EDGE_SHAPES)
+def test_corr81_forward(cuda, C, H, W):
+    from islam_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(C * 1000 + H)
+    f1 = torch.randn(B, C, H, W, generator=g)
+    f2 = torch.randn(B, C, H, W, generator=g)
+    out = ops.corr81_forward(f1.to(cuda), f2.to(cuda)).cpu().numpy()
+    ref = cwrap.corr81_fwd(f1.numpy(), f2.numpy())
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_corr81_forward_full_batch(cuda):
+    """BASELINE size: B=8 at the largest level, against the oracle on a slice + linearity property."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn(8, 32, 112, 160, generator=g).to(cuda)
+    f2 = torch.randn(8, 32, 112, 160, generator=g).to(cuda)
+    out = ops.corr81_forward(f1, f2)
+    ref = cwrap.corr81_fwd(f1[3:4].cpu().numpy(), f2[3:4].cpu().numpy())
+    np.testing.assert_allclose(out[3:4].cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    out2 = ops.corr81_forward(2.0 * f1, f2)                     # linear in each argument
+    torch.testing.assert_close(out2, 2.0 * out, rtol=1e-6, atol=1e-6)
+    # centre channel (dy=dx=0) is the per-pixel mean product
+    torch.testing.assert_close(out[:, 40], (f1 * f2).mean(1), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('C,H,W', [(8, 14, 20), (5, 9, 33), (32, 28, 40), (3, 8, 32)])
+def test_corr81_backward(cuda, C, H, W):
+    from islam_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(C + W)
+    f1 = torch.randn(B, C, H, W, generator=g)
+    f2 = torch.randn(B, C, H, W, generator=g)
+    go = torch.randn(B, 81, H, W, generator=g)
+    a = f1.to(cuda).requires_grad_(True)
+    b = f2.to(cuda).requires_grad_(True)
+    ops.FunctionCorrelation(a, b).backward(go.to(cuda))
+    r1, r2 = cwrap.corr81_bwd(f1.numpy(), f2.numpy(), go.numpy())
+    np.testing.assert_allclose(a.grad.cpu().numpy(), r1, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), r2, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('C,H,W,scale', [(128, 14, 20, 0.625), (96, 28, 40, 1.25), (64, 56, 80, 2.5), (32, 112, 160, 5.0),
+                                         (3, 1, 1, 1.0), (2, 5, 1, 1.0), (4, 7, 9, 1.0)])
+def test_warp_mask(cuda, C, H, W, scale):
+    from islam_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    flo = torch.randn(B, 2, H, W, generator=g) * (3.0 / scale)
+    flo[0, :, 0, 0] = 0.0                                        # exact-integer sample position
+    out = ops.warp_mask(x.to(cuda), flo.to(cuda), scale).cpu().numpy()
+    ref = cwrap.warp(x.numpy(), (flo * scale).numpy())
+    # bit-exact coordinates; the 4-tap sum is evaluated in the same order -> exact up to fma-free rounding
+    np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
+    # and against torch's own grid_sample (what the reference calls), run on the GPU
+    xx = torch.arange(0, W).view(1, -1).repeat(H, 1)
+    yy = torch.arange(0, H).view(-1, 1).repeat(1, W)
+    grid = torch.cat((xx.view(1, 1, H, W).repeat(B, 1, 1, 1), yy.view(1, 1, H, W).repeat(B, 1, 1, 1)), 1).float()
+    vg = grid + flo * scale
+    vg[:, 0] = 2.0 * vg[:, 0].clone() / max(W - 1, 1) - 1.0
+    vg[:, 1] = 2.0 * vg[:, 1].clone() / max(H - 1, 1) - 1.0
+    vg = vg.permute(0, 2, 3, 1)
+    o = torch.nn.functional.grid_sample(x, vg, align_corners=True)
+    m = torch.nn.functional.grid_sample(torch.ones_like(x), vg, align_corners=True)
+    m[m < 0.9999] = 0
+    m[m > 0] = 1
+    np.testing.assert_allclose(out, (o * m).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('with_edge', [False, True])
+def test_scale_ls(cuda, with_edge):
+    from islam_amd import ops
+    B, H, W = 3, 112, 160
+    rng = np.random.default_rng(3)
+    disp = rng.uniform(0.0, 12.0, (B, 1, H, W)).astype(np.float32)
+    flow = rng.normal(0, 3.0, (B, 2, H, W)).astype(np.float32)
+    flow[:, :, :4, :4] = 0.0                                    # zero-flow pixels are masked out
+    q = rng.normal(size=(B, 4)) * 0.05
+    q[:, 3] = 1.0
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pose = np.concatenate([rng.normal(size=(B, 3)), q], 1).astype(np.float32)
+    intr = np.tile(np.array([[214.7, 214.7, 130.0, 55.3]], np.float32), (B, 1))
+    base = np.array([0.54, 0.25, 0.11], np.float32)
+    th = np.array([5.0, 1.0, 1.0], np.float32)
+    edge = (rng.uniform(size=(B, H, W)) > 0.6) if with_edge else None
+    t = lambda a: torch.tensor(a, device=cuda)
+    s, z, m, dm, sums = ops.scale_ls(t(disp), t(flow), t(pose), t(intr), t(base), t(edge) if with_edge else None, t(th))
+    for b in range(B):
+        so, zo, mo, dmo, (MM, Mw) = oscale.scale_from_disp_flow(disp[b], flow[b], pose[b], *intr[b], base[b],
+                                                               edge[b] if with_edge else None, th[b])
+        assert (m[b].cpu().numpy() != mo).mean() < 1e-4          # float32 boundary ties only
+        np.testing.assert_array_equal(dm[b].cpu().numpy(), dmo)
+        np.testing.assert_allclose(z[b].cpu().numpy(), zo, rtol=1e-6)
+        np.testing.assert_allclose(sums[b, 0].item(), MM, rtol=1e-4)
+        np.testing.assert_allclose(sums[b, 1].item(), Mw, rtol=1e-4, atol=1e-3 * abs(MM))
+        np.testing.assert_allclose(s[b].item(), so, rtol=2e-4, atol=1e-6)
+    assert sums[:, 17].cpu().numpy().tolist() == m.reshape(B, -1).sum(1).cpu().numpy().tolist()
+
+
+def test_scale_ls_empty_mask_is_nan(cuda):
+    from islam_amd import ops
+    B, H, W = 1, 16, 16
+    z = torch.zeros
+    s, *_ = ops.scale_ls(z(B, 1, H, W, device=cuda), z(B, 2, H, W, device=cuda),
+                         torch.tensor([[0., 0, 1, 0, 0, 0, 1]], device=cuda), torch.tensor([[100., 100, 8, 8]], device=cuda),
+                         torch.tensor([0.5], device=cuda), None, torch.tensor([1.0], device=cuda))
+    assert torch.isnan(s).all()                                 # reference: s = 0/0
