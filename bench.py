@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PVGO Levenberg-Marquardt iterations per second on the 5000-frame graph.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+For N>1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL).
+
+Workload = BASELINE.json configs[3] geometry on ONE graph ("Synthetic 5000-frame KITTI-shape graph"),
+which is what BASELINE.json's metric is quoted on: N=5001 nodes / 5000 links, fp64, KITTI loss weights
+(run_kitti.sh:5), IMU quantities produced by the HIP pre-integration kernels, everything resident in HBM
+before the timed region.  One bench "step" = one complete run_pvgo optimisation of that graph from the same
+initial state (pvgo.py:168-180: <=10 optimizer.step() calls, each with its inner damped retries).
+An "LM iteration" = one damped normal-equation solve + trial step + loss / trust-region evaluation (one pass
+of PyPose's inner ``while self.last <= self.loss`` loop); the linearisation of each optimizer.step() is
+inside the timed region and amortised over its iterations.
+
+value = LM iterations of all ranks' work / wall time (max over ranks).  N>1: the single graph is sharded
+over the ranks (strong scaling; islam_amd/dist_pvgo.py), interface blocks exchanged over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LOSS_WEIGHT = (1, 0.1, 10, 0.1)  # run_kitti.sh:5
+N_FRAMES = 5001
+# algorithmic HBM bytes per node of the dominant kernel (bt_eliminate level 0), DESIGN.md section 4:
+# read Hd 81 + Ho 81 + rhs 9, write fac 252 + inv 9 + damped diagonal 9  doubles
+ELIM_BYTES_PER_NODE = (81 + 81 + 9 + 252 + 9 + 9) * 8
+
+
+def build_problem(device, n_frames=N_FRAMES):
+    """Config-4 graph; IMU dead-reckoning init and motion-mode deltas from the HIP integrator (train.py:236-246)."""
+    from islam_amd import ops, synthetic
+    tr = synthetic.car_trajectory(n_frames)
+    t64 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+    seg_h = np.ascontiguousarray(tr['rgb2imu_sync'] - tr['rgb2imu_sync'][0], dtype=np.int64)
+    seg_d = torch.tensor(seg_h, device=device)
+    dt, gyro, acc = t64(tr['imu_dts']), t64(tr['gyros']), t64(tr['accels'])
+    ip, ir, iv = t64(tr['init']['pos']), t64(tr['init']['rot']), t64(tr['init']['vel'])
+    z3 = torch.zeros(3, dtype=torch.float64, device=device)
+    pos, rot, vel = ops.imu_preint(dt, gyro, acc, seg_d, seg_h, ip, ir, iv, tr['gravity'], False)
+    dpos, drot, dvel = ops.imu_preint(dt, gyro, acc, seg_d, seg_h, z3, ir, z3, tr['gravity'], True)
+    prob = dict(init_nodes=torch.cat([pos, rot], 1).contiguous(), init_vels=vel.contiguous(),
+                vo=t64(tr['vo_motions']), drots=drot.contiguous(), dtrans=dpos.contiguous(), dvels=dvel.contiguous(),
+                dts=t64(tr['dts']))
+    return prob, tr
+
+
+def cpu_baseline(prob_host):
+    """Oracle (CPU restatement of the PyPose LM, oracle/pvgo.py) on the host cores: banded mode at full size."""
+    from oracle import pvgo as opvgo
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:          # pragma: no cover
+        threadpool_limits = None
+    t0 = time.perf_counter()
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    out = opvgo.run_pvgo(**prob_host, loss_weight=LOSS_WEIGHT, mode='banded', return_optimizer=True)
+    if ctx is not None:
+        ctx.unregister() if hasattr(ctx, 'unregister') else None
+    dt = time.perf_counter() - t0
+    trials = len(out[5].trace)
+    # the faithful dense formulation (what PyPose builds) on a bounded sample: N=513
+    n_small = 513
+    small = {k: (v[:n_small] if k in ('init_nodes', 'init_vels') else v[:n_small - 1]) for k, v in prob_host.items()}
+    t1 = time.perf_counter()
+    out_d = opvgo.run_pvgo(**small, loss_weight=LOSS_WEIGHT, mode='dense', max_steps=1, return_optimizer=True)
+    dt_d = time.perf_counter() - t1
+    return {
+        'value': trials / dt, 'unit': 'LM iters/s', 'cores': 1, 'kind': 'port',
+        'sample': 'oracle/pvgo.py banded (block-tridiagonal) mode, the full N=%d graph, %d LM iterations in %.2f s, 1 thread'
+                  % (prob_host['init_nodes'].shape[0], trials, dt),
+        'dense_pypose_style': {'value': len(out_d[5].trace) / dt_d, 'unit': 'LM iters/s', 'N': n_small,
+                               'cores': os.cpu_count(),
+                               'sample': 'dense J / block_diag W / dense Cholesky as PyPose builds them, first optimizer.step '
+                                         'only, N=%d (N=5001 needs >60 GB)' % n_small},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=N_FRAMES)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from islam_amd import ops
+    prob, tr = build_problem(device, args.frames)
+    N = prob['init_nodes'].shape[0]
+    prm = ops.pvgo_default_params(LOSS_WEIGHT, radius=1e4)
+
+    if world == 1:
+        ws = ops.pvgo_workspace(N, device)
+        nodes = torch.empty_like(prob['init_nodes'])
+        vels = torch.empty_like(prob['init_vels'])
+
+        def step():
+            nodes.copy_(prob['init_nodes'])
+            vels.copy_(prob['init_vels'])
+            res, _ = ops.pvgo_run_chain(nodes, vels, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'],
+                                        prm, workspace=ws)
+            return res.trials, res.steps
+    else:
+        from islam_amd import dist_pvgo
+        solver = dist_pvgo.ShardedChainPVGO(prob['init_nodes'], prob['init_vels'], prob['vo'], prob['drots'], prob['dtrans'],
+                                            prob['dvels'], prob['dts'], LOSS_WEIGHT, radius=1e4, group=None)
+
+        def step():
+            r = solver.run()
+            return r['trials'], r['steps']
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    trials = steps_lm = 0
+    for _ in range(args.steps):
+        a, b = step()
+        trials += a
+        steps_lm += b
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+        lin, _ = ops.pvgo_linearize(prob['init_nodes'], prob['init_vels'], prob['vo'], prob['drots'], prob['dtrans'],
+                                    prob['dvels'], prob['dts'])
+        w4 = [x ** 2 for x in LOSS_WEIGHT]
+        Hd, Ho, rhs = ops.pvgo_build_normal(lin, prob['dts'], N, w4)
+        ws2 = ops.pvgo_workspace(N, device)
+        reps, acc_ms, levels = 30, None, None
+        for i in range(reps + 3):
+            _, ms, levels = ops.pvgo_solve_chain_timed(Hd.clone(), Ho, rhs, 1e-4, workspace=ws2)
+            if i >= 3:
+                acc_ms = ms if acc_ms is None else [a + b for a, b in zip(acc_ms, ms)]
+        ms = [a / reps for a in acc_ms]
+        nl = len(levels)
+        names = ['eliminate_L%d' % l for l in range(nl)] + ['backsub_L%d' % l for l in range(nl - 2, -1, -1)]
+        kern = dict(zip(names, [round(x * 1e3, 2) for x in ms]))      # microseconds
+        elim0_s = ms[0] * 1e-3
+        alg_bytes = ELIM_BYTES_PER_NODE * N
+        achieved = alg_bytes / elim0_s / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                    'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': elim0_s * 1e6,
+                    'solve_launch_us': kern, 'levels_n_m_P': levels,
+                    'note': 'latency-bound: %d dependent 9x9 block pivots on the critical path' % sum(l[1] for l in levels)}
+        value = trials / elapsed
+        out = {
+            'metric': 'pvgo_lm_iters_per_sec', 'value': value, 'unit': 'LM iters/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[3]: synthetic %d-frame KITTI-shape chain graph (N=%d nodes, E=%d links), '
+                                   'full run_pvgo LM loop per step' % (N - 1, N, N - 1),
+                       'loss_weight': list(LOSS_WEIGHT), 'radius': 1e4, 'parallelism': 'graph sharded over %d GPU(s)' % world},
+            'lm_iters_per_step': trials / args.steps, 'optimizer_steps_per_step': steps_lm / args.steps,
+            'us_per_lm_iter': elapsed / trials * 1e6,
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline:
+            host = {k: v.cpu().numpy() for k, v in (('init_nodes', prob['init_nodes']), ('init_vels', prob['init_vels']),
+                                                     ('vo_motions', prob['vo']), ('imu_drots', prob['drots']),
+                                                     ('imu_dtrans', prob['dtrans']), ('imu_dvels', prob['dvels']),
+                                                     ('dts', prob['dts']))}
+            host['links'] = tr['links']
+            out['cpu_baseline'] = cpu_baseline(host)
+            out['speedup_vs_cpu_port'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

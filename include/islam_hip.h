@@ -136,6 +136,11 @@ int islam_pvgo_build_normal(const double* lin, const double* dts, int N, const d
 /* Hd.diag += Hd.diag*damping (in place, cumulative), then solve -> dx (N,9).  status (device int[4]). */
 int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                            const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
+/* Profiling variant: HIP events around every launch of one solve (on `stream`).  ms[i] = duration of launch i
+ * (eliminate level 0..L-1, then back-substitution L-2..0), plan[3*l..] = (nodes, segment length, segments). */
+int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
+                                 const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx,
+                                 float* ms, int* plan, int* nlaunch, void* stream);
 /* X <- Exp(sign*dx[:, :6]) * X ; v += sign*dx[:, 6:]  (LieTensor.add_) */
 int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N,
                        double* nodes_out, double* vels_out, void* stream);

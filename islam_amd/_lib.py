@@ -50,6 +50,9 @@ SIGNATURES = {
                                 [c_void_p] * 4),
     'islam_pvgo_solve_chain': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                         c_void_p, c_void_p]),
+    'islam_pvgo_solve_chain_timed': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
+                                                              c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int),
+                                                              ctypes.POINTER(c_int), c_void_p]),
     'islam_pvgo_retract': (c_int, [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 3),
     'islam_pvgo_vo_loss_fwd': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_vo_loss_bwd': (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 2),

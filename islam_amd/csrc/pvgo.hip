@@ -207,51 +207,73 @@ struct LevelDst {
     double* x;                   // n x 9, written when the level consists of one segment
 };
 
-// column `lane` of the augmented matrix [S | U | F^T | g] of node k (F^T columns come from elsewhere)
-__device__ __forceinline__ void load_cols(const LevelSrc& s, int k, int n, int lane, double damping, double (&m)[9]) {
+// Column `lane` of the augmented matrix [S | U | F^T | g] of node k (F^T columns come from elsewhere).
+// Per-lane source pointers are fixed for the whole segment (LaneSrc); a node's column is A - B - C
+// (level 0: A only).  issue() only loads -- every lane runs the same 9/27 loads, disabled terms read valid
+// memory and are dropped by a select in combine() -- so the loads of node c+2 are in flight while node c
+// is being eliminated and are first touched one full node later.
+struct LaneSrc {
+    const double *A, *B, *C;
+    int nsA, nsB, nsC;        // stride between nodes (doubles)
+    int sa, sb, sc;           // stride between rows
+    bool isS, isU, isG;
+};
+struct RawCols { double a[9], b[9], c[9]; };
+
+__device__ __forceinline__ LaneSrc lane_source(const LevelSrc& s, int lane) {
+    LaneSrc L;
+    L.isS = lane < 9; L.isU = lane >= 9 && lane < 18; L.isG = lane == 27;
+    const int cu = L.isU ? lane - 9 : 0, cs = L.isS ? lane : 0;
+    L.nsA = L.nsB = L.nsC = L.isG ? 9 : 81;
+    L.sa = L.sb = L.sc = L.isG ? 1 : 9;
+    if (s.level0) {
+        L.A = L.isU ? s.Ho + cu : L.isG ? s.rhs0 : s.Hd + cs;
+        L.B = L.C = L.A;
+    } else {
+        L.A = L.isU ? s.fill + 81 + cu : L.isG ? s.rsep : s.Dsep + cs;      // U: fill[k+1]
+        L.B = L.isG ? s.cgR : s.cR + cs;
+        L.C = L.isG ? s.cgL + 9 : s.cL + 81 + cs;                            // contribution of segment k+1
+    }
+    return L;
+}
+
+__device__ __forceinline__ void issue_cols(const LaneSrc& L, bool level0, int k, RawCols& raw) {
+    const double* pa = L.A + (size_t)k * L.nsA;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) m[r] = 0.0;
-    if (lane < 9) {
-        if (s.level0) {
+    for (int r = 0; r < 9; ++r) raw.a[r] = pa[r * L.sa];
+    if (!level0) {
+        const double* pb = L.B + (size_t)k * L.nsB;
+        const double* pc = L.C + (size_t)k * L.nsC;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) m[r] = s.Hd[(size_t)k * 81 + r * 9 + lane];
+        for (int r = 0; r < 9; ++r) raw.b[r] = pb[r * L.sb];
 #pragma unroll
-            for (int r = 0; r < 9; ++r)
-                if (r == lane) {
-                    m[r] = m[r] + m[r] * damping;            // A.diagonal().add_(A.diagonal()*damping), kept for retries
-                    s.Hd[(size_t)k * 81 + r * 10] = m[r];
-                }
-        } else {
-            const bool hasL = (k + 1) < s.Pprev;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                double v = s.Dsep[(size_t)k * 81 + r * 9 + lane] - s.cR[(size_t)k * 81 + r * 9 + lane];
-                if (hasL) v -= s.cL[(size_t)(k + 1) * 81 + r * 9 + lane];
-                m[r] = v;
-            }
-        }
-    } else if (lane < 18) {
-        if (k + 1 < n) {
-            const int c = lane - 9;
-            const double* O = s.level0 ? (s.Ho + (size_t)k * 81) : (s.fill + (size_t)(k + 1) * 81);
-#pragma unroll
-            for (int r = 0; r < 9; ++r) m[r] = O[r * 9 + c];
-        }
-    } else if (lane == 27) {
-        if (s.level0) {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) m[r] = s.rhs0[(size_t)k * 9 + r];
-        } else {
-            const bool hasL = (k + 1) < s.Pprev;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                double v = s.rsep[(size_t)k * 9 + r] - s.cgR[(size_t)k * 9 + r];
-                if (hasL) v -= s.cgL[(size_t)(k + 1) * 9 + r];
-                m[r] = v;
-            }
-        }
+        for (int r = 0; r < 9; ++r) raw.c[r] = pc[r * L.sc];
     }
 }
+
+__device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s, int k, int n, int lane, double damping,
+                                             const RawCols& raw, double (&m)[9]) {
+    const bool ua = L.isS || L.isG || (L.isU && (k + 1) < n);
+    if (s.level0) {
+        double dg = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = ua ? raw.a[r] : 0.0;
+            if (r == lane) { v = v + v * damping; dg = v; }   // A.diagonal().add_(A.diagonal()*damping), kept for retries
+            m[r] = v;
+        }
+        if (lane < 9) s.Hd[(size_t)k * 81 + lane * 10] = dg;
+    } else {
+        const bool ub = L.isS || L.isG;
+        const bool uc = ub && (k + 1) < s.Pprev;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) m[r] = (ua ? raw.a[r] : 0.0) - (ub ? raw.b[r] : 0.0) - (uc ? raw.c[r] : 0.0);
+    }
+}
+
+// LDS hand-off inside a one-wave workgroup: LDS instructions of a wave execute in order, so only the
+// compiler must be kept from reordering; no vmcnt wait (global prefetches and stores stay in flight).
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // pairs (a <= b) of the symmetric 9x9 accumulation F~^T F~ handled by lanes 0..44
 __constant__ unsigned char kPairA[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2,
@@ -312,25 +334,32 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     const bool has_right = sR < n;
     const double damping = src.state ? src.state[2] : src.damping_override;
 
+    const LaneSrc LS = lane_source(src, lane);
+    const bool level0 = src.level0 != 0;
     double mcol[9], nb[9];
-    load_cols(src, c0, n, lane, damping, mcol);
+    RawCols raw;
+    issue_cols(LS, level0, c0, raw);
+    combine_cols(LS, src, c0, n, lane, damping, raw, mcol);
     if (has_left && lane >= 18 && lane < 27) {          // spike F^T: coupling (left separator rows, c0 cols) transposed
         const int jj = lane - 18;
         const double* O = src.level0 ? (src.Ho + (size_t)(c0 - 1) * 81) : (src.fill + (size_t)c0 * 81);
 #pragma unroll
         for (int r = 0; r < 9; ++r) mcol[r] = O[jj * 9 + r];
     }
+    if (c0 + 1 < n) issue_cols(LS, level0, c0 + 1, raw);
     double accL = 0.0;
     int bad = 0;
 
     for (int t = 0; t < cnt; ++t) {
         const int c = c0 + t;
         const bool last = (t == cnt - 1);
-        if (c + 1 < n) load_cols(src, c + 1, n, lane, damping, nb);
+        // software pipeline: the loads of node c+1 were issued one node ago; those of node c+2 go out now
+        if (c + 1 < n) combine_cols(LS, src, c + 1, n, lane, damping, raw, nb);
         else {
 #pragma unroll
             for (int r = 0; r < 9; ++r) nb[r] = 0.0;
         }
+        if (!last && c + 2 < n) issue_cols(LS, level0, c + 2, raw);
         // ---- Cholesky elimination of the 9 unknowns of node c, applied to all 28 columns
         double myinv = 0.0;
 #pragma unroll
@@ -357,7 +386,7 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
 #pragma unroll
             for (int r = 0; r < 9; ++r) Xs[(lane - 9) * XS + r] = mcol[r];
         }
-        __syncthreads();
+        lds_sync();
         // ---- Schur update T = X^T X, X = [U~ | F~ | y~]:  entries (r, cb), r < 9, cb < 19
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
             const int b = lane < 45 ? kPairB[lane] : 9;
             accL += dot9(Xs + (9 + a) * XS, Xs + (9 + b) * XS);
         }
-        __syncthreads();
+        lds_sync();
         if (!last) {
             if (lane < 9) {
 #pragma unroll
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
                 for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
             }
         }
-        __syncthreads();
+        lds_sync();
     }
     if (has_left) {
         if (lane < 45) {
@@ -619,7 +648,7 @@ int plan_levels(int N, const int seg_len[2], LevelPlan out[3]) {
         L.n = n;
         bool single = (l == 2) || n <= 40;
         if (!single) {
-            int m = (seg_len && seg_len[l] > 0) ? seg_len[l] : 0;
+            int m = (seg_len && l < 2 && seg_len[l] > 0) ? std::max(seg_len[l], 4) : 0;
             if (m <= 0) {
                 // balance the dependent chains: m_l + (rest) ; ~cube root split for two cuts, sqrt for the last
                 if (l == 0) m = std::max(4, (int)std::lround(std::cbrt((double)n) * 1.15));
@@ -684,9 +713,12 @@ Workspace carve(void* base, int N) {
 
 // enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
 int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
-                  double damping, int N, const int seg_len[2], double* dx, hipStream_t s) {
+                  double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
+                  int* nev = nullptr) {
     LevelPlan plan[3];
     const int nl = plan_levels(N, seg_len, plan);
+    int ne = 0;
+    if (evs) (void)hipEventRecord(evs[ne++], s);
     for (int l = 0; l < nl; ++l) {
         LevelSrc src{};
         LevelDst dst{};
@@ -702,13 +734,16 @@ int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double
         dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
         dst.x = (l == 0) ? dx : b.x;
         hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, w.flags);
+        if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     for (int l = nl - 2; l >= 0; --l) {
         const LevelBufs& b = w.lv[l];
         double* x = (l == 0) ? dx : b.x;
         hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
                            plan[l].m);
+        if (evs) (void)hipEventRecord(evs[ne++], s);
     }
+    if (nev) *nev = ne;
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -770,6 +805,36 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
     ISLAM_HIP_CHECK(hipMemcpyAsync(&flag, w.flags, sizeof(int), hipMemcpyDeviceToHost, s));
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
     if (flag) return fail(ISLAM_ENOTPD, "islam_pvgo_solve_chain: non-positive pivot (matrix not positive definite)");
+    return ISLAM_OK;
+}
+
+// Profiling variant of islam_pvgo_solve_chain: HIP events around every launch of one solve, on the stream the
+// kernels run on.  ms[i] = duration of launch i (eliminate level 0..L-1, then back-substitution L-2..0);
+// plan[3*l+0..2] = (nodes, segment length, segments) of level l.  Returns the number of launches in *nlaunch.
+int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
+                                 const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, float* ms,
+                                 int* plan_out, int* nlaunch, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_solve_chain_timed: N=%d < 1", N);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_solve_chain_timed: workspace too small");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    hipEvent_t evs[8];
+    for (auto& e : evs) ISLAM_HIP_CHECK(hipEventCreate(&e));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    int ne = 0;
+    int rc = enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, s, evs, &ne);
+    if (rc != ISLAM_OK) return rc;
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i + 1 < ne; ++i) ISLAM_HIP_CHECK(hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
+    for (auto& e : evs) (void)hipEventDestroy(e);
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    for (int l = 0; l < 3; ++l) {
+        plan_out[3 * l] = l < nl ? plan[l].n : 0;
+        plan_out[3 * l + 1] = l < nl ? plan[l].m : 0;
+        plan_out[3 * l + 2] = l < nl ? plan[l].P : 0;
+    }
+    *nlaunch = ne - 1;
     return ISLAM_OK;
 }
 
