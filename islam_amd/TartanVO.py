@@ -1,0 +1,126 @@
+"""TartanVO front-end with the reference's call surface (reference TartanVO.py:15-198).
+
+Differences in HOW (not WHAT): the edge mask is computed on the device (islam_amd/edges.py) instead of a
+host round trip through OpenCV; the per-sample Python loop over scale_from_disp_flow is ONE batched HIP
+launch (islam_scale_ls) whose gradient w.r.t. the pose is rebuilt from the first-order sums the kernel
+accumulates; the two frozen nets can run under bf16 autocast (BASELINE config 2: "bf16 nets / fp64 LM").
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lietensor as pp
+from . import ops
+from .edges import edge_mask
+from .nets import VONet
+from .transformation import cvtSE3_pypose, tartan2kitti_pypose
+
+DISP_TH = {'kitti': 5, 'tartanair': 1, 'euroc': 1}          # TartanVO.py:161
+
+
+def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th):
+    """Batched dense_ba.scale_from_disp_flow (dense_ba.py:88-176), differentiable w.r.t. ``pose_enu`` (SE3 LieTensor).
+
+    Value: the HIP reduction.  Gradient: s = Mw/MM with M linear in a = K t^ and w linear in R, so
+    ds = (dMw - s dMM)/MM is a linear functional of (a, R) whose coefficients are sums over the masked pixels
+    (islam_amd/csrc/scale_ls.hip); it is re-attached through the same LieTensor ops the reference differentiates
+    (T.Inv().rotation() acting on points, T.Inv().translation(), dense_ba.py:142-166)."""
+    s, z, mask, dmask, sums = ops.scale_ls(disp, flow, pose_enu.tensor(), intr4, baseline, edge, disp_th)
+    if not pose_enu.requires_grad:
+        return s, z, mask, dmask
+    dev, dt = s.device, pose_enu.dtype
+    sums = sums.to(dt)
+    intr4 = intr4.to(dev, dt)
+    fx, fy, cx, cy = intr4.unbind(-1)
+    MM = sums[:, 0]
+    sv = s.to(dt)
+    # d s / d a  and  d s / d R  (B,3), (B,3,3)
+    dMw_da = torch.stack([-sums[:, 2], -sums[:, 3], sums[:, 4]], -1)
+    dMM_da = torch.stack([-2 * sums[:, 5], -2 * sums[:, 6], 2 * sums[:, 7]], -1)
+    ga = (dMw_da - sv[:, None] * dMM_da) / MM[:, None]
+    GR = torch.stack([fx[:, None] * sums[:, 8:11], fy[:, None] * sums[:, 11:14], sums[:, 14:17]], 1) / MM[:, None, None]
+    Tinv = pose_enu.Inv()
+    t = Tinv.translation()
+    tn = torch.nn.functional.normalize(t, dim=-1)
+    a = torch.stack([fx * tn[:, 0] + cx * tn[:, 2], fy * tn[:, 1] + cy * tn[:, 2], tn[:, 2]], -1)
+    R = Tinv.rotation()
+    eye = torch.eye(3, dtype=dt, device=dev)
+    cols = torch.stack([R.Act(eye[j].expand(R.shape[0], 3)) for j in range(3)], -1)      # (B,3,3), column j = R e_j
+    sur = (ga.detach() * a).sum(-1) + (GR.detach() * cols).sum((-1, -2))
+    return sv.detach() + (sur - sur.detach()), z, mask, dmask
+
+
+class TartanVO(nn.Module):
+    def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
+                 device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
+        self.device_id = device_id
+        self.correct_scale = correct_scale
+        self.use_kitti_coord = use_kitti_coord
+        self.pose_std = torch.tensor([0.13, 0.13, 0.13, 0.013, 0.013, 0.013]).cuda(self.device_id)
+        self.vonet = VONet(fix_parts=fix_parts)
+        self.vonet.frozen_dtype = frozen_dtype
+        for name, part in ((vo_model_name, self.vonet), (flow_model_name, self.vonet.flowNet),
+                           (pose_model_name, self.vonet.flowPoseNet), (stereo_model_name, self.vonet.stereoNet)):
+            if name is not None and name != '':
+                self.load_model(part, name)
+        self.vonet = self.vonet.cuda(self.device_id)
+
+    def load_model(self, model, modelname):
+        """TartanVO.py:49-87: suffix matching of state-dict keys with a size check."""
+        pretrain = torch.load(modelname, map_location='cuda:%d' % self.device_id)
+        own = model.state_dict()
+        picked = {}
+        for k, v in pretrain.items():
+            for kk, vv in own.items():
+                if (k.endswith(kk) or kk.endswith(k)) and v.size() == vv.size():
+                    picked[kk] = v
+        if not picked:
+            raise Exception('Could not load model from %s.' % modelname, 'load_model')
+        for kk in own:
+            if kk not in picked:
+                print('! [load_model] Key {} in model but not in {}!'.format(kk, modelname))
+        own.update(picked)
+        model.load_state_dict(own)
+        return model
+
+    def forward(self, sample, is_train=True, given_scale=None):
+        self.vonet.train() if is_train else self.vonet.eval()               # BN batch statistics when training (F4)
+        with torch.set_grad_enabled(is_train):
+            dev = self.device_id
+            img0 = sample['img0'].cuda(dev, non_blocking=True)
+            img1 = sample['img1'].cuda(dev, non_blocking=True)
+            intrinsic = sample['intrinsic'].cuda(dev, non_blocking=True)
+            img0_norm = sample['img0_norm'].cuda(dev, non_blocking=True)
+            img0_r_norm = sample['img0_r_norm'].cuda(dev, non_blocking=True)
+            intrinsic_calib = sample['intrinsic_calib']
+            baseline = torch.linalg.norm(sample['extrinsic'][:, :3], dim=1)
+            precalc_flow = sample['flow'] if 'flow' in sample else None
+
+            flow, disp, pose = self.vonet(img0, img1, img0_norm, img0_r_norm, intrinsic)
+            pose = pose * self.pose_std
+            flow, disp = flow.detach(), disp.detach()
+            res = {}
+            if given_scale is not None:
+                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * given_scale.view(-1, 1)
+                pose = torch.cat([trans, pose[:, 3:]], dim=1)
+            elif not self.correct_scale:
+                flow = flow * 5 if precalc_flow is None else precalc_flow.cuda(dev)     # pixels at 1/4 res
+                disp = disp * (50 / 4)
+                pose_enu = tartan2kitti_pypose(pose)
+                edge = edge_mask(img0)
+                th = torch.tensor([float(DISP_TH[d]) for d in sample['datatype']])
+                intr4 = intrinsic_calib.float() / 4
+                scale, depth, mask, depth_mask = stereo_scale(disp, flow, pose_enu, intr4, baseline.float(), edge, th)
+                res.update(flow=flow, disp=disp, mask=mask, depth=depth, depth_mask=depth_mask, baseline=baseline[0],
+                           intrinsic=intrinsic_calib[0] / 4)
+                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * scale.view(-1, 1)
+                pose = torch.cat([trans, pose[:, 3:]], dim=1)
+            else:
+                scale = torch.norm(sample['motion'][:, :3], dim=1).cuda(dev)
+                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * scale.view(-1, 1)
+                pose = torch.cat([trans, pose[:, 3:]], dim=1)
+            res['motion'] = tartan2kitti_pypose(pose) if self.use_kitti_coord else cvtSE3_pypose(pose)
+            return res

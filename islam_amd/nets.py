@@ -1,0 +1,370 @@
+"""Network definitions of the TartanVO front-end for PyTorch-ROCm (MIOpen / hipBLASLt convolutions).
+
+These are re-implementations (table-driven builders) of the reference's module graph with IDENTICAL
+state-dict keys and forward arithmetic, so the released checkpoints load unchanged
+(SURVEY.md section 5 "Checkpoint / resume": 765 keys = flowNet 128 + stereoNet 517 + flowPoseNet 120):
+  PWCDCNet     <- Network/PWC/PWCNet.py:58-292     (correlation / warp run on the HIP kernels)
+  StereoNet7   <- Network/StereoNet7.py:13-146, Network/PSM/submodule.py:10-43,66-155,
+                  Network/PSM/hourglass.py:6-77
+  VOFlowRes    <- Network/VOFlowNet.py:7-39,42-194  (config=1, intrinsic, down_scale, stereo=0)
+  VONet        <- Network/VONet.py:5-39
+  IMUCorrector_CNN_GRU_WO_COV <- Network/IMUDenoiseNet.py:9-62
+tests/test_nets_cpu.py checks key sets, shapes and forward outputs against golden vectors generated
+by importing the reference modules (tests/golden/make_net_golden.py).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# the two native ops of the flow network; tests may substitute CPU stand-ins for them
+corr_fn = ops.FunctionCorrelation
+
+
+class _WarpNoGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, scale):
+        return ops.warp_mask(x, flow, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError('warp backward is not built yet (SURVEY.md section 8f rank 1); the flow network is '
+                                  'frozen in every shipped configuration (--fix-model-parts flow stereo)')
+
+
+def warp_fn(x, flow, scale):
+    return _WarpNoGrad.apply(x, flow, scale)
+
+
+# ------------------------------------------------------------------------------------------ PWC-DC-Net
+def _conv_lrelu(cin, cout, stride=1, dilation=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, dilation, dilation, bias=True), nn.LeakyReLU(0.1))
+
+
+class PWCDCNet(nn.Module):
+    PYR = (3, 16, 32, 64, 96, 128, 196)             # channels of pyramid levels 0..6
+    DENSE = (128, 128, 96, 64, 32)                  # DenseNet decoder widths
+    WARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}
+
+    def __init__(self, md=4, flow_norm=20.0, uncertainty=False):
+        super().__init__()
+        assert not uncertainty, 'VONet builds the flow net with uncertainty=False (Network/VONet.py:10)'
+        self.flow_norm, self.uncertainty = flow_norm, uncertainty
+        for l in range(1, 7):
+            cin, cout = self.PYR[l - 1], self.PYR[l]
+            first, second = ('a', 'aa') if l < 6 else ('aa', 'a')       # level 6 is declared aa -> a -> b
+            setattr(self, 'conv%d%s' % (l, first), _conv_lrelu(cin, cout, stride=2))
+            setattr(self, 'conv%d%s' % (l, second), _conv_lrelu(cout, cout))
+            setattr(self, 'conv%db' % l, _conv_lrelu(cout, cout))
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        nd = (2 * md + 1) ** 2
+        for l in range(6, 1, -1):
+            od = nd if l == 6 else nd + self.PYR[l] + 4
+            c = od
+            for i, w in enumerate(self.DENSE):
+                setattr(self, 'conv%d_%d' % (l, i), _conv_lrelu(c, w))
+                c += w
+            setattr(self, 'predict_flow%d' % l, nn.Conv2d(c, 2, 3, 1, 1, bias=True))
+            setattr(self, 'deconv%d' % l, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+            if l > 2:
+                setattr(self, 'upfeat%d' % l, nn.ConvTranspose2d(c, 2, 4, 2, 1, bias=True))
+        c2 = nd + self.PYR[2] + 4 + sum(self.DENSE)
+        for i, (cin, cout, dil) in enumerate([(c2, 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16),
+                                               (64, 32, 1)], 1):
+            setattr(self, 'dc_conv%d' % i, _conv_lrelu(cin, cout, dilation=dil))
+        self.dc_conv7 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode='fan_in')
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def _pyramid(self, im):
+        feats, x = [], im
+        for l in range(1, 7):
+            order = ('a', 'aa', 'b') if l < 6 else ('aa', 'a', 'b')
+            for s in order:
+                x = getattr(self, 'conv%d%s' % (l, s))(x)
+            feats.append(x)
+        return feats                                   # levels 1..6
+
+    def _dense(self, l, x):
+        for i in range(5):
+            x = torch.cat((getattr(self, 'conv%d_%d' % (l, i))(x), x), 1)
+        return x
+
+    def _corr(self, a, b):
+        return self.leakyRELU(corr_fn(a.float().contiguous(), b.float().contiguous()).to(a.dtype))
+
+    def forward(self, x):
+        p1, p2 = self._pyramid(x[:, 0:3]), self._pyramid(x[:, 3:6])
+        x = self._dense(6, self._corr(p1[5], p2[5]))
+        flows = {}
+        for l in range(5, 1, -1):
+            flows[l + 1] = getattr(self, 'predict_flow%d' % (l + 1))(x)
+            up_flow = getattr(self, 'deconv%d' % (l + 1))(flows[l + 1])
+            up_feat = getattr(self, 'upfeat%d' % (l + 1))(x)
+            warped = warp_fn(p2[l - 1].float(), up_flow.float(), self.WARP_SCALE[l]).to(x.dtype)
+            x = torch.cat((self._corr(p1[l - 1], warped), p1[l - 1], up_flow, up_feat), 1)
+            x = self._dense(l, x)
+        flow2 = self.predict_flow2(x)
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
+        flow2 = flow2 + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        return (flow2, flows[3], flows[4], flows[5], flows[6]), (None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------ StereoNet7
+def _convbn(cin, cout, k, stride, pad, dilation):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, dilation if dilation > 1 else pad, dilation, bias=False),
+                         nn.BatchNorm2d(cout))
+
+
+class _PSMBlock(nn.Module):
+    def __init__(self, cin, cout, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Sequential(_convbn(cin, cout, 3, stride, 1, 1), nn.ReLU(inplace=True))
+        self.conv2 = _convbn(cout, cout, 3, 1, 1, 1)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class feature_extraction(nn.Module):
+    def __init__(self, last_planes=32, bigger=False, middleblock=16):
+        super().__init__()
+        self.bigger = bigger
+        relu = lambda: nn.ReLU(inplace=True)
+        self.firstconv = nn.Sequential(_convbn(3, 32, 3, 2, 1, 1), relu(), _convbn(32, 32, 3, 1, 1, 1), relu(),
+                                       _convbn(32, 32, 3, 1, 1, 1), relu())
+        self._c = 32
+        self.layer1 = self._layer(32, 3, 1)
+        self.layer2 = self._layer(64, middleblock, 2)
+        self.layer3 = self._layer(128, 3, 1)
+        self.layer4 = self._layer(128, 3, 1)
+        for i, k in enumerate((64, 32, 16, 8), 1):
+            setattr(self, 'branch%d' % i, nn.Sequential(nn.AvgPool2d((k, k), stride=(k, k)), _convbn(128, 32, 1, 1, 0, 1), relu()))
+        self.lastconv = nn.Sequential(_convbn(320 + (32 if bigger else 0), 128, 3, 1, 1, 1), relu(),
+                                      nn.Conv2d(128, last_planes, 1, 1, 0, bias=False))
+
+    def _layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self._c != planes:
+            down = nn.Sequential(nn.Conv2d(self._c, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        mods = [_PSMBlock(self._c, planes, stride, down)]
+        self._c = planes
+        mods += [_PSMBlock(planes, planes, 1, None) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        o0 = self.layer1(self.firstconv(x))
+        raw = self.layer2(o0)
+        skip = self.layer4(self.layer3(raw))
+        hw = [skip.shape[2], skip.shape[3]]
+        br = [F.interpolate(getattr(self, 'branch%d' % i)(skip), hw, mode='bilinear', align_corners=True) for i in (4, 3, 2, 1)]
+        feat = torch.cat([raw, skip] + br, 1)
+        if self.bigger:
+            feat = torch.cat((F.interpolate(feat, [hw[0] * 2, hw[1] * 2], mode='bilinear', align_corners=True), o0), 1)
+        return self.lastconv(feat)
+
+
+class _HGConv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.inp_dim = cin
+        self.conv = nn.Conv2d(cin, cout, k, 1, (k - 1) // 2, bias=True)
+
+    def forward(self, x):
+        assert x.shape[1] == self.inp_dim, '{} {}'.format(x.shape[1], self.inp_dim)
+        return self.conv(x)
+
+
+class _HGResidual(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.relu = nn.ReLU()
+        h = int(cout / 2)
+        self.conv1, self.conv2, self.conv3 = _HGConv(cin, h, 1), _HGConv(h, h, 3), _HGConv(h, cout, 1)
+        self.skip_layer = _HGConv(cin, cout, 1)
+        self.need_skip = cin != cout
+
+    def forward(self, x):
+        res = self.skip_layer(x) if self.need_skip else x
+        y = self.conv3(self.relu(self.conv2(self.relu(self.conv1(self.relu(x))))))
+        return y + res
+
+
+class Hourglass(nn.Module):
+    def __init__(self, n, f, increase=0):
+        super().__init__()
+        nf = f + increase
+        self.up1 = _HGResidual(f, nf)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.n = n
+        self.low2 = Hourglass(n - 1, nf, 0) if n > 1 else _HGResidual(nf, nf)
+        self.low3 = _HGResidual(nf, nf)
+        self.up2 = nn.Upsample(scale_factor=2, mode='bilinear')
+
+    def forward(self, x):
+        u = self.up1(x)
+        return u + self.up2(self.low3(self.low2(self.pool1(u))))
+
+
+class SSP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        for i, k in enumerate((64, 32, 16, 8), 1):
+            setattr(self, 'branch%d' % i, nn.Sequential(nn.AvgPool2d((k, k), stride=(k, k)), nn.Conv2d(c, int(c / 4), 1, 1, 0),
+                                                        nn.ReLU(inplace=True)))
+
+    def forward(self, x):
+        hw = [x.shape[2], x.shape[3]]
+        return torch.cat([x] + [F.interpolate(getattr(self, 'branch%d' % i)(x), hw, mode='bilinear') for i in (4, 3, 2, 1)], 1)
+
+
+class StereoNet7(nn.Module):
+    def __init__(self, version=0, uncertainty=False, act_fun='relu'):
+        super().__init__()
+        self.version = version
+        self.feature_extraction = feature_extraction(last_planes=64, bigger=True, middleblock=3)
+        self.actfun = F.selu if act_fun == 'selu' else F.relu
+        self.conv_c0 = nn.Conv2d(134, 64, 3, padding=1)
+        self.conv_c1 = Hourglass(2, 64, 0)
+        self.conv_c2 = Hourglass(2, 64, 0)
+        self.conv_c2_SSP = SSP(64)
+        self.conv_c3 = Hourglass(2, 128, 64)
+        self.conv_c4 = Hourglass(2, 192, 64)
+        self.conv_c5 = nn.Conv2d(256, 384, 3, padding=1)
+        self.conv_c6 = nn.Conv2d(384, 512, 3, padding=1)
+        self.deconv_c7 = nn.ConvTranspose2d(896, 320, 4, 2, 1)
+        self.deconv_c8 = nn.ConvTranspose2d(576, 192, 4, 2, 1)
+        self.conv_c8 = Hourglass(2, 192, 0)
+        self.deconv_c9 = nn.ConvTranspose2d(384, 128, 4, 2, 1)
+        self.conv_c9 = Hourglass(2, 128, 0)
+        self.deconv_c10 = nn.ConvTranspose2d(256, 64, 4, 2, 1)
+        self.conv_c10 = Hourglass(2, 64, 0)
+        self.deconv_c11 = nn.ConvTranspose2d(128, 64, 4, 2, 1)
+        self.conv_c12 = nn.Conv2d(64, 16, 1, padding=0)
+        self.conv_c13 = nn.Conv2d(16, 1, 1, padding=0)
+        self.conv_c6_2 = nn.Conv2d(512, 512, 3, padding=1)
+        self.deconv_c7_2 = nn.ConvTranspose2d(512, 512, 4, 2, 1)
+
+    def forward(self, x):
+        assert x.shape[1] % 2 == 0
+        B, C2, H, W = x.shape
+        f = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))          # left/right stacked along the batch
+        f = f.view(B, f.shape[1] * 2, f.shape[2], f.shape[3])
+        x = torch.cat((f, F.interpolate(x, scale_factor=0.5, mode='bilinear')), 1)
+        act, pool = self.actfun, lambda t: F.max_pool2d(t, kernel_size=2)
+        cat0 = self.conv_c1(self.conv_c0(x))                                  # 1/2, 64
+        cat1 = self.conv_c2_SSP(pool(self.conv_c2(cat0)))                     # 1/4, 128
+        cat2 = pool(self.conv_c3(cat1))                                       # 1/8, 192
+        cat3 = pool(self.conv_c4(cat2))                                       # 1/16, 256
+        cat4 = pool(act(self.conv_c5(cat3)))                                  # 1/32, 384
+        x = act(self.conv_c6_2(pool(act(self.conv_c6(cat4)))))                # 1/64, 512
+        x = torch.cat((act(self.deconv_c7_2(x)), cat4), 1)
+        x = torch.cat((act(self.deconv_c7(x)), cat3), 1)
+        x = torch.cat((self.conv_c8(act(self.deconv_c8(x))), cat2), 1)
+        x = torch.cat((self.conv_c9(act(self.deconv_c9(x))), cat1), 1)
+        x = torch.cat((self.conv_c10(act(self.deconv_c10(x))), cat0), 1)
+        x = act(self.deconv_c11(x))
+        return self.conv_c13(act(self.conv_c12(x))), None
+
+
+# ------------------------------------------------------------------------------------------ VOFlowRes
+def _conv_relu(cin, cout, stride):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, 1), nn.ReLU(inplace=True))
+
+
+def _linear_relu(cin, cout):
+    return nn.Sequential(nn.Linear(cin, cout), nn.ReLU(inplace=True))
+
+
+class _PoseBlock(nn.Module):
+    def __init__(self, cin, cout, stride, downsample):
+        super().__init__()
+        self.conv1 = _conv_relu(cin, cout, stride)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, 1)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)), inplace=True)
+
+
+class VOFlowRes(nn.Module):
+    def __init__(self, intrinsic=True, down_scale=True, config=1, stereo=0, fix_parts=(), **_unused):
+        super().__init__()
+        assert intrinsic and down_scale and config == 1 and stereo == 0, \
+            'only the configuration VONet instantiates is built (Network/VONet.py:16)'
+        mods = [_conv_relu(4, 32, 2), _conv_relu(32, 32, 1), _conv_relu(32, 32, 1)]
+        c = 32
+        for planes, blocks in ((64, 3), (128, 4), (128, 6), (256, 7), (256, 3)):
+            layer = [_PoseBlock(c, planes, 2, nn.Conv2d(c, planes, 1, 2))]
+            layer += [_PoseBlock(planes, planes, 1, None) for _ in range(1, blocks)]
+            mods.append(nn.Sequential(*layer))
+            c = planes
+        self.feat_net = nn.Sequential(*mods)
+        dim = 256 * 6
+        self.voflow_trans = nn.Sequential(_linear_relu(dim, 128), _linear_relu(128, 32), nn.Linear(32, 3))
+        self.voflow_rot = nn.Sequential(_linear_relu(dim, 128), _linear_relu(128, 32), nn.Linear(32, 3))
+        for name, part in (('feat', self.feat_net), ('rot', self.voflow_rot), ('trans', self.voflow_trans)):
+            if name in fix_parts:
+                for p in part.parameters():
+                    p.requires_grad = False
+
+    def forward(self, x, extrinsic=None):
+        x = self.feat_net(x)
+        x = x.view(x.shape[0], -1)
+        return torch.cat((self.voflow_trans(x), self.voflow_rot(x)), 1)
+
+
+# ------------------------------------------------------------------------------------------ VONet
+class VONet(nn.Module):
+    def __init__(self, fix_parts=('flow', 'stereo')):
+        super().__init__()
+        self.flowNet = PWCDCNet(uncertainty=False)
+        self.stereoNet = StereoNet7()
+        self.flowPoseNet = VOFlowRes(intrinsic=True, down_scale=True, stereo=0, fix_parts=fix_parts)
+        for name, net in (('flow', self.flowNet), ('stereo', self.stereoNet)):
+            if name in fix_parts:
+                for p in net.parameters():
+                    p.requires_grad = False
+        self.frozen_dtype = None        # e.g. torch.bfloat16: autocast dtype of the two frozen nets (BASELINE config 2)
+
+    def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic):
+        dev = img0.device.type
+        with torch.autocast(dev, dtype=self.frozen_dtype, enabled=self.frozen_dtype is not None):
+            flow = self.flowNet(torch.cat([img0, img1], 1))[0][0]
+            disp = self.stereoNet(torch.cat((img0_norm, img0_r_norm), 1))[0]
+        flow, disp = flow.float(), disp.float()
+        disp = F.interpolate(disp, scale_factor=0.25, mode='nearest')
+        pose = self.flowPoseNet(torch.cat([flow, intrinsic], 1))
+        return flow, disp, pose
+
+
+# ------------------------------------------------------------------------------------------ IMU denoiser
+class IMUCorrector_CNN_GRU_WO_COV(nn.Module):
+    def __init__(self, in_channel=6, out_channel=64, hidden_size=128, kernel_size=10, num_layers=1):
+        super().__init__()
+        self.hidden_size, self.num_layers = hidden_size, num_layers
+        self.conv1 = nn.Conv1d(in_channel, out_channel, kernel_size=kernel_size, stride=10)
+        self.gelu = nn.GELU()
+        self.gru = nn.GRU(out_channel, hidden_size, num_layers, batch_first=True)
+        self.encoder = nn.Sequential(self.conv1, nn.GELU(), self.gru)      # aliases kept for state-dict key parity
+        self.pose_decoder = nn.Sequential(nn.Linear(hidden_size, 64), nn.GELU(), nn.Linear(64, 6), nn.GELU())
+
+    def forward(self, data, eval=True):
+        self.train() if not eval else self.eval()
+        with torch.set_grad_enabled(not eval):
+            acc, gyro = data['acc'], data['gyro']
+            if acc.dim() == 2:
+                acc, gyro = acc.unsqueeze(0), gyro.unsqueeze(0)
+            x = self.gelu(self.conv1(torch.cat([acc, gyro], -1).permute(0, 2, 1))).permute(0, 2, 1)
+            out = self.pose_decoder(self.gru(x)[0])
+            rep = torch.full((out.shape[1],), 10, dtype=torch.long, device=acc.device)
+            rep[-1] = acc.shape[1] - 10 * out.shape[1] + 10       # the last step also covers the remainder (Q14)
+            out = torch.repeat_interleave(out, rep, dim=1)
+            return (out[..., 0:3] + acc).squeeze(0), (out[..., 3:6] + gyro).squeeze(0), None, None

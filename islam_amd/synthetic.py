@@ -89,14 +89,14 @@ def stereo_batch(batch, height=448, width=640, seed=1234, max_flow=8.0, disp_ran
     """
     import torch
     g = torch.Generator().manual_seed(seed)
-    lo = torch.rand(batch, 3, height // 8 + 4, width // 8 + 16, generator=g)
+    lo = torch.rand(batch, 3, height // 8 + 12, width // 8 + 24, generator=g)      # 48 / 96 px margins
     base = torch.nn.functional.interpolate(lo, scale_factor=8, mode='bicubic', align_corners=False).clamp(0, 1)
     flows = (torch.rand(batch, 2, generator=g) * 2 - 1) * max_flow * 4      # px at full res
     disps = disp_range[0] + torch.rand(batch, generator=g) * (disp_range[1] - disp_range[0])
 
     def crop(img, dx, dy):
-        x0 = 64 + int(round(dx))
-        y0 = 16 + int(round(dy))
+        x0 = 96 + int(round(dx))
+        y0 = 48 + int(round(dy))
         return img[:, y0:y0 + height, x0:x0 + width]
 
     img0 = torch.stack([crop(base[b], 0, 0) for b in range(batch)])

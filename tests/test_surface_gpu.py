@@ -1,0 +1,151 @@
+"""GPU tests of the drop-in Python surface (run_pvgo / IMUModule / TartanVO / bilevel loop) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from islam_amd import synthetic
+from oracle import imu as oimu, lie, pvgo as opvgo
+from tests.helpers import chain_problem, se3_log_err
+
+pytestmark = pytest.mark.gpu
+LW = (1, 0.1, 10, 0.1)
+
+
+def test_run_pvgo_surface_matches_oracle(cuda):
+    """train.py-shaped call: float32 CPU inputs, VO motions on the device with grad; outputs as pvgo.py:205."""
+    from islam_amd import lietensor as pp
+    from islam_amd.pvgo import run_pvgo
+    prob, _ = chain_problem(9)
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    vo = f32(prob['vo_motions']).to(cuda).requires_grad_(True)
+    tl, rl, nodes, vels, covs = run_pvgo(pp.SE3(f32(prob['init_nodes'])), f32(prob['init_vels']), pp.SE3(vo),
+                                         torch.tensor(prob['links']), f32(prob['dts']), pp.SO3(f32(prob['imu_drots'])),
+                                         f32(prob['imu_dtrans']), f32(prob['imu_dvels']), device='cuda', radius=1e4,
+                                         loss_weight=LW, target='vo')
+    p32 = {k: (np.asarray(v, np.float32).astype(np.float64) if k != 'links' else v) for k, v in prob.items()}
+    otl, orl, on, ov, ocov = opvgo.run_pvgo(**p32, loss_weight=LW, mode='dense')
+    assert nodes.device.type == 'cpu' and vels.device.type == 'cpu' and nodes.dtype == torch.float32
+    assert isinstance(nodes, pp.LieTensor) and nodes.shape == (9, 7) and vels.shape == (9, 3)
+    err = se3_log_err(nodes.numpy().astype(np.float64), on)
+    ref = np.maximum(np.linalg.norm(lie.se3_log(on), axis=-1), 1e-6)
+    assert (err / ref).max() < 1e-4                                   # north_star tolerance (float32 I/O rounding included)
+    np.testing.assert_allclose(vels.numpy(), ov, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tl.detach().cpu().numpy(), otl, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(rl.detach().cpu().numpy(), orl, rtol=2e-3, atol=1e-9)
+    assert set(covs) == set(ocov) and all(np.array_equal(covs[k], ocov[k]) for k in covs)
+    # one-step back-propagation (train.py:280-283): gradient reaches the VO motions, PyPose convention (7th entry 0)
+    loss_bp = torch.cat((1.0 * rl, 0.1 * tl))
+    loss_bp.backward(torch.ones_like(loss_bp))
+    g = vo.grad.cpu().numpy()
+    og = opvgo.vo_loss_grad(opvgo.run_pvgo(**p32, loss_weight=LW, mode='dense', return_optimizer=True)[5].nodes, prob['links'],
+                            p32['vo_motions'], np.full(8, 0.1), np.full(8, 1.0))
+    assert np.all(g[:, 6] == 0)
+    np.testing.assert_allclose(g, og, rtol=5e-3, atol=1e-5)
+
+
+def test_run_pvgo_rejects_what_is_not_built(cuda):
+    from islam_amd.pvgo import UnsupportedGraphError, run_pvgo
+    prob, _ = chain_problem(5)
+    args = [torch.tensor(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions')]
+    links = torch.tensor(prob['links']).clone()
+    links[2, 1] = 0                                                    # a loop closure
+    rest = [torch.tensor(prob[k]) for k in ('dts', 'imu_drots', 'imu_dtrans', 'imu_dvels')]
+    with pytest.raises(UnsupportedGraphError):
+        run_pvgo(*args, links, *rest, device='cuda')
+    with pytest.raises(RuntimeError):
+        run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cpu')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_imu_module_matches_oracle(cuda, dtype):
+    from islam_amd.imu_integrator import IMUModule
+    tr = synthetic.car_trajectory(41, seed=5)
+    bias_a, bias_g = np.array([0.01, -0.02, 0.03]), np.array([1e-3, 2e-3, -1e-3])
+    mod = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], bias_a, bias_g, tr['init'], tr['gravity'], tr['rgb2imu_sync'],
+                    device='cuda', denoise_model_name=None, denoise_accel=True, denoise_gyro=False, dtype=dtype)
+    npdt = {torch.float32: np.float32, torch.float64: np.float64}[dtype]
+    init = dict(pos=tr['gt_pos'][8], rot=tr['gt_quat'][8], vel=tr['gt_vel'][8])
+    for motion in (False, True):
+        pos, rot, covs, vel = mod.integrate(8, 16, init, motion_mode=motion)
+        ref = oimu.integrate(tr['accels'], tr['gyros'], tr['imu_dts'], tr['rgb2imu_sync'], 8, 16, init, tr['gravity'], motion,
+                             accel_bias=bias_a, gyro_bias=None, dtype=npdt)
+        assert covs == [] and pos.device.type == 'cpu' and pos.shape[0] == (8 if motion else 9)
+        np.testing.assert_array_equal(pos.numpy(), ref[0])
+        np.testing.assert_array_equal(rot.tensor().numpy(), ref[1])
+        np.testing.assert_array_equal(vel.numpy(), ref[2])
+
+
+def test_tartanvo_forward_and_bilevel_step(cuda):
+    """Plumbing of BASELINE config 1/2 at reduced batch: TartanVO forward (HIP correlation/warp/scale, train-mode BN),
+    IMU, PVGO, backward into the pose head only; then one optimizer step."""
+    from islam_amd import lietensor as pp
+    from islam_amd.TartanVO import TartanVO
+    from islam_amd.bilevel import BilevelLoop
+    from islam_amd.imu_integrator import IMUModule
+    torch.manual_seed(0)
+    B = 2
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True)
+    # random weights predict garbage disparity; pin the stereo head to a constant 10 px so the scale mask is non-empty
+    with torch.no_grad():
+        vo.vonet.stereoNet.conv_c13.weight.zero_()
+        vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+    tr = synthetic.car_trajectory(2 * B + 1, seed=9)
+    imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], np.zeros(3), np.zeros(3), tr['init'], tr['gravity'],
+                    tr['rgb2imu_sync'], device='cuda', denoise_model_name=None, denoise_accel=True, denoise_gyro=False)
+    loop = BilevelLoop(vo, imu, pp.identity_SE3(), tr['init'], batch_size=B)
+    w0 = [p.detach().clone() for p in vo.vonet.flowPoseNet.parameters()]
+    for k in range(2):
+        sample = synthetic.stereo_batch(B, seed=100 + k)
+        sample['link'] = sample['link'] + k * B
+        loss = loop.step(sample)
+        assert np.isfinite(loss)
+    res = vo(synthetic.stereo_batch(B, seed=7))
+    assert res['motion'].shape == (B, 7) and res['flow'].shape == (B, 2, 112, 160) and res['disp'].shape == (B, 1, 112, 160)
+    assert res['mask'].dtype == torch.bool and res['depth'].shape == (B, 112, 160)
+    q = res['motion'].tensor()[:, 3:]
+    torch.testing.assert_close(q.norm(dim=1), torch.ones(B, device=q.device), rtol=1e-4, atol=1e-4)
+    grads = [p.grad for p in vo.vonet.flowPoseNet.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads) and any(g.abs().sum() > 0 for g in grads)
+    assert all(p.grad is None for p in vo.vonet.flowNet.parameters())          # frozen (F5)
+    loop.end_epoch()
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(w0, vo.vonet.flowPoseNet.parameters()))
+    assert len(loop.pgo_poses) == 2 * B + 1
+
+
+def test_stereo_scale_gradient_matches_autograd(cuda):
+    """d scale / d pose from the kernel's first-order sums vs plain autograd through the reference formula."""
+    from islam_amd import lietensor as pp
+    from islam_amd.TartanVO import stereo_scale
+    B, H, W = 2, 40, 56
+    g = torch.Generator().manual_seed(1)
+    disp = (torch.rand(B, 1, H, W, generator=g) * 10 + 2).to(cuda)
+    flow = (torch.randn(B, 2, H, W, generator=g) * 2).to(cuda)
+    intr = torch.tensor([[60.0, 60.0, 28.0, 20.0]]).repeat(B, 1)
+    base = torch.tensor([0.5, 0.3])
+    th = torch.tensor([1.0, 1.0])
+    xi = (torch.randn(B, 6, generator=g, dtype=torch.float64) * 0.2).to(cuda).requires_grad_(True)
+    pose = pp.se3(xi).Exp()
+    s, z, mask, dmask = stereo_scale(disp, flow, pose, intr, base, None, th)
+    s.sum().backward()
+    g_kernel = xi.grad.clone()
+    # reference formula with torch autograd on the same masked pixels (dense_ba.py:135-166), float64
+    xi2 = xi.detach().clone().requires_grad_(True)
+    Tinv = pp.se3(xi2).Exp().Inv()
+    tot = 0
+    for b in range(B):
+        fx, fy, cx, cy = [float(v) for v in intr[b]]
+        u, v = torch.meshgrid(torch.arange(W, dtype=torch.float64, device=cuda), torch.arange(H, dtype=torch.float64, device=cuda), indexing='xy')
+        zz = z[b].double()
+        P = torch.stack([zz * (u - cx) / fx, zz * (v - cy) / fy, zz], -1)
+        R, t = Tinv[b].rotation(), Tinv[b].translation()
+        tn = torch.nn.functional.normalize(t, dim=0)
+        K = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float64, device=cuda)
+        a = K @ tn
+        bb = (R.Act(P.reshape(-1, 3)) @ K.T).reshape(H, W, 3)
+        fu, fv = flow[b, 0].double() + u, flow[b, 1].double() + v
+        M1, w1 = a[2] * fu - a[0], bb[..., 0] - bb[..., 2] * fu
+        M2, w2 = a[2] * fv - a[1], bb[..., 1] - bb[..., 2] * fv
+        m = mask[b]
+        tot = tot + (M1[m] * w1[m] + M2[m] * w2[m]).sum() / (M1[m] ** 2 + M2[m] ** 2).sum()
+    tot.backward()
+    torch.testing.assert_close(g_kernel, xi2.grad, rtol=2e-3, atol=1e-5)
