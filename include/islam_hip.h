@@ -141,6 +141,26 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
 int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                                  const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx,
                                  float* ms, int* plan, int* nlaunch, void* stream);
+/* ---- multi-GPU building blocks (islam_amd/dist_pvgo.py; no reference counterpart: the reference is single-GPU).
+ * plan9 receives (nodes, segment length, segments) for up to 3 levels; returns the number of levels. */
+int islam_pvgo_plan(int N, const int seg_len[2], int* plan9);
+/* Eliminate level-0 segments [seg0, seg0+nseg) of an N-node chain.  Hd/Ho/rhs/fac/inv are LOCAL arrays whose row 0 is
+ * global node `node0`.  products: 351*P0 doubles, array-major (Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P |
+ * cgR 9P); only the local segments' rows are written, so a zero-initialised buffer can be summed over ranks. */
+int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
+                               int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
+                               void* stream);
+/* Levels >= 1 from the summed products -> x1 (n1,9): the step at the level-0 separators (run redundantly per rank). */
+int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
+                             double* x1, int* flags, void* stream);
+/* Back-substitution of the local segments into the LOCAL dx (row 0 = global node `node0`). */
+int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
+                             int seg0, int nseg, double* dx, void* stream);
+/* Trial step on M links (M+1 node rows): retract on a copy, residuals, partial sums part[2*nblk] =
+ * (sum r^2, sum JD.(2R+JD)) per 64-link block (ppost.TrustRegion.update's denominator is -sum). */
+int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
+                     const double* dtrans, const double* dvels, const double* dts, const double* lin, int M,
+                     double* nodes_t, double* vels_t, double* part, void* stream);
 /* X <- Exp(sign*dx[:, :6]) * X ; v += sign*dx[:, 6:]  (LieTensor.add_) */
 int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N,
                        double* nodes_out, double* vels_out, void* stream);

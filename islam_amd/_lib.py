@@ -53,6 +53,13 @@ SIGNATURES = {
     'islam_pvgo_solve_chain_timed': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                               c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int),
                                                               ctypes.POINTER(c_int), c_void_p]),
+    'islam_pvgo_plan': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'islam_pvgo_shard_eliminate': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int] +
+                                   [c_void_p] * 5),
+    'islam_pvgo_reduced_solve': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t] + [c_void_p] * 3),
+    'islam_pvgo_shard_backsub': (c_int, [c_void_p] * 3 + [c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p,
+                                                          c_void_p]),
+    'islam_pvgo_trial': (c_int, [c_void_p] * 9 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_retract': (c_int, [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 3),
     'islam_pvgo_vo_loss_fwd': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_vo_loss_bwd': (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 2),

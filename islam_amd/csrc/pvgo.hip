@@ -321,11 +321,12 @@ __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, 
 }
 
 // One wavefront per segment: eliminate the segment's interior nodes onto its two separators.
-__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags) {
+__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
+                                                           int solve_here) {
     __shared__ __attribute__((aligned(16))) double Xs[19 * XS];
     __shared__ __attribute__((aligned(16))) double Tn[19 * XS];
     const int lane = threadIdx.x;
-    const int p = blockIdx.x;
+    const int p = blockIdx.x + seg0;
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     }
     if (bad && lane == 0) atomicOr(flags, 1);
 
-    if (gridDim.x == 1) {          // single segment: the whole level is factored, solve it here
+    if (solve_here) {              // single segment: the whole level is factored, solve it here
         __syncthreads();
         double xn[9], xL[9];
 #pragma unroll
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
 // expand the solution of the separators (xsep, from the next level) into this level's interior nodes
 __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
                                                          const double* __restrict__ xsep, double* __restrict__ x, int n,
-                                                         int m) {
+                                                         int m, int seg0) {
     const int lane = threadIdx.x;
-    const int p = blockIdx.x;
+    const int p = blockIdx.x + seg0;
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -733,14 +734,15 @@ int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double
         dst.fac = b.fac; dst.inv = b.inv; dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR;
         dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
         dst.x = (l == 0) ? dx : b.x;
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, w.flags);
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, w.flags, 0,
+                           plan[l].P == 1 ? 1 : 0);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     for (int l = nl - 2; l >= 0; --l) {
         const LevelBufs& b = w.lv[l];
         double* x = (l == 0) ? dx : b.x;
         hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
-                           plan[l].m);
+                           plan[l].m, 0);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     if (nev) *nev = ne;
@@ -835,6 +837,110 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
         plan_out[3 * l + 2] = l < nl ? plan[l].P : 0;
     }
     *nlaunch = ne - 1;
+    return ISLAM_OK;
+}
+
+// ---- sharded (multi-GPU) building blocks: the level-0 segments are split over the ranks, the level-0 products
+// (separator blocks, Schur contributions, fill) are summed over the ranks (RCCL all-reduce of a zero-initialised
+// buffer), levels >= 1 are solved redundantly by every rank, the back-substitution is local again.
+int islam_pvgo_plan(int N, const int seg_len[2], int* plan9) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_plan: N=%d < 1", N);
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    for (int l = 0; l < 3; ++l) {
+        plan9[3 * l] = l < nl ? plan[l].n : 0;
+        plan9[3 * l + 1] = l < nl ? plan[l].m : 0;
+        plan9[3 * l + 2] = l < nl ? plan[l].P : 0;
+    }
+    return nl;
+}
+
+static void products_view(double* base, int P, LevelBufs& b) {
+    b.Dsep = base; b.rsep = base + 81 * (size_t)P; b.cL = base + 90 * (size_t)P; b.cR = base + 171 * (size_t)P;
+    b.fill = base + 252 * (size_t)P; b.cgL = base + 333 * (size_t)P; b.cgR = base + 342 * (size_t)P;
+}
+
+// Eliminate level-0 segments [seg0, seg0+nseg).  Hd/Ho/rhs/fac/inv are LOCAL arrays whose element 0 is global node
+// `node0`; products = 351*P0 doubles (array-major: Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P | cgR 9P),
+// only the rows of the local segments are written.  flags: device int[1], OR-ed with 1 on a non-positive pivot.
+int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
+                               int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
+                               void* stream) {
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: N=%d is a single-level problem, nothing to shard", N);
+    if (seg0 < 0 || nseg < 1 || seg0 + nseg > plan[0].P) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: bad segment range");
+    LevelSrc src{};
+    LevelDst dst{};
+    src.level0 = 1;
+    src.Hd = Hd - (ptrdiff_t)node0 * 81; src.Ho = Ho - (ptrdiff_t)node0 * 81; src.rhs0 = rhs - (ptrdiff_t)node0 * 9;
+    src.state = nullptr; src.damping_override = damping;
+    LevelBufs b{};
+    products_view(products, plan[0].P, b);
+    dst.fac = fac - (ptrdiff_t)node0 * FAC; dst.inv = inv - (ptrdiff_t)node0 * 9;
+    dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
+    dst.x = nullptr;
+    hipLaunchKernelGGL(bt_eliminate_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m, flags,
+                       seg0, 0);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// Levels >= 1 from the (summed) level-0 products -> x1 (plan[1].n x 9), the solution at the level-0 separators.
+int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
+                             double* x1, int* flags, void* stream) {
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: single-level problem");
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: workspace too small");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    LevelBufs pb{};
+    products_view(const_cast<double*>(products), plan[0].P, pb);
+    for (int l = 1; l < nl; ++l) {
+        LevelSrc src{};
+        LevelDst dst{};
+        const LevelBufs& prev = (l == 1) ? pb : w.lv[l - 1];
+        src.level0 = 0; src.Dsep = prev.Dsep; src.rsep = prev.rsep; src.cL = prev.cL; src.cR = prev.cR; src.cgL = prev.cgL;
+        src.cgR = prev.cgR; src.fill = prev.fill; src.Pprev = plan[l - 1].P;
+        const LevelBufs& b = w.lv[l];
+        dst.fac = b.fac; dst.inv = b.inv; dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL;
+        dst.cgR = b.cgR; dst.fill = b.fill;
+        dst.x = (l == 1) ? x1 : b.x;
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, flags, 0,
+                           plan[l].P == 1 ? 1 : 0);
+    }
+    for (int l = nl - 2; l >= 1; --l) {
+        const LevelBufs& b = w.lv[l];
+        double* x = (l == 1) ? x1 : b.x;
+        hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
+                           plan[l].m, 0);
+    }
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// Back-substitution of the local level-0 segments; dx is a LOCAL array (element 0 = global node `node0`).
+int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
+                             int seg0, int nseg, double* dx, void* stream) {
+    LevelPlan plan[3];
+    const int nl = plan_levels(N, seg_len, plan);
+    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
+    hipLaunchKernelGGL(bt_backsub_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
+                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// Trial step on M links (nodes/vels/dx hold M+1 rows): writes nodes_t/vels_t (M+1 rows) and part (2 per 64-link block:
+// sum r^2 at the trial point, sum JD.(2R+JD)).  Same kernel islam_pvgo_run_chain launches.
+int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
+                     const double* dtrans, const double* dvels, const double* dts, const double* lin, int M, double* nodes_t,
+                     double* vels_t, double* part, void* stream) {
+    if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
+    hipLaunchKernelGGL(trial_kernel, dim3((M + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
+                       dvels, dts, lin, M, nodes_t, vels_t, part);
+    ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 

@@ -1,0 +1,234 @@
+"""PVGO of ONE chain graph sharded over the GPUs of a node (BASELINE configs[3]).
+
+The reference is single-GPU; this is new design.  One process per GPU (torch.distributed, backend "nccl" = RCCL
+over xGMI).  The level-0 segments of the partitioned block Cholesky are split into contiguous ranges, one per rank.
+Per LM trial a rank
+  1. eliminates its own segments                     (islam_pvgo_shard_eliminate, local)
+  2. ALL-REDUCE #1: the level-0 products -- separator blocks of J^T W J / J^T W r, Schur contributions, fill --
+     351 doubles per segment, summed into a zero-initialised buffer (each row is written by exactly one rank)
+  3. solves levels >= 1 redundantly                    (islam_pvgo_reduced_solve, ~N/20 nodes)
+  4. back-substitutes its own segments, applies the trial step to its own links    (local)
+  5. ALL-REDUCE #2: [sum r^2, sum JD.(2R+JD)] + the new state of each rank's first node (halo for the
+     neighbour's boundary link): 2 + 10*world doubles
+  6. takes the accept/reject decision (LMControl, replicated: every rank sees identical all-reduced scalars).
+Ranks cut the chain only at separator nodes, so no 9x9 block is ever split between ranks.
+
+The compute backend is injected (``backend=``): HipBackend in production; tests/np_shard_backend.py (numpy on the
+oracle) lets the collective pattern be exercised with gloo on CPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .lm_control import LMControl
+
+
+def shard_plan(N, plan0, world):
+    """Contiguous split of the level-0 segments.  plan0 = (n, m, P).  Returns per-rank dicts."""
+    n, m, P = plan0
+    assert n == N
+    stride = m + 1
+    if world > P:
+        raise ValueError('cannot shard %d segments over %d ranks' % (P, world))
+    bounds = [int(round(r * P / world)) for r in range(world + 1)]
+    out = []
+    for r in range(world):
+        seg0, seg1 = bounds[r], bounds[r + 1]
+        first = seg0 * stride                              # first interior node of the first local segment
+        sR = (seg1 - 1) * stride + m                       # right separator of the last local segment
+        has_right = sR < N
+        node0 = first - 1 if seg0 > 0 else 0               # left separator included (its coupling block and its step)
+        node1 = min(sR + 1, N - 1) if has_right else N - 1 # one node past the right separator (link sR builds Hd[sR])
+        own1 = sR if has_right else N - 1                  # owned links: [node0, own1)
+        out.append(dict(seg0=seg0, nseg=seg1 - seg0, node0=node0, node1=node1, n_own_links=own1 - node0,
+                        has_left=seg0 > 0, has_right=has_right, sep_left=seg0 - 1, first_node=first))
+    return out
+
+
+class HipBackend:
+    """Local compute on the MI355X through the C ABI (stage-level entry points of include/islam_hip.h)."""
+
+    def __init__(self, device):
+        from . import ops
+        self.ops, self.dev = ops, device
+        self.flags = torch.zeros(4, dtype=torch.int32, device=device)
+
+    def plan(self, N, seg_len):
+        from ._lib import lib
+        sl = (ctypes.c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+        p = (ctypes.c_int * 9)()
+        nl = lib().islam_pvgo_plan(N, sl, p)
+        return [(p[3 * l], p[3 * l + 1], p[3 * l + 2]) for l in range(nl)]
+
+    def to_local(self, x):
+        return x.to(self.dev, torch.float64).contiguous()
+
+    def linearize(self, nodes, vels, data):
+        return self.ops.pvgo_linearize(nodes, vels, data['poses'], data['drots'], data['dtrans'], data['dvels'], data['dts'])[0]
+
+    def initial_loss(self, lin, n_own):
+        rows = lin[[0, 1, 2, 3, 4, 5, 24, 25, 26, 36, 37, 38, 39, 40, 41], :n_own]
+        return (rows * rows).sum().reshape(1)
+
+    def build(self, lin, data, nloc, w4):
+        return self.ops.pvgo_build_normal(lin, data['dts'], nloc, w4)
+
+    def eliminate(self, H, damping, N, seg_len, sh, products, scratch):
+        from ._lib import c_double, c_int, check, lib, ptr, stream_ptr
+        Hd, Ho, rhs = H
+        sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+        check(lib().islam_pvgo_shard_eliminate(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, sh['node0'], sh['seg0'],
+                                               sh['nseg'], ptr(products), ptr(scratch['fac']), ptr(scratch['inv']),
+                                               ptr(self.flags), stream_ptr(self.dev)))
+
+    def reduced_solve(self, products, N, seg_len, n1, scratch):
+        from ._lib import c_int, c_size_t, check, lib, ptr, stream_ptr
+        sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+        ws, nbytes = scratch['ws']
+        x1 = scratch['x1']
+        check(lib().islam_pvgo_reduced_solve(ptr(products), N, sl, ptr(ws), c_size_t(nbytes), ptr(x1), ptr(self.flags),
+                                             stream_ptr(self.dev)))
+        return x1
+
+    def backsub(self, x1, N, seg_len, sh, scratch):
+        from ._lib import c_int, check, lib, ptr, stream_ptr
+        sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+        dx = scratch['dx']
+        check(lib().islam_pvgo_shard_backsub(ptr(scratch['fac']), ptr(scratch['inv']), ptr(x1), N, sl, sh['node0'], sh['seg0'],
+                                             sh['nseg'], ptr(dx), stream_ptr(self.dev)))
+        if sh['has_left']:
+            dx[0] = x1[sh['sep_left']]
+        return dx
+
+    def trial(self, nodes, vels, dx, data, lin, n_own, scratch):
+        from ._lib import check, lib, ptr, stream_ptr
+        nt, vt, part = scratch['nodes_t'], scratch['vels_t'], scratch['part']
+        # lin is component-major with the LOCAL link count as stride; the kernel is given that stride through a view
+        lin_own = lin if lin.shape[1] == n_own else lin[:, :n_own].contiguous()
+        check(lib().islam_pvgo_trial(ptr(nodes), ptr(vels), ptr(dx), ptr(data['poses']), ptr(data['drots']), ptr(data['dtrans']),
+                                     ptr(data['dvels']), ptr(data['dts']), ptr(lin_own), n_own, ptr(nt), ptr(vt), ptr(part),
+                                     stream_ptr(self.dev)))
+        nblk = (n_own + 63) // 64
+        return nt, vt, part[:2 * nblk].view(nblk, 2).sum(0)
+
+    def failed(self):
+        return bool(self.flags[0].item())
+
+    def make_scratch(self, N, nloc, n1, P0):
+        from . import ops
+        d = self.dev
+        z = lambda *s: torch.zeros(s, dtype=torch.float64, device=d)
+        return dict(fac=z(nloc, 252), inv=z(nloc, 9), dx=z(nloc, 9), nodes_t=z(nloc, 7), vels_t=z(nloc, 3),
+                    part=z(2 * ((nloc + 63) // 64) + 2), x1=z(max(n1, 1), 9), ws=ops.pvgo_workspace(N, d),
+                    products=z(351 * P0))
+
+
+class ShardedChainPVGO:
+    """run_pvgo's LM loop (pvgo.py:168-180) on one chain graph split over ``world`` ranks."""
+
+    def __init__(self, init_nodes, init_vels, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, seg_len=(0, 0),
+                 group=None, backend=None, rank=None, world=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.be = backend if backend is not None else HipBackend(init_nodes.device)
+        self.N = init_nodes.shape[0]
+        self.seg_len = seg_len
+        self.levels = self.be.plan(self.N, seg_len)
+        if len(self.levels) < 2:
+            raise ValueError('N=%d is solved by a single wavefront; nothing to shard' % self.N)
+        self.P0, self.n1 = self.levels[0][2], self.levels[1][0]
+        self.sh = shard_plan(self.N, self.levels[0], self.world)[self.rank]
+        self.all_sh = shard_plan(self.N, self.levels[0], self.world)
+        self.w4 = [float(x) ** 2 for x in loss_weight[:4]]
+        self.radius = radius
+        a, b = self.sh['node0'], self.sh['node1']
+        L = self.be.to_local
+        self.init_nodes, self.init_vels = L(init_nodes), L(init_vels)
+        self.data = dict(poses=L(poses[a:b]), drots=L(drots[a:b]), dtrans=L(dtrans[a:b]), dvels=L(dvels[a:b]), dts=L(dts[a:b]))
+        self.nloc = b - a + 1
+        self.scratch = self.be.make_scratch(self.N, self.nloc, self.n1, self.P0)
+
+    # ---- the algorithm as a generator: every ``yield t`` is "all-reduce (sum) t in place across the ranks"
+    def _steps(self, max_steps=10, patience=3, decreasing=1e-3):
+        sh, be, N = self.sh, self.be, self.N
+        a, b = sh['node0'], sh['node1']
+        nodes, vels = self.init_nodes[a:b + 1].clone(), self.init_vels[a:b + 1].clone()
+        ctl = LMControl(radius=self.radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
+        n_own = sh['n_own_links']
+        products = self.scratch['products']
+        trials = 0
+        while ctl.continual:
+            lin = be.linearize(nodes, vels, self.data)
+            if not ctl.has_loss:
+                l0 = be.initial_loss(lin, n_own)
+                yield l0
+                ctl.set_initial_loss(float(l0[0]))
+            H = be.build(lin, self.data, self.nloc, self.w4)
+            ctl.begin_step()
+            while True:
+                products.zero_()
+                be.eliminate(H, ctl.damping, N, self.seg_len, sh, products, self.scratch)
+                yield products                                          # all-reduce #1: J^T W J / J^T W r interface blocks
+                x1 = be.reduced_solve(products, N, self.seg_len, self.n1, self.scratch)
+                dx = be.backsub(x1, N, self.seg_len, sh, self.scratch)
+                nt, vt, sums = be.trial(nodes, vels, dx, self.data, lin, n_own, self.scratch)
+                msg = torch.zeros(2 + 10 * self.world, dtype=torch.float64, device=sums.device)
+                msg[:2] = sums
+                first_local = sh['first_node'] - a                      # this rank's first interior node, local index
+                msg[2 + 10 * self.rank:2 + 10 * self.rank + 7] = nt[first_local]
+                msg[2 + 10 * self.rank + 7:2 + 10 * self.rank + 10] = vt[first_local]
+                yield msg                                               # all-reduce #2: loss, trust-region sums, halo
+                trials += 1
+                if be.failed():
+                    ctl.solver_failed()
+                    break
+                accepted = ctl.after_trial(float(msg[0]), float(msg[1]))
+                if accepted:
+                    nodes[:n_own + 1] = nt[:n_own + 1]
+                    vels[:n_own + 1] = vt[:n_own + 1]
+                    if sh['has_right'] and self.rank + 1 < self.world and b > sh['node0'] + n_own:
+                        h = msg[2 + 10 * (self.rank + 1):2 + 10 * (self.rank + 2)]      # neighbour's first node = my last row
+                        nodes[b - a] = h[:7]
+                        vels[b - a] = h[7:]
+                    break
+            ctl.end_step()
+        # assemble the full solution on every rank (sum of zero-padded owned rows)
+        full = torch.zeros(N, 10, dtype=torch.float64, device=nodes.device)
+        own_rows = slice(1 if sh['has_left'] else 0, n_own + 1)                                # left separator belongs to the previous rank
+        full[a + own_rows.start:a + own_rows.stop, :7] = nodes[own_rows]
+        full[a + own_rows.start:a + own_rows.stop, 7:] = vels[own_rows]
+        yield full
+        self.result = dict(nodes=full[:, :7].contiguous(), vels=full[:, 7:].contiguous(), steps=ctl.steps, trials=trials,
+                           loss=ctl.loss, trace=ctl.trace)
+
+    def run(self, **kw):
+        for t in self._steps(**kw):
+            if self.world > 1:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return self.result
+
+
+def run_lockstep(solvers, **kw):
+    """Drive several ShardedChainPVGO instances ("virtual ranks") in one process: the all-reduce is a plain sum.
+    Used by the single-GPU test of the sharded path."""
+    gens = [s._steps(**kw) for s in solvers]
+    while True:
+        bufs = []
+        for g in gens:
+            try:
+                bufs.append(next(g))
+            except StopIteration:
+                bufs.append(None)
+        if all(b is None for b in bufs):
+            break
+        assert all(b is not None for b in bufs), 'virtual ranks diverged'
+        tot = bufs[0].clone()
+        for b in bufs[1:]:
+            tot += b.to(tot.device)
+        for b in bufs:
+            b.copy_(tot.to(b.device))
+    return [s.result for s in solvers]

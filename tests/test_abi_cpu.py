@@ -1,0 +1,113 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every symbol
+include/islam_hip.h declares (no compute calls: there is no GPU here), host-only entry points behave, and the
+repository obeys the oracle / product separation rule."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from islam_amd import _lib
+    return _lib.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'islam_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(islam_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from islam_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), 'libislam_hip.so does not export %s' % s
+        assert s in _lib.SIGNATURES, 'islam_amd/_lib.py has no ctypes signature for %s' % s
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_shared_object_contains_gfx950_code():
+    from islam_amd import _lib
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/clang-offload-bundler', '--list', '--type=o', '--input=' + _lib.LIB_PATH],
+                         capture_output=True, text=True)
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob, 'no gfx950 code object embedded'
+    assert b'gfx942' not in blob and b'sm_' not in blob       # single target, no compatibility paths
+
+
+def test_host_only_entry_points(lib):
+    from islam_amd import _lib
+    assert lib.islam_abi_version() == 1
+    p = _lib.PvgoParams()
+    lib.islam_pvgo_default_params(ctypes.byref(p))
+    assert (p.radius, p.vmin, p.vmax, p.reject, p.max_steps, p.patience, p.decreasing) == (1e4, 1e-4, 1e32, 16, 10, 3, 1e-3)
+    assert (p.high, p.low, p.up, p.down, p.factor, p.rmin, p.rmax) == (0.5, 1e-3, 2.0, 0.5, 0.5, 1e-6, 1e16)
+    assert lib.islam_pvgo_workspace_bytes(0) == 0
+    b1, b2 = lib.islam_pvgo_workspace_bytes(9), lib.islam_pvgo_workspace_bytes(5001)
+    assert 0 < b1 < b2 < 64 << 20
+    assert lib.islam_imu_scratch_bytes(50001, 5000, 1) >= 8 * (4 * 55001 + 4 * 5001 + 7 * 5000)
+    # argument validation happens before any device work
+    rc = lib.islam_corr81_fwd(None, None, None, 0, 1, 1, 1, None)
+    assert rc == -1 and b'bad shape' in lib.islam_last_error()
+    rc = lib.islam_pvgo_linearize(None, None, None, None, None, None, None, 1, None, None, None)
+    assert rc == -1
+
+
+def test_level_plan_matches_python_mirror(lib):
+    from tests.np_shard_backend import plan_levels
+    for N in (1, 2, 9, 40, 41, 64, 100, 257, 1000, 5001, 20000):
+        for seg in ((0, 0), (4, 4), (19, 15), (7, 0), (2, 3)):
+            sl = (ctypes.c_int * 2)(*seg)
+            out = (ctypes.c_int * 9)()
+            nl = lib.islam_pvgo_plan(N, sl, out)
+            got = [(out[3 * l], out[3 * l + 1], out[3 * l + 2]) for l in range(nl)]
+            assert got == plan_levels(N, seg), (N, seg)
+            n = N
+            for (nn, m, P) in got[:-1]:
+                assert nn == n and m >= 4 and P == -(-n // (m + 1))
+                n = n // (m + 1)
+            assert got[-1] == (n, n, 1)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'islam_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(base, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M) or 'liboracle' in text or '#include "../../oracle' in text:
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    uses = [m.start() for m in re.finditer(r'from oracle', bench)]
+    a, b = bench.index('def cpu_baseline'), bench.index('def main')
+    assert uses and all(a < u < b for u in uses)
+    entry = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    assert entry.index('def smoke') < entry.index('from oracle')
+    assert 'parity unpinned' in open(os.path.join(ROOT, 'oracle', '__init__.py')).read()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from islam_amd import ops
+    from islam_amd.imu_integrator import IMUModule
+    from islam_amd.pvgo import run_pvgo
+    with pytest.raises(RuntimeError):
+        ops.corr81_forward(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4))
+    with pytest.raises(RuntimeError):
+        run_pvgo(torch.zeros(3, 7), torch.zeros(3, 3), torch.zeros(2, 7), torch.tensor([[0, 1], [1, 2]]), torch.zeros(2),
+                 torch.zeros(2, 4), torch.zeros(2, 3), torch.zeros(2, 3), device='cpu')
+    with pytest.raises(RuntimeError):
+        IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')

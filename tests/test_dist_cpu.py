@@ -1,0 +1,97 @@
+"""world_size=2 (and 3) gloo test of the sharded PVGO driver on CPU: the collective pattern, the shard plan and the
+replicated LM control of islam_amd/dist_pvgo.py, with the numpy/oracle backend standing in for the HIP kernels.
+The result must equal the single-process oracle LM on the whole graph."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from islam_amd import dist_pvgo
+from islam_amd.lm_control import LMControl
+from oracle import pvgo as opvgo
+from tests.helpers import chain_problem
+from tests.np_shard_backend import NumpyBackend, plan_levels
+
+LW = (1, 0.1, 10, 0.1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, F, seg, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    prob, _ = chain_problem(F)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    solver = dist_pvgo.ShardedChainPVGO(t(prob['init_nodes']), t(prob['init_vels']), t(prob['vo_motions']), t(prob['imu_drots']),
+                                        t(prob['imu_dtrans']), t(prob['imu_dvels']), t(prob['dts']), LW, radius=1e4,
+                                        seg_len=seg, backend=NumpyBackend())
+    r = solver.run()
+    np.savez(os.path.join(out_dir, 'r%d.npz' % rank), nodes=r['nodes'].numpy(), vels=r['vels'].numpy(),
+             trace=np.array([(a, b, float(c)) for a, b, c in r['trace']]), trials=r['trials'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,F,seg', [(2, 120, (0, 0)), (3, 97, (5, 4)), (2, 60, (7, 0))])
+def test_sharded_lm_gloo(tmp_path, world, F, seg):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, F, seg, str(tmp_path)), nprocs=world, join=True)
+    prob, _ = chain_problem(F)
+    ref = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True)[5]
+    outs = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    for o in outs:                                        # every rank holds the full, identical solution
+        np.testing.assert_array_equal(o['nodes'], outs[0]['nodes'])
+        np.testing.assert_array_equal(o['trace'], outs[0]['trace'])
+    assert int(outs[0]['trials']) == len(ref.trace)
+    np.testing.assert_array_equal(outs[0]['trace'][:, 2], [float(t[2]) for t in ref.trace])
+    np.testing.assert_allclose(outs[0]['trace'][:, 0], [t[0] for t in ref.trace], rtol=1e-8)
+    np.testing.assert_allclose(outs[0]['nodes'], ref.nodes, atol=1e-8)
+    np.testing.assert_allclose(outs[0]['vels'], ref.vels, atol=1e-8)
+
+
+def test_shard_plan_covers_chain_exactly_once():
+    for N, seg, world in [(5001, (0, 0), 8), (5001, (19, 15), 4), (200, (4, 0), 7), (100, (9, 0), 2), (4000, (0, 0), 3)]:
+        lv = plan_levels(N, seg)
+        n, m, P = lv[0]
+        sh = dist_pvgo.shard_plan(N, lv[0], world)
+        assert sum(s['nseg'] for s in sh) == P and sh[0]['seg0'] == 0
+        owned = np.zeros(N - 1, int)
+        nodes = np.zeros(N, int)
+        for s in sh:
+            owned[s['node0']:s['node0'] + s['n_own_links']] += 1
+            lo = s['node0'] + (1 if s['has_left'] else 0)
+            nodes[lo:s['node0'] + s['n_own_links'] + 1] += 1
+            assert (s['node0'] == 0) == (not s['has_left'])
+            if s['has_left']:
+                assert (s['node0'] + 1) % (m + 1) == 0             # rank boundaries sit on separator nodes
+        assert np.all(owned == 1) and np.all(nodes == 1)
+
+
+def test_lm_control_matches_oracle_trust_region():
+    """Host control (sharded path) vs the oracle's TrustRegion/StopOnPlateau on a scripted loss sequence."""
+    ctl = LMControl(radius=1e4)
+    tr = opvgo.TrustRegion(radius=1e4)
+    ctl.set_initial_loss(10.0)
+    ctl.begin_step()
+    seq = [(12.0, -3.0), (11.0, -2.5), (9.0, -1.5)]
+    last = 10.0
+    for loss, q in seq:
+        kept = ctl.after_trial(loss, q)
+        JD, R = np.array([1.0]), np.array([(q - 1.0) / 2.0])      # JD.(2R+JD) = q
+        tr.update(last, loss, JD, R)
+        assert np.isclose(ctl.damping, tr.pg['damping']) and np.isclose(ctl.down, tr.pg['down'])
+        assert kept == (not (last < loss))
+    ctl.end_step()
+    assert ctl.loss == 9.0 and ctl.reject_count == 2 and ctl.steps == 1 and ctl.continual

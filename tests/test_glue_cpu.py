@@ -1,0 +1,128 @@
+"""CPU tests of the host-side mirror: LieTensor shim (values vs the oracle, PyPose gradient conventions vs finite
+differences), transformation helpers, device-side Canny stand-in (property tests; OpenCV parity is unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from islam_amd import edges, lietensor as pp, transformation as tf
+from oracle import lie
+
+
+def _r(shape, seed, scale=1.0):
+    return torch.tensor(np.random.default_rng(seed).normal(size=shape) * scale, dtype=torch.float64)
+
+
+def test_values_match_oracle():
+    xi, yi = _r((6, 6), 0, 0.6), _r((6, 6), 1, 0.6)
+    X, Y = pp.se3(xi).Exp(), pp.se3(yi).Exp()
+    Xn, Yn = lie.se3_exp(xi.numpy()), lie.se3_exp(yi.numpy())
+    np.testing.assert_allclose(X.tensor().numpy(), Xn, atol=1e-14)
+    np.testing.assert_allclose((X @ Y).tensor().numpy(), lie.se3_mul(Xn, Yn), atol=1e-14)
+    np.testing.assert_allclose(X.Inv().tensor().numpy(), lie.se3_inv(Xn), atol=1e-14)
+    np.testing.assert_allclose(X.Log().tensor().numpy(), xi.numpy(), atol=1e-13)
+    p = _r((6, 3), 2)
+    np.testing.assert_allclose((X @ p).numpy(), lie.se3_act(Xn, p.numpy()), atol=1e-14)
+    np.testing.assert_allclose(X.rotation().Log().tensor().numpy(), lie.so3_log(Xn[:, 3:]), atol=1e-14)
+    np.testing.assert_allclose(X.matrix()[:, :3, :3].numpy(), lie.quat_matrix(Xn[:, 3:]), atol=1e-14)
+    assert isinstance(X[2:4], pp.LieTensor) and X[2:4].ltype is pp.SE3_type and X[1].shape == (7,)
+    assert isinstance(X.cpu().detach().clone(), pp.LieTensor) and not isinstance(X.tensor(), pp.LieTensor)
+    assert isinstance(X.numpy(), np.ndarray) and len(X) == 6
+    assert isinstance(torch.cat((X.translation(), X.rotation().tensor()), 1), torch.Tensor)
+    assert pp.SE3([0, 0, 0, 0, 0, 0, 1]).dtype == torch.get_default_dtype()
+    assert [type(m) for m in X][:1] == [pp.LieTensor]
+
+
+@pytest.mark.parametrize('op', ['mul_left', 'mul_right', 'inv', 'log', 'act', 'exp'])
+def test_gradients_are_left_tangent_padded(op):
+    """g_X[:6] = d f(Exp(d) X) / d d at d=0, g_X[6] = 0  (SURVEY Appendix C item 9)."""
+    X0, Y0 = lie.se3_exp(_r((6,), 3, 0.5).numpy()), lie.se3_exp(_r((6,), 4, 0.5).numpy())
+    w6, w3 = np.linspace(0.3, 1.1, 6), np.array([0.7, -0.4, 1.3])
+    pt = np.array([0.5, -1.0, 2.0])
+
+    def f_np(X):
+        if op == 'mul_left':
+            return float(w6 @ lie.se3_log(lie.se3_mul(X, Y0)))
+        if op == 'mul_right':
+            return float(w6 @ lie.se3_log(lie.se3_mul(Y0, X)))
+        if op == 'inv':
+            return float(w6 @ lie.se3_log(lie.se3_inv(X)))
+        if op == 'log':
+            return float(w6 @ lie.se3_log(X))
+        return float(w3 @ lie.se3_act(X, pt))
+
+    if op == 'exp':
+        xi = _r((6,), 5, 0.4).requires_grad_(True)
+        (torch.tensor(w6) @ (pp.se3(xi).Exp() @ pp.SE3(torch.tensor(Y0))).Log().tensor()).backward()
+        h, fd = 1e-6, np.zeros(6)
+        g = lambda v: float(w6 @ lie.se3_log(lie.se3_mul(lie.se3_exp(v), Y0)))
+        for k in range(6):
+            e = np.zeros(6)
+            e[k] = h
+            fd[k] = (g(xi.detach().numpy() + e) - g(xi.detach().numpy() - e)) / (2 * h)
+        np.testing.assert_allclose(xi.grad.numpy(), fd, atol=1e-7)
+        return
+    X = torch.tensor(X0, requires_grad=True)
+    XL, YL = pp.SE3(X), pp.SE3(torch.tensor(Y0))
+    if op == 'mul_left':
+        out = torch.tensor(w6) @ (XL @ YL).Log().tensor()
+    elif op == 'mul_right':
+        out = torch.tensor(w6) @ (YL @ XL).Log().tensor()
+    elif op == 'inv':
+        out = torch.tensor(w6) @ XL.Inv().Log().tensor()
+    elif op == 'log':
+        out = torch.tensor(w6) @ XL.Log().tensor()
+    else:
+        out = torch.tensor(w3) @ (XL @ torch.tensor(pt))
+    out.backward()
+    h, fd = 1e-6, np.zeros(6)
+    for k in range(6):
+        e = np.zeros(6)
+        e[k] = h
+        fd[k] = (f_np(lie.se3_mul(lie.se3_exp(e), X0)) - f_np(lie.se3_mul(lie.se3_exp(-e), X0))) / (2 * h)
+    np.testing.assert_allclose(X.grad.numpy()[:6], fd, atol=1e-7)
+    assert X.grad[6] == 0
+
+
+def test_transformation_helpers():
+    m6 = _r((5, 6), 7, 0.2)
+    X = tf.cvtSE3_pypose(m6)
+    np.testing.assert_allclose(X.tensor().numpy(), np.concatenate([m6[:, :3].numpy(), lie.so3_exp(m6[:, 3:].numpy())], 1), atol=1e-15)
+    T = lie.from_matrix_SE3(np.array(tf._T_AXES))
+    K = tf.tartan2kitti_pypose(m6)
+    np.testing.assert_allclose(K.tensor().numpy(), lie.se3_mul(lie.se3_mul(T[None], X.tensor().numpy()), lie.se3_inv(T)[None]), atol=1e-14)
+    # NED (x fwd, y right, z down) -> camera (x right, y down, z fwd): a forward motion becomes +z
+    fwd = tf.tartan2kitti_pypose(torch.tensor([[1.0, 0, 0, 0, 0, 0]], dtype=torch.float64)).tensor().numpy()[0]
+    np.testing.assert_allclose(fwd[:3], [0, 0, 1], atol=1e-15)
+    T0 = pp.SE3(torch.tensor(lie.se3_exp(_r((6,), 8, 0.3).numpy())))
+    P = tf.motion2pose_pypose(K, T0)
+    assert P.shape == (6, 7)
+    acc = T0.tensor().numpy()
+    for k in range(5):                                            # sequential left-to-right products (G2)
+        acc = lie.se3_mul(acc, K.tensor().numpy()[k])
+        np.testing.assert_array_equal(P.tensor().numpy()[k + 1], acc)
+    np.testing.assert_allclose(tf.pose2motion_pypose(P).tensor().numpy(), K.tensor().numpy(), atol=1e-14)
+    assert P.dtype == torch.float64
+
+
+def test_edge_mask_properties():
+    H, W = 64, 96
+    img = torch.full((1, 3, H, W), 0.2)
+    img[:, :, :, 48:] = 0.8                                       # one vertical step edge
+    e = edges.canny_u8((img * 255).to(torch.uint8))
+    cols = torch.nonzero(e[0].any(0)).flatten().tolist()
+    assert cols in ([47], [48]) and e[0, 5:-5, cols[0]].all()      # a single-pixel-wide line (non-maximum suppression)
+    m = edges.edge_mask(img)
+    assert m.shape == (1, 16, 24) and m.dtype == torch.bool
+    band = torch.nonzero(m[0].any(0)).flatten()
+    assert 3 <= len(band) <= 6 and band.min() >= 9 and band.max() <= 14      # 5x5 dilation of the line at x=12
+    assert not edges.edge_mask(torch.full((1, 3, H, W), 0.5)).any()           # flat image: no edges
+    # hysteresis: a weak edge survives only when connected to a strong one
+    img2 = torch.full((1, 3, H, W), 0.3)
+    img2[:, :, :32, 48:] = 0.3 + 70 / 255 / 4 * 2                 # gradient magnitude between low and high after Sobel
+    weak_only = edges.canny_u8((img2 * 255).to(torch.uint8))
+    img2[:, :, 32:, 48:] = 0.9
+    joined = edges.canny_u8((img2 * 255).to(torch.uint8))
+    assert joined[0, 2:30, 46:50].any() or not weak_only.any()
+    # quarter resize: mean of the centre 2x2 of each 4x4 cell, round half up
+    u8 = torch.arange(16, dtype=torch.uint8).reshape(1, 1, 4, 4)
+    assert edges.quarter_resize_u8(u8).item() == (5 + 6 + 9 + 10 + 2) // 4

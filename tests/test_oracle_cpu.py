@@ -1,0 +1,276 @@
+"""CPU tests pinning the ORACLE (no GPU, no product code): closed forms against independent mathematics
+(scipy Rotation, finite differences, dense linear algebra, torch grid_sample), and the reference's only
+in-repo known-answer vector (dense_ba.py:29-47)."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+from scipy.spatial.transform import Rotation
+
+from oracle import cwrap, imu as oimu, lie, pvgo as opvgo
+from tests.helpers import chain_problem
+
+LW = (1, 0.1, 10, 0.1)
+
+
+def test_reference_known_answer_pixel2point():
+    """The docstring example of reference dense_ba.py:29-47 (the only golden vector the reference ships)."""
+    f, H, W = 2.0, 9, 9
+    K = np.array([[f, 0, H / 2], [0, f, W / 2], [0, 0, 1]])
+    px = np.array([[0.5, 0.0], [1.0, 0.0], [0.0, 1.3], [1.0, 0.0], [0.5, 1.5], [5.0, 1.5]])
+    d = np.array([5.0, 3.0, 6.5, 2.0, 0.5, 0.7])
+    pts = np.stack([(px[:, 0] - K[0, 2]) * d / K[0, 0], (px[:, 1] - K[1, 2]) * d / K[1, 1], d], -1)   # z K^-1 [u v 1]
+    want = np.array([[-10.0, -11.25, 5.0], [-5.25, -6.75, 3.0], [-14.625, -10.4, 6.5], [-3.5, -4.5, 2.0], [-1.0, -0.75, 0.5],
+                     [0.175, -1.05, 0.7]])
+    np.testing.assert_allclose(pts, want, atol=1e-12)
+
+
+def test_so3_se3_closed_forms_vs_scipy():
+    rng = np.random.default_rng(0)
+    phi = rng.normal(size=(200, 3))
+    phi *= rng.uniform(0.0, 3.0, (200, 1)) / np.linalg.norm(phi, axis=1, keepdims=True)      # |phi| < pi
+    phi[0] = 0
+    phi[1] = [1e-9, 0, 0]
+    q = lie.so3_exp(phi)
+    np.testing.assert_allclose(q, Rotation.from_rotvec(phi).as_quat(), atol=2e-16 * 10)
+    np.testing.assert_allclose(lie.so3_log(q), phi, atol=1e-14)
+    np.testing.assert_allclose(lie.so3_log(-q), phi, atol=1e-14)             # atan branch: q and -q agree
+    np.testing.assert_allclose(lie.quat_matrix(q), Rotation.from_rotvec(phi).as_matrix(), atol=1e-14)
+    p = rng.normal(size=(200, 3))
+    np.testing.assert_allclose(lie.quat_act(q, p), Rotation.from_rotvec(phi).apply(p), atol=1e-14)
+    xi = rng.normal(size=(200, 6)) * 0.7
+    X = lie.se3_exp(xi)
+    np.testing.assert_allclose(lie.se3_log(X), xi, atol=1e-13)
+    np.testing.assert_allclose(lie.se3_mul(X, lie.se3_inv(X))[:, :3], 0, atol=1e-14)
+    np.testing.assert_allclose(lie.se3_Jl(xi) @ lie.se3_Jl_inv(xi), np.broadcast_to(np.eye(6), (200, 6, 6)), atol=1e-12)
+    np.testing.assert_allclose(lie.so3_Jl(phi) @ lie.so3_Jl_inv(phi), np.broadcast_to(np.eye(3), (200, 3, 3)), atol=1e-9)   # 5e-10 at |phi|=1e-9: PyPose's eps-switched closed forms cancel
+
+
+def test_left_jacobians_by_finite_differences():
+    rng = np.random.default_rng(1)
+    xi = rng.normal(size=(20, 6)) * 0.5
+    X = lie.se3_exp(xi)
+    h = 1e-6
+    J = np.zeros((20, 6, 6))
+    for k in range(6):
+        e = np.zeros(6)
+        e[k] = h
+        J[:, :, k] = (lie.se3_log(lie.se3_mul(lie.se3_exp(e)[None], X)) - lie.se3_log(lie.se3_mul(lie.se3_exp(-e)[None], X))) / (2 * h)
+    np.testing.assert_allclose(J, lie.se3_Jl_inv(xi), atol=5e-9)
+    # Ad: X Exp(d) = Exp(Ad_X d) X
+    d = rng.normal(size=6) * 1e-3
+    lhs = lie.se3_mul(X, lie.se3_exp(d)[None])
+    rhs = lie.se3_mul(lie.se3_exp((lie.se3_adj(X) @ d)), X)
+    np.testing.assert_allclose(lhs, rhs, atol=1e-8)
+
+
+def test_pvgo_jacobian_blocks_by_finite_differences():
+    """A_e, B_k (PyPose left-perturbation convention) and the compat translation Jacobian."""
+    prob, _ = chain_problem(6)
+    n, v = prob['init_nodes'], prob['init_vels']
+    args = (prob['links'], prob['vo_motions'], prob['imu_drots'], prob['imu_dtrans'], prob['imu_dvels'], prob['dts'])
+    res = opvgo.residuals(n, v, *args)
+    A, B = opvgo.jac_blocks(n, prob['links'], prob['vo_motions'], prob['imu_drots'], res[0], res[2])
+    J = opvgo.jacobian_dense(6, prob['links'], A, B, prob['dts'])
+    Jt = opvgo.jacobian_dense(6, prob['links'], A, B, prob['dts'], true_translation_jacobian=True, nodes=n)
+    h = 1e-6
+    R0 = np.concatenate([r.reshape(-1) for r in res])
+    for node in (0, 2, 5):
+        for c in range(6):
+            d = np.zeros((6, 6))
+            d[node, c] = h
+            # (a) group retraction Exp(d) X  -> true Jacobian
+            nn, _ = opvgo.retract(n, v, d, np.zeros_like(v))
+            Rp = np.concatenate([r.reshape(-1) for r in opvgo.residuals(nn, v, *args)])
+            fd = (Rp - R0) / h
+            np.testing.assert_allclose(fd, Jt[:, 7 * node + c], atol=2e-4)
+            # (b) the pose-graph / rotation rows agree between compat and true; transvel rows differ by -[t]x
+            rows_tv = slice(6 * 5 + 6 * 5, None)
+            np.testing.assert_allclose(J[:6 * 5 + 6 * 5, 7 * node + c], Jt[:6 * 5 + 6 * 5, 7 * node + c], atol=0)
+            if c < 3:
+                np.testing.assert_allclose(J[rows_tv, 7 * node + c], Jt[rows_tv, 7 * node + c], atol=0)
+    assert np.abs(J[:, 6::7][:, :6]).max() == 0                       # pad column of every pose is identically 0
+    # velocities: plain vector parameters
+    for node in (1, 4):
+        for c in range(3):
+            vv = v.copy()
+            vv[node, c] += h
+            Rp = np.concatenate([r.reshape(-1) for r in opvgo.residuals(n, vv, *args)])
+            np.testing.assert_allclose((Rp - R0) / h, J[:, 42 + 3 * node + c], atol=1e-6)
+
+
+@pytest.mark.parametrize('F', [5, 9, 40])
+def test_dense_and_banded_modes_agree(F):
+    """The faithful dense PyPose formulation and the block-tridiagonal one are the same algorithm."""
+    prob, _ = chain_problem(F)
+    a = opvgo.run_pvgo(**prob, loss_weight=LW, mode='dense', return_optimizer=True)
+    b = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True)
+    assert [t[2] for t in a[5].trace] == [t[2] for t in b[5].trace]
+    np.testing.assert_allclose(a[2], b[2], atol=1e-9)
+    np.testing.assert_allclose(a[3], b[3], atol=1e-9)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-7, atol=1e-12)
+
+
+def test_lm_control_flow():
+    """PyPose's control flow: unweighted accept test, cumulative damping, reject limit, StopOnPlateau."""
+    prob, _ = chain_problem(9)
+    out = opvgo.run_pvgo(**prob, loss_weight=LW, mode='dense', return_optimizer=True)
+    opt = out[5]
+    tr = opt.trace
+    assert len(tr) >= 1 and tr[0][2] is True
+    damp = [t[1] for t in tr]
+    assert all(d > 0 for d in damp)
+    # node 0 is re-anchored to the initial first pose by align_to
+    np.testing.assert_allclose(out[2][0], prob['init_nodes'][0], atol=1e-12)
+    # the raw-slice translation Jacobian PyPose's autograd yields makes the iteration depend on the world
+    # origin; with the true left-perturbation Jacobian [I, -[t]x] the relative geometry is origin-independent.
+    def rel_after_shift(ttj):
+        outs = []
+        for shift in (np.zeros(3), np.array([100.0, -50.0, 3.0])):
+            p2 = dict(prob)
+            p2['init_nodes'] = prob['init_nodes'].copy()
+            p2['init_nodes'][:, :3] += shift
+            o = opvgo.run_pvgo(**p2, loss_weight=LW, mode='dense', true_translation_jacobian=ttj)
+            outs.append(lie.se3_mul(lie.se3_inv(o[2][:-1]), o[2][1:]))
+        return np.abs(outs[0] - outs[1]).max()
+    assert rel_after_shift(True) < 1e-6
+    assert rel_after_shift(False) > 1e-5
+
+
+def test_vo_loss_gradient_convention():
+    prob, _ = chain_problem(7)
+    n, P = prob['init_nodes'], prob['vo_motions']
+    gt, gr = np.linspace(1, 2, 6), np.linspace(0.5, 1, 6)
+    g = opvgo.vo_loss_grad(n, prob['links'], P, gt, gr)
+    assert np.all(g[:, 6] == 0)
+    h = 1e-6
+    f = lambda PP: float(np.sum(gt * opvgo.vo_loss(n, prob['links'], PP)[0] + gr * opvgo.vo_loss(n, prob['links'], PP)[1]))
+    for e in (0, 3):
+        for c in range(6):
+            d = np.zeros((6, 6))
+            d[e, c] = h
+            Pp = lie.se3_mul(lie.se3_exp(d), P)          # left perturbation of the VO motion
+            np.testing.assert_allclose((f(Pp) - f(P)) / h, g[e, c], rtol=1e-3, atol=1e-6)
+
+
+def test_imu_oracle_against_independent_integration():
+    """The C restatement vs a direct numpy transcription of the PyPose formulas (sequential products)."""
+    rng = np.random.default_rng(2)
+    S = 23
+    dt = rng.uniform(0.005, 0.02, S)
+    gyro = rng.normal(0, 0.3, (S, 3))
+    acc = rng.normal(0, 1, (S, 3)) + [0, 0, 9.81]
+    p0, v0 = np.array([1.0, 2, 3]), np.array([0.5, -0.2, 0.1])
+    r0 = Rotation.from_rotvec([0.2, -0.1, 0.3])
+    pos, rot, vel = cwrap.imu_integrate(dt, gyro, acc, [0, S], p0, r0.as_quat(), v0, 9.81, False)
+    incre = [Rotation.identity()]
+    for j in range(S):
+        incre.append(incre[-1] * Rotation.from_rotvec(gyro[j] * dt[j]))
+    g = np.array([0, 0, 9.81])
+    iv, ip, it = np.zeros(3), np.zeros(3), 0.0
+    for j in range(S):
+        a = acc[j] - (r0 * incre[j + 1]).inv().apply(g)
+        ra = incre[j].apply(a)
+        ip = ip + iv * dt[j] + ra * 0.5 * dt[j] ** 2
+        iv = iv + ra * dt[j]
+        it += dt[j]
+    np.testing.assert_allclose(vel[1], v0 + r0.apply(iv), atol=1e-12)
+    np.testing.assert_allclose(pos[1], p0 + r0.apply(ip) + v0 * it, atol=1e-12)
+    qr = (r0 * incre[-1]).as_quat()
+    assert min(np.abs(rot[1] - qr).max(), np.abs(rot[1] + qr).max()) < 1e-13
+    np.testing.assert_array_equal(pos[0], p0)
+    # motion mode: zero initial position / velocity, relative rotation
+    dpos, drot, dvel = cwrap.imu_integrate(dt, gyro, acc, [0, S], p0, r0.as_quat(), v0, 9.81, True)
+    np.testing.assert_allclose(dvel[0], r0.apply(iv), atol=1e-12)
+    np.testing.assert_allclose(dpos[0], r0.apply(ip), atol=1e-12)
+    qd = incre[-1].as_quat()
+    assert min(np.abs(drot[0] - qd).max(), np.abs(drot[0] + qd).max()) < 1e-13
+
+
+def test_imu_oracle_sincos_accuracy_and_scan_order():
+    xs = np.concatenate([np.linspace(-0.785, 0.785, 2001), np.linspace(-50, 50, 501)])
+    s, c = np.array([cwrap.sincos(float(x)) for x in xs]).T
+    np.testing.assert_allclose(s, np.sin(xs), atol=2.3e-16 * 4)
+    np.testing.assert_allclose(c, np.cos(xs), atol=2.3e-16 * 4)
+    # float32 and float64 paths are separate instantiations of the same source
+    tr_dt, g, a = np.full(10, 0.01), np.full((10, 3), 0.1), np.tile([0, 0, 9.81], (10, 1))
+    p64 = cwrap.imu_integrate(tr_dt, g, a, [0, 10], np.zeros(3), [0, 0, 0, 1], np.zeros(3), 9.81, False, np.float64)
+    p32 = cwrap.imu_integrate(tr_dt, g, a, [0, 10], np.zeros(3), [0, 0, 0, 1], np.zeros(3), 9.81, False, np.float32)
+    assert p32[0].dtype == np.float32
+    np.testing.assert_allclose(p32[0], p64[0], atol=1e-5)
+
+
+def test_imu_empty_interval_rule():
+    """imu_integrator.py:134-140: a frame without IMU samples zeroes the velocity and holds rotation (and position)."""
+    dt, g, a = np.full(6, 0.01), np.full((6, 3), 0.2), np.tile([0.3, 0, 9.81], (6, 1))
+    seg = [0, 3, 3, 6]
+    init = dict(pos=np.ones(3), rot=np.array([0, 0, 0, 1.0]), vel=np.array([1.0, 0, 0]))
+    pos, rot, vel = oimu.cwrap.imu_integrate(dt, g, a, seg, init['pos'], init['rot'], init['vel'], 9.81, False)
+    np.testing.assert_array_equal(vel[2], 0)
+    np.testing.assert_array_equal(pos[2], pos[1])
+    np.testing.assert_array_equal(rot[2], rot[1])
+    dpos, drot, dvel = oimu.cwrap.imu_integrate(dt, g, a, seg, init['pos'], init['rot'], init['vel'], 9.81, True)
+    np.testing.assert_array_equal(dpos[1], 0)
+    np.testing.assert_array_equal(dvel[1], 0)
+    np.testing.assert_allclose(drot[1], [0, 0, 0, 1], atol=1e-15)
+
+
+def test_correlation_oracle_vs_torch_unfold():
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(2, 7, 9, 11, generator=g), torch.randn(2, 7, 9, 11, generator=g)
+    out = cwrap.corr81_fwd(f1.numpy(), f2.numpy())
+    pad = F.pad(f2, (4, 4, 4, 4))
+    ref = torch.stack([(f1 * pad[:, :, dy:dy + 9, dx:dx + 11]).mean(1) for dy in range(9) for dx in range(9)], 1)
+    np.testing.assert_allclose(out, ref.numpy(), rtol=1e-5, atol=1e-6)
+    # gradients: oracle backward kernels vs autograd of the unfold formulation
+    a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    pad = F.pad(b, (4, 4, 4, 4))
+    o = torch.stack([(a * pad[:, :, dy:dy + 9, dx:dx + 11]).mean(1) for dy in range(9) for dx in range(9)], 1)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    g1, g2 = cwrap.corr81_bwd(f1.numpy(), f2.numpy(), go.numpy())
+    np.testing.assert_allclose(g1, a.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2, b.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_warp_oracle_vs_torch_grid_sample():
+    """PWCDCNet.warp calls torch's grid_sample; the C restatement must agree with it (torch CPU kernel)."""
+    import torch
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 4, 14, 20
+    x, flo = torch.randn(B, C, H, W, generator=g), torch.randn(B, 2, H, W, generator=g) * 4
+    xx = torch.arange(0, W).view(1, -1).repeat(H, 1)
+    yy = torch.arange(0, H).view(-1, 1).repeat(1, W)
+    grid = torch.cat((xx.view(1, 1, H, W).repeat(B, 1, 1, 1), yy.view(1, 1, H, W).repeat(B, 1, 1, 1)), 1).float()
+    vg = grid + flo
+    vg[:, 0] = 2.0 * vg[:, 0].clone() / max(W - 1, 1) - 1.0
+    vg[:, 1] = 2.0 * vg[:, 1].clone() / max(H - 1, 1) - 1.0
+    vg = vg.permute(0, 2, 3, 1)
+    o = torch.nn.functional.grid_sample(x, vg, align_corners=True)
+    m = torch.nn.functional.grid_sample(torch.ones_like(x), vg, align_corners=True)
+    m[m < 0.9999] = 0
+    m[m > 0] = 1
+    np.testing.assert_allclose(cwrap.warp(x.numpy(), flo.numpy()), (o * m).numpy(), atol=1e-6)
+
+
+def test_scale_oracle_recovers_known_scale():
+    """Synthetic scene: points at known depth moved by a known motion; the 1-DoF LS returns |t|."""
+    from oracle import scale as oscale
+    H, W = 60, 80
+    fx = fy = 100.0
+    cx, cy, base = 40.0, 30.0, 0.5
+    rng = np.random.default_rng(0)
+    z = rng.uniform(4, 20, (H, W))
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64), indexing='xy')
+    P = np.stack([z * (u - cx) / fx, z * (v - cy) / fy, z], -1)
+    motion = np.concatenate([[0.3, -0.05, 0.8], lie.so3_exp(np.array([0.01, -0.02, 0.005]))])      # frame0 -> frame1 pose
+    Ti = lie.se3_inv(motion)
+    P1 = lie.se3_act(Ti[None, None, :], P)
+    flow = np.stack([fx * P1[..., 0] / P1[..., 2] + cx - u, fy * P1[..., 1] / P1[..., 2] + cy - v])
+    disp = fx * base / z
+    direction = motion.copy()
+    direction[:3] /= np.linalg.norm(direction[:3])          # the network predicts an up-to-scale translation
+    s, zz, mask, dmask, _ = oscale.scale_from_disp_flow(disp[None], flow, direction, fx, fy, cx, cy, base, None, 1.0)
+    assert mask.sum() > 500
+    np.testing.assert_allclose(s, np.linalg.norm(motion[:3]), rtol=2e-3)
