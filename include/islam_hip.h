@@ -112,6 +112,8 @@ typedef struct {
     double damping;       /* final damping */
 } islam_pvgo_result;
 
+#define ISLAM_PVGO_MAX_LEVELS 6   /* levels of the partitioned block Cholesky; plan arrays hold 3*ISLAM_PVGO_MAX_LEVELS ints */
+
 void islam_pvgo_default_params(islam_pvgo_params* p);
 size_t islam_pvgo_workspace_bytes(int N);
 
@@ -137,12 +139,13 @@ int islam_pvgo_build_normal(const double* lin, const double* dts, int N, const d
 int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                            const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
 /* Profiling variant: HIP events around every launch of one solve (on `stream`).  ms[i] = duration of launch i
- * (eliminate level 0..L-1, then back-substitution L-2..0), plan[3*l..] = (nodes, segment length, segments). */
+ * (eliminate level 0..L-1, then back-substitution L-2..0; at most 2*ISLAM_PVGO_MAX_LEVELS-1 entries),
+ * plan[3*l..] = (nodes, segment length, segments) for l < ISLAM_PVGO_MAX_LEVELS. */
 int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                                  const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx,
                                  float* ms, int* plan, int* nlaunch, void* stream);
 /* ---- multi-GPU building blocks (islam_amd/dist_pvgo.py; no reference counterpart: the reference is single-GPU).
- * plan9 receives (nodes, segment length, segments) for up to 3 levels; returns the number of levels. */
+ * plan9 receives (nodes, segment length, segments) for ISLAM_PVGO_MAX_LEVELS levels (unused = 0); returns the level count. */
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9);
 /* Eliminate level-0 segments [seg0, seg0+nseg) of an N-node chain.  Hd/Ho/rhs/fac/inv are LOCAL arrays whose row 0 is
  * global node `node0`.  products: 351*P0 doubles, array-major (Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P |

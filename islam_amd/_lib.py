@@ -17,6 +17,7 @@ c_void_p, c_int, c_int64, c_double, c_float, c_size_t = (ctypes.c_void_p, ctypes
                                                          ctypes.c_double, ctypes.c_float, ctypes.c_size_t)
 
 SCALE_NBLK, SCALE_NSUM = 16, 18
+MAX_LEVELS = 6          # ISLAM_PVGO_MAX_LEVELS
 
 
 class PvgoParams(ctypes.Structure):

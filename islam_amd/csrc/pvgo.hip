@@ -253,17 +253,20 @@ __device__ __forceinline__ void issue_cols(const LaneSrc& L, bool level0, int k,
 
 __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s, int k, int n, int lane, double damping,
                                              const RawCols& raw, double (&m)[9]) {
-    const bool ua = L.isS || L.isG || (L.isU && (k + 1) < n);
     if (s.level0) {
+        // lanes that own no column (spike lanes, lanes >= 28) carry don't-care values: they are overwritten by the
+        // spike / never stored, so no per-element select is needed except at the chain's last node (no coupling)
+        const bool zeroU = L.isU && (k + 1) >= n;
         double dg = 0.0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            double v = ua ? raw.a[r] : 0.0;
+            double v = zeroU ? 0.0 : raw.a[r];
             if (r == lane) { v = v + v * damping; dg = v; }   // A.diagonal().add_(A.diagonal()*damping), kept for retries
             m[r] = v;
         }
         if (lane < 9) s.Hd[(size_t)k * 81 + lane * 10] = dg;
     } else {
+        const bool ua = L.isS || L.isG || (L.isU && (k + 1) < n);
         const bool ub = L.isS || L.isG;
         const bool uc = ub && (k + 1) < s.Pprev;
 #pragma unroll
@@ -281,34 +284,64 @@ __constant__ unsigned char kPairA[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 
 __constant__ unsigned char kPairB[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7,
                                          8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
 
-__device__ __forceinline__ double dot9(const double* a, const double* b) {
+// LDS column (9 doubles, 16-byte aligned) -> registers with four 16-byte reads and one 8-byte read
+__device__ __forceinline__ void ldcol(const double* p, double (&c)[9]) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+    const double2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+    c[0] = v0.x; c[1] = v0.y; c[2] = v1.x; c[3] = v1.y; c[4] = v2.x; c[5] = v2.y; c[6] = v3.x; c[7] = v3.y; c[8] = p[8];
+}
+__device__ __forceinline__ double dot9r(const double (&a)[9], const double (&b)[9]) {
     double s = a[0] * b[0];
 #pragma unroll
     for (int q = 1; q < 9; ++q) s = fma(a[q], b[q], s);
     return s;
 }
 
-// Back-substitution through one segment (nodes c0 .. c0+cnt-1), right to left.
-// xn = solution of the node right of the segment (0 if none), xL = solution of the left separator (0 if none).
+__device__ __forceinline__ double rcp_nr(double p) {      // v_rcp_f64 (~2^-23) + two Newton steps: full double accuracy
+    double r = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-p, r, 1.0);
+    return fma(r, e, r);
+}
+
+// rows of the stored factor of one node needed by lane r: row r of D L^T (9), of U~ (9), of F~ (9), y~[r], 1/p_r
+struct FacRow { double lt[9], u[9], f[9], y, iv; };
+
+__device__ __forceinline__ void load_facrow(const double* __restrict__ fac, const double* __restrict__ inv, int c, int r,
+                                            FacRow& o) {
+    const double* f = fac + (size_t)c * FAC;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.lt[i] = f[i * 9 + r];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o.u[q] = f[(9 + q) * 9 + r];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o.f[q] = f[(18 + q) * 9 + r];
+    o.y = f[27 * 9 + r];
+    o.iv = inv[(size_t)c * 9 + r];
+}
+
+// Back-substitution through one segment (nodes c0 .. c0+cnt-1), right to left; the factor rows of node c-1 are
+// fetched while node c is being solved.  xn = solution right of the segment (0 if none), xL = left separator's (0 if none).
 __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, const double* __restrict__ inv,
                                                 double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
                                                 const double (&xL)[9]) {
     const int r = lane < 9 ? lane : 8;
+    FacRow cur, nxt;
+    load_facrow(fac, inv, c0 + cnt - 1, r, cur);
     for (int c = c0 + cnt - 1; c >= c0; --c) {
-        const double* f = fac + (size_t)c * FAC;
-        double lt[9], w = f[27 * 9 + r];
+        load_facrow(fac, inv, max(c - 1, c0), r, nxt);       // unconditional (clamped): same memory ops on every path
+        __builtin_amdgcn_sched_barrier(0);
+        double w = cur.y;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) lt[i] = f[i * 9 + r];              // row r of L^T
+        for (int q = 0; q < 9; ++q) w = fma(-cur.u[q], xn[q], w);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) w = fma(-f[(9 + q) * 9 + r], xn[q], w);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) w = fma(-f[(18 + q) * 9 + r], xL[q], w);
-        const double iv = inv[(size_t)c * 9 + r];
+        for (int q = 0; q < 9; ++q) w = fma(-cur.f[q], xL[q], w);
 #pragma unroll
         for (int i = 8; i >= 0; --i) {
-            double xi = bcast(w * iv, i);
+            double xi = bcast(w * cur.iv, i);
             xn[i] = xi;
-            w = fma(-lt[i], xi, w);      // only rows r < i matter; rows >= i are never read again
+            w = fma(-cur.lt[i], xi, w);      // only rows r < i matter; rows >= i are never read again
         }
         if (lane < 9) {
             double mine = 0.0;
@@ -317,14 +350,26 @@ __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, 
                 if (i == lane) mine = xn[i];
             x[(size_t)c * 9 + lane] = mine;
         }
+        // the rows of node c-1 were requested at the top of this iteration; make their arrival an explicit event HERE
+        // (empty asm with in/out operands), so the next iteration's arithmetic carries no loop-carried memory wait
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            asm volatile("" : "+v"(nxt.lt[i]));
+            asm volatile("" : "+v"(nxt.u[i]));
+            asm volatile("" : "+v"(nxt.f[i]));
+        }
+        asm volatile("" : "+v"(nxt.y));
+        asm volatile("" : "+v"(nxt.iv));
+        cur = nxt;
     }
 }
 
-// One wavefront per segment: eliminate the segment's interior nodes onto its two separators.
+// One wavefront per segment: eliminate the segment's interior nodes onto its two separators (LDL^T, no square roots).
 __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
                                                            int solve_here) {
-    __shared__ __attribute__((aligned(16))) double Xs[19 * XS];
-    __shared__ __attribute__((aligned(16))) double Tn[19 * XS];
+    __shared__ __attribute__((aligned(16))) double Xa[19 * XS];     // X   = [U- | F- | y-]  (rows of L^-1 [U F^T g])
+    __shared__ __attribute__((aligned(16))) double Xb[19 * XS];     // D^-1 X
+    __shared__ __attribute__((aligned(16))) double Tn[19 * XS];     // X^T D^-1 X entries feeding the next node
     const int lane = threadIdx.x;
     const int p = blockIdx.x + seg0;
     const int stride = m + 1;
@@ -335,74 +380,93 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     const bool has_right = sR < n;
     const double damping = src.state ? src.state[2] : src.damping_override;
 
+    // Schur-update work split, fixed per lane: entries (r, cb) = X[:,r] . D^-1 X[:,cb] for cb = g, g+7, g+14
+    const int tr = lane % 9, tg = lane / 9;                         // lanes 0..62 (g <= 6); lane 63 idles
+    const bool t_on = tg < 7;
+    const bool t_third = t_on && (tg + 14) < 19;
+    const int pa = lane < 45 ? kPairA[lane] : lane - 45;            // left-separator accumulation F-^T D^-1 [F- | y-]
+    const int pb = lane < 45 ? kPairB[lane] : 9;
+    const bool acc_on = has_left && lane < 54;
+
     const LaneSrc LS = lane_source(src, lane);
     const bool level0 = src.level0 != 0;
     double mcol[9], nb[9];
     RawCols raw;
     issue_cols(LS, level0, c0, raw);
     combine_cols(LS, src, c0, n, lane, damping, raw, mcol);
-    if (has_left && lane >= 18 && lane < 27) {          // spike F^T: coupling (left separator rows, c0 cols) transposed
-        const int jj = lane - 18;
-        const double* O = src.level0 ? (src.Ho + (size_t)(c0 - 1) * 81) : (src.fill + (size_t)c0 * 81);
+    if (lane >= 18 && lane < 27) {                      // spike F^T: coupling (left separator rows, c0 cols) transposed
+        if (has_left) {
+            const int jj = lane - 18;
+            const double* O = src.level0 ? (src.Ho + (size_t)(c0 - 1) * 81) : (src.fill + (size_t)c0 * 81);
 #pragma unroll
-        for (int r = 0; r < 9; ++r) mcol[r] = O[jj * 9 + r];
+            for (int r = 0; r < 9; ++r) mcol[r] = O[jj * 9 + r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) mcol[r] = 0.0;
+        }
     }
-    if (c0 + 1 < n) issue_cols(LS, level0, c0 + 1, raw);
     double accL = 0.0;
     int bad = 0;
 
     for (int t = 0; t < cnt; ++t) {
         const int c = c0 + t;
         const bool last = (t == cnt - 1);
-        // software pipeline: the loads of node c+1 were issued one node ago; those of node c+2 go out now
-        if (c + 1 < n) combine_cols(LS, src, c + 1, n, lane, damping, raw, nb);
-        else {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) nb[r] = 0.0;
-        }
-        if (!last && c + 2 < n) issue_cols(LS, level0, c + 2, raw);
-        // ---- Cholesky elimination of the 9 unknowns of node c, applied to all 28 columns
-        double myinv = 0.0;
+        // prefetch: the columns of node c+1 are requested now and first touched after the whole elimination and Schur
+        // update of node c (~1 us later).  Unconditional (index clamped) so that every path through the loop body issues
+        // the same memory operations and the compiler can place an exact, late s_waitcnt.
+        issue_cols(LS, level0, min(c + 1, n - 1), raw);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LDL^T elimination of the 9 unknowns of node c, applied to all 28 columns
+        double ipv[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             double piv = bcast(mcol[i], i);
             if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-            double rs = rsqrt(piv);
-            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);   // one Newton step: full double accuracy
-            if (lane == i) myinv = rs;
-            double li[9];
+            const double ip = rcp_nr(piv);
+            ipv[i] = ip;
+            const double f = mcol[i] * ip;
 #pragma unroll
-            for (int r = i + 1; r < 9; ++r) li[r] = bcast(mcol[r], i) * rs;
-            mcol[i] *= rs;
-#pragma unroll
-            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-li[r], mcol[i], mcol[r]);
+            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
         }
         if (lane < 28) {
             double* f = dst.fac + (size_t)c * FAC + lane * 9;
 #pragma unroll
             for (int r = 0; r < 9; ++r) f[r] = mcol[r];
         }
-        if (lane < 9) dst.inv[(size_t)c * 9 + lane] = myinv;
-        if (lane >= 9 && lane < 28) {
+        if (lane == 0) {
+            double* iv = dst.inv + (size_t)c * 9;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) Xs[(lane - 9) * XS + r] = mcol[r];
+            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+        }
+        if (lane >= 9 && lane < 28) {
+            double* xa = Xa + (lane - 9) * XS;
+            double* xb = Xb + (lane - 9) * XS;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
         }
         lds_sync();
-        // ---- Schur update T = X^T X, X = [U~ | F~ | y~]:  entries (r, cb), r < 9, cb < 19
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = q * 64 + lane;
-            if (e < 171) {
-                const int cb = e / 9, r = e - cb * 9;
-                Tn[cb * XS + r] = dot9(Xs + r * XS, Xs + cb * XS);
+        // ---- Schur update: T = X^T D^-1 X, entries (r, cb), r < 9 (U- columns), cb < 19
+        if (t_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + tr * XS, ca);
+            ldcol(Xb + tg * XS, cbv);
+            Tn[tg * XS + tr] = dot9r(ca, cbv);
+            ldcol(Xb + (tg + 7) * XS, cbv);
+            Tn[(tg + 7) * XS + tr] = dot9r(ca, cbv);
+            if (t_third) {
+                ldcol(Xb + (tg + 14) * XS, cbv);
+                Tn[(tg + 14) * XS + tr] = dot9r(ca, cbv);
             }
         }
-        if (has_left && lane < 54) {                    // F~^T F~ (45 pairs) and F~^T y~ (9), kept in registers
-            const int a = lane < 45 ? kPairA[lane] : lane - 45;
-            const int b = lane < 45 ? kPairB[lane] : 9;
-            accL += dot9(Xs + (9 + a) * XS, Xs + (9 + b) * XS);
+        if (acc_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + (9 + pa) * XS, ca);
+            ldcol(Xb + (9 + pb) * XS, cbv);
+            accL += dot9r(ca, cbv);
         }
         lds_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < n) combine_cols(LS, src, c + 1, n, lane, damping, raw, nb);
         if (!last) {
             if (lane < 9) {
 #pragma unroll
@@ -438,9 +502,8 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     }
     if (has_left) {
         if (lane < 45) {
-            const int a = kPairA[lane], b = kPairB[lane];
-            dst.cL[(size_t)p * 81 + a * 9 + b] = accL;
-            dst.cL[(size_t)p * 81 + b * 9 + a] = accL;
+            dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
+            dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
         } else if (lane < 54) {
             dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
         }
@@ -479,13 +542,60 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// trial step: retract on a copy, new residuals, loss and trust-region denominator partials
+// state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
+//        [8] reject_count [9] accepted [10] error [11] has_loss
+// report (host-visible copy written after every trial): same slots as seen by the step that just ran, [15] = sequence number
+struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; };
+
+// pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
+__device__ void lm_control(double s, double q, double* __restrict__ st, int* flags, const TRParams& tr,
+                           double* __restrict__ report, double seq) {
+    double rep[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rep[i] = 0.0;
+    if (flags[0] != 0) {                 // solver failed: PyPose prints and breaks the step, nothing changes
+        flags[0] = 0;
+        rep[0] = st[0]; rep[1] = st[1]; rep[2] = st[2]; rep[8] = st[8]; rep[10] = 1.0;
+        st[8] = 0.0;
+    } else {
+        const double last = st[1];
+        const double quality = (last - s) / (-q);
+        double radius = 1.0 / st[2], down = st[4];
+        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
+        else if (quality > tr.low) { down = tr.down; }
+        else { radius = radius * down; down = down * tr.factor; }
+        down = fmax(tr.rmin, fmin(down, tr.rmax));
+        radius = fmax(tr.rmin, fmin(radius, tr.rmax));
+        st[3] = radius; st[4] = down; st[2] = 1.0 / radius; st[5] = quality; st[6] = s; st[7] = -q;
+        rep[1] = last; rep[2] = st[2]; rep[3] = radius; rep[4] = down; rep[5] = quality; rep[6] = s; rep[7] = -q;
+        if (last < s && st[8] < (double)tr.reject) {       // reject: the host keeps the old iterate, loss = last
+            st[0] = last;
+            st[8] += 1.0;
+            rep[0] = last; rep[8] = st[8]; rep[9] = 0.0;
+        } else {                                           // step kept (also when the reject limit is exhausted)
+            rep[0] = s; rep[8] = st[8]; rep[9] = 1.0;
+            st[0] = s;
+            st[1] = s;                                     // next optimizer.step(): self.last = self.loss
+            st[8] = 0.0;
+        }
+    }
+    if (report) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) report[i] = rep[i];
+        __threadfence_system();
+        __hip_atomic_store(&report[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// trial step: retract on a copy, new residuals, loss and trust-region denominator partials; the last block to
+// finish sums the partials in index order (deterministic) and takes the LM decision (no separate control launch).
 __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
                                                     const double* __restrict__ dx, const double* __restrict__ poses,
                                                     const double* __restrict__ drots, const double* __restrict__ dtrans,
                                                     const double* __restrict__ dvels, const double* __restrict__ dts,
                                                     const double* __restrict__ lin, int M, double* __restrict__ nodes_t,
-                                                    double* __restrict__ vels_t, double* __restrict__ part) {
+                                                    double* __restrict__ vels_t, double* part, double* st, int* flags,
+                                                    unsigned* ticket, TRParams tr, double* report, double seq) {
     int k = blockIdx.x * 64 + threadIdx.x;
     double sq = 0.0, qd = 0.0;
     if (k < M) {
@@ -521,11 +631,28 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     sq = wave_sum(sq);
     qd = wave_sum(qd);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = sq; part[2 * blockIdx.x + 1] = qd; }
+    if (st == nullptr) return;           // stage-level call: no control
+    // ---- last block takes the decision
+    int last_block = 0;
+    if (threadIdx.x == 0) {
+        __threadfence();                                              // publish this block's partial
+        last_block = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    last_block = __builtin_amdgcn_readfirstlane(last_block);
+    if (!last_block) return;
+    __threadfence();                                                  // acquire the other blocks' partials
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) {
+        s += __hip_atomic_load(&part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q += __hip_atomic_load(&part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        *ticket = 0u;
+        lm_control(s, q, st, flags, tr, report, seq);
+    }
 }
-
-// state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
-//        [8] reject_count [9] accepted [10] error [11] has_loss
-struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; };
 
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
                                                             double* __restrict__ st, int* flags) {
@@ -533,43 +660,11 @@ __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restr
     for (int i = threadIdx.x; i < nblk; i += 64) s += loss_part[i];
     s = wave_sum(s);
     if (threadIdx.x == 0) {
-        if (st[11] == 0.0) { st[0] = s; st[11] = 1.0; }   // self.loss only computed on the very first step
-        st[1] = st[0];                                     // self.last = self.loss
+        st[0] = s;                                         // self.loss of the very first optimizer.step()
+        st[1] = s;                                         // self.last = self.loss
         st[8] = 0.0;
-        st[9] = 0.0;
-        st[10] = 0.0;
+        st[11] = 1.0;
         flags[0] = 0;
-    }
-}
-
-__global__ __launch_bounds__(64) void control_trial_kernel(const double* __restrict__ part, int nblk,
-                                                            double* __restrict__ st, int* flags, TRParams tr) {
-    double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) { s += part[2 * i]; q += part[2 * i + 1]; }
-    s = wave_sum(s);
-    q = wave_sum(q);
-    if (threadIdx.x == 0) {
-        if (flags[0] != 0) { st[10] = 1.0; st[9] = 0.0; return; }     // solver failed: PyPose breaks the step
-        const double last = st[1];
-        st[6] = s;
-        st[7] = -q;
-        const double quality = (last - s) / (-q);
-        st[5] = quality;
-        double radius = 1.0 / st[2], down = st[4];
-        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
-        else if (quality > tr.low) { down = tr.down; }
-        else { radius = radius * down; down = down * tr.factor; }
-        down = fmax(tr.rmin, fmin(down, tr.rmax));
-        radius = fmax(tr.rmin, fmin(radius, tr.rmax));
-        st[3] = radius; st[4] = down; st[2] = 1.0 / radius;
-        if (last < s && st[8] < (double)tr.reject) {       // reject: undo, loss = last
-            st[0] = last;
-            st[8] += 1.0;
-            st[9] = 0.0;
-        } else {
-            st[0] = s;
-            st[9] = 1.0;
-        }
     }
 }
 
@@ -639,30 +734,43 @@ __global__ __launch_bounds__(64) void align_kernel(const double* __restrict__ no
 // ------------------------------------------------------------------------------------------
 // host side
 struct LevelPlan { int n, m, P, nsep; };
+constexpr int MAXL = ISLAM_PVGO_MAX_LEVELS;
 
-int plan_levels(int N, const int seg_len[2], LevelPlan out[3]) {
-    // level sizes: a level with n <= 40 nodes (or the third level) is solved by a single wavefront
-    int nl = 0;
-    int n = N;
-    for (int l = 0; l < 3; ++l) {
-        LevelPlan L;
-        L.n = n;
-        bool single = (l == 2) || n <= 40;
-        if (!single) {
-            int m = (seg_len && l < 2 && seg_len[l] > 0) ? std::max(seg_len[l], 4) : 0;
-            if (m <= 0) {
-                // balance the dependent chains: m_l + (rest) ; ~cube root split for two cuts, sqrt for the last
-                if (l == 0) m = std::max(4, (int)std::lround(std::cbrt((double)n) * 1.15));
-                else m = std::max(4, (int)std::lround(std::sqrt((double)n)));
-            }
-            if (m + 1 >= n) single = true;
-            else { L.m = m; L.P = (n + m) / (m + 1); L.nsep = n / (m + 1); }
+// Level sizes.  The critical path is (sum of segment lengths + last level) dependent node steps plus two launches
+// per extra level, so many short levels beat few long ones: with t_node ~ 1.4 (eliminate + back-substitute, us) and
+// ~1.8 us per launch boundary the optimum at N=5001 is 5 levels of 4-5 nodes.  seg_len[0..1] > 0 pin the segment
+// length of the first two levels (tests, tuning); every other level uses the uniform length of the best depth.
+int plan_levels(int N, const int seg_len[2], LevelPlan out[MAXL]) {
+    const double t_node = 1.4, t_launch = 1.8;
+    auto build = [&](int m_auto, int depth, LevelPlan* o, double* cost) {
+        int nl = 0, n = N;
+        double c = 0.0;
+        for (int l = 0; l < MAXL; ++l) {
+            LevelPlan L;
+            L.n = n;
+            int m = (seg_len && l < 2 && seg_len[l] > 0) ? std::max(seg_len[l], 4) : m_auto;
+            const bool single = (l == MAXL - 1) || (l >= depth - 1) || (m + 1 >= n) || n <= 12;
+            if (single) { L.m = n; L.P = 1; L.nsep = 0; o[nl++] = L; c += n * t_node + t_launch; break; }
+            L.m = m; L.P = (n + m) / (m + 1); L.nsep = n / (m + 1);
+            o[nl++] = L;
+            c += m * t_node + 2 * t_launch;
+            n = L.nsep;
         }
-        if (single) { L.m = n; L.P = 1; L.nsep = 0; out[nl++] = L; break; }
-        out[nl++] = L;
-        n = L.nsep;
+        *cost = c;
+        return nl;
+    };
+    LevelPlan best[MAXL];
+    int best_nl = 0;
+    double best_cost = 1e300;
+    for (int depth = 1; depth <= MAXL; ++depth) {
+        const int m = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
+        LevelPlan cand[MAXL];
+        double cost;
+        const int nl = build(m, depth, cand, &cost);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_nl = nl; for (int i = 0; i < nl; ++i) best[i] = cand[i]; }
     }
-    return nl;
+    for (int i = 0; i < best_nl; ++i) out[i] = best[i];
+    return best_nl;
 }
 
 struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x; };
@@ -670,11 +778,11 @@ struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill,
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
     int* flags;
-    LevelBufs lv[3];
+    LevelBufs lv[MAXL];
     size_t bytes;
 };
 
-// carve the workspace; sizes use worst-case level shapes (level l has at most N / 5^l nodes)
+// carve the workspace; sizes use worst-case level shapes (segment length >= 4: level l has at most N / 5^l + 2 nodes)
 Workspace carve(void* base, int N) {
     Workspace w;
     char* p = (char*)base;
@@ -693,7 +801,7 @@ Workspace carve(void* base, int N) {
     w.state = take(16);
     w.flags = (int*)take(2);
     int n = N;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < MAXL; ++l) {
         LevelBufs& b = w.lv[l];
         int segs = n / 5 + 2;     // m >= 4 -> stride >= 5
         b.fac = take((size_t)n * FAC);
@@ -716,7 +824,7 @@ Workspace carve(void* base, int N) {
 int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
                   double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
                   int* nev = nullptr) {
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
     int ne = 0;
     if (evs) (void)hipEventRecord(evs[ne++], s);
@@ -820,7 +928,7 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_solve_chain_timed: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
-    hipEvent_t evs[8];
+    hipEvent_t evs[2 * MAXL + 2];
     for (auto& e : evs) ISLAM_HIP_CHECK(hipEventCreate(&e));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
     int ne = 0;
@@ -829,9 +937,9 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i + 1 < ne; ++i) ISLAM_HIP_CHECK(hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
     for (auto& e : evs) (void)hipEventDestroy(e);
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < MAXL; ++l) {
         plan_out[3 * l] = l < nl ? plan[l].n : 0;
         plan_out[3 * l + 1] = l < nl ? plan[l].m : 0;
         plan_out[3 * l + 2] = l < nl ? plan[l].P : 0;
@@ -845,9 +953,9 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
 // buffer), levels >= 1 are solved redundantly by every rank, the back-substitution is local again.
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9) {
     if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_plan: N=%d < 1", N);
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < MAXL; ++l) {
         plan9[3 * l] = l < nl ? plan[l].n : 0;
         plan9[3 * l + 1] = l < nl ? plan[l].m : 0;
         plan9[3 * l + 2] = l < nl ? plan[l].P : 0;
@@ -866,7 +974,7 @@ static void products_view(double* base, int P, LevelBufs& b) {
 int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
                                int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
                                void* stream) {
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: N=%d is a single-level problem, nothing to shard", N);
     if (seg0 < 0 || nseg < 1 || seg0 + nseg > plan[0].P) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: bad segment range");
@@ -889,7 +997,7 @@ int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, 
 // Levels >= 1 from the (summed) level-0 products -> x1 (plan[1].n x 9), the solution at the level-0 separators.
 int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
                              double* x1, int* flags, void* stream) {
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: single-level problem");
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: workspace too small");
@@ -923,7 +1031,7 @@ int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2]
 // Back-substitution of the local level-0 segments; dx is a LOCAL array (element 0 = global node `node0`).
 int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
                              int seg0, int nseg, double* dx, void* stream) {
-    LevelPlan plan[3];
+    LevelPlan plan[MAXL];
     const int nl = plan_levels(N, seg_len, plan);
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
     hipLaunchKernelGGL(bt_backsub_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
@@ -939,7 +1047,8 @@ int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, 
                      double* vels_t, double* part, void* stream) {
     if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
     hipLaunchKernelGGL(trial_kernel, dim3((M + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
-                       dvels, dts, lin, M, nodes_t, vels_t, part);
+                       dvels, dts, lin, M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{},
+                       (double*)nullptr, 0.0);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -991,14 +1100,22 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
     const int M = N - 1, nblk = (M + 63) / 64;
+    // status block in pinned, device-visible host memory: the deciding block of trial_kernel writes it, the host polls
+    // its sequence number (no stream synchronisation, no copy on the critical path)
     static thread_local double* host_state = nullptr;
-    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 16 * sizeof(double), hipHostMallocDefault));
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 16 * sizeof(double), hipHostMallocMapped));
+    double* report = nullptr;
+    ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
+    volatile double* hs = host_state;
+    hs[15] = 0.0;
 
     double init[16] = {0};
     init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
     init[3] = prm->radius;
     init[4] = prm->down;
     ISLAM_HIP_CHECK(hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));       // flags[0] solver error, flags[2] ticket
+    unsigned* ticket = reinterpret_cast<unsigned*>(w.flags + 2);
     TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject};
 
     double* cur_n = nodes;  double* cur_v = vels;      // current iterate (caller's buffers)
@@ -1012,36 +1129,46 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
                            w.lin, w.loss_part);
         hipLaunchKernelGGL(build_normal_kernel, dim3((N + 63) / 64), dim3(64), 0, s, w.lin, dts, N, prm->w[0], prm->w[1],
                            prm->w[2], prm->w[3], prm->vmin, prm->vmax, w.Hd, w.Ho, w.rhs);
-        hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nblk, w.state, w.flags);
+        if (steps == 0) hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nblk, w.state, w.flags);
         int reject_count = 0;
         double last = 0.0;
         bool broke = false;
         for (;;) {           // while self.last <= self.loss
             int rc = enqueue_solve(w, w.Hd, w.Ho, w.rhs, w.state, 0.0, N, prm->seg_len, w.dx, s);
             if (rc != ISLAM_OK) return rc;
+            const double seq = (double)(trials + 1);
             hipLaunchKernelGGL(trial_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
-                               dts, w.lin, M, tri_n, tri_v, w.part);
-            hipLaunchKernelGGL(control_trial_kernel, dim3(1), dim3(64), 0, s, w.part, nblk, w.state, w.flags, tr);
+                               dts, w.lin, M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq);
             ISLAM_LAUNCH_CHECK();
-            ISLAM_HIP_CHECK(hipMemcpyAsync(host_state, w.state, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
-            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+            // wait for the decision (poll the pinned status block; fall back to a stream sync after ~2 s)
+            {
+                unsigned long spins = 0;
+                while (hs[15] != seq) {
+                    if (++spins > 400000000ul) {
+                        ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                        if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: no status from the device (trial %d)", trials + 1);
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
             ++trials;
-            last = host_state[1];
-            damping = host_state[2];
-            if (host_state[10] != 0.0) {      // "Linear solver failed. Breaking optimization step..."
+            last = hs[1];
+            damping = hs[2];
+            if (hs[10] != 0.0) {      // "Linear solver failed. Breaking optimization step..."
                 status = ISLAM_ENOTPD;
-                loss = host_state[0];
+                loss = hs[0];
+                reject_count = (int)hs[8];
                 broke = true;
                 break;
             }
-            const bool accepted = host_state[9] != 0.0;
+            const bool accepted = hs[9] != 0.0;
             if (trace && trials <= trace_cap) {
-                trace[3 * (trials - 1)] = host_state[6];
+                trace[3 * (trials - 1)] = hs[6];
                 trace[3 * (trials - 1) + 1] = damping;
                 trace[3 * (trials - 1) + 2] = accepted ? 1.0 : 0.0;
             }
-            loss = host_state[0];
-            reject_count = (int)host_state[8];
+            loss = hs[0];
+            reject_count = (int)hs[8];
             if (accepted) { std::swap(cur_n, tri_n); std::swap(cur_v, tri_v); break; }
         }
         ++steps;

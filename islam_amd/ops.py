@@ -194,12 +194,12 @@ def pvgo_solve_chain_timed(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None)
     ws, nbytes = workspace
     dx = torch.empty((N, 9), dtype=torch.float64, device=Hd.device)
     sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
-    ms = (c_float * 8)()
-    plan = (c_int * 9)()
+    ms = (c_float * 16)()
+    plan = (c_int * (3 * _lib.MAX_LEVELS))()
     nl = c_int(0)
     check(lib().islam_pvgo_solve_chain_timed(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, ptr(ws), c_size_t(nbytes),
                                              ptr(dx), ms, plan, ctypes.byref(nl), stream_ptr(Hd.device)))
-    levels = [(plan[3 * l], plan[3 * l + 1], plan[3 * l + 2]) for l in range(3) if plan[3 * l] > 0]
+    levels = [(plan[3 * l], plan[3 * l + 1], plan[3 * l + 2]) for l in range(_lib.MAX_LEVELS) if plan[3 * l] > 0]
     return dx, [ms[i] for i in range(nl.value)], levels
 
 

@@ -8,24 +8,35 @@ import torch
 from oracle import pvgo as opvgo
 
 
+MAXL = 6
+
+
 def plan_levels(N, seg_len=(0, 0)):
-    """Mirror of plan_levels() in islam_amd/csrc/pvgo.hip."""
-    out, n = [], N
-    for l in range(3):
-        single = (l == 2) or n <= 40
-        m = 0
-        if not single:
-            m = max(seg_len[l], 4) if (l < 2 and seg_len[l] > 0) else 0
-            if m <= 0:
-                m = max(4, int(round(np.cbrt(n) * 1.15))) if l == 0 else max(4, int(round(np.sqrt(n))))
-            if m + 1 >= n:
-                single = True
-        if single:
-            out.append((n, n, 1))
-            break
-        out.append((n, m, (n + m) // (m + 1)))
-        n = n // (m + 1)
-    return out
+    """Mirror of plan_levels() in islam_amd/csrc/pvgo.hip (same arithmetic, same tie-breaking)."""
+    import math
+    t_node, t_launch = 1.4, 1.8
+
+    def build(m_auto, depth):
+        out, n, c = [], N, 0.0
+        for l in range(MAXL):
+            m = max(seg_len[l], 4) if (l < 2 and seg_len[l] > 0) else m_auto
+            single = (l == MAXL - 1) or (l >= depth - 1) or (m + 1 >= n) or n <= 12
+            if single:
+                out.append((n, n, 1))
+                c += n * t_node + t_launch
+                break
+            out.append((n, m, (n + m) // (m + 1)))
+            c += m * t_node + 2 * t_launch
+            n = n // (m + 1)
+        return out, c
+
+    best, best_cost = None, 1e300
+    for depth in range(1, MAXL + 1):
+        m = max(4, int(math.ceil(math.pow(float(N), 1.0 / depth))) - 1)
+        cand, cost = build(m, depth)
+        if cost < best_cost - 1e-9:
+            best, best_cost = cand, cost
+    return best
 
 
 class NumpyBackend:

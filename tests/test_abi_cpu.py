@@ -67,7 +67,7 @@ def test_level_plan_matches_python_mirror(lib):
     for N in (1, 2, 9, 40, 41, 64, 100, 257, 1000, 5001, 20000):
         for seg in ((0, 0), (4, 4), (19, 15), (7, 0), (2, 3)):
             sl = (ctypes.c_int * 2)(*seg)
-            out = (ctypes.c_int * 9)()
+            out = (ctypes.c_int * 18)()
             nl = lib.islam_pvgo_plan(N, sl, out)
             got = [(out[3 * l], out[3 * l + 1], out[3 * l + 2]) for l in range(nl)]
             assert got == plan_levels(N, seg), (N, seg)
@@ -75,7 +75,7 @@ def test_level_plan_matches_python_mirror(lib):
             for (nn, m, P) in got[:-1]:
                 assert nn == n and m >= 4 and P == -(-n // (m + 1))
                 n = n // (m + 1)
-            assert got[-1] == (n, n, 1)
+            assert got[-1] == (n, n, 1) and len(got) <= 6
 
 
 def test_product_never_touches_the_oracle():
