@@ -168,12 +168,9 @@ def main():
         for i in range(reps + 3):
             _, ms, levels = ops.pvgo_solve_chain_timed(Hd.clone(), Ho, rhs, 1e-4, workspace=ws2)
             if i >= 3:
-                acc_ms = ms if acc_ms is None else [a + b for a, b in zip(acc_ms, ms)]
-        ms = [a / reps for a in acc_ms]
-        nl = len(levels)
-        names = ['eliminate_L%d' % l for l in range(nl)] + ['backsub_L%d' % l for l in range(nl - 2, -1, -1)]
-        kern = dict(zip(names, [round(x * 1e3, 2) for x in ms]))      # microseconds
-        elim0_s = ms[0] * 1e-3
+                acc_ms = dict(ms) if acc_ms is None else {k: acc_ms[k] + ms[k] for k in ms}
+        kern = {k: round(v / reps * 1e3, 2) for k, v in acc_ms.items()}      # microseconds per launch
+        elim0_s = kern['eliminate_L0'] * 1e-6
         alg_bytes = ELIM_BYTES_PER_NODE * N
         achieved = alg_bytes / elim0_s / 1e9
         roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

@@ -140,12 +140,14 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
                            const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
 /* Profiling variant: HIP events around every launch of one solve (on `stream`).  ms[i] = duration of launch i
  * (eliminate level 0..L-1, then back-substitution L-2..0; at most 2*ISLAM_PVGO_MAX_LEVELS-1 entries),
- * plan[3*l..] = (nodes, segment length, segments) for l < ISLAM_PVGO_MAX_LEVELS. */
+ * plan[3*l..] = (nodes, segment length, segments) for l < ISLAM_PVGO_MAX_LEVELS, plan[3*ISLAM_PVGO_MAX_LEVELS] = first
+ * level solved inside the single-workgroup top kernel (3*ISLAM_PVGO_MAX_LEVELS+1 ints). */
 int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                                  const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx,
                                  float* ms, int* plan, int* nlaunch, void* stream);
 /* ---- multi-GPU building blocks (islam_amd/dist_pvgo.py; no reference counterpart: the reference is single-GPU).
- * plan9 receives (nodes, segment length, segments) for ISLAM_PVGO_MAX_LEVELS levels (unused = 0); returns the level count. */
+ * plan9 (3*ISLAM_PVGO_MAX_LEVELS+1 ints) receives (nodes, segment length, segments) per level (unused = 0) and, last,
+ * the first level that runs inside the single-workgroup top kernel; returns the level count. */
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9);
 /* Eliminate level-0 segments [seg0, seg0+nseg) of an N-node chain.  Hd/Ho/rhs/fac/inv are LOCAL arrays whose row 0 is
  * global node `node0`.  products: 351*P0 doubles, array-major (Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P |

@@ -365,13 +365,14 @@ __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, 
 }
 
 // One wavefront per segment: eliminate the segment's interior nodes onto its two separators (LDL^T, no square roots).
-__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
-                                                           int solve_here) {
-    __shared__ __attribute__((aligned(16))) double Xa[19 * XS];     // X   = [U- | F- | y-]  (rows of L^-1 [U F^T g])
-    __shared__ __attribute__((aligned(16))) double Xb[19 * XS];     // D^-1 X
-    __shared__ __attribute__((aligned(16))) double Tn[19 * XS];     // X^T D^-1 X entries feeding the next node
-    const int lane = threadIdx.x;
-    const int p = blockIdx.x + seg0;
+// LDS per wave: Xa = [U- | F- | y-] (rows of L^-1 [U F^T g]), Xb = D^-1 Xa, Tn = Xa^T D^-1 Xa entries for the next node
+constexpr int LDS_PER_WAVE = 3 * 19 * XS;
+
+__device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
+                                                  int lane, double* __restrict__ lds) {
+    double* Xa = lds;
+    double* Xb = lds + 19 * XS;
+    double* Tn = lds + 2 * 19 * XS;
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -393,17 +394,20 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     double mcol[9], nb[9];
     RawCols raw;
     issue_cols(LS, level0, c0, raw);
+    // spike F^T: coupling (left separator rows, c0 cols) transposed; requested together with the first node's columns
+    // (every lane loads from a valid address, lanes outside 18..26 / segments without a left separator discard it)
+    double spike[9];
+    {
+        const int jj = (lane >= 18 && lane < 27) ? lane - 18 : 0;
+        const int cl = has_left ? c0 : 1;
+        const double* O = src.level0 ? (src.Ho + (size_t)(cl - 1) * 81) : (src.fill + (size_t)cl * 81);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) spike[r] = O[jj * 9 + r];
+    }
     combine_cols(LS, src, c0, n, lane, damping, raw, mcol);
-    if (lane >= 18 && lane < 27) {                      // spike F^T: coupling (left separator rows, c0 cols) transposed
-        if (has_left) {
-            const int jj = lane - 18;
-            const double* O = src.level0 ? (src.Ho + (size_t)(c0 - 1) * 81) : (src.fill + (size_t)c0 * 81);
+    if (lane >= 18 && lane < 27) {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) mcol[r] = O[jj * 9 + r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) mcol[r] = 0.0;
-        }
+        for (int r = 0; r < 9; ++r) mcol[r] = has_left ? spike[r] : 0.0;
     }
     double accL = 0.0;
     int bad = 0;
@@ -509,22 +513,17 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
         }
     }
     if (bad && lane == 0) atomicOr(flags, 1);
-
-    if (solve_here) {              // single segment: the whole level is factored, solve it here
-        __syncthreads();
-        double xn[9], xL[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
-        backsub_segment(dst.fac, dst.inv, dst.x, 0, n, lane, xn, xL);
-    }
 }
 
-// expand the solution of the separators (xsep, from the next level) into this level's interior nodes
-__global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
-                                                         const double* __restrict__ xsep, double* __restrict__ x, int n,
-                                                         int m, int seg0) {
-    const int lane = threadIdx.x;
-    const int p = blockIdx.x + seg0;
+// one wavefront per workgroup, one segment per workgroup (the large levels)
+__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_PER_WAVE];
+    eliminate_segment(src, dst, n, m, blockIdx.x + seg0, flags, threadIdx.x, lds);
+}
+
+__device__ __forceinline__ void backsub_level_segment(const double* __restrict__ fac, const double* __restrict__ inv,
+                                                      const double* __restrict__ xsep, double* __restrict__ x, int n, int m,
+                                                      int p, int lane) {
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -539,6 +538,44 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
     }
     if (has_right && lane < 9) x[(size_t)sR * 9 + lane] = xsep[(size_t)p * 9 + lane];
     backsub_segment(fac, inv, x, c0, cnt, lane, xn, xL);
+}
+
+// The small top of the level tree in ONE launch: a single workgroup of up to 8 wavefronts runs every remaining level
+// (wave w = segment w), separated by workgroup barriers instead of kernel boundaries: up-sweep, root solve, down-sweep.
+constexpr int MAXTOP = 4;
+struct TopArgs {
+    LevelSrc src[MAXTOP];
+    LevelDst dst[MAXTOP];
+    int n[MAXTOP], m[MAXTOP], P[MAXTOP];
+    int nl;
+};
+
+__global__ __launch_bounds__(512) void bt_top_kernel(TopArgs a, int* flags) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* lds = lds_all + wave * LDS_PER_WAVE;
+    for (int l = 0; l < a.nl; ++l) {
+        if (wave < a.P[l]) eliminate_segment(a.src[l], a.dst[l], a.n[l], a.m[l], wave, flags, lane, lds);
+        __syncthreads();                       // the level's products are visible to the whole workgroup
+    }
+    const int top = a.nl - 1;                  // P[top] == 1: the root level is fully factored by wave 0
+    if (wave == 0) {
+        double xn[9], xL[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
+        backsub_segment(a.dst[top].fac, a.dst[top].inv, a.dst[top].x, 0, a.n[top], lane, xn, xL);
+    }
+    for (int l = top - 1; l >= 0; --l) {
+        __syncthreads();
+        if (wave < a.P[l]) backsub_level_segment(a.dst[l].fac, a.dst[l].inv, a.dst[l + 1].x, a.dst[l].x, a.n[l], a.m[l], wave, lane);
+    }
+}
+
+// expand the solution of the separators (xsep, from the next level) into this level's interior nodes
+__global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
+                                                         const double* __restrict__ xsep, double* __restrict__ x, int n,
+                                                         int m, int seg0) {
+    backsub_level_segment(fac, inv, xsep, x, n, m, blockIdx.x + seg0, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -735,42 +772,41 @@ __global__ __launch_bounds__(64) void align_kernel(const double* __restrict__ no
 // host side
 struct LevelPlan { int n, m, P, nsep; };
 constexpr int MAXL = ISLAM_PVGO_MAX_LEVELS;
+constexpr int TOPW = 1;                        // wavefronts of the top kernel's workgroup (see plan_levels)
+struct SolvePlan { LevelPlan lv[MAXL]; int nl; int top; };   // levels >= top run inside bt_top_kernel
 
-// Level sizes.  The critical path is (sum of segment lengths + last level) dependent node steps plus two launches
-// per extra level, so many short levels beat few long ones: with t_node ~ 1.4 (eliminate + back-substitute, us) and
-// ~1.8 us per launch boundary the optimum at N=5001 is 5 levels of 4-5 nodes.  seg_len[0..1] > 0 pin the segment
-// length of the first two levels (tests, tuning); every other level uses the uniform length of the best depth.
-int plan_levels(int N, const int seg_len[2], LevelPlan out[MAXL]) {
-    const double t_node = 1.4, t_launch = 1.8;
-    auto build = [&](int m_auto, int depth, LevelPlan* o, double* cost) {
-        int nl = 0, n = N;
-        double c = 0.0;
+// Level tree.  The critical path is a chain of dependent node steps (~2.3 us each: eliminate + back-substitute) plus
+// ~4 us per level boundary (launch + the first dependent loads of data another CU just wrote), so many short levels
+// beat few long ones: the optimum at N=5001 is 5 levels of 4-5 nodes.  A level that fits TOPW segments could run with
+// the rest of the tree inside ONE workgroup (bt_top_kernel); measured on MI355X this only pays for the root level
+// (the inter-level latency is memory round trips, not launch overhead), hence TOPW = 1.
+// seg_len[0..1] > 0 pin the segment length of levels 0 / 1 (tests, tuning).
+int plan_levels(int N, const int seg_len[2], SolvePlan& best) {
+    const double t_node = 2.3, t_launch = 4.0;
+    double best_cost = 1e300;
+    best.nl = 0;
+    for (int depth = 1; depth <= MAXL; ++depth) {
+        const int m_auto = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
+        SolvePlan c;
+        c.nl = 0;
+        int n = N;
         for (int l = 0; l < MAXL; ++l) {
             LevelPlan L;
             L.n = n;
-            int m = (seg_len && l < 2 && seg_len[l] > 0) ? std::max(seg_len[l], 4) : m_auto;
-            const bool single = (l == MAXL - 1) || (l >= depth - 1) || (m + 1 >= n) || n <= 12;
-            if (single) { L.m = n; L.P = 1; L.nsep = 0; o[nl++] = L; c += n * t_node + t_launch; break; }
+            int m = m_auto;
+            if (seg_len && l < 2 && seg_len[l] > 0) m = std::max(seg_len[l], 4);
+            if (l == MAXL - 1 || l >= depth - 1 || m + 1 >= n || n <= 12) { L.m = n; L.P = 1; L.nsep = 0; c.lv[c.nl++] = L; break; }
             L.m = m; L.P = (n + m) / (m + 1); L.nsep = n / (m + 1);
-            o[nl++] = L;
-            c += m * t_node + 2 * t_launch;
+            c.lv[c.nl++] = L;
             n = L.nsep;
         }
-        *cost = c;
-        return nl;
-    };
-    LevelPlan best[MAXL];
-    int best_nl = 0;
-    double best_cost = 1e300;
-    for (int depth = 1; depth <= MAXL; ++depth) {
-        const int m = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
-        LevelPlan cand[MAXL];
-        double cost;
-        const int nl = build(m, depth, cand, &cost);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best_nl = nl; for (int i = 0; i < nl; ++i) best[i] = cand[i]; }
+        c.top = c.nl - 1;
+        while (c.top > 0 && c.lv[c.top - 1].P <= TOPW && (c.nl - (c.top - 1)) <= MAXTOP) --c.top;
+        double cost = t_launch;
+        for (int l = 0; l < c.nl; ++l) cost += c.lv[l].m * t_node + (l < c.top ? 2 * t_launch : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
     }
-    for (int i = 0; i < best_nl; ++i) out[i] = best[i];
-    return best_nl;
+    return best.nl;
 }
 
 struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x; };
@@ -820,42 +856,76 @@ Workspace carve(void* base, int N) {
     return w;
 }
 
-// enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
-int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
-                  double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
-                  int* nev = nullptr) {
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+static LevelDst level_dst(const LevelBufs& b, double* x) {
+    LevelDst d{};
+    d.fac = b.fac; d.inv = b.inv; d.Dsep = b.Dsep; d.rsep = b.rsep; d.cL = b.cL; d.cR = b.cR; d.cgL = b.cgL; d.cgR = b.cgR;
+    d.fill = b.fill; d.x = x;
+    return d;
+}
+static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
+    LevelSrc s{};
+    s.level0 = 0; s.Dsep = pb.Dsep; s.rsep = pb.rsep; s.cL = pb.cL; s.cR = pb.cR; s.cgL = pb.cgL; s.cgR = pb.cgR;
+    s.fill = pb.fill; s.Pprev = Pprev;
+    return s;
+}
+
+// Enqueue levels [lbegin, nl): `first` describes the source of level lbegin (level-0 arrays, or the level-0 products when
+// lbegin == 1), xout receives the solution of level lbegin.  Big levels: one launch each way; levels >= sp.top: one launch.
+int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const LevelSrc& first, const LevelBufs* first_prev,
+                   double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev) {
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)bt_top_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            TOPW * LDS_PER_WAVE * (int)sizeof(double)));
+        lds_attr_set = true;
+    }
+    const int nl = sp.nl, top = std::max(sp.top, lbegin);
     int ne = 0;
     if (evs) (void)hipEventRecord(evs[ne++], s);
-    for (int l = 0; l < nl; ++l) {
-        LevelSrc src{};
-        LevelDst dst{};
-        if (l == 0) {
-            src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = state; src.damping_override = damping;
-        } else {
-            const LevelBufs& pb = w.lv[l - 1];
-            src.level0 = 0; src.Dsep = pb.Dsep; src.rsep = pb.rsep; src.cL = pb.cL; src.cR = pb.cR; src.cgL = pb.cgL;
-            src.cgR = pb.cgR; src.fill = pb.fill; src.Pprev = plan[l - 1].P;
-        }
-        const LevelBufs& b = w.lv[l];
-        dst.fac = b.fac; dst.inv = b.inv; dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR;
-        dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
-        dst.x = (l == 0) ? dx : b.x;
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, w.flags, 0,
-                           plan[l].P == 1 ? 1 : 0);
+    auto src_of = [&](int l) {
+        if (l == lbegin) return first;
+        const LevelBufs& pb = (l - 1 == lbegin - 1 && first_prev) ? *first_prev : w.lv[l - 1];
+        return level_src_from(pb, sp.lv[l - 1].P);
+    };
+    auto x_of = [&](int l) { return l == lbegin ? xout : w.lv[l].x; };
+    for (int l = lbegin; l < top; ++l) {
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(sp.lv[l].P), dim3(64), 0, s, src_of(l), level_dst(w.lv[l], x_of(l)),
+                           sp.lv[l].n, sp.lv[l].m, flags, 0);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
-    for (int l = nl - 2; l >= 0; --l) {
-        const LevelBufs& b = w.lv[l];
-        double* x = (l == 0) ? dx : b.x;
-        hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
-                           plan[l].m, 0);
+    {
+        TopArgs a{};
+        a.nl = nl - top;
+        int maxP = 1;
+        for (int i = 0; i < a.nl; ++i) {
+            const int l = top + i;
+            a.src[i] = src_of(l);
+            a.dst[i] = level_dst(w.lv[l], x_of(l));
+            a.n[i] = sp.lv[l].n; a.m[i] = sp.lv[l].m; a.P[i] = sp.lv[l].P;
+            maxP = std::max(maxP, sp.lv[l].P);
+        }
+        hipLaunchKernelGGL(bt_top_kernel, dim3(1), dim3(64 * maxP), maxP * LDS_PER_WAVE * sizeof(double), s, a, flags);
+        if (evs) (void)hipEventRecord(evs[ne++], s);
+    }
+    for (int l = top - 1; l >= lbegin; --l) {
+        hipLaunchKernelGGL(bt_backsub_kernel, dim3(sp.lv[l].P), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1), x_of(l),
+                           sp.lv[l].n, sp.lv[l].m, 0);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     if (nev) *nev = ne;
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+// enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
+int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
+                  double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
+                  int* nev = nullptr) {
+    SolvePlan sp;
+    plan_levels(N, seg_len, sp);
+    LevelSrc src{};
+    src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = state; src.damping_override = damping;
+    return enqueue_levels(w, sp, 0, src, nullptr, dx, w.flags, s, evs, nev);
 }
 
 }  // namespace
@@ -937,13 +1007,14 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i + 1 < ne; ++i) ISLAM_HIP_CHECK(hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
     for (auto& e : evs) (void)hipEventDestroy(e);
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
     for (int l = 0; l < MAXL; ++l) {
-        plan_out[3 * l] = l < nl ? plan[l].n : 0;
-        plan_out[3 * l + 1] = l < nl ? plan[l].m : 0;
-        plan_out[3 * l + 2] = l < nl ? plan[l].P : 0;
+        plan_out[3 * l] = l < nl ? sp.lv[l].n : 0;
+        plan_out[3 * l + 1] = l < nl ? sp.lv[l].m : 0;
+        plan_out[3 * l + 2] = l < nl ? sp.lv[l].P : 0;
     }
+    plan_out[3 * MAXL] = sp.top;
     *nlaunch = ne - 1;
     return ISLAM_OK;
 }
@@ -953,13 +1024,14 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
 // buffer), levels >= 1 are solved redundantly by every rank, the back-substitution is local again.
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9) {
     if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_plan: N=%d < 1", N);
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
     for (int l = 0; l < MAXL; ++l) {
-        plan9[3 * l] = l < nl ? plan[l].n : 0;
-        plan9[3 * l + 1] = l < nl ? plan[l].m : 0;
-        plan9[3 * l + 2] = l < nl ? plan[l].P : 0;
+        plan9[3 * l] = l < nl ? sp.lv[l].n : 0;
+        plan9[3 * l + 1] = l < nl ? sp.lv[l].m : 0;
+        plan9[3 * l + 2] = l < nl ? sp.lv[l].P : 0;
     }
+    plan9[3 * MAXL] = sp.top;
     return nl;
 }
 
@@ -974,8 +1046,9 @@ static void products_view(double* base, int P, LevelBufs& b) {
 int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
                                int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
                                void* stream) {
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
+    const LevelPlan* plan = sp.lv;
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: N=%d is a single-level problem, nothing to shard", N);
     if (seg0 < 0 || nseg < 1 || seg0 + nseg > plan[0].P) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: bad segment range");
     LevelSrc src{};
@@ -989,7 +1062,7 @@ int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, 
     dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
     dst.x = nullptr;
     hipLaunchKernelGGL(bt_eliminate_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m, flags,
-                       seg0, 0);
+                       seg0);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -997,42 +1070,22 @@ int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, 
 // Levels >= 1 from the (summed) level-0 products -> x1 (plan[1].n x 9), the solution at the level-0 separators.
 int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
                              double* x1, int* flags, void* stream) {
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: single-level problem");
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
-    hipStream_t s = as_stream(stream);
     LevelBufs pb{};
-    products_view(const_cast<double*>(products), plan[0].P, pb);
-    for (int l = 1; l < nl; ++l) {
-        LevelSrc src{};
-        LevelDst dst{};
-        const LevelBufs& prev = (l == 1) ? pb : w.lv[l - 1];
-        src.level0 = 0; src.Dsep = prev.Dsep; src.rsep = prev.rsep; src.cL = prev.cL; src.cR = prev.cR; src.cgL = prev.cgL;
-        src.cgR = prev.cgR; src.fill = prev.fill; src.Pprev = plan[l - 1].P;
-        const LevelBufs& b = w.lv[l];
-        dst.fac = b.fac; dst.inv = b.inv; dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL;
-        dst.cgR = b.cgR; dst.fill = b.fill;
-        dst.x = (l == 1) ? x1 : b.x;
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(plan[l].P), dim3(64), 0, s, src, dst, plan[l].n, plan[l].m, flags, 0,
-                           plan[l].P == 1 ? 1 : 0);
-    }
-    for (int l = nl - 2; l >= 1; --l) {
-        const LevelBufs& b = w.lv[l];
-        double* x = (l == 1) ? x1 : b.x;
-        hipLaunchKernelGGL(bt_backsub_kernel, dim3(plan[l].P), dim3(64), 0, s, b.fac, b.inv, w.lv[l + 1].x, x, plan[l].n,
-                           plan[l].m, 0);
-    }
-    ISLAM_LAUNCH_CHECK();
-    return ISLAM_OK;
+    products_view(const_cast<double*>(products), sp.lv[0].P, pb);
+    return enqueue_levels(w, sp, 1, level_src_from(pb, sp.lv[0].P), &pb, x1, flags, as_stream(stream), nullptr, nullptr);
 }
 
 // Back-substitution of the local level-0 segments; dx is a LOCAL array (element 0 = global node `node0`).
 int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
                              int seg0, int nseg, double* dx, void* stream) {
-    LevelPlan plan[MAXL];
-    const int nl = plan_levels(N, seg_len, plan);
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
+    const LevelPlan* plan = sp.lv;
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
     hipLaunchKernelGGL(bt_backsub_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
                        inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0);

@@ -58,7 +58,7 @@ class HipBackend:
         from ._lib import lib
         sl = (ctypes.c_int * 2)(int(seg_len[0]), int(seg_len[1]))
         from ._lib import MAX_LEVELS
-        p = (ctypes.c_int * (3 * MAX_LEVELS))()
+        p = (ctypes.c_int * (3 * MAX_LEVELS + 1))()
         nl = lib().islam_pvgo_plan(N, sl, p)
         return [(p[3 * l], p[3 * l + 1], p[3 * l + 2]) for l in range(nl)]
 

@@ -187,7 +187,7 @@ def pvgo_solve_chain(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
 
 
 def pvgo_solve_chain_timed(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
-    """One solve with HIP events around each launch.  Returns (dx, [ms per launch], [(n, m, P) per level])."""
+    """One solve with HIP events around each launch.  Returns (dx, {launch name: ms}, [(n, m, P) per level])."""
     N = Hd.shape[0]
     if workspace is None:
         workspace = pvgo_workspace(N, Hd.device)
@@ -195,12 +195,15 @@ def pvgo_solve_chain_timed(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None)
     dx = torch.empty((N, 9), dtype=torch.float64, device=Hd.device)
     sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
     ms = (c_float * 16)()
-    plan = (c_int * (3 * _lib.MAX_LEVELS))()
+    plan = (c_int * (3 * _lib.MAX_LEVELS + 1))()
     nl = c_int(0)
     check(lib().islam_pvgo_solve_chain_timed(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, ptr(ws), c_size_t(nbytes),
                                              ptr(dx), ms, plan, ctypes.byref(nl), stream_ptr(Hd.device)))
     levels = [(plan[3 * l], plan[3 * l + 1], plan[3 * l + 2]) for l in range(_lib.MAX_LEVELS) if plan[3 * l] > 0]
-    return dx, [ms[i] for i in range(nl.value)], levels
+    top = plan[3 * _lib.MAX_LEVELS]
+    names = ['eliminate_L%d' % l for l in range(top)] + ['top_L%d-%d' % (top, len(levels) - 1)] + \
+        ['backsub_L%d' % l for l in range(top - 1, -1, -1)]
+    return dx, dict(zip(names, [ms[i] for i in range(nl.value)])), levels
 
 
 def pvgo_retract(nodes, vels, dx, sign=1.0):

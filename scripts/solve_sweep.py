@@ -18,8 +18,8 @@ for seg in [(4, 0), (8, 0), (16, 0), (32, 0), (64, 0), (128, 0), (0, 0)]:
     acc = None
     for i in range(23):
         _, ms, lv = ops.pvgo_solve_chain_timed(Hd_d.clone(), Ho_d, rhs, 1e-4, seg_len=seg, workspace=ws)
-        if i >= 3: acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
-    us = [round(a / 20 * 1e3, 1) for a in acc]
+        if i >= 3: acc = dict(ms) if acc is None else {k: acc[k] + ms[k] for k in ms}
+    us = {k: round(a / 20 * 1e3, 1) for k, a in acc.items()}
     # whole-solve wall time without per-launch events
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,4 +27,4 @@ for seg in [(4, 0), (8, 0), (16, 0), (32, 0), (64, 0), (128, 0), (0, 0)]:
     e0.record()
     for i in range(20): ops.pvgo_solve_chain(H2[i], Ho_d, rhs, 1e-4, seg_len=seg, workspace=ws)
     e1.record(); torch.cuda.synchronize()
-    print(seg, lv, 'per-launch us', us, 'sum', round(sum(us), 1), 'solve wall us (incl. sync+flag copy)', round(e0.elapsed_time(e1) / 20 * 1e3, 1))
+    print(seg, lv, 'per-launch us', us, 'sum', round(sum(us.values()), 1), 'solve wall us (incl. sync+flag copy)', round(e0.elapsed_time(e1) / 20 * 1e3, 1))

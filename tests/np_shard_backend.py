@@ -8,35 +8,35 @@ import torch
 from oracle import pvgo as opvgo
 
 
-MAXL = 6
+MAXL, TOPW, MAXTOP = 6, 1, 4
 
 
-def plan_levels(N, seg_len=(0, 0)):
+def plan_levels(N, seg_len=(0, 0), with_top=False):
     """Mirror of plan_levels() in islam_amd/csrc/pvgo.hip (same arithmetic, same tie-breaking)."""
     import math
-    t_node, t_launch = 1.4, 1.8
-
-    def build(m_auto, depth):
-        out, n, c = [], N, 0.0
-        for l in range(MAXL):
-            m = max(seg_len[l], 4) if (l < 2 and seg_len[l] > 0) else m_auto
-            single = (l == MAXL - 1) or (l >= depth - 1) or (m + 1 >= n) or n <= 12
-            if single:
-                out.append((n, n, 1))
-                c += n * t_node + t_launch
-                break
-            out.append((n, m, (n + m) // (m + 1)))
-            c += m * t_node + 2 * t_launch
-            n = n // (m + 1)
-        return out, c
-
-    best, best_cost = None, 1e300
+    t_node, t_launch = 2.3, 4.0
+    best, best_cost, best_top = None, 1e300, 0
     for depth in range(1, MAXL + 1):
-        m = max(4, int(math.ceil(math.pow(float(N), 1.0 / depth))) - 1)
-        cand, cost = build(m, depth)
+        m_auto = max(4, int(math.ceil(math.pow(float(N), 1.0 / depth))) - 1)
+        lv, n = [], N
+        for l in range(MAXL):
+            m = m_auto
+            if l < 2 and seg_len[l] > 0:
+                m = max(seg_len[l], 4)
+            if l == MAXL - 1 or l >= depth - 1 or m + 1 >= n or n <= 12:
+                lv.append((n, n, 1))
+                break
+            lv.append((n, m, (n + m) // (m + 1)))
+            n = n // (m + 1)
+        top = len(lv) - 1
+        while top > 0 and lv[top - 1][2] <= TOPW and (len(lv) - (top - 1)) <= MAXTOP:
+            top -= 1
+        cost = t_launch
+        for l, (_, m, _) in enumerate(lv):
+            cost += m * t_node + (2 * t_launch if l < top else 0.0)
         if cost < best_cost - 1e-9:
-            best, best_cost = cand, cost
-    return best
+            best, best_cost, best_top = lv, cost, top
+    return (best, best_top) if with_top else best
 
 
 class NumpyBackend:

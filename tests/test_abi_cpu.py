@@ -67,10 +67,11 @@ def test_level_plan_matches_python_mirror(lib):
     for N in (1, 2, 9, 40, 41, 64, 100, 257, 1000, 5001, 20000):
         for seg in ((0, 0), (4, 4), (19, 15), (7, 0), (2, 3)):
             sl = (ctypes.c_int * 2)(*seg)
-            out = (ctypes.c_int * 18)()
+            out = (ctypes.c_int * 19)()
             nl = lib.islam_pvgo_plan(N, sl, out)
             got = [(out[3 * l], out[3 * l + 1], out[3 * l + 2]) for l in range(nl)]
-            assert got == plan_levels(N, seg), (N, seg)
+            ref, top = plan_levels(N, seg, with_top=True)
+            assert got == ref and out[18] == top, (N, seg)
             n = N
             for (nn, m, P) in got[:-1]:
                 assert nn == n and m >= 4 and P == -(-n // (m + 1))
