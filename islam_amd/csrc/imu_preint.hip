@@ -149,16 +149,45 @@ __global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, cons
 }
 
 // B: sequential rotation chain over frames.  R0[i] = rotation at the start of frame i, R0[nframes] = final.
+// The products must be taken strictly left to right (bit-exact contract), so one lane walks the chain; the other
+// lanes of the workgroup stream the per-frame increments into LDS ahead of it and the results back out, so the
+// walking lane never waits on HBM (5000 frames: 1.7 ms with per-step global loads -> ~0.1 ms).
+constexpr int CHAIN_CHUNK = 512;
+
 template <class T>
-__global__ void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
-                                 const T* __restrict__ init_rot, T* __restrict__ R0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Q<T> r = ldq(init_rot);
-    stq(r, R0);
-    for (int i = 0; i < nframes; ++i) {
-        const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
-        if (F > 0) r = qmul(r, ldq(ir + 4 * ((size_t)a + i + F)));
-        stq(r, R0 + 4 * (size_t)(i + 1));
+__global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                                         const T* __restrict__ init_rot, T* __restrict__ R0) {
+    __shared__ T dq[CHAIN_CHUNK][4];       // per-frame increment incre_r_i[F_i]
+    __shared__ T out[CHAIN_CHUNK][4];      // R0[i+1]
+    __shared__ int has[CHAIN_CHUNK];       // F_i > 0
+    __shared__ T carry[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        Q<T> r = ldq(init_rot);
+        stq(r, carry);
+        stq(r, R0);
+    }
+    for (int base = 0; base < nframes; base += CHAIN_CHUNK) {
+        const int cnt = min(CHAIN_CHUNK, nframes - base);
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 256) {
+            const int i = base + j;
+            const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+            has[j] = F > 0;
+            const T* src = ir + 4 * ((size_t)a + i + F);
+            dq[j][0] = src[0]; dq[j][1] = src[1]; dq[j][2] = src[2]; dq[j][3] = src[3];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Q<T> r = ldq(carry);
+            for (int j = 0; j < cnt; ++j) {
+                if (has[j]) r = qmul(r, ldq(dq[j]));
+                stq(r, out[j]);
+            }
+            stq(r, carry);
+        }
+        __syncthreads();
+        for (int j = tid; j < cnt * 4; j += 256) R0[4 * (size_t)(base + 1) + j] = (&out[0][0])[j];
     }
 }
 
@@ -224,26 +253,49 @@ __global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, cons
         stq(qmul(ai, b), out_rot + 4 * (size_t)i);
         return;
     }
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    T p[3] = {init_pos[0], init_pos[1], init_pos[2]}, v[3] = {init_vel[0], init_vel[1], init_vel[2]};
-    for (int c = 0; c < 3; ++c) { out_pos[c] = p[c]; out_vel[c] = v[c]; }
-    stq(ldq(R0), out_rot);
-    T sp[3] = {p[0], p[1], p[2]};
-    for (int i = 0; i < nframes; ++i) {
-        const int F = (int)(seg[i + 1] - seg[i]);
-        const T* l = loc + 7 * (size_t)i;
-        T sv[3];
-        if (F == 0) {                               // imu_integrator.py:134-140: vel zeroed, pos / rot held
-            sv[0] = sv[1] = sv[2] = 0;
-        } else {
-            for (int c = 0; c < 3; ++c) {
-                sv[c] = v[c] + l[c];
-                sp[c] = p[c] + l[3 + c] + v[c] * l[6];
-            }
+    // world mode: sequential p/v chain (one lane), per-frame terms staged through LDS by the whole workgroup
+    __shared__ T sl[CHAIN_CHUNK][7];
+    __shared__ T so[CHAIN_CHUNK][6];
+    __shared__ int sF[CHAIN_CHUNK];
+    __shared__ T carry[9];                 // p (3), v (3), held position sp (3)
+    const int tid = threadIdx.x;
+    if (blockIdx.x != 0) return;
+    if (tid == 0) {
+        for (int c = 0; c < 3; ++c) {
+            carry[c] = init_pos[c]; carry[3 + c] = init_vel[c]; carry[6 + c] = init_pos[c];
+            out_pos[c] = init_pos[c]; out_vel[c] = init_vel[c];
         }
-        const size_t row = (size_t)i + 1;
-        for (int c = 0; c < 3; ++c) { out_pos[3 * row + c] = sp[c]; out_vel[3 * row + c] = sv[c]; p[c] = sp[c]; v[c] = sv[c]; }
-        stq(ldq(R0 + 4 * row), out_rot + 4 * row);
+        stq(ldq(R0), out_rot);
+    }
+    for (int base = 0; base < nframes; base += CHAIN_CHUNK) {
+        const int cnt = min(CHAIN_CHUNK, nframes - base);
+        __syncthreads();
+        for (int j = tid; j < cnt; j += blockDim.x) sF[j] = (int)(seg[base + j + 1] - seg[base + j]);
+        for (int j = tid; j < cnt * 7; j += blockDim.x) (&sl[0][0])[j] = loc[7 * (size_t)base + j];
+        __syncthreads();
+        if (tid == 0) {
+            T p[3] = {carry[0], carry[1], carry[2]}, v[3] = {carry[3], carry[4], carry[5]}, sp[3] = {carry[6], carry[7], carry[8]};
+            for (int j = 0; j < cnt; ++j) {
+                T sv[3];
+                if (sF[j] == 0) {                           // imu_integrator.py:134-140: vel zeroed, pos / rot held
+                    sv[0] = sv[1] = sv[2] = 0;
+                } else {
+                    for (int c = 0; c < 3; ++c) {
+                        sv[c] = v[c] + sl[j][c];
+                        sp[c] = p[c] + sl[j][3 + c] + v[c] * sl[j][6];
+                    }
+                }
+                for (int c = 0; c < 3; ++c) { so[j][c] = sp[c]; so[j][3 + c] = sv[c]; p[c] = sp[c]; v[c] = sv[c]; }
+            }
+            for (int c = 0; c < 3; ++c) { carry[c] = p[c]; carry[3 + c] = v[c]; carry[6 + c] = sp[c]; }
+        }
+        __syncthreads();
+        for (int j = tid; j < cnt * 3; j += blockDim.x) {
+            const int f = j / 3, c = j - 3 * f;
+            out_pos[3 * (size_t)(base + 1) + j] = so[f][c];
+            out_vel[3 * (size_t)(base + 1) + j] = so[f][3 + c];
+        }
+        for (int j = tid; j < cnt * 4; j += blockDim.x) out_rot[4 * (size_t)(base + 1) + j] = R0[4 * (size_t)(base + 1) + j];
     }
 }
 
@@ -256,12 +308,12 @@ int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframe
     const size_t lds = 2 * 4 * (size_t)(maxF + 1) * sizeof(T);
     if (lds > 64 * 1024) return fail(ISLAM_EARG, "islam_imu_preint: %d IMU samples in one frame interval exceed the LDS scan buffer", maxF);
     hipLaunchKernelGGL(scan_kernel<T>, dim3(nframes), dim3(64), lds, s, dt, gyro, seg, ir);
-    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(64), 0, s, seg, nframes, ir, ir0, R0);
+    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, ir, ir0, R0);
     hipLaunchKernelGGL(frame_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, dt, acc, seg, nframes, ir, R0, (T)gravity, loc);
     if (motion_mode)
         hipLaunchKernelGGL(finish_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 1, opos, orot, ovel);
     else
-        hipLaunchKernelGGL(finish_kernel<T>, dim3(1), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 0, opos, orot, ovel);
+        hipLaunchKernelGGL(finish_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, R0, loc, ip, iv, 0, opos, orot, ovel);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
