@@ -43,8 +43,11 @@ int islam_abi_version(void);
  * Replaces Network/PWC/correlation.py:281-331 (_FunctionCorrelation.forward) and its two CUDA
  * kernels kernel_Correlation_rearrange (:8-33) + kernel_Correlation_updateOutput (:35-103):
  *   out[b,(dy+4)*9+(dx+4),y,x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c,y+dy,x+dx],  dy,dx in [-4,4], zero pad.
- * f1,f2: (B,C,H,W) float32; out: (B,81,H,W) float32. */
-int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* stream);
+ * f1,f2: (B,C,H,W) float32; out: (B,81,H,W) float32.
+ * scratch: islam_corr81_scratch_bytes(B,C,H,W) bytes or NULL.  Small pyramid levels have too few tiles to fill the chip;
+ * with scratch the channels are split over workgroups and summed in a fixed order (deterministic). */
+size_t islam_corr81_scratch_bytes(int B, int C, int H, int W);
+int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream);
 
 /* Correlation backward.  Replaces correlation.py:334-383 with kernels updateGradFirst (:105-167) and
  * updateGradSecond (:169-233).  g1 and/or g2 may be NULL (needs_input_grad false). */

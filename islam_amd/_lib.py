@@ -35,7 +35,8 @@ class PvgoResult(ctypes.Structure):
 SIGNATURES = {
     'islam_last_error': (ctypes.c_char_p, []),
     'islam_abi_version': (c_int, []),
-    'islam_corr81_fwd': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    'islam_corr81_scratch_bytes': (c_size_t, [c_int] * 4),
+    'islam_corr81_fwd': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p]),
     'islam_corr81_bwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     'islam_warp_mask': (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 4 + [c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),

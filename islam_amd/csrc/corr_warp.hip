@@ -16,6 +16,8 @@
 // LDS (five 8-byte reads per channel) feeds up to four FMAs.  Writes are 128-byte row segments.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 using namespace islam;
@@ -27,13 +29,22 @@ constexpr int CC = 16;                  // channels per LDS chunk
 constexpr int F2W = TW + 8, F2H = TH + 8;
 constexpr int F2RS = F2W;               // row stride (floats), even -> 8-byte aligned pairs
 
-__global__ __launch_bounds__(576) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                          float* __restrict__ out, int C, int H, int W) {
+constexpr int NT = 576;                                  // 16 x 4 x 9 threads
+constexpr int STG2 = (CC * F2H * F2W + NT - 1) / NT;     // staging registers per thread (f2 halo tile)
+constexpr int STG1 = (CC * TH * TW + NT - 1) / NT;       // (f1 tile)
+
+// One workgroup = one 32x4 pixel tile of one image and one channel slice [c_begin, c_end).  With a single slice the
+// result (sum / C) goes straight to `out`; with several slices (small pyramid levels: too few tiles to fill 256 CUs)
+// every slice writes its partial sum to `part[slice]` and corr81_reduce_kernel adds the slices in index order.
+__global__ __launch_bounds__(NT) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         float* __restrict__ out, float* __restrict__ part, int B, int C,
+                                                         int H, int W, int nslice, int cps) {
     __shared__ __attribute__((aligned(16))) float s1[CC * TH * TW];
     __shared__ __attribute__((aligned(16))) float s2[CC * F2H * F2RS];
     const int tx = threadIdx.x, ty = threadIdx.y, dyi = threadIdx.z;      // 16 x 4 x 9
     const int tid = tx + 16 * ty + 64 * dyi;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / nslice, slice = blockIdx.z - b * nslice;
+    const int c_begin = slice * cps, c_end = min(C, c_begin + cps);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t plane = (size_t)H * W;
     const float* f1b = f1 + (size_t)b * C * plane;
@@ -43,26 +54,54 @@ __global__ __launch_bounds__(576) void corr81_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 9; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
-    for (int cb = 0; cb < C; cb += CC) {
-        const int nc = min(CC, C - cb);
+    // staging map, identical for every chunk: element q of this lane -> (channel in chunk, global offset, LDS slot)
+    int g2[STG2], l2[STG2], c2[STG2], g1[STG1], c1[STG1];
+#pragma unroll
+    for (int q = 0; q < STG2; ++q) {
+        const int i = tid + q * NT;
+        const int c = i / (F2H * F2W), rem = i - c * (F2H * F2W);
+        const int ly = rem / F2W, lx = rem - ly * F2W;
+        const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+        const bool ok = i < CC * F2H * F2W && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        c2[q] = ok ? c : CC;                              // CC = never fetched
+        g2[q] = ok ? gy * W + gx : 0;
+        l2[q] = i < CC * F2H * F2W ? (c * F2H + ly) * F2RS + lx : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < STG1; ++q) {
+        const int i = tid + q * NT;
+        const int c = i / (TH * TW), rem = i - c * (TH * TW);
+        const int ly = rem / TW, lx = rem - ly * TW;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const bool ok = i < CC * TH * TW && gy < H && gx < W;
+        c1[q] = ok ? c : CC;
+        g1[q] = ok ? gy * W + gx : 0;
+    }
+    // software pipeline over channel chunks: the global loads of chunk k+1 are in flight (in registers) while chunk k
+    // is consumed from LDS
+    float r2[STG2], r1[STG1];
+    auto fetch = [&](int cb, int nc) {
+#pragma unroll
+        for (int q = 0; q < STG2; ++q) r2[q] = c2[q] < nc ? f2b[(size_t)(cb + c2[q]) * plane + g2[q]] : 0.f;
+#pragma unroll
+        for (int q = 0; q < STG1; ++q) r1[q] = c1[q] < nc ? f1b[(size_t)(cb + c1[q]) * plane + g1[q]] : 0.f;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < STG2; ++q)
+            if (l2[q] >= 0) s2[l2[q]] = r2[q];
+#pragma unroll
+        for (int q = 0; q < STG1; ++q)
+            if (tid + q * NT < CC * TH * TW) s1[tid + q * NT] = r1[q];
+    };
+
+    fetch(c_begin, min(CC, c_end - c_begin));
+    for (int cb = c_begin; cb < c_end; cb += CC) {
+        const int nc = min(CC, c_end - cb);
+        __syncthreads();                         // previous chunk fully consumed
+        commit();
         __syncthreads();
-        for (int i = tid; i < nc * F2H * F2W; i += 576) {
-            const int c = i / (F2H * F2W), rem = i - c * (F2H * F2W);
-            const int ly = rem / F2W, lx = rem - ly * F2W;
-            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = f2b[(size_t)(cb + c) * plane + (size_t)gy * W + gx];
-            s2[(c * F2H + ly) * F2RS + lx] = v;
-        }
-        for (int i = tid; i < nc * TH * TW; i += 576) {
-            const int c = i / (TH * TW), rem = i - c * (TH * TW);
-            const int ly = rem / TW, lx = rem - ly * TW;
-            const int gy = y0 + ly, gx = x0 + lx;
-            float v = 0.f;
-            if (gy < H && gx < W) v = f1b[(size_t)(cb + c) * plane + (size_t)gy * W + gx];
-            s1[(c * TH + ly) * TW + lx] = v;
-        }
-        __syncthreads();
+        if (cb + CC < c_end) fetch(cb + CC, min(CC, c_end - cb - CC));
         for (int c = 0; c < nc; ++c) {
             const float2 a = *reinterpret_cast<const float2*>(&s1[(c * TH + ty) * TW + 2 * tx]);
             const float* row = &s2[(c * F2H + ty + dyi) * F2RS + 2 * tx];
@@ -81,15 +120,30 @@ __global__ __launch_bounds__(576) void corr81_fwd_kernel(const float* __restrict
         }
     }
     const int gy = y0 + ty, gx = x0 + 2 * tx;
-    if (gy < H) {
-        const float fc = (float)C;
-        float* ob = out + ((size_t)b * 81 + (size_t)dyi * 9) * plane + (size_t)gy * W + gx;
+    if (gy < H && gx < W) {
+        const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
+        float* dst = nslice == 1 ? out : part + (size_t)slice * B * 81 * plane;
+        float* ob = dst + ((size_t)b * 81 + (size_t)dyi * 9) * plane + (size_t)gy * W + gx;
+        const bool pair = (gx + 1 < W) && ((((size_t)gy * W + gx) & 1) == 0) && ((plane & 1) == 0);   // 8-byte aligned pair
 #pragma unroll
         for (int dx = 0; dx < 9; ++dx) {
-            if (gx < W) ob[(size_t)dx * plane] = acc0[dx] / fc;
-            if (gx + 1 < W) ob[(size_t)dx * plane + 1] = acc1[dx] / fc;
+            if (pair) {
+                *reinterpret_cast<float2*>(ob + (size_t)dx * plane) = make_float2(acc0[dx] * sc, acc1[dx] * sc);
+            } else {
+                ob[(size_t)dx * plane] = acc0[dx] * sc;
+                if (gx + 1 < W) ob[(size_t)dx * plane + 1] = acc1[dx] * sc;
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void corr81_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
+                                                             int nslice, float inv_c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int k = 1; k < nslice; ++k) s += part[(size_t)k * n + i];       // fixed order: deterministic
+    out[i] = s * inv_c;
 }
 
 // gradient w.r.t. the first input:  g1[b,c,y,x] = (1/C) sum_{p,o} gout[b,(p+4)*9+(o+4),y,x] * f2[b,c,y+p,x+o]
@@ -157,10 +211,13 @@ __global__ __launch_bounds__(256) void corr81_bwd_kernel(const float* __restrict
 // PWCDCNet.warp.  The coordinate pipeline restates torch's grid_sample(align_corners=True) in the
 // same float32 operation order (normalise to [-1,1], un-normalise, floor, corner weights
 // nw=(x1-ix)(y1-iy) ...), so fused multiply-add contraction is disabled here.
+constexpr int WCH = 16;       // channels per lane
+
 __global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict__ x, const float* __restrict__ flow,
                                                          float scale, float* __restrict__ out, int C, int H, int W) {
 #pragma clang fp contract(off)
-    const int b = blockIdx.z;
+    const int ngrp = (C + WCH - 1) / WCH;
+    const int b = blockIdx.z / ngrp, c0 = (blockIdx.z % ngrp) * WCH;
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
@@ -187,18 +244,29 @@ __global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict_
     if (v01) m += ne;
     if (v10) m += sw;
     if (v11) m += se;
-    const float mask = (m < 0.9999f) ? 0.f : 1.f;      // PWCNet.py:203-204 (NaN m: both tests false in torch -> stays NaN*...; treated as 1)
+    const float mask = (m < 0.9999f) ? 0.f : 1.f;      // PWCNet.py:203-204
     const size_t o00 = (size_t)yi0 * W + xi0, o01 = (size_t)yi0 * W + xi1, o10 = (size_t)yi1 * W + xi0, o11 = (size_t)yi1 * W + xi1;
-    const float* xb = x + (size_t)b * C * plane;
-    float* ob = out + (size_t)b * C * plane + pix;
-    for (int c = 0; c < C; ++c) {
-        const float* p = xb + (size_t)c * plane;
-        float s = 0.f;
-        if (v00) s += p[o00] * nw;
-        if (v01) s += p[o01] * ne;
-        if (v10) s += p[o10] * sw;
-        if (v11) s += p[o11] * se;
-        ob[(size_t)c * plane] = s * mask;
+    const float* xb = x + ((size_t)b * C + c0) * plane;
+    float* ob = out + ((size_t)b * C + c0) * plane + pix;
+    const int nc = min(WCH, C - c0);
+    // all taps of the channel group are requested before the first is used (loads are unconditional on valid
+    // addresses; invalid corners are dropped by the selects)
+    float t00[WCH], t01[WCH], t10[WCH], t11[WCH];
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) {
+        const float* p = xb + (size_t)(c < nc ? c : 0) * plane;
+        t00[c] = p[o00]; t01[c] = p[o01]; t10[c] = p[o10]; t11[c] = p[o11];
+    }
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) {
+        if (c < nc) {
+            float s = 0.f;
+            if (v00) s += t00[c] * nw;
+            if (v01) s += t01[c] * ne;
+            if (v10) s += t10[c] * sw;
+            if (v11) s += t11[c] * se;
+            ob[(size_t)c * plane] = s * mask;
+        }
     }
 }
 
@@ -206,10 +274,29 @@ __global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict_
 
 extern "C" {
 
-int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* stream) {
+size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
+    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int chunks = (C + CC - 1) / CC;
+    int nslice = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
+    if (nslice <= 1) return 0;
+    return (size_t)nslice * B * 81 * H * W * sizeof(float);
+}
+
+int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_corr81_fwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B), block(16, 4, 9);
-    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, C, H, W);
+    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int chunks = (C + CC - 1) / CC;
+    int nslice = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
+    if (nslice > 1 && scratch == nullptr) nslice = 1;                   // no scratch: single pass
+    const int cps = ((chunks + nslice - 1) / nslice) * CC;              // channels per slice (whole chunks)
+    nslice = (C + cps - 1) / cps;
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
+    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps);
+    if (nslice > 1) {
+        const size_t n = (size_t)B * 81 * H * W;
+        hipLaunchKernelGGL(corr81_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           (const float*)scratch, out, n, nslice, 1.0f / (float)C);
+    }
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -226,7 +313,7 @@ int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float*
 
 int islam_warp_mask(const float* x, const float* flow, float scale, float* out, int B, int C, int H, int W, void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask: bad shape (%d,%d,%d,%d)", B, C, H, W);
-    dim3 grid((W + 63) / 64, (H + 3) / 4, B), block(256);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B * ((C + WCH - 1) / WCH)), block(256);
     hipLaunchKernelGGL(warp_mask_kernel, grid, block, 0, as_stream(stream), x, flow, scale, out, C, H, W);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;

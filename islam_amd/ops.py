@@ -24,7 +24,9 @@ def corr81_forward(first, second):
     assert first.dtype == torch.float32 and second.dtype == torch.float32 and first.shape == second.shape
     B, C, H, W = first.shape
     out = torch.empty((B, 81, H, W), dtype=torch.float32, device=first.device)
-    check(lib().islam_corr81_fwd(ptr(first), ptr(second), ptr(out), B, C, H, W, stream_ptr(first.device)))
+    nbytes = lib().islam_corr81_scratch_bytes(B, C, H, W)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=first.device) if nbytes else None
+    check(lib().islam_corr81_fwd(ptr(first), ptr(second), ptr(out), B, C, H, W, ptr(scratch), stream_ptr(first.device)))
     return out
 
 

@@ -56,7 +56,7 @@ def test_host_only_entry_points(lib):
     assert 0 < b1 < b2 < 64 << 20
     assert lib.islam_imu_scratch_bytes(50001, 5000, 1) >= 8 * (4 * 55001 + 4 * 5001 + 7 * 5000)
     # argument validation happens before any device work
-    rc = lib.islam_corr81_fwd(None, None, None, 0, 1, 1, 1, None)
+    rc = lib.islam_corr81_fwd(None, None, None, 0, 1, 1, 1, None, None)
     assert rc == -1 and b'bad shape' in lib.islam_last_error()
     rc = lib.islam_pvgo_linearize(None, None, None, None, None, None, None, 1, None, None, None)
     assert rc == -1
