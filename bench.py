@@ -85,6 +85,46 @@ def cpu_baseline(prob_host):
     }
 
 
+def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
+    """Secondary metric of BASELINE.json ("stereo-VIO frames/sec", configs[1] shapes): the bilevel loop body of
+    train.py:200-299 -- TartanVO forward at 448x640 (bf16 frozen nets, HIP correlation/warp/scale), 2x IMU integrate,
+    run_pvgo on the 9-node window, one-step backward -- on synthetic stereo pairs, random-init weights."""
+    from islam_amd import lietensor as pp, synthetic
+    from islam_amd.TartanVO import TartanVO
+    from islam_amd.bilevel import BilevelLoop
+    from islam_amd.imu_integrator import IMUModule
+    torch.manual_seed(0)
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, frozen_dtype=torch.bfloat16)
+    with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
+        vo.vonet.stereoNet.conv_c13.weight.zero_()
+        vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+    n = (steps + warmup) * batch + 1
+    tr = synthetic.car_trajectory(n, seed=3)
+    imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], np.zeros(3), np.zeros(3), tr['init'], tr['gravity'],
+                    tr['rgb2imu_sync'], device=str(device), denoise_model_name=None, denoise_accel=True, denoise_gyro=False)
+    loop = BilevelLoop(vo, imu, pp.identity_SE3(), tr['init'], batch_size=batch, device=str(device))
+    samples = []
+    for k in range(2):
+        smp = synthetic.stereo_batch(batch, seed=50 + k)
+        samples.append({kk: (v.to(device) if isinstance(v, torch.Tensor) and (kk.startswith('img') or kk == 'intrinsic') else v)
+                        for kk, v in smp.items()})
+    t_fwd = 0.0
+    for k in range(steps + warmup):
+        smp = dict(samples[k % 2])
+        smp['link'] = samples[k % 2]['link'] + k * batch
+        if k == warmup:
+            torch.cuda.synchronize()
+            loop.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
+            t0 = time.perf_counter()
+        loop.step(smp)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tm = loop.timing
+    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo', 'nets': 'bf16 autocast (frozen flow+stereo), fp32 pose head',
+            'ms_per_batch': el / steps * 1e3, 'stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
+            'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,6 +132,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frames', type=int, default=N_FRAMES)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-frontend', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -103,13 +144,18 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # (several ranks share a GPU only in the gloo self-test below)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('ISLAM_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for 1-GPU self-tests
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from islam_amd import ops
     prob, tr = build_problem(device, args.frames)
@@ -190,6 +236,11 @@ def main():
             'us_per_lm_iter': elapsed / trials * 1e6,
             'roofline': roofline,
         }
+        if not args.no_frontend and world == 1:
+            try:
+                out['stereo_vio'] = vio_frames_per_sec(device)
+            except Exception as e:           # the headline metric must still be reported
+                out['stereo_vio'] = {'error': repr(e)[:300]}
         if not args.no_cpu_baseline:
             host = {k: v.cpu().numpy() for k, v in (('init_nodes', prob['init_nodes']), ('init_vels', prob['init_vels']),
                                                      ('vo_motions', prob['vo']), ('imu_drots', prob['drots']),

@@ -60,6 +60,11 @@ int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float*
 int islam_warp_mask(const float* x, const float* flow, float scale, float* out, int B, int C, int H, int W,
                     void* stream);
 
+/* Backward of islam_warp_mask (autograd of PWCNet.py:195-206; the mask is piecewise constant).
+ * gx (B,C,H,W) and gflow (B,2,H,W) must be ZERO-INITIALISED by the caller (atomic scatter). */
+int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const float* gout, float* gx, float* gflow,
+                        int B, int C, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- stereo scale recovery */
 
 /* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176

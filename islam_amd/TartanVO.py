@@ -61,7 +61,7 @@ class TartanVO(nn.Module):
         self.use_kitti_coord = use_kitti_coord
         self.pose_std = torch.tensor([0.13, 0.13, 0.13, 0.013, 0.013, 0.013]).cuda(self.device_id)
         self.vonet = VONet(fix_parts=fix_parts)
-        self.vonet.frozen_dtype = frozen_dtype
+        self.vonet.set_frozen_dtype(frozen_dtype)
         for name, part in ((vo_model_name, self.vonet), (flow_model_name, self.vonet.flowNet),
                            (pose_model_name, self.vonet.flowPoseNet), (stereo_model_name, self.vonet.stereoNet)):
             if name is not None and name != '':

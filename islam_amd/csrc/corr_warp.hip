@@ -270,6 +270,63 @@ __global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict_
     }
 }
 
+// Backward of warp_mask_kernel (what autograd derives for PWCNet.py:195-206): the mask is piecewise constant, so
+// d out = mask * d grid_sample.  gx (same shape as x) and gflow (B,2,H,W) must be zero-initialised: the four taps scatter
+// with atomics (like torch's own grid_sampler backward) and the channel groups accumulate into gflow.
+__global__ __launch_bounds__(256) void warp_mask_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                             float scale, const float* __restrict__ gout, float* gx_,
+                                                             float* gflow, int C, int H, int W) {
+    const int ngrp = (C + WCH - 1) / WCH;
+    const int b = blockIdx.z / ngrp, c0 = (blockIdx.z % ngrp) * WCH;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    float ix, iy;
+    {
+#pragma clang fp contract(off)
+        const float fx = flow[((size_t)b * 2 + 0) * plane + pix] * scale;
+        const float fy = flow[((size_t)b * 2 + 1) * plane + pix] * scale;
+        const float vx = (float)px + fx, vy = (float)py + fy;
+        const float gxn = 2.0f * vx / (float)(W > 1 ? W - 1 : 1) - 1.0f;
+        const float gyn = 2.0f * vy / (float)(H > 1 ? H - 1 : 1) - 1.0f;
+        ix = ((gxn + 1.0f) / 2.0f) * (float)(W - 1);
+        iy = ((gyn + 1.0f) / 2.0f) * (float)(H - 1);
+    }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float nw = (x1f - ix) * (y1f - iy), ne = (ix - x0f) * (y1f - iy);
+    const float sw = (x1f - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    const bool vx0 = x0f >= 0.f && x0f <= (float)(W - 1), vx1 = x1f >= 0.f && x1f <= (float)(W - 1);
+    const bool vy0 = y0f >= 0.f && y0f <= (float)(H - 1), vy1 = y1f >= 0.f && y1f <= (float)(H - 1);
+    const bool v00 = vx0 && vy0, v01 = vx1 && vy0, v10 = vx0 && vy1, v11 = vx1 && vy1;
+    const int xi0 = vx0 ? (int)x0f : 0, xi1 = vx1 ? (int)x1f : 0, yi0 = vy0 ? (int)y0f : 0, yi1 = vy1 ? (int)y1f : 0;
+    float m = 0.f;
+    if (v00) m += nw;
+    if (v01) m += ne;
+    if (v10) m += sw;
+    if (v11) m += se;
+    if (m < 0.9999f) return;                         // masked pixel: no gradient
+    const size_t o00 = (size_t)yi0 * W + xi0, o01 = (size_t)yi0 * W + xi1, o10 = (size_t)yi1 * W + xi0, o11 = (size_t)yi1 * W + xi1;
+    const int nc = min(WCH, C - c0);
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < nc; ++c) {
+        const size_t cp = ((size_t)b * C + c0 + c) * plane;
+        const float g = gout[cp + pix];
+        const float* p = x + cp;
+        float* q = gx_ + cp;
+        if (v00) { atomicAdd(q + o00, g * nw); const float t = p[o00]; gix -= t * (y1f - iy) * g; giy -= t * (x1f - ix) * g; }
+        if (v01) { atomicAdd(q + o01, g * ne); const float t = p[o01]; gix += t * (y1f - iy) * g; giy -= t * (ix - x0f) * g; }
+        if (v10) { atomicAdd(q + o10, g * sw); const float t = p[o10]; gix -= t * (iy - y0f) * g; giy += t * (x1f - ix) * g; }
+        if (v11) { atomicAdd(q + o11, g * se); const float t = p[o11]; gix += t * (iy - y0f) * g; giy += t * (ix - x0f) * g; }
+    }
+    // d ix / d flow_x = scale * (W-1)/max(W-1,1), same for y
+    const float kx = W > 1 ? scale : 0.f, ky = H > 1 ? scale : 0.f;
+    atomicAdd(gflow + ((size_t)b * 2 + 0) * plane + pix, gix * kx);
+    atomicAdd(gflow + ((size_t)b * 2 + 1) * plane + pix, giy * ky);
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,6 +372,15 @@ int islam_warp_mask(const float* x, const float* flow, float scale, float* out, 
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask: bad shape (%d,%d,%d,%d)", B, C, H, W);
     dim3 grid((W + 63) / 64, (H + 3) / 4, B * ((C + WCH - 1) / WCH)), block(256);
     hipLaunchKernelGGL(warp_mask_kernel, grid, block, 0, as_stream(stream), x, flow, scale, out, C, H, W);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const float* gout, float* gx, float* gflow, int B,
+                        int C, int H, int W, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask_bwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B * ((C + WCH - 1) / WCH)), block(256);
+    hipLaunchKernelGGL(warp_mask_bwd_kernel, grid, block, 0, as_stream(stream), x, flow, scale, gout, gx, gflow, C, H, W);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

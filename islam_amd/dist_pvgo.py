@@ -113,8 +113,10 @@ class HipBackend:
         nblk = (n_own + 63) // 64
         return nt, vt, part[:2 * nblk].view(nblk, 2).sum(0)
 
-    def failed(self):
-        return bool(self.flags[0].item())
+    def failed_flag(self):
+        f = self.flags[:1].to(torch.float64)
+        self.flags.zero_()
+        return f[0]
 
     def make_scratch(self, N, nloc, n1, P0):
         from . import ops
@@ -177,22 +179,25 @@ class ShardedChainPVGO:
                 x1 = be.reduced_solve(products, N, self.seg_len, self.n1, self.scratch)
                 dx = be.backsub(x1, N, self.seg_len, sh, self.scratch)
                 nt, vt, sums = be.trial(nodes, vels, dx, self.data, lin, n_own, self.scratch)
-                msg = torch.zeros(2 + 10 * self.world, dtype=torch.float64, device=sums.device)
+                msg = torch.zeros(3 + 10 * self.world, dtype=torch.float64, device=sums.device)
                 msg[:2] = sums
+                msg[2] = be.failed_flag()                               # >0 on any rank: a pivot was not positive
                 first_local = sh['first_node'] - a                      # this rank's first interior node, local index
-                msg[2 + 10 * self.rank:2 + 10 * self.rank + 7] = nt[first_local]
-                msg[2 + 10 * self.rank + 7:2 + 10 * self.rank + 10] = vt[first_local]
+                o = 3 + 10 * self.rank
+                msg[o:o + 7] = nt[first_local]
+                msg[o + 7:o + 10] = vt[first_local]
                 yield msg                                               # all-reduce #2: loss, trust-region sums, halo
                 trials += 1
-                if be.failed():
+                host = msg[:3].tolist()                                 # the one device->host read of the trial
+                if host[2] > 0:
                     ctl.solver_failed()
                     break
-                accepted = ctl.after_trial(float(msg[0]), float(msg[1]))
+                accepted = ctl.after_trial(host[0], host[1])
                 if accepted:
                     nodes[:n_own + 1] = nt[:n_own + 1]
                     vels[:n_own + 1] = vt[:n_own + 1]
                     if sh['has_right'] and self.rank + 1 < self.world and b > sh['node0'] + n_own:
-                        h = msg[2 + 10 * (self.rank + 1):2 + 10 * (self.rank + 2)]      # neighbour's first node = my last row
+                        h = msg[3 + 10 * (self.rank + 1):3 + 10 * (self.rank + 2)]      # neighbour's first node = my last row
                         nodes[b - a] = h[:7]
                         vels[b - a] = h[7:]
                     break

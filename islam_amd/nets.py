@@ -22,19 +22,9 @@ from . import ops
 corr_fn = ops.FunctionCorrelation
 
 
-class _WarpNoGrad(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, flow, scale):
-        return ops.warp_mask(x, flow, scale)
-
-    @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError('warp backward is not built yet (SURVEY.md section 8f rank 1); the flow network is '
-                                  'frozen in every shipped configuration (--fix-model-parts flow stereo)')
-
-
 def warp_fn(x, flow, scale):
-    return _WarpNoGrad.apply(x, flow, scale)
+    """PWCDCNet.warp on the HIP kernels, differentiable w.r.t. features and flow (islam_warp_mask / _bwd)."""
+    return ops.warp(x, flow, scale)
 
 
 # ------------------------------------------------------------------------------------------ PWC-DC-Net
@@ -255,7 +245,7 @@ class StereoNet7(nn.Module):
         assert x.shape[1] % 2 == 0
         B, C2, H, W = x.shape
         f = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))          # left/right stacked along the batch
-        f = f.view(B, f.shape[1] * 2, f.shape[2], f.shape[3])
+        f = f.reshape(B, f.shape[1] * 2, f.shape[2], f.shape[3])
         x = torch.cat((f, F.interpolate(x, scale_factor=0.5, mode='bilinear')), 1)
         act, pool = self.actfun, lambda t: F.max_pool2d(t, kernel_size=2)
         cat0 = self.conv_c1(self.conv_c0(x))                                  # 1/2, 64
@@ -332,14 +322,27 @@ class VONet(nn.Module):
             if name in fix_parts:
                 for p in net.parameters():
                     p.requires_grad = False
-        self.frozen_dtype = None        # e.g. torch.bfloat16: autocast dtype of the two frozen nets (BASELINE config 2)
+        # BASELINE config 2 ("bf16 nets"): autocast dtype of the frozen nets.  Measured on MI355X (MIOpen, B=8, 448x640):
+        # stereo net fp32 NCHW 59 ms -> bf16 NHWC 26 ms; the flow net is fastest in fp32 NCHW (14 ms; bf16 16 ms, NHWC 20 ms),
+        # so only the stereo net (77 % of the FLOPs) is switched.
+        self.frozen_dtype = None
+        self.flow_dtype = None
+
+    def set_frozen_dtype(self, dtype):
+        self.frozen_dtype = dtype
+        if dtype is not None:
+            self.stereoNet.to(memory_format=torch.channels_last)
 
     def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic):
         dev = img0.device.type
-        with torch.autocast(dev, dtype=self.frozen_dtype, enabled=self.frozen_dtype is not None):
+        with torch.autocast(dev, dtype=self.flow_dtype, enabled=self.flow_dtype is not None):
             flow = self.flowNet(torch.cat([img0, img1], 1))[0][0]
-            disp = self.stereoNet(torch.cat((img0_norm, img0_r_norm), 1))[0]
-        flow, disp = flow.float(), disp.float()
+        x = torch.cat((img0_norm, img0_r_norm), 1)
+        if self.frozen_dtype is not None:
+            x = x.contiguous(memory_format=torch.channels_last)
+        with torch.autocast(dev, dtype=self.frozen_dtype, enabled=self.frozen_dtype is not None):
+            disp = self.stereoNet(x)[0]
+        flow, disp = flow.float(), disp.float().contiguous()
         disp = F.interpolate(disp, scale_factor=0.25, mode='nearest')
         pose = self.flowPoseNet(torch.cat([flow, intrinsic], 1))
         return flow, disp, pose

@@ -59,8 +59,31 @@ def FunctionCorrelation(tenFirst, tenSecond):
     return _Correlation.apply(tenFirst, tenSecond)
 
 
+class _WarpMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, scale):
+        ctx.save_for_backward(x, flow)
+        ctx.scale = float(scale)
+        return warp_mask(x, flow, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, flow = ctx.saved_tensors
+        x, flow, g = _f32c(x), _f32c(flow), _f32c(g)
+        B, C, H, W = x.shape
+        gx, gflow = torch.zeros_like(x), torch.zeros_like(flow)
+        check(lib().islam_warp_mask_bwd(ptr(x), ptr(flow), c_float(ctx.scale), ptr(g), ptr(gx), ptr(gflow), B, C, H, W,
+                                        stream_ptr(x.device)))
+        return gx, gflow, None
+
+
+def warp(x, flow, scale=1.0):
+    """Differentiable PWCDCNet.warp(x, flow*scale) (Network/PWC/PWCNet.py:170-206)."""
+    return _WarpMask.apply(x, flow, scale)
+
+
 def warp_mask(x, flow, scale=1.0):
-    """PWCDCNet.warp(x, flow*scale) (Network/PWC/PWCNet.py:170-206), forward only (flow net is frozen, F5)."""
+    """PWCDCNet.warp(x, flow*scale) (Network/PWC/PWCNet.py:170-206), forward value only."""
     require_cuda(x, flow)
     x, flow = _f32c(x), _f32c(flow)
     B, C, H, W = x.shape

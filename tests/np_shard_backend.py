@@ -184,9 +184,9 @@ class NumpyBackend:
         vt[:n_own + 1] = torch.from_numpy(vv)
         return nt, vt, torch.tensor([loss, q], dtype=torch.float64)
 
-    def failed(self):
+    def failed_flag(self):
         f, self._failed = self._failed, False
-        return f
+        return torch.tensor(1.0 if f else 0.0, dtype=torch.float64)
 
     def make_scratch(self, N, nloc, n1, P0):
         return dict(products=torch.zeros(351 * P0, dtype=torch.float64))

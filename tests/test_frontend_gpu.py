@@ -121,3 +121,30 @@ def test_scale_ls_empty_mask_is_nan(cuda):
                          torch.tensor([[0., 0, 1, 0, 0, 0, 1]], device=cuda), torch.tensor([[100., 100, 8, 8]], device=cuda),
                          torch.tensor([0.5], device=cuda), None, torch.tensor([1.0], device=cuda))
     assert torch.isnan(s).all()                                 # reference: s = 0/0
+
+
+@pytest.mark.parametrize('C,H,W,scale', [(20, 14, 20, 0.625), (3, 9, 33, 2.5), (32, 28, 40, 5.0), (2, 5, 1, 1.0)])
+def test_warp_backward_matches_torch_autograd(cuda, C, H, W, scale):
+    """islam_warp_mask_bwd vs autograd through torch's grid_sample formulation of PWCDCNet.warp (PWCNet.py:170-206)."""
+    from islam_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(C * 31 + W)
+    x0 = torch.randn(B, C, H, W, generator=g)
+    f0 = torch.randn(B, 2, H, W, generator=g) * (2.0 / scale)
+    go = torch.randn(B, C, H, W, generator=g).to(cuda)
+    x, fl = x0.to(cuda).requires_grad_(True), f0.to(cuda).requires_grad_(True)
+    ops.warp(x, fl, scale).backward(go)
+    xr, fr = x0.to(cuda).requires_grad_(True), f0.to(cuda).requires_grad_(True)
+    xx = torch.arange(0, W, device=cuda).view(1, -1).repeat(H, 1)
+    yy = torch.arange(0, H, device=cuda).view(-1, 1).repeat(1, W)
+    grid = torch.cat((xx.view(1, 1, H, W).repeat(B, 1, 1, 1), yy.view(1, 1, H, W).repeat(B, 1, 1, 1)), 1).float()
+    vg = grid + fr * scale
+    vgx = 2.0 * vg[:, 0] / max(W - 1, 1) - 1.0
+    vgy = 2.0 * vg[:, 1] / max(H - 1, 1) - 1.0
+    vgrid = torch.stack((vgx, vgy), -1)
+    out = torch.nn.functional.grid_sample(xr, vgrid, align_corners=True)
+    m = torch.nn.functional.grid_sample(torch.ones_like(xr), vgrid, align_corners=True).detach()
+    m = (m >= 0.9999).float()
+    (out * m).backward(go)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(fl.grad, fr.grad, rtol=1e-3, atol=1e-4)

@@ -149,3 +149,16 @@ def test_stereo_scale_gradient_matches_autograd(cuda):
         tot = tot + (M1[m] * w1[m] + M2[m] * w2[m]).sum() / (M1[m] ** 2 + M2[m] ** 2).sum()
     tot.backward()
     torch.testing.assert_close(g_kernel, xi2.grad, rtol=2e-3, atol=1e-5)
+
+
+def test_flow_net_trains_end_to_end(cuda):
+    """with correlation backward + warp backward the flow network can be un-frozen."""
+    from islam_amd import nets
+    torch.manual_seed(0)
+    net = nets.PWCDCNet().to(cuda)
+    x = torch.rand(1, 6, 128, 192, device=cuda)
+    flows, _ = net(x)
+    sum(f.abs().mean() for f in flows).backward()
+    for name in ('conv1a.0.weight', 'conv6b.0.weight', 'conv3_0.0.weight', 'upfeat4.weight', 'dc_conv7.weight'):
+        g = dict(net.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, name
