@@ -188,6 +188,101 @@ __global__ __launch_bounds__(64) void build_normal_kernel(const double* __restri
     b[6] = -gv.x; b[7] = -gv.y; b[8] = -gv.z;
 }
 
+// Fused linearise + build (what the LM loop launches): a workgroup of 64 lanes linearises 64 consecutive links (the
+// first one is a halo shared with the previous workgroup), hands the weighted per-link pieces over through LDS and builds
+// the blocks of its 63 nodes.  Same arithmetic as linearize_kernel + build_normal_kernel, one launch, no re-read of `lin`.
+constexpr int LB_NODES = 63;
+constexpr int LB_REC = 41;          // Srr 9 | Srp 9 | Spp 9 | gr 3 | gp 3 | rv 3 | rt 3 | dt 1, +1 pad
+
+__global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                       const double* __restrict__ poses, const double* __restrict__ drots,
+                                                       const double* __restrict__ dtrans, const double* __restrict__ dvels,
+                                                       const double* __restrict__ dts, int N, double w0, double w1, double w2,
+                                                       double w3, double vmin, double vmax, double* __restrict__ lin,
+                                                       double* __restrict__ loss_part, double* __restrict__ Hd,
+                                                       double* __restrict__ Ho, double* __restrict__ rhs) {
+    __shared__ double sl[64][LB_REC];
+    const int M = N - 1;
+    const int lane = threadIdx.x;
+    const int L = blockIdx.x * LB_NODES - 1 + lane;          // link handled by this lane
+    double sq = 0.0;
+    if (L >= 0 && L < M) {
+        SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
+        const double dt = dts[L];
+        LinkRes r = link_residuals(Xi, Xj, ld3(vels + 3 * L), ld3(vels + 3 * (L + 1)), se3_load(poses + 7 * L),
+                                   ld4(drots + 4 * L), ld3(dtrans + 3 * L), ld3(dvels + 3 * L), dt);
+        M3<double> Ji = so3_Jl_inv(r.ephi);
+        M3<double> R = qmat(r.pre.q);
+        M3<double> G = Ji * R;
+        M3<double> C = Ji * (skew(r.pre.t) * R - se3_Q(r.erho, r.ephi) * G);
+        M3<double> B = so3_Jl_inv(r.er) * qmat(r.rpre);
+        if (lane > 0 || blockIdx.x == 0) {                    // the halo link belongs to the previous workgroup
+            double rec[LIN_C];
+            rec[0] = r.erho.x; rec[1] = r.erho.y; rec[2] = r.erho.z;
+            rec[3] = r.ephi.x; rec[4] = r.ephi.y; rec[5] = r.ephi.z;
+            m3_store(G, rec + 6);
+            m3_store(C, rec + 15);
+            rec[24] = r.er.x; rec[25] = r.er.y; rec[26] = r.er.z;
+            m3_store(B, rec + 27);
+            rec[36] = r.rv.x; rec[37] = r.rv.y; rec[38] = r.rv.z;
+            rec[39] = r.rt.x; rec[40] = r.rt.y; rec[41] = r.rt.z;
+#pragma unroll
+            for (int c = 0; c < LIN_C; ++c) lin[(size_t)c * M + L] = rec[c];
+            sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+        }
+        M3<double> Gt = transpose(G), Ct = transpose(C), Bt = transpose(B);
+        M3<double> GtG = Gt * G;
+        double* o = sl[lane];
+        m3_store(w0 * GtG + w3 * m3_identity<double>(), o);
+        m3_store(w0 * (Gt * C), o + 9);
+        m3_store(w0 * (Ct * C + GtG) + w2 * (Bt * B), o + 18);
+        V3<double> gr = w0 * (Gt * r.erho) + w3 * r.rt;
+        V3<double> gp = w0 * (Ct * r.erho + Gt * r.ephi) + w2 * (Bt * r.er);
+        o[27] = gr.x; o[28] = gr.y; o[29] = gr.z; o[30] = gp.x; o[31] = gp.y; o[32] = gp.z;
+        o[33] = r.rv.x; o[34] = r.rv.y; o[35] = r.rv.z; o[36] = r.rt.x; o[37] = r.rt.y; o[38] = r.rt.z; o[39] = dt;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) loss_part[blockIdx.x] = sq;
+    __syncthreads();
+    const int k = blockIdx.x * LB_NODES + lane;               // node built by this lane: links k-1 (slot lane), k (slot lane+1)
+    if (lane >= LB_NODES || k >= N) return;
+    const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const M3<double> I = m3_identity<double>();
+    M3<double> Hrr = Z, Hrp = Z, Hpp = Z;
+    V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
+    double hvv = 0.0, hrv = 0.0;
+    if (k > 0) {
+        const double* a = sl[lane];
+        Hrr = Hrr + m3_load(a); Hrp = Hrp + m3_load(a + 9); Hpp = Hpp + m3_load(a + 18);
+        gr = gr + ld3(a + 27); gp = gp + ld3(a + 30);
+        gv = gv - w1 * ld3(a + 33);
+        hvv += w1;
+    }
+    double* o = Ho + (size_t)k * 81;
+    if (k < M) {
+        const double* a = sl[lane + 1];
+        const M3<double> Srr = m3_load(a), Srp = m3_load(a + 9), Spp = m3_load(a + 18);
+        const double dt = a[39];
+        Hrr = Hrr + Srr; Hrp = Hrp + Srp; Hpp = Hpp + Spp;
+        gr = gr - ld3(a + 27); gp = gp - ld3(a + 30);
+        gv = gv + w1 * ld3(a + 33) - (w3 * dt) * ld3(a + 36);
+        hvv += w1 + w3 * dt * dt;
+        hrv = w3 * dt;
+        put3x3(o, 0, 0, -1.0 * Srr); put3x3(o, 0, 3, -1.0 * Srp); put3x3(o, 0, 6, Z);
+        put3x3(o, 3, 0, -1.0 * transpose(Srp)); put3x3(o, 3, 3, -1.0 * Spp); put3x3(o, 3, 6, Z);
+        put3x3(o, 6, 0, (-w3 * dt) * I); put3x3(o, 6, 3, Z); put3x3(o, 6, 6, (-w1) * I);
+    }
+    double* h = Hd + (size_t)k * 81;
+    put3x3(h, 0, 0, Hrr); put3x3(h, 0, 3, Hrp); put3x3(h, 0, 6, hrv * I);
+    put3x3(h, 3, 0, transpose(Hrp)); put3x3(h, 3, 3, Hpp); put3x3(h, 3, 6, Z);
+    put3x3(h, 6, 0, hrv * I); put3x3(h, 6, 3, Z); put3x3(h, 6, 6, hvv * I);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) h[d * 10] = fmin(fmax(h[d * 10], vmin), vmax);   // A.diagonal().clamp_(min, max)
+    double* bb = rhs + (size_t)k * 9;
+    bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
+    bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
+}
+
 // ------------------------------------------------------------------------------------------
 // partitioned block-tridiagonal Cholesky
 struct LevelSrc {
@@ -813,6 +908,7 @@ struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill,
 
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
+    double *lin2, *Hd2, *Ho2, *rhs2;          // second linearisation buffer (speculative next step)
     int* flags;
     LevelBufs lv[MAXL];
     size_t bytes;
@@ -826,11 +922,15 @@ Workspace carve(void* base, int N) {
     const int M = std::max(N - 1, 1);
     const int nblk = (M + 63) / 64;
     w.lin = take((size_t)LIN_C * M);
-    w.loss_part = take(nblk);
+    w.loss_part = take(nblk + 2);
     w.part = take(2 * (size_t)nblk);
     w.Hd = take((size_t)N * 81);
     w.Ho = take((size_t)N * 81);
     w.rhs = take((size_t)N * 9);
+    w.lin2 = take((size_t)LIN_C * M);
+    w.Hd2 = take((size_t)N * 81);
+    w.Ho2 = take((size_t)N * 81);
+    w.rhs2 = take((size_t)N * 9);
     w.dx = take((size_t)N * 9);
     w.nodes_t = take((size_t)N * 7);
     w.vels_t = take((size_t)N * 3);
@@ -1176,22 +1276,34 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
     int steps = 0, trials = 0, patience_count = 0, status = ISLAM_OK;
     bool continual = true;
     double loss = 0.0, damping = init[2];
+    // Two linearisation buffers: while the host waits for the decision of trial t, the GPU already linearises at the
+    // trial point (the next optimizer.step() if the trial is accepted -- the common case); on a reject the old buffer
+    // (with its cumulatively damped diagonal) is simply kept.
+    double* LIN[2] = {w.lin, w.lin2};
+    double* HD[2] = {w.Hd, w.Hd2};
+    double* HO[2] = {w.Ho, w.Ho2};
+    double* RH[2] = {w.rhs, w.rhs2};
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    auto enqueue_linbuild = [&](const double* xn, const double* xv, int b) {
+        hipLaunchKernelGGL(linbuild_kernel, dim3(nlb), dim3(64), 0, s, xn, xv, poses, drots, dtrans, dvels, dts, N, prm->w[0],
+                           prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax, LIN[b], w.loss_part, HD[b], HO[b], RH[b]);
+    };
+    int pb = 0;
+    enqueue_linbuild(cur_n, cur_v, pb);
+    hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+    bool speculate = true;
     while (continual) {
-        // ---- optimizer.step()
-        hipLaunchKernelGGL(linearize_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, poses, drots, dtrans, dvels, dts, M,
-                           w.lin, w.loss_part);
-        hipLaunchKernelGGL(build_normal_kernel, dim3((N + 63) / 64), dim3(64), 0, s, w.lin, dts, N, prm->w[0], prm->w[1],
-                           prm->w[2], prm->w[3], prm->vmin, prm->vmax, w.Hd, w.Ho, w.rhs);
-        if (steps == 0) hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nblk, w.state, w.flags);
+        // ---- optimizer.step()   (its linearisation is already enqueued)
         int reject_count = 0;
         double last = 0.0;
         bool broke = false;
         for (;;) {           // while self.last <= self.loss
-            int rc = enqueue_solve(w, w.Hd, w.Ho, w.rhs, w.state, 0.0, N, prm->seg_len, w.dx, s);
+            int rc = enqueue_solve(w, HD[pb], HO[pb], RH[pb], w.state, 0.0, N, prm->seg_len, w.dx, s);
             if (rc != ISLAM_OK) return rc;
             const double seq = (double)(trials + 1);
             hipLaunchKernelGGL(trial_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
-                               dts, w.lin, M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq);
+                               dts, LIN[pb], M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq);
+            if (speculate) enqueue_linbuild(tri_n, tri_v, 1 - pb);
             ISLAM_LAUNCH_CHECK();
             // wait for the decision (poll the pinned status block; fall back to a stream sync after ~2 s)
             {
@@ -1222,7 +1334,14 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
             }
             loss = hs[0];
             reject_count = (int)hs[8];
-            if (accepted) { std::swap(cur_n, tri_n); std::swap(cur_v, tri_v); break; }
+            if (accepted) {
+                std::swap(cur_n, tri_n); std::swap(cur_v, tri_v);
+                if (!speculate) enqueue_linbuild(cur_n, cur_v, 1 - pb);
+                pb = 1 - pb;
+                speculate = true;
+                break;
+            }
+            speculate = false;        // after a reject: linearise the next step only once a trial is accepted
         }
         ++steps;
         // ---- scheduler.step(loss)   (StopOnPlateau)
@@ -1230,7 +1349,10 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
         if ((last - loss) < prm->decreasing) ++patience_count; else patience_count = 0;
         if (patience_count >= prm->patience) continual = false;
         if (reject_count >= prm->reject) continual = false;
-        if (broke) { /* PyPose keeps looping through the scheduler; the plateau counter stops it */ }
+        if (broke) {
+            // PyPose keeps looping through the scheduler (the plateau counter stops it): same iterate, new linearisation
+            if (continual) { enqueue_linbuild(cur_n, cur_v, pb); speculate = true; }
+        }
     }
     if (cur_n != nodes) {
         ISLAM_HIP_CHECK(hipMemcpyAsync(nodes, cur_n, (size_t)N * 7 * sizeof(double), hipMemcpyDeviceToDevice, s));
