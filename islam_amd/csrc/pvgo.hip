@@ -369,6 +369,13 @@ __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s
     }
 }
 
+#ifdef ISLAM_PROBE
+__device__ long long islam_probe_buf[512];
+#define PROBE(slot) do { if (lane == 0 && p == 1 && src.level0) islam_probe_buf[(slot)] = clock64(); } while (0)
+#else
+#define PROBE(slot) do { } while (0)
+#endif
+
 // LDS hand-off inside a one-wave workgroup: LDS instructions of a wave execute in order, so only the
 // compiler must be kept from reordering; no vmcnt wait (global prefetches and stores stay in flight).
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -483,6 +490,11 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     const int pa = lane < 45 ? kPairA[lane] : lane - 45;            // left-separator accumulation F-^T D^-1 [F- | y-]
     const int pb = lane < 45 ? kPairB[lane] : 9;
     const bool acc_on = has_left && lane < 54;
+    // role of this lane when the next node's columns are formed: S columns and g take (next - update), U columns take
+    // the next node's coupling unchanged, spike columns take -(update) (0 without a left separator)
+    const bool use_nb = lane < 18 || lane == 27;
+    const bool use_tn = lane < 9 || lane == 27 || (has_left && lane >= 18 && lane < 27);
+    const int tn_off = (lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
 
     const LaneSrc LS = lane_source(src, lane);
     const bool level0 = src.level0 != 0;
@@ -507,9 +519,11 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     double accL = 0.0;
     int bad = 0;
 
+    PROBE(0);
     for (int t = 0; t < cnt; ++t) {
         const int c = c0 + t;
         const bool last = (t == cnt - 1);
+        PROBE(8 * t + 1);
         // prefetch: the columns of node c+1 are requested now and first touched after the whole elimination and Schur
         // update of node c (~1 us later).  Unconditional (index clamped) so that every path through the loop body issues
         // the same memory operations and the compiler can place an exact, late s_waitcnt.
@@ -519,24 +533,15 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
         double ipv[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            double piv = bcast(mcol[i], i);
-            if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+            const double piv = bcast(mcol[i], i);
+            bad |= !(piv > 0.0);                 // off the critical path; a non-positive pivot only poisons this solve
             const double ip = rcp_nr(piv);
             ipv[i] = ip;
             const double f = mcol[i] * ip;
 #pragma unroll
             for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
         }
-        if (lane < 28) {
-            double* f = dst.fac + (size_t)c * FAC + lane * 9;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) f[r] = mcol[r];
-        }
-        if (lane == 0) {
-            double* iv = dst.inv + (size_t)c * 9;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
-        }
+        PROBE(8 * t + 2);
         if (lane >= 9 && lane < 28) {
             double* xa = Xa + (lane - 9) * XS;
             double* xb = Xb + (lane - 9) * XS;
@@ -544,6 +549,7 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
             for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
         }
         lds_sync();
+        PROBE(8 * t + 3);
         // ---- Schur update: T = X^T D^-1 X, entries (r, cb), r < 9 (U- columns), cb < 19
         if (t_on) {
             double ca[9], cbv[9];
@@ -564,22 +570,28 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
             accL += dot9r(ca, cbv);
         }
         lds_sync();
+        PROBE(8 * t + 4);
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n) combine_cols(LS, src, c + 1, n, lane, damping, raw, nb);
+        // the factor goes out only now: vmcnt retires in order, so stores issued before the combine above would have to
+        // COMPLETE (write acknowledged, ~0.3 us) before the prefetched columns could be touched
+        if (lane < 28) {
+            double* f = dst.fac + (size_t)c * FAC + lane * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) f[r] = mcol[r];
+        }
+        if (lane == 0) {
+            double* iv = dst.inv + (size_t)c * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+        }
+        PROBE(8 * t + 5);
         if (!last) {
-            if (lane < 9) {
+            // next node's columns, branch-free: (own column of the next node) - (Schur update column), per-lane role
+            double tcol[9];
+            ldcol(Tn + tn_off, tcol);
 #pragma unroll
-                for (int r = 0; r < 9; ++r) mcol[r] = nb[r] - Tn[lane * XS + r];
-            } else if (lane < 18) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) mcol[r] = nb[r];
-            } else if (lane < 27) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) mcol[r] = has_left ? -Tn[(lane - 9) * XS + r] : 0.0;
-            } else if (lane == 27) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) mcol[r] = nb[r] - Tn[18 * XS + r];
-            }
+            for (int r = 0; r < 9; ++r) mcol[r] = (use_nb ? nb[r] : 0.0) - (use_tn ? tcol[r] : 0.0);
         } else if (has_right) {
             // contributions to the right separator (reduced node p) and the separator's own blocks
             for (int e = lane; e < 81; e += 64) {
@@ -607,8 +619,15 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
             dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
         }
     }
+    PROBE(100);
     if (bad && lane == 0) atomicOr(flags, 1);
 }
+
+#ifdef ISLAM_PROBE
+extern "C" int islam_probe_read(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_probe_buf), sizeof(long long) * 512) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // one wavefront per workgroup, one segment per workgroup (the large levels)
 __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0) {
