@@ -178,6 +178,11 @@ int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, 
 int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N,
                        double* nodes_out, double* vels_out, void* stream);
 
+/* VO factors on ARBITRARY edges (loop closures; pvgo.py:36-39): out (24,E) component-major =
+ * e(6) | G(9) | C(9) with d e/d delta_j = [[G,C],[0,G]], d e/d delta_i = -that.  Used by the dense general-topology
+ * path (islam_amd/pvgo_dense.py). */
+int islam_pvgo_linearize_edges(const double* nodes, const int64_t* edges, const double* poses, int E, double* out,
+                               void* stream);
 /* vo_loss forward/backward (pvgo.py:67-78 with PyPose's left-tangent gradient convention).
  * fwd: e (E,6) = Log(P^-1 Xi^-1 Xj); trans_loss, rot_loss (E).  bwd: grad_poses (E,7), last column 0. */
 int islam_pvgo_vo_loss_fwd(const double* nodes, const int64_t* edges, const double* poses, int E,

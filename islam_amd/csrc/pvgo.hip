@@ -831,6 +831,28 @@ __global__ __launch_bounds__(64) void retract_kernel(const double* __restrict__ 
     vels_o[3 * k] = v.x; vels_o[3 * k + 1] = v.y; vels_o[3 * k + 2] = v.z;
 }
 
+// VO factor of an ARBITRARY edge (i, j) (loop closures; pvgo.py:36-39): residual e = Log(P^-1 Xi^-1 Xj) and the blocks
+// G, C of d e / d delta_j = [[G, C],[0, G]] (d e / d delta_i = -that).  out: (24, E) component-major.
+__global__ __launch_bounds__(64) void vo_edge_linearize_kernel(const double* __restrict__ nodes, const int64_t* __restrict__ edges,
+                                                                const double* __restrict__ poses, int E, double* __restrict__ out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    SE3<double> Xi = se3_load(nodes + 7 * edges[2 * e]), Xj = se3_load(nodes + 7 * edges[2 * e + 1]);
+    SE3<double> pre = se3_mul(se3_inv(se3_load(poses + 7 * e)), se3_inv(Xi));
+    V3<double> rho, phi;
+    se3_log(se3_mul(pre, Xj), rho, phi);
+    M3<double> Ji = so3_Jl_inv(phi);
+    M3<double> R = qmat(pre.q);
+    M3<double> G = Ji * R;
+    M3<double> C = Ji * (skew(pre.t) * R - se3_Q(rho, phi) * G);
+    double rec[24];
+    rec[0] = rho.x; rec[1] = rho.y; rec[2] = rho.z; rec[3] = phi.x; rec[4] = phi.y; rec[5] = phi.z;
+    m3_store(G, rec + 6);
+    m3_store(C, rec + 15);
+#pragma unroll
+    for (int c = 0; c < 24; ++c) out[(size_t)c * E + e] = rec[c];
+}
+
 __global__ __launch_bounds__(64) void vo_loss_fwd_kernel(const double* __restrict__ nodes, const int64_t* __restrict__ edges,
                                                           const double* __restrict__ poses, int E, double* __restrict__ err6,
                                                           double* __restrict__ tl, double* __restrict__ rl) {
@@ -1230,6 +1252,14 @@ int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx
     if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_retract: N=%d < 1", N);
     hipLaunchKernelGGL(retract_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, dx, sign, N,
                        nodes_out, vels_out);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_linearize_edges(const double* nodes, const int64_t* edges, const double* poses, int E, double* out,
+                               void* stream) {
+    if (E < 1) return fail(ISLAM_EARG, "islam_pvgo_linearize_edges: E=%d < 1", E);
+    hipLaunchKernelGGL(vo_edge_linearize_kernel, dim3((E + 63) / 64), dim3(64), 0, as_stream(stream), nodes, edges, poses, E, out);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

@@ -35,9 +35,7 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     if reproj is not None:
         raise UnsupportedGraphError('the reprojection factor (pvgo.py:53-61) is not built yet (SURVEY.md section 8f rank 2)')
     N = len(init_nodes)
-    if not _is_canonical_chain(links, N):
-        raise UnsupportedGraphError('only the chain topology train.py produces (links[k] = [k, k+1]) is built; '
-                                    'general graphs are SURVEY.md section 8f rank 4')
+    chain = _is_canonical_chain(links, N)
     out_dtype = pp._plain(init_nodes).dtype if isinstance(init_nodes, torch.Tensor) else torch.get_default_dtype()
     t64 = lambda x: pp._plain(torch.as_tensor(x)).detach().to(dev, torch.float64).contiguous()
     nodes, vels = t64(init_nodes).clone(), t64(init_vels).clone()
@@ -46,8 +44,14 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     edges = torch.as_tensor(links).to(dev, torch.int64).contiguous()
     target0 = nodes[0].clone()
 
-    prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
-    res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm)
+    if chain:            # the topology train.py produces: block-tridiagonal fast path, whole LM loop in one library call
+        prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
+        res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm)
+    else:                # loop closures / arbitrary links: dense formulation on the device (islam_amd/pvgo_dense.py)
+        from .pvgo_dense import run_lm_dense
+        if N > 4000:
+            raise UnsupportedGraphError('dense general-topology path is sized for N <= 4000 nodes (got %d)' % N)
+        nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
 
     if target == 'vo':
         vo = vo_motions if isinstance(vo_motions, torch.Tensor) else torch.as_tensor(vo_motions)

@@ -47,11 +47,9 @@ def test_run_pvgo_rejects_what_is_not_built(cuda):
     from islam_amd.pvgo import UnsupportedGraphError, run_pvgo
     prob, _ = chain_problem(5)
     args = [torch.tensor(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions')]
-    links = torch.tensor(prob['links']).clone()
-    links[2, 1] = 0                                                    # a loop closure
     rest = [torch.tensor(prob[k]) for k in ('dts', 'imu_drots', 'imu_dtrans', 'imu_dvels')]
     with pytest.raises(UnsupportedGraphError):
-        run_pvgo(*args, links, *rest, device='cuda')
+        run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cuda', reproj=object())
     with pytest.raises(RuntimeError):
         run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cpu')
 
@@ -162,3 +160,30 @@ def test_flow_net_trains_end_to_end(cuda):
     for name in ('conv1a.0.weight', 'conv6b.0.weight', 'conv3_0.0.weight', 'upfeat4.weight', 'dc_conv7.weight'):
         g = dict(net.named_parameters())[name].grad
         assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, name
+
+
+def test_run_pvgo_general_topology_matches_oracle(cuda):
+    """Loop closures / non-consecutive links: dense path on the GPU vs the oracle's dense LM."""
+    from islam_amd import lietensor as pp
+    from islam_amd.pvgo import run_pvgo
+    F = 21
+    prob, tr = chain_problem(F)
+    links = prob['links'].copy()
+    vo = prob['vo_motions'].copy()
+    gt = np.concatenate([tr['gt_pos'], tr['gt_quat']], 1)
+    rng = np.random.default_rng(5)
+    for e, (i, j) in {3: (0, 9), 11: (4, 17), 19: (20, 2)}.items():      # replace three chain edges by long-range ones
+        links[e] = (i, j)
+        rel = lie.se3_mul(lie.se3_inv(gt[i]), gt[j])
+        vo[e] = lie.se3_mul(rel, lie.se3_exp(rng.normal(0, 0.01, 6)))
+    p2 = dict(prob, links=links, vo_motions=vo)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    tl, rl, nodes, vels, _ = run_pvgo(pp.SE3(t(p2['init_nodes'])), t(p2['init_vels']), pp.SE3(t(vo).to(cuda)), torch.tensor(links),
+                                      t(p2['dts']), pp.SO3(t(p2['imu_drots'])), t(p2['imu_dtrans']), t(p2['imu_dvels']),
+                                      device='cuda', loss_weight=LW)
+    otl, orl, on, ov, _ = opvgo.run_pvgo(**p2, loss_weight=LW, mode='dense')
+    err = se3_log_err(nodes.numpy(), on)
+    ref = np.maximum(np.linalg.norm(lie.se3_log(on), axis=-1), 1e-6)
+    assert (err / ref).max() < 1e-6
+    np.testing.assert_allclose(vels.numpy(), ov, atol=1e-7)
+    np.testing.assert_allclose(tl.cpu().numpy(), otl, rtol=1e-6, atol=1e-10)
