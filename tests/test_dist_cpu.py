@@ -95,3 +95,43 @@ def test_lm_control_matches_oracle_trust_region():
         assert kept == (not (last < loss))
     ctl.end_step()
     assert ctl.loss == 9.0 and ctl.reject_count == 2 and ctl.steps == 1 and ctl.continual
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from islam_amd.dist_train import allreduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    net[2].bias.requires_grad_(False)
+    x = torch.full((4, 7), float(rank + 1))
+    net(x).sum().backward()
+    net[0].bias.grad = None                                   # a parameter that saw no gradient on this rank
+    nb = allreduce_gradients(net.parameters(), average=False, bucket_bytes=64)
+    torch.save({'g': [None if p.grad is None else p.grad.clone() for p in net.parameters()], 'nb': nb},
+               os.path.join(out_dir, 'g%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo(tmp_path):
+    """Config-5 exchange: bucketed sum of the pose-head gradients over 2 ranks equals the single-process sum."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), 'g%d.pt' % r)) for r in range(2)]
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    tot = None
+    for r in range(2):
+        net.zero_grad()
+        net(torch.full((4, 7), float(r + 1))).sum().backward()
+        g = [p.grad.clone() for p in net.parameters()]
+        g[1] = torch.zeros_like(g[1])
+        tot = g if tot is None else [a + b for a, b in zip(tot, g)]
+    assert outs[0]['nb'] > 1
+    for r in range(2):
+        for got, want, p in zip(outs[r]['g'], tot, range(4)):
+            if p == 3:
+                continue                                       # frozen parameter: untouched
+            torch.testing.assert_close(got, want)
