@@ -217,10 +217,14 @@ def main():
                 acc_ms = dict(ms) if acc_ms is None else {k: acc_ms[k] + ms[k] for k in ms}
         kern = {k: round(v / reps * 1e3, 2) for k, v in acc_ms.items()}      # microseconds per launch
         elim0_s = kern['eliminate_L0'] * 1e-6
-        alg_bytes = ELIM_BYTES_PER_NODE * N
+        alg_bytes = ELIM_BYTES_PER_NODE * N + 351 * 8 * levels[0][2]       # + the per-segment products handed to level 1
         achieved = alg_bytes / elim0_s / 1e9
+        traffic = None                   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_eliminate_L0.json')
+        if os.path.exists(tpath) and N == N_FRAMES:
+            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                    'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': elim0_s * 1e6,
                     'solve_launch_us': kern, 'levels_n_m_P': levels,
                     'note': 'latency-bound: %d dependent 9x9 block pivots on the critical path' % sum(l[1] for l in levels)}

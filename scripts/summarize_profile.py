@@ -30,7 +30,7 @@ for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     acc, cnt = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(f)):
         if r.get('Counter_Name') == ctr:
-            k = r.get('Kernel_Name', '')[:70]
+            k = r.get('Kernel_Name', '')[:60] + ' grid=' + str(r.get('Grid_Size', ''))
             acc[k] += float(r.get('Counter_Value', 0))
             cnt[k] += 1
     print('== %s per dispatch (raw counter units, KB) ==' % ctr)
