@@ -87,7 +87,7 @@ def cpu_baseline(prob_host):
 
 def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     """Secondary metric of BASELINE.json ("stereo-VIO frames/sec", configs[1] shapes): the bilevel loop body of
-    train.py:200-299 -- TartanVO forward at 448x640 (bf16 frozen nets, HIP correlation/warp/scale), 2x IMU integrate,
+    train.py:200-299 -- TartanVO forward at 448x640 (bf16 stereo net, HIP correlation/warp/scale), 2x IMU integrate,
     run_pvgo on the 9-node window, one-step backward -- on synthetic stereo pairs, random-init weights."""
     from islam_amd import lietensor as pp, synthetic
     from islam_amd.TartanVO import TartanVO
@@ -120,7 +120,7 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tm = loop.timing
-    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo', 'nets': 'bf16 autocast (frozen flow+stereo), fp32 pose head',
+    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo', 'nets': 'stereo net bf16 NHWC (77 % of the FLOPs), flow net + pose head fp32 (MIOpen runs the flow net fastest in fp32)',
             'ms_per_batch': el / steps * 1e3, 'stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
             'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic'}
 
