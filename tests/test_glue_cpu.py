@@ -126,3 +126,35 @@ def test_edge_mask_properties():
     # quarter resize: mean of the centre 2x2 of each 4x4 cell, round half up
     u8 = torch.arange(16, dtype=torch.uint8).reshape(1, 1, 4, 4)
     assert edges.quarter_resize_u8(u8).item() == (5 + 6 + 9 + 10 + 2) // 4
+
+
+def test_preprocess_matches_reference_geometry():
+    """Device-side CropCenter / Normalize / intrinsics layer vs a plain numpy restatement of Datasets/utils.py."""
+    from islam_amd import preprocess
+    # KITTI raw 375x1242 -> fix-ratio upscale to 448x1484, crop x1=422 (SURVEY section 8d config 1)
+    assert preprocess.crop_center_geometry(375, 1242) == (448, 1484, 422, 0)
+    assert preprocess.crop_center_geometry(480, 640) == (480, 640, 0, 16)          # TartanAir: crop only
+    assert preprocess.crop_center_geometry(480, 752) == (480, 752, 56, 16)          # EuRoC
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 2, 480, 752
+    imgs = [torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8) for _ in range(3)]
+    calib = torch.tensor([[458.6, 457.3, 367.2, 248.4]]).repeat(B, 1)
+    ext = torch.tensor([[0.11, 0, 0, 0, 0, 0, 1.0]]).repeat(B, 1)
+    s = preprocess.make_sample(*imgs, calib, ext, ['euroc'] * B)
+    assert s['img0'].shape == (B, 3, 448, 640) and s['intrinsic'].shape == (B, 2, 112, 160)
+    ref = imgs[0][:, 16:464, 56:696].permute(0, 3, 1, 2).float() / 255.0          # no resize needed: pure crop, exact
+    torch.testing.assert_close(s['img0'], ref, rtol=0, atol=0)
+    mean = torch.tensor(preprocess.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(preprocess.IMAGENET_STD).view(1, 3, 1, 1)
+    torch.testing.assert_close(s['img0_norm'], (ref - mean) / std)
+    np.testing.assert_allclose(s['intrinsic_calib'].numpy(), [[458.6, 457.3, 367.2 - 56, 248.4 - 16]] * B, rtol=1e-6)
+    u = (np.arange(W, dtype=np.float32) - 367.2 + 0.5) / 458.6
+    v = (np.arange(H, dtype=np.float32) - 248.4 + 0.5) / 457.3
+    np.testing.assert_allclose(s['intrinsic'][0, 0, 0].numpy(), u[56:696][::4], rtol=1e-6)
+    np.testing.assert_allclose(s['intrinsic'][0, 1, :, 0].numpy(), v[16:464][::4], rtol=1e-6)
+    # resize path: intrinsics scale with the image, the layer stays consistent with the scaled calibration
+    k = preprocess.make_sample(*[torch.randint(0, 256, (1, 375, 1242, 3), generator=g, dtype=torch.uint8) for _ in range(3)],
+                               torch.tensor([[718.856, 718.856, 607.1928, 185.2157]]), ext[:1], ['kitti'])
+    sc = 448 / 375
+    np.testing.assert_allclose(k['intrinsic_calib'][0].numpy(), [718.856 * 1484 / 1242, 718.856 * sc, 607.1928 * 1484 / 1242 - 422, 185.2157 * sc], rtol=1e-5)
+    assert k['img0'].shape == (1, 3, 448, 640) and 0.0 <= float(k['img0'].min()) and float(k['img0'].max()) <= 1.0
