@@ -46,6 +46,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// XCD-aware work mapping.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, dispatch section; speed
+// only, never correctness).  Every kernel of the LM loop splits its node / link / segment range into 8 CONTIGUOUS parts,
+// part x handled by the workgroups with b % 8 == x, so data produced for a stretch of the chain stays in the L2 of the XCD
+// that consumes it in the next launch (the levels of the block solver hand ~4 KB per segment to each other).
+// Launch with xcd_grid(total) workgroups; returns the logical index or -1 for the padding workgroups.
+__host__ __device__ __forceinline__ int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
+__device__ __forceinline__ int xcd_index(int b, int total) {
+    const int Q = (total + 7) / 8;
+    const int s = (b & 7) * Q + (b >> 3);
+    return s < total ? s : -1;
+}
+
 __device__ __forceinline__ double bcast(double v, int src) {   // src must be wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, src);
@@ -204,7 +216,9 @@ __global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__
     __shared__ double sl[64][LB_REC];
     const int M = N - 1;
     const int lane = threadIdx.x;
-    const int L = blockIdx.x * LB_NODES - 1 + lane;          // link handled by this lane
+    const int blk = xcd_index(blockIdx.x, (N + LB_NODES - 1) / LB_NODES);
+    if (blk < 0) return;
+    const int L = blk * LB_NODES - 1 + lane;                  // link handled by this lane
     double sq = 0.0;
     if (L >= 0 && L < M) {
         SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__
         M3<double> G = Ji * R;
         M3<double> C = Ji * (skew(r.pre.t) * R - se3_Q(r.erho, r.ephi) * G);
         M3<double> B = so3_Jl_inv(r.er) * qmat(r.rpre);
-        if (lane > 0 || blockIdx.x == 0) {                    // the halo link belongs to the previous workgroup
+        if (lane > 0 || blk == 0) {                           // the halo link belongs to the previous workgroup
             double rec[LIN_C];
             rec[0] = r.erho.x; rec[1] = r.erho.y; rec[2] = r.erho.z;
             rec[3] = r.ephi.x; rec[4] = r.ephi.y; rec[5] = r.ephi.z;
@@ -242,9 +256,9 @@ __global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__
         o[33] = r.rv.x; o[34] = r.rv.y; o[35] = r.rv.z; o[36] = r.rt.x; o[37] = r.rt.y; o[38] = r.rt.z; o[39] = dt;
     }
     sq = wave_sum(sq);
-    if (lane == 0) loss_part[blockIdx.x] = sq;
+    if (lane == 0) loss_part[blk] = sq;
     __syncthreads();
-    const int k = blockIdx.x * LB_NODES + lane;               // node built by this lane: links k-1 (slot lane), k (slot lane+1)
+    const int k = blk * LB_NODES + lane;               // node built by this lane: links k-1 (slot lane), k (slot lane+1)
     if (lane >= LB_NODES || k >= N) return;
     const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
     const M3<double> I = m3_identity<double>();
@@ -630,9 +644,12 @@ extern "C" int islam_probe_read(long long* out) {
 #endif
 
 // one wavefront per workgroup, one segment per workgroup (the large levels)
-__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0) {
+__global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
+                                                           int nseg) {
     __shared__ __attribute__((aligned(16))) double lds[LDS_PER_WAVE];
-    eliminate_segment(src, dst, n, m, blockIdx.x + seg0, flags, threadIdx.x, lds);
+    const int p = xcd_index(blockIdx.x, nseg);
+    if (p < 0) return;
+    eliminate_segment(src, dst, n, m, p + seg0, flags, threadIdx.x, lds);
 }
 
 __device__ __forceinline__ void backsub_level_segment(const double* __restrict__ fac, const double* __restrict__ inv,
@@ -688,8 +705,10 @@ __global__ __launch_bounds__(512) void bt_top_kernel(TopArgs a, int* flags) {
 // expand the solution of the separators (xsep, from the next level) into this level's interior nodes
 __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
                                                          const double* __restrict__ xsep, double* __restrict__ x, int n,
-                                                         int m, int seg0) {
-    backsub_level_segment(fac, inv, xsep, x, n, m, blockIdx.x + seg0, threadIdx.x);
+                                                         int m, int seg0, int nseg) {
+    const int p = xcd_index(blockIdx.x, nseg);
+    if (p < 0) return;
+    backsub_level_segment(fac, inv, xsep, x, n, m, p + seg0, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -747,9 +766,11 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
                                                     const double* __restrict__ lin, int M, double* __restrict__ nodes_t,
                                                     double* __restrict__ vels_t, double* part, double* st, int* flags,
                                                     unsigned* ticket, TRParams tr, double* report, double seq) {
-    int k = blockIdx.x * 64 + threadIdx.x;
+    const int nblk = (M + 63) / 64;
+    const int blk = xcd_index(blockIdx.x, nblk);
+    int k = blk * 64 + threadIdx.x;
     double sq = 0.0, qd = 0.0;
-    if (k < M) {
+    if (blk >= 0 && k < M) {
         const double* di = dx + (size_t)k * 9;
         const double* dj = dx + (size_t)(k + 1) * 9;
         V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
@@ -781,7 +802,7 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     }
     sq = wave_sum(sq);
     qd = wave_sum(qd);
-    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sq; part[2 * blockIdx.x + 1] = qd; }
+    if (threadIdx.x == 0 && blk >= 0) { part[2 * blk] = sq; part[2 * blk + 1] = qd; }
     if (st == nullptr) return;           // stage-level call: no control
     // ---- last block takes the decision
     int last_block = 0;
@@ -793,7 +814,7 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     if (!last_block) return;
     __threadfence();                                                  // acquire the other blocks' partials
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) {
+    for (int i = threadIdx.x; i < nblk; i += 64) {
         s += __hip_atomic_load(&part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q += __hip_atomic_load(&part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1030,8 +1051,8 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
     };
     auto x_of = [&](int l) { return l == lbegin ? xout : w.lv[l].x; };
     for (int l = lbegin; l < top; ++l) {
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(sp.lv[l].P), dim3(64), 0, s, src_of(l), level_dst(w.lv[l], x_of(l)),
-                           sp.lv[l].n, sp.lv[l].m, flags, 0);
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, src_of(l), level_dst(w.lv[l], x_of(l)),
+                           sp.lv[l].n, sp.lv[l].m, flags, 0, sp.lv[l].P);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     {
@@ -1049,8 +1070,8 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     for (int l = top - 1; l >= lbegin; --l) {
-        hipLaunchKernelGGL(bt_backsub_kernel, dim3(sp.lv[l].P), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1), x_of(l),
-                           sp.lv[l].n, sp.lv[l].m, 0);
+        hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1),
+                           x_of(l), sp.lv[l].n, sp.lv[l].m, 0, sp.lv[l].P);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     if (nev) *nev = ne;
@@ -1202,8 +1223,8 @@ int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, 
     dst.fac = fac - (ptrdiff_t)node0 * FAC; dst.inv = inv - (ptrdiff_t)node0 * 9;
     dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
     dst.x = nullptr;
-    hipLaunchKernelGGL(bt_eliminate_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m, flags,
-                       seg0);
+    hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m,
+                       flags, seg0, nseg);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -1228,8 +1249,8 @@ int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double*
     const int nl = plan_levels(N, seg_len, sp);
     const LevelPlan* plan = sp.lv;
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
-    hipLaunchKernelGGL(bt_backsub_kernel, dim3(nseg), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
-                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0);
+    hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
+                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0, nseg);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -1240,7 +1261,7 @@ int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, 
                      const double* dtrans, const double* dvels, const double* dts, const double* lin, int M, double* nodes_t,
                      double* vels_t, double* part, void* stream) {
     if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
-    hipLaunchKernelGGL(trial_kernel, dim3((M + 63) / 64), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
+    hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
                        dvels, dts, lin, M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{},
                        (double*)nullptr, 0.0);
     ISLAM_LAUNCH_CHECK();
@@ -1334,7 +1355,7 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
     double* RH[2] = {w.rhs, w.rhs2};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
     auto enqueue_linbuild = [&](const double* xn, const double* xv, int b) {
-        hipLaunchKernelGGL(linbuild_kernel, dim3(nlb), dim3(64), 0, s, xn, xv, poses, drots, dtrans, dvels, dts, N, prm->w[0],
+        hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(64), 0, s, xn, xv, poses, drots, dtrans, dvels, dts, N, prm->w[0],
                            prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax, LIN[b], w.loss_part, HD[b], HO[b], RH[b]);
     };
     int pb = 0;
@@ -1350,7 +1371,7 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
             int rc = enqueue_solve(w, HD[pb], HO[pb], RH[pb], w.state, 0.0, N, prm->seg_len, w.dx, s);
             if (rc != ISLAM_OK) return rc;
             const double seq = (double)(trials + 1);
-            hipLaunchKernelGGL(trial_kernel, dim3(nblk), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
+            hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid(nblk)), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
                                dts, LIN[pb], M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq);
             if (speculate) enqueue_linbuild(tri_n, tri_v, 1 - pb);
             ISLAM_LAUNCH_CHECK();
