@@ -394,7 +394,7 @@ class LieTensor(torch.Tensor):
         raise TypeError('matrix() needs SO3/SE3')
 
     def Act(self, p):
-        d, p = _plain(self), _plain(p)
+        d, p = _promote(_plain(self), _plain(p))
         if self.ltype is SE3_type:
             return _SE3Act.apply(d, p)
         if self.ltype is SO3_type:
@@ -403,7 +403,7 @@ class LieTensor(torch.Tensor):
 
     def _mul(self, other):
         if isinstance(other, LieTensor):
-            a, b = _plain(self), _plain(other)
+            a, b = _promote(_plain(self), _plain(other))
             if self.ltype is SE3_type and other.ltype is SE3_type:
                 return LieTensor(_SE3Mul.apply(a, b), SE3_type)
             if self.ltype is SO3_type and other.ltype is SO3_type:
@@ -418,6 +418,14 @@ class LieTensor(torch.Tensor):
 
     def __repr__(self):
         return '%s:\n%s' % (self.ltype, _plain(self).__repr__())
+
+
+def _promote(a, b):
+    """Binary group ops follow torch's type promotion (float32 x float64 -> float64), like plain tensor arithmetic."""
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    return a, b
 
 
 def SE3(data):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from islam_amd import edges, lietensor as pp, transformation as tf
+from islam_amd import edges, evaluate, lietensor as pp, transformation as tf
 from oracle import lie
 
 
@@ -158,3 +158,18 @@ def test_preprocess_matches_reference_geometry():
     sc = 448 / 375
     np.testing.assert_allclose(k['intrinsic_calib'][0].numpy(), [718.856 * 1484 / 1242, 718.856 * sc, 607.1928 * 1484 / 1242 - 422, 185.2157 * sc], rtol=1e-5)
     assert k['img0'].shape == (1, 3, 448, 640) and 0.0 <= float(k['img0'].min()) and float(k['img0'].max()) <= 1.0
+
+
+def test_ate_evaluator_known_answers():
+    """Rigid + similarity alignment recover a known transform; RPE of a trajectory against itself is zero."""
+    rng = np.random.default_rng(0)
+    gt = np.cumsum(rng.normal(size=(50, 3)), 0)
+    R = lie.quat_matrix(lie.so3_exp(np.array([0.3, -0.2, 0.5])))
+    est = (gt - np.array([1.0, 2.0, 3.0])) @ R / 1.7
+    assert evaluate.ate(est, gt, with_scale=True)[0] < 1e-9
+    assert evaluate.ate(est * 1.7, gt)[0] < 1e-9
+    noisy = gt + rng.normal(scale=0.1, size=gt.shape)
+    a = evaluate.ate(noisy, gt)[0]
+    assert 0.1 < a < 0.25
+    X = np.concatenate([gt, np.tile([0, 0, 0, 1.0], (50, 1))], 1)
+    assert evaluate.rpe(X, X) == (0.0, 0.0)
