@@ -135,6 +135,34 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
                          const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes,
                          islam_pvgo_result* result, double* trace, int trace_cap, void* stream);
 
+/* Sparse reprojection factor, the optional 5th residual of the graph (pvgo.py:53-61,130-143,163-165 with
+ * dense_ba.py:276-305 SparseReprojectionLoss and pypose reprojerr/point2pixel):
+ *   err[k][j] = pixel(K, T_k^-1 * points[k][j]) - targets[k][j],  T_k = rgb2imu^-1 (X_k^-1 X_{k+1}) rgb2imu,
+ * weight (loss_weight[4]/K)^2 per row.  Link k couples only nodes k, k+1, so the system stays block-tridiagonal. */
+typedef struct {
+    const double* points;     /* (N-1, K, 3) device: SparseReprojectionLoss.point3d (camera frame of node k) */
+    const double* targets;    /* (N-1, K, 2) device: SparseReprojectionLoss.target (pixels in frame k+1) */
+    int K;                    /* SparseReprojectionLoss.N keypoints per link */
+    double fx, fy, cx, cy;    /* SparseReprojectionLoss.K */
+    double rgb2imu[7];        /* camera->IMU pose [t, q xyzw] */
+    double weight;            /* (loss_weight[4]/K)^2, pvgo.py:131 */
+    int compat_first_motion;  /* 1: replicate pvgo.py:57 `motion[0] = 0.1` (link 0 becomes a constant residual) */
+} islam_pvgo_reproj;
+
+#define ISLAM_REPROJ_REC 32   /* doubles per link written by islam_pvgo_reproj_reduce */
+
+/* islam_pvgo_run_chain with the reprojection factor (reproj == NULL: identical to islam_pvgo_run_chain). */
+int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses, const double* drots,
+                                const double* dtrans, const double* dvels, const double* dts, int N,
+                                const islam_pvgo_params* prm, const islam_pvgo_reproj* reproj, void* workspace,
+                                size_t workspace_bytes, islam_pvgo_result* result, double* trace, int trace_cap,
+                                void* stream);
+/* Stage-level: per-link reduction over the K keypoints at nodes (dx == NULL) or at Exp(dx)*nodes (dx (N,9)):
+ * red (N-1, ISLAM_REPROJ_REC) = [ J^T J upper triangle (21, row-major) | J^T r (6) | r^T r (1) | pad ], J = d err / d eta
+ * for the left perturbation T_k <- Exp(eta) T_k (unweighted). */
+int islam_pvgo_reproj_reduce(const double* nodes, const double* dx, int N, const islam_pvgo_reproj* reproj,
+                             double* red, void* stream);
+
 /* Stage-level entry points (same kernels the loop above launches; exported for parity tests/profiling). */
 /* residuals + Jacobian blocks per link -> lin (42 x M, component-major), loss_part (nblocks) */
 int islam_pvgo_linearize(const double* nodes, const double* vels, const double* poses, const double* drots,

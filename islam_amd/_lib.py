@@ -31,6 +31,14 @@ class PvgoResult(ctypes.Structure):
     _fields_ = [('steps', c_int), ('trials', c_int), ('status', c_int), ('loss', c_double), ('damping', c_double)]
 
 
+class PvgoReproj(ctypes.Structure):
+    _fields_ = [('points', c_void_p), ('targets', c_void_p), ('K', c_int), ('fx', c_double), ('fy', c_double),
+                ('cx', c_double), ('cy', c_double), ('rgb2imu', c_double * 7), ('weight', c_double),
+                ('compat_first_motion', c_int)]
+
+
+REPROJ_REC = 32         # ISLAM_REPROJ_REC
+
 # name -> (restype, argtypes); every symbol include/islam_hip.h declares
 SIGNATURES = {
     'islam_last_error': (ctypes.c_char_p, []),
@@ -48,6 +56,10 @@ SIGNATURES = {
     'islam_pvgo_workspace_bytes': (c_size_t, [c_int]),
     'islam_pvgo_run_chain': (c_int, [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p, c_size_t,
                                                       ctypes.POINTER(PvgoResult), c_void_p, c_int, c_void_p]),
+    'islam_pvgo_run_chain_reproj': (c_int, [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), ctypes.POINTER(PvgoReproj),
+                                                             c_void_p, c_size_t, ctypes.POINTER(PvgoResult), c_void_p, c_int,
+                                                             c_void_p]),
+    'islam_pvgo_reproj_reduce': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(PvgoReproj), c_void_p, c_void_p]),
     'islam_pvgo_linearize': (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 3),
     'islam_pvgo_build_normal': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_double), c_double, c_double] +
                                 [c_void_p] * 4),

@@ -2,7 +2,7 @@
 expects.  ``islam_amd.compat.install()`` registers
 
     pypose                         -> islam_amd.lietensor   (only the names train.py / the kept modules touch)
-    TartanVO, pvgo, imu_integrator -> islam_amd.TartanVO / .pvgo / .imu_integrator
+    TartanVO, pvgo, imu_integrator, dense_ba -> islam_amd.TartanVO / .pvgo / .imu_integrator / .dense_ba
     Datasets.transformation        -> islam_amd.transformation (PyPose-side helpers only)
     Network.PWC.correlation        -> FunctionCorrelation on the HIP kernel
 
@@ -12,8 +12,8 @@ import types
 
 
 def install(force=False):
-    from . import TartanVO, imu_integrator, lietensor, ops, pvgo, transformation
-    table = {'pypose': lietensor, 'TartanVO': TartanVO, 'pvgo': pvgo, 'imu_integrator': imu_integrator}
+    from . import TartanVO, dense_ba, imu_integrator, lietensor, ops, pvgo, transformation
+    table = {'pypose': lietensor, 'TartanVO': TartanVO, 'pvgo': pvgo, 'imu_integrator': imu_integrator, 'dense_ba': dense_ba}
     for name, mod in table.items():
         if force or name not in sys.modules:
             sys.modules[name] = mod

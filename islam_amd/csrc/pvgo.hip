@@ -200,6 +200,120 @@ __global__ __launch_bounds__(64) void build_normal_kernel(const double* __restri
     b[6] = -gv.x; b[7] = -gv.y; b[8] = -gv.z;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse reprojection factor (pvgo.py:53-61 + dense_ba.py:276-305).  Link k: T = C^-1 (X_k^-1 X_{k+1}) C,
+// err_j = pixel(K, T^-1 P_j) - target_j.  Under the left perturbation T <- Exp(eta) T:  d p'/d eta = R_T^T [-I, [P]x], so
+// with a = (f/z) R^T[row] - (f c/z^2) R^T[2]:  d err / d eta = [-a, a x P].  Node perturbations enter through
+// eta = +-Ad(C^-1 X_k^-1) delta (same +/- pattern as the VO factor), applied per link in linbuild / trial.
+struct ReprojDev {
+    const double* points;
+    const double* targets;
+    int K;
+    double fx, fy, cx, cy;
+    SE3<double> C;
+    double weight;
+    int compat_first;
+};
+constexpr int RP_REC = ISLAM_REPROJ_REC;    // 21 (J^T J upper) + 6 (J^T r) + 1 (r^T r), padded to 32
+constexpr int RP_NSUM = 28;
+
+// one workgroup per link, lanes stride over the keypoints; fixed-order reduction (bit-reproducible)
+__global__ __launch_bounds__(256) void reproj_reduce_kernel(const double* __restrict__ nodes, const double* __restrict__ dx,
+                                                             int M, ReprojDev rp, double* __restrict__ red) {
+    __shared__ double sw[4][RP_NSUM];
+    const int L = xcd_index(blockIdx.x, M);
+    if (L < 0) return;
+    SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
+    if (dx) {
+        const double* di = dx + (size_t)L * 9;
+        Xi = se3_mul(se3_exp(ld3(di), ld3(di + 3)), Xi);
+        Xj = se3_mul(se3_exp(ld3(di + 9), ld3(di + 12)), Xj);
+    }
+    SE3<double> motion = se3_mul(se3_inv(Xi), Xj);
+    const bool frozen = rp.compat_first && L == 0;              // pvgo.py:57: motion[0] = 0.1 (all seven entries)
+    if (frozen) motion = {{0.1, 0.1, 0.1}, {0.1, 0.1, 0.1, 0.1}};
+    const SE3<double> Tinv = se3_inv(se3_mul(se3_mul(se3_inv(rp.C), motion), rp.C));
+    const M3<double> Rm = qmat(Tinv.q);
+    const V3<double> r0{Rm.a00, Rm.a01, Rm.a02}, r1{Rm.a10, Rm.a11, Rm.a12}, r2{Rm.a20, Rm.a21, Rm.a22};
+    double acc[RP_NSUM];
+#pragma unroll
+    for (int i = 0; i < RP_NSUM; ++i) acc[i] = 0.0;
+    const double* P0 = rp.points + (size_t)L * rp.K * 3;
+    const double* T0 = rp.targets + (size_t)L * rp.K * 2;
+    for (int j = threadIdx.x; j < rp.K; j += blockDim.x) {
+        const V3<double> P = ld3(P0 + 3 * j);
+        const V3<double> p = qact(Tinv.q, P) + Tinv.t;
+        double den = fmax(fabs(p.z), 2.2250738585072014e-308);     // homo2cart: |z| clamped to finfo.tiny, sign kept
+        den = p.z >= 0.0 ? den : -den;
+        const double ru = (rp.fx * p.x + rp.cx * p.z) / den - T0[2 * j];
+        const double rv = (rp.fy * p.y + rp.cy * p.z) / den - T0[2 * j + 1];
+        const double iz = 1.0 / den;
+        const V3<double> au = (rp.fx * iz) * r0 - (rp.fx * p.x * iz * iz) * r2;
+        const V3<double> av = (rp.fy * iz) * r1 - (rp.fy * p.y * iz * iz) * r2;
+        const V3<double> cu = cross(au, P), cv = cross(av, P);
+        const double ju[6] = {-au.x, -au.y, -au.z, cu.x, cu.y, cu.z};
+        const double jv[6] = {-av.x, -av.y, -av.z, cv.x, cv.y, cv.z};
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[o++] += ju[a] * ju[b] + jv[a] * jv[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += ju[a] * ru + jv[a] * rv;
+        acc[27] += ru * ru + rv * rv;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < RP_NSUM; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) sw[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < RP_REC) {
+        double s = 0.0;
+        if (threadIdx.x < RP_NSUM) {
+            for (int w2 = 0; w2 < nw; ++w2) s += sw[w2][threadIdx.x];
+            if (frozen && threadIdx.x < 27) s = 0.0;            // a constant residual: no Jacobian
+        }
+        red[(size_t)L * RP_REC + threadIdx.x] = s;
+    }
+}
+
+// per-link pieces of the reprojection factor in node coordinates: A = M^T S M, g = M^T b with M = Ad(C^-1 X_i^-1)
+struct ReprojLink { M3<double> Arr, Arp, App; V3<double> gr, gp; };
+
+__device__ __forceinline__ M3<double> sym_from(const double* u, int r0, int c0) {   // 3x3 sub-block of a packed upper 6x6
+    auto at = [&](int r, int c) { if (r > c) { int t = r; r = c; c = t; } return u[r * 6 - r * (r - 1) / 2 + (c - r)]; };
+    return {at(r0, c0), at(r0, c0 + 1), at(r0, c0 + 2), at(r0 + 1, c0), at(r0 + 1, c0 + 1), at(r0 + 1, c0 + 2),
+            at(r0 + 2, c0), at(r0 + 2, c0 + 1), at(r0 + 2, c0 + 2)};
+}
+
+__device__ __forceinline__ void reproj_adjoint(const ReprojDev& rp, SE3<double> Xi, M3<double>& R, M3<double>& T) {
+    const SE3<double> Y = se3_mul(se3_inv(rp.C), se3_inv(Xi));
+    R = qmat(Y.q);
+    T = skew(Y.t) * R;
+}
+
+__device__ __forceinline__ ReprojLink reproj_link(const double* __restrict__ rec, const ReprojDev& rp, SE3<double> Xi) {
+    double u[RP_NSUM];
+#pragma unroll
+    for (int i = 0; i < RP_NSUM; ++i) u[i] = rec[i];
+    const M3<double> Saa = sym_from(u, 0, 0), Sab = sym_from(u, 0, 3), Sbb = sym_from(u, 3, 3);
+    const V3<double> ba{u[21], u[22], u[23]}, bb{u[24], u[25], u[26]};
+    M3<double> R, T;
+    reproj_adjoint(rp, Xi, R, T);
+    const M3<double> Rt = transpose(R), Tt = transpose(T);
+    const M3<double> X1 = Saa * T + Sab * R;                    // (S M) top-right
+    const M3<double> X2 = transpose(Sab) * T + Sbb * R;         // (S M) bottom-right
+    ReprojLink o;
+    o.Arr = Rt * (Saa * R);
+    o.Arp = Rt * X1;
+    o.App = Tt * X1 + Rt * X2;
+    o.gr = tmul(R, ba);
+    o.gp = tmul(T, ba) + tmul(R, bb);
+    return o;
+}
+
 // Fused linearise + build (what the LM loop launches): a workgroup of 64 lanes linearises 64 consecutive links (the
 // first one is a halo shared with the previous workgroup), hands the weighted per-link pieces over through LDS and builds
 // the blocks of its 63 nodes.  Same arithmetic as linearize_kernel + build_normal_kernel, one launch, no re-read of `lin`.
@@ -212,7 +326,8 @@ __global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__
                                                        const double* __restrict__ dts, int N, double w0, double w1, double w2,
                                                        double w3, double vmin, double vmax, double* __restrict__ lin,
                                                        double* __restrict__ loss_part, double* __restrict__ Hd,
-                                                       double* __restrict__ Ho, double* __restrict__ rhs) {
+                                                       double* __restrict__ Ho, double* __restrict__ rhs,
+                                                       const double* __restrict__ red, ReprojDev rp) {
     __shared__ double sl[64][LB_REC];
     const int M = N - 1;
     const int lane = threadIdx.x;
@@ -243,15 +358,24 @@ __global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__
 #pragma unroll
             for (int c = 0; c < LIN_C; ++c) lin[(size_t)c * M + L] = rec[c];
             sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+            if (red) sq += red[(size_t)L * RP_REC + 27];
         }
         M3<double> Gt = transpose(G), Ct = transpose(C), Bt = transpose(B);
         M3<double> GtG = Gt * G;
         double* o = sl[lane];
-        m3_store(w0 * GtG + w3 * m3_identity<double>(), o);
-        m3_store(w0 * (Gt * C), o + 9);
-        m3_store(w0 * (Ct * C + GtG) + w2 * (Bt * B), o + 18);
+        M3<double> Srr = w0 * GtG + w3 * m3_identity<double>();
+        M3<double> Srp = w0 * (Gt * C);
+        M3<double> Spp = w0 * (Ct * C + GtG) + w2 * (Bt * B);
         V3<double> gr = w0 * (Gt * r.erho) + w3 * r.rt;
         V3<double> gp = w0 * (Ct * r.erho + Gt * r.ephi) + w2 * (Bt * r.er);
+        if (red) {                                            // 5th residual: same +/- coupling pattern as the VO factor
+            const ReprojLink q = reproj_link(red + (size_t)L * RP_REC, rp, Xi);
+            Srr = Srr + rp.weight * q.Arr; Srp = Srp + rp.weight * q.Arp; Spp = Spp + rp.weight * q.App;
+            gr = gr + rp.weight * q.gr; gp = gp + rp.weight * q.gp;
+        }
+        m3_store(Srr, o);
+        m3_store(Srp, o + 9);
+        m3_store(Spp, o + 18);
         o[27] = gr.x; o[28] = gr.y; o[29] = gr.z; o[30] = gp.x; o[31] = gp.y; o[32] = gp.z;
         o[33] = r.rv.x; o[34] = r.rv.y; o[35] = r.rv.z; o[36] = r.rt.x; o[37] = r.rt.y; o[38] = r.rt.z; o[39] = dt;
     }
@@ -765,7 +889,9 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
                                                     const double* __restrict__ dvels, const double* __restrict__ dts,
                                                     const double* __restrict__ lin, int M, double* __restrict__ nodes_t,
                                                     double* __restrict__ vels_t, double* part, double* st, int* flags,
-                                                    unsigned* ticket, TRParams tr, double* report, double seq) {
+                                                    unsigned* ticket, TRParams tr, double* report, double seq,
+                                                    const double* __restrict__ red_lin, const double* __restrict__ red_trial,
+                                                    ReprojDev rp) {
     const int nblk = (M + 63) / 64;
     const int blk = xcd_index(blockIdx.x, nblk);
     int k = blk * 64 + threadIdx.x;
@@ -799,6 +925,19 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
             R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
         qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
              dot(j4, 2.0 * R4 + j4);
+        if (red_lin) {           // reprojection rows: (J D)^T (2 R + J D) = u^T (2 b + S u), u = Ad(C^-1 X_i^-1)(d_j - d_i)
+            sq += red_trial[(size_t)k * RP_REC + 27];
+            double u[RP_NSUM];
+#pragma unroll
+            for (int i = 0; i < RP_NSUM; ++i) u[i] = red_lin[(size_t)k * RP_REC + i];
+            M3<double> Ra, Ta;
+            reproj_adjoint(rp, se3_load(nodes + 7 * k), Ra, Ta);
+            const V3<double> ua = Ra * ddr + Ta * ddp, ub = Ra * ddp;
+            const V3<double> sa = sym_from(u, 0, 0) * ua + sym_from(u, 0, 3) * ub;
+            const V3<double> sb = tmul(sym_from(u, 0, 3), ua) + sym_from(u, 3, 3) * ub;
+            const V3<double> ba{u[21], u[22], u[23]}, bb{u[24], u[25], u[26]};
+            qd += dot(ua, 2.0 * ba + sa) + dot(ub, 2.0 * bb + sb);
+        }
     }
     sq = wave_sum(sq);
     qd = wave_sum(qd);
@@ -971,6 +1110,7 @@ struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill,
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
     double *lin2, *Hd2, *Ho2, *rhs2;          // second linearisation buffer (speculative next step)
+    double *red, *red2;                       // reprojection factor: per-link reductions (same double buffering)
     int* flags;
     LevelBufs lv[MAXL];
     size_t bytes;
@@ -993,6 +1133,8 @@ Workspace carve(void* base, int N) {
     w.Hd2 = take((size_t)N * 81);
     w.Ho2 = take((size_t)N * 81);
     w.rhs2 = take((size_t)N * 9);
+    w.red = take((size_t)M * RP_REC);
+    w.red2 = take((size_t)M * RP_REC);
     w.dx = take((size_t)N * 9);
     w.nodes_t = take((size_t)N * 7);
     w.vels_t = take((size_t)N * 3);
@@ -1263,7 +1405,7 @@ int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, 
     if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
     hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
                        dvels, dts, lin, M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{},
-                       (double*)nullptr, 0.0);
+                       (double*)nullptr, 0.0, (const double*)nullptr, (const double*)nullptr, ReprojDev{});
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -1312,11 +1454,50 @@ int islam_pvgo_align(const double* nodes, const double* vels, const double* targ
     return ISLAM_OK;
 }
 
+static int reproj_dev(const islam_pvgo_reproj* r, ReprojDev& d) {
+    if (!r->points || !r->targets || r->K < 1) return fail(ISLAM_EARG, "islam_pvgo_reproj: null points/targets or K=%d < 1", r->K);
+    d.points = r->points; d.targets = r->targets; d.K = r->K;
+    d.fx = r->fx; d.fy = r->fy; d.cx = r->cx; d.cy = r->cy;
+    d.C = {{r->rgb2imu[0], r->rgb2imu[1], r->rgb2imu[2]}, {r->rgb2imu[3], r->rgb2imu[4], r->rgb2imu[5], r->rgb2imu[6]}};
+    d.weight = r->weight;
+    d.compat_first = r->compat_first_motion;
+    return ISLAM_OK;
+}
+
+static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s) {
+    const int waves = std::min(4, std::max(1, (rp.K + 127) / 128));
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 0, s, nodes, dx, M, rp, red);
+}
+
+int islam_pvgo_reproj_reduce(const double* nodes, const double* dx, int N, const islam_pvgo_reproj* reproj, double* red,
+                             void* stream) {
+    if (N < 2 || !reproj) return fail(ISLAM_EARG, "islam_pvgo_reproj_reduce: N=%d < 2 or null reproj", N);
+    ReprojDev rp{};
+    int rc = reproj_dev(reproj, rp);
+    if (rc != ISLAM_OK) return rc;
+    enqueue_reproj_reduce(nodes, dx, N - 1, rp, red, as_stream(stream));
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
                          const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, void* workspace,
                          size_t workspace_bytes, islam_pvgo_result* result, double* trace, int trace_cap, void* stream) {
+    return islam_pvgo_run_chain_reproj(nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, nullptr, workspace,
+                                       workspace_bytes, result, trace, trace_cap, stream);
+}
+
+int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
+                                const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                                const islam_pvgo_reproj* reproj, void* workspace, size_t workspace_bytes,
+                                islam_pvgo_result* result, double* trace, int trace_cap, void* stream) {
     if (N < 2) return fail(ISLAM_EARG, "islam_pvgo_run_chain: N=%d < 2", N);
     if (!prm || !result) return fail(ISLAM_EARG, "islam_pvgo_run_chain: null params/result");
+    ReprojDev rp{};
+    if (reproj) {
+        int rc = reproj_dev(reproj, rp);
+        if (rc != ISLAM_OK) return rc;
+    }
     if (workspace_bytes < islam_pvgo_workspace_bytes(N))
         return fail(ISLAM_EARG, "islam_pvgo_run_chain: workspace %zu < %zu bytes", workspace_bytes,
                     islam_pvgo_workspace_bytes(N));
@@ -1354,12 +1535,16 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
     double* HO[2] = {w.Ho, w.Ho2};
     double* RH[2] = {w.rhs, w.rhs2};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
-    auto enqueue_linbuild = [&](const double* xn, const double* xv, int b) {
+    double* RED[2] = {w.red, w.red2};
+    // red_ready: RED[b] already holds the reduction at (xn): the trial pass computed it for the accept test
+    auto enqueue_linbuild = [&](const double* xn, const double* xv, int b, bool red_ready) {
+        if (reproj && !red_ready) enqueue_reproj_reduce(xn, nullptr, M, rp, RED[b], s);
         hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(64), 0, s, xn, xv, poses, drots, dtrans, dvels, dts, N, prm->w[0],
-                           prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax, LIN[b], w.loss_part, HD[b], HO[b], RH[b]);
+                           prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax, LIN[b], w.loss_part, HD[b], HO[b], RH[b],
+                           reproj ? RED[b] : (const double*)nullptr, rp);
     };
     int pb = 0;
-    enqueue_linbuild(cur_n, cur_v, pb);
+    enqueue_linbuild(cur_n, cur_v, pb, false);
     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
     bool speculate = true;
     while (continual) {
@@ -1371,9 +1556,13 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
             int rc = enqueue_solve(w, HD[pb], HO[pb], RH[pb], w.state, 0.0, N, prm->seg_len, w.dx, s);
             if (rc != ISLAM_OK) return rc;
             const double seq = (double)(trials + 1);
+            // reprojection factor at the trial point Exp(dx)*cur: its r^T r joins the trial loss, and it IS the reduction
+            // of the next linearisation if the trial is accepted
+            if (reproj) enqueue_reproj_reduce(cur_n, w.dx, M, rp, RED[1 - pb], s);
             hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid(nblk)), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
-                               dts, LIN[pb], M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq);
-            if (speculate) enqueue_linbuild(tri_n, tri_v, 1 - pb);
+                               dts, LIN[pb], M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq,
+                               reproj ? RED[pb] : (const double*)nullptr, reproj ? RED[1 - pb] : (const double*)nullptr, rp);
+            if (speculate) enqueue_linbuild(tri_n, tri_v, 1 - pb, true);
             ISLAM_LAUNCH_CHECK();
             // wait for the decision (poll the pinned status block; fall back to a stream sync after ~2 s)
             {
@@ -1406,7 +1595,7 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
             reject_count = (int)hs[8];
             if (accepted) {
                 std::swap(cur_n, tri_n); std::swap(cur_v, tri_v);
-                if (!speculate) enqueue_linbuild(cur_n, cur_v, 1 - pb);
+                if (!speculate) enqueue_linbuild(cur_n, cur_v, 1 - pb, true);
                 pb = 1 - pb;
                 speculate = true;
                 break;
@@ -1421,7 +1610,7 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
         if (reject_count >= prm->reject) continual = false;
         if (broke) {
             // PyPose keeps looping through the scheduler (the plateau counter stops it): same iterate, new linearisation
-            if (continual) { enqueue_linbuild(cur_n, cur_v, pb); speculate = true; }
+            if (continual) { enqueue_linbuild(cur_n, cur_v, pb, true); speculate = true; }
         }
     }
     if (cur_n != nodes) {

@@ -158,21 +158,49 @@ def pvgo_workspace(N, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
-def pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, params, workspace=None, trace_cap=0):
+def pvgo_reproj_struct(points, targets, K4, rgb2imu, weight, compat_first_motion=True):
+    """islam_pvgo_reproj over float64 device tensors points (M,K,3), targets (M,K,2); keeps them alive on the struct."""
+    require_cuda(points, targets)
+    assert points.dtype == torch.float64 and targets.dtype == torch.float64 and points.is_contiguous() and targets.is_contiguous()
+    assert points.shape[:2] == targets.shape[:2] and points.shape[2] == 3 and targets.shape[2] == 2
+    r = _lib.PvgoReproj()
+    r.points, r.targets, r.K = points.data_ptr(), targets.data_ptr(), int(points.shape[1])
+    r.fx, r.fy, r.cx, r.cy = [float(v) for v in K4]
+    for i, v in enumerate(rgb2imu):
+        r.rgb2imu[i] = float(v)
+    r.weight = float(weight)
+    r.compat_first_motion = int(bool(compat_first_motion))
+    r._keep = (points, targets)
+    return r
+
+
+def pvgo_reproj_reduce(nodes, reproj, dx=None):
+    """Per-link keypoint reduction (M, 32): [J^T J upper (21) | J^T r (6) | r^T r | pad] at nodes or Exp(dx)*nodes."""
+    require_cuda(nodes, dx)
+    N = nodes.shape[0]
+    red = torch.empty((N - 1, _lib.REPROJ_REC), dtype=torch.float64, device=nodes.device)
+    check(lib().islam_pvgo_reproj_reduce(ptr(nodes), ptr(dx), N, ctypes.byref(reproj), ptr(red), stream_ptr(nodes.device)))
+    return red
+
+
+def pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, params, workspace=None, trace_cap=0, reproj=None):
     """In-place LM on float64 device tensors.  Returns (PvgoResult, trace ndarray (trials,3) or None)."""
     require_cuda(nodes, vels, poses, drots, dtrans, dvels, dts)
     for t in (nodes, vels, poses, drots, dtrans, dvels, dts):
         assert t.dtype == torch.float64 and t.is_contiguous()
     N = nodes.shape[0]
+    if reproj is not None:
+        assert reproj._keep[0].shape[0] == N - 1, 'reprojection factor needs one keypoint set per link'
     if workspace is None:
         workspace = pvgo_workspace(N, nodes.device)
     ws, nbytes = workspace
     res = _lib.PvgoResult()
     trace = np.zeros((trace_cap, 3), dtype=np.float64) if trace_cap > 0 else None
     tp = trace.ctypes.data_as(c_void_p) if trace is not None else c_void_p(0)
-    check(lib().islam_pvgo_run_chain(ptr(nodes), ptr(vels), ptr(poses), ptr(drots), ptr(dtrans), ptr(dvels), ptr(dts), N,
-                                     ctypes.byref(params), ptr(ws), c_size_t(nbytes), ctypes.byref(res), tp, trace_cap,
-                                     stream_ptr(nodes.device)))
+    check(lib().islam_pvgo_run_chain_reproj(ptr(nodes), ptr(vels), ptr(poses), ptr(drots), ptr(dtrans), ptr(dvels), ptr(dts), N,
+                                            ctypes.byref(params), ctypes.byref(reproj) if reproj is not None else None,
+                                            ptr(ws), c_size_t(nbytes), ctypes.byref(res), tp, trace_cap,
+                                            stream_ptr(nodes.device)))
     if trace is not None:
         trace = trace[:min(res.trials, trace_cap)]
     return res, trace

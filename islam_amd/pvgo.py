@@ -7,7 +7,8 @@ What runs where:
     motions with PyPose's gradient convention, so ``loss_bp.backward`` in train.py:280-283 works unchanged;
   * imu_loss (:95-111) is O(N) glue on the LieTensor shim (the IMU epoch carries no gradient in the
     reference release).
-The information matrices of pvgo.py:125-143 are scalar multiples of the identity; they enter as four scalars.
+The information matrices of pvgo.py:125-143 are scalar multiples of the identity; they enter as four scalars (five with
+the optional sparse reprojection factor ``reproj``, islam_amd/dense_ba.py).
 """
 import numpy as np
 import torch
@@ -32,10 +33,19 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     dev = torch.device(device)
     if dev.type != 'cuda':
         raise RuntimeError("islam_amd.run_pvgo runs on the MI355X only (device=%r); there is no CPU fallback" % (device,))
-    if reproj is not None:
-        raise UnsupportedGraphError('the reprojection factor (pvgo.py:53-61) is not built yet (SURVEY.md section 8f rank 2)')
     N = len(init_nodes)
     chain = _is_canonical_chain(links, N)
+    rp = None
+    if reproj is not None:               # 5th residual (pvgo.py:53-61,130-143): SparseReprojectionLoss-like object
+        if not chain:
+            raise UnsupportedGraphError('the reprojection factor couples consecutive nodes (pvgo.py:54-56): chain links only')
+        w5 = (loss_weight[4] / reproj.N) ** 2                                                  # pvgo.py:131
+        K = reproj.K.detach().cpu().double()
+        rp = ops.pvgo_reproj_struct(reproj.point3d.detach().to(dev, torch.float64).contiguous(),
+                                    reproj.target.detach().to(dev, torch.float64).contiguous(),
+                                    (K[0, 0], K[1, 1], K[0, 2], K[1, 2]),
+                                    pp._plain(reproj.rgb2imu_pose).detach().cpu().double().reshape(7).tolist(), w5,
+                                    getattr(reproj, 'compat_first_motion', True))
     out_dtype = pp._plain(init_nodes).dtype if isinstance(init_nodes, torch.Tensor) else torch.get_default_dtype()
     t64 = lambda x: pp._plain(torch.as_tensor(x)).detach().to(dev, torch.float64).contiguous()
     nodes, vels = t64(init_nodes).clone(), t64(init_vels).clone()
@@ -46,7 +56,7 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
 
     if chain:            # the topology train.py produces: block-tridiagonal fast path, whole LM loop in one library call
         prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
-        res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm)
+        res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm, reproj=rp)
     else:                # loop closures / arbitrary links: dense formulation on the device (islam_amd/pvgo_dense.py)
         from .pvgo_dense import run_lm_dense
         if N > 4000:
@@ -75,6 +85,8 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     covs = {'vo_rot': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_rot': np.ones(n1) * loss_weight[2] ** 2,
             'vo_trans': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_vel': np.ones(n1) * loss_weight[1] ** 2,
             'transvel': np.ones(n1) * loss_weight[3] ** 2}
+    if reproj is not None:
+        covs['reproj'] = np.ones(n1) * (loss_weight[4] / reproj.N) ** 2                        # pvgo.py:202-203
     if return_info:
         return trans_loss, rot_loss, nodes_out, vels_out, covs, res
     return trans_loss, rot_loss, nodes_out, vels_out, covs

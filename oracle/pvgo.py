@@ -19,6 +19,7 @@ import numpy as np
 import scipy.linalg as sla
 
 from . import lie
+from . import reproj as oreproj
 
 
 # ------------------------------------------------------------------ residuals
@@ -93,12 +94,14 @@ def jacobian_dense(N, edges, A, B, dts, true_translation_jacobian=False, nodes=N
     return J
 
 
-def weight_vector(E, M, loss_weight, dtype):
+def weight_vector(E, M, loss_weight, dtype, reproj_n=0):
     """pvgo.py:125-162: all information matrices are scalar*I, so W is diagonal.
-    Order follows the model outputs: [VO 6E | imu_vel 3M | imu_rot 3M | transvel 3M]."""
+    Order follows the model outputs: [VO 6E | imu_vel 3M | imu_rot 3M | transvel 3M | reproj 2*n*M (pvgo.py:130-131)]."""
     lw = loss_weight
-    return np.concatenate([np.full(6 * E, lw[0] ** 2), np.full(3 * M, lw[1] ** 2),
-                           np.full(3 * M, lw[2] ** 2), np.full(3 * M, lw[3] ** 2)]).astype(dtype)
+    w = [np.full(6 * E, lw[0] ** 2), np.full(3 * M, lw[1] ** 2), np.full(3 * M, lw[2] ** 2), np.full(3 * M, lw[3] ** 2)]
+    if reproj_n:
+        w.append(np.full(2 * reproj_n * M, (lw[4] / reproj_n) ** 2))
+    return np.concatenate(w).astype(dtype)
 
 
 def retract(nodes, vels, D_nodes6, D_vels):
@@ -138,11 +141,18 @@ class TrustRegion:
 class _DenseLin:
     """PyPose's linear algebra: dense J, dense A = J^T W J, dense Cholesky (ppos.Cholesky)."""
 
-    def __init__(self, nodes, inp, res, A_e, B_k, w, ttj):
+    def __init__(self, nodes, inp, res, A_e, B_k, w, ttj, J_rp=None):
         edges, dts = inp[0], inp[5]
         N = nodes.shape[0]
         self.N, self.dt = N, nodes.dtype
         self.J = jacobian_dense(N, edges, A_e, B_k, dts, ttj, nodes)
+        if J_rp is not None:                                  # 5th output: link k couples nodes k, k+1 (pvgo.py:54-56)
+            M, n2 = J_rp.shape[0], J_rp.shape[1]
+            Jr = np.zeros((M * n2, 10 * N), dtype=self.J.dtype)
+            for k in range(M):
+                Jr[n2 * k:n2 * (k + 1), 7 * (k + 1):7 * (k + 1) + 6] = J_rp[k]
+                Jr[n2 * k:n2 * (k + 1), 7 * k:7 * k + 6] = -J_rp[k]
+            self.J = np.concatenate([self.J, Jr], 0)
         R = np.concatenate([r.reshape(-1) for r in res])
         JTW = self.J.T * w[None, :]
         self.A = JTW @ self.J
@@ -169,7 +179,7 @@ class _BandedLin:
     clamp value 1e-4 and its right-hand side 0, so its step is exactly 0), canonical chain
     links [k, k+1] only; banded Cholesky (bandwidth 17)."""
 
-    def __init__(self, nodes, inp, res, A_e, B_k, w4, ttj):
+    def __init__(self, nodes, inp, res, A_e, B_k, w4, ttj, J_rp=None, w_rp=0.0):
         edges, dts = inp[0], np.asarray(inp[5]).reshape(-1)
         N = nodes.shape[0]
         M = N - 1
@@ -179,11 +189,14 @@ class _BandedLin:
         dt = nodes.dtype
         self.N, self.dt, self.A_e, self.B_k, self.dts = N, dt, A_e, B_k, dts
         w0, w1, w2, w3 = [dt.type(x) for x in w4]
-        e, rv, er, rt = res
+        e, rv, er, rt = res[:4]
+        self.J_rp = J_rp
         I3 = np.eye(3, dtype=dt)
         S = w0 * (np.swapaxes(A_e, 1, 2) @ A_e)
         S[:, :3, :3] += w3 * I3
         S[:, 3:, 3:] += w2 * (np.swapaxes(B_k, 1, 2) @ B_k)
+        if J_rp is not None:
+            S += dt.type(w_rp) * (np.swapaxes(J_rp, 1, 2) @ J_rp)
         Hd = np.zeros((N, 9, 9), dt)
         Ho = np.zeros((M, 9, 9), dt)
         Hd[:-1, :6, :6] += S
@@ -199,6 +212,8 @@ class _BandedLin:
         gp = w0 * (np.swapaxes(A_e, 1, 2) @ e[:, :, None])[:, :, 0]
         gp[:, 3:] += w2 * (np.swapaxes(B_k, 1, 2) @ er[:, :, None])[:, :, 0]
         gp[:, :3] += w3 * rt
+        if J_rp is not None:
+            gp += dt.type(w_rp) * (np.swapaxes(J_rp, 1, 2) @ res[4][:, :, None])[:, :, 0]
         g = np.zeros((N, 9), dt)
         g[1:, :6] += gp
         g[:-1, :6] -= gp
@@ -226,15 +241,19 @@ class _BandedLin:
         jd_av = Dv[:-1] - Dv[1:]
         jd_rot = (self.B_k @ dp[:, 3:, None])[:, :, 0]
         jd_tv = dp[:, :3] - self.dts[:, None] * Dv[:-1]
-        return np.concatenate([jd_vo.reshape(-1), jd_av.reshape(-1), jd_rot.reshape(-1), jd_tv.reshape(-1)])
+        out = [jd_vo.reshape(-1), jd_av.reshape(-1), jd_rot.reshape(-1), jd_tv.reshape(-1)]
+        if self.J_rp is not None:
+            out.append((self.J_rp @ dp[:, :, None]).reshape(-1))
+        return np.concatenate(out)
 
 
 class LM:
     """pp.optim.LM with Cholesky solver + TrustRegion strategy, as constructed at pvgo.py:169-171."""
 
     def __init__(self, nodes, vels, radius=1e4, vmin=1e-4, vmax=1e32, reject=16, mode='dense',
-                 true_translation_jacobian=False):
+                 true_translation_jacobian=False, reproj=None, compat_first_motion=True):
         self.nodes, self.vels = nodes.copy(), vels.copy()
+        self.reproj, self.compat_first = reproj, compat_first_motion
         self.strategy = TrustRegion(radius=radius)
         self.min, self.max, self.reject = vmin, vmax, reject
         self.reject_count = 0
@@ -245,7 +264,10 @@ class LM:
         self.trace = []   # (loss, damping, accepted) per inner iteration
 
     def _res(self, inp):
-        return residuals(self.nodes, self.vels, *inp)
+        res = residuals(self.nodes, self.vels, *inp)
+        if self.reproj is not None:                          # pvgo.py:53-61
+            res = res + (oreproj.residual(self.reproj, self.nodes, self.compat_first),)
+        return res
 
     def step(self, inp, loss_weight):
         edges, poses, drots, dtrans, dvels, dts = inp
@@ -254,10 +276,14 @@ class LM:
         res = self._res(inp)
         R = np.concatenate([r.reshape(-1) for r in res])
         A_e, B_k = jac_blocks(self.nodes, edges, poses, drots, res[0], res[2])
+        J_rp, n_rp = None, 0
+        if self.reproj is not None:
+            J_rp, n_rp = oreproj.jac_link(self.reproj, self.nodes, self.compat_first), self.reproj.N
         if self.mode == 'dense':
-            lin = _DenseLin(self.nodes, inp, res, A_e, B_k, weight_vector(E, M, loss_weight, dt), self.ttj)
+            lin = _DenseLin(self.nodes, inp, res, A_e, B_k, weight_vector(E, M, loss_weight, dt, n_rp), self.ttj, J_rp)
         else:
-            lin = _BandedLin(self.nodes, inp, res, A_e, B_k, [x ** 2 for x in loss_weight[:4]], self.ttj)
+            lin = _BandedLin(self.nodes, inp, res, A_e, B_k, [x ** 2 for x in loss_weight[:4]], self.ttj, J_rp,
+                             (loss_weight[4] / n_rp) ** 2 if n_rp else 0.0)
         if self.loss is None:
             self.loss = loss_unweighted(res)
         self.last = self.loss
@@ -344,14 +370,15 @@ def align_to(nodes, vels, target, idx=0):
 
 def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtrans, imu_dvels,
              radius=1e4, loss_weight=(1, 1, 1, 1), target='vo', mode='dense', dtype=np.float64,
-             true_translation_jacobian=False, max_steps=10, return_optimizer=False):
+             true_translation_jacobian=False, max_steps=10, return_optimizer=False, reproj=None,
+             compat_first_motion=True):
     """pvgo.py:122-205 on numpy arrays.  Returns (trans_loss, rot_loss, nodes, vels, covs[, optimizer])."""
     c = lambda a: np.ascontiguousarray(np.asarray(a), dtype=dtype)
     init_nodes, init_vels, vo_motions = c(init_nodes), c(init_vels), c(vo_motions)
     dts, imu_drots, imu_dtrans, imu_dvels = c(dts), c(imu_drots), c(imu_dtrans), c(imu_dvels)
     links = np.asarray(links, dtype=np.int64)
     opt = LM(init_nodes, init_vels, radius=radius, vmin=1e-4, mode=mode,
-             true_translation_jacobian=true_translation_jacobian)
+             true_translation_jacobian=true_translation_jacobian, reproj=reproj, compat_first_motion=compat_first_motion)
     sched = StopOnPlateau(opt, steps=max_steps, patience=3, decreasing=1e-3)
     inp = (links, vo_motions, imu_drots, imu_dtrans, imu_dvels, dts)
     while sched.continual():
@@ -366,5 +393,7 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     covs = {'vo_rot': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_rot': np.ones(n) * loss_weight[2] ** 2,
             'vo_trans': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_vel': np.ones(n) * loss_weight[1] ** 2,
             'transvel': np.ones(n) * loss_weight[3] ** 2}
+    if reproj is not None:
+        covs['reproj'] = np.ones(n) * (loss_weight[4] / reproj.N) ** 2                   # pvgo.py:131,202-203
     out = (tl, rl, nodes, vels, covs)
     return out + (opt,) if return_optimizer else out

@@ -173,3 +173,24 @@ def test_ate_evaluator_known_answers():
     assert 0.1 < a < 0.25
     X = np.concatenate([gt, np.tile([0, 0, 0, 1.0], (50, 1))], 1)
     assert evaluate.rpe(X, X) == (0.0, 0.0)
+
+
+def test_dense_ba_helpers_known_answers():
+    """pixel2point against the reference's own docstring vector (dense_ba.py:29-47); proj mask; keypoint sampler."""
+    from islam_amd import dense_ba
+    K = torch.tensor([[2.0, 0, 4.5], [0, 2.0, 4.5], [0, 0, 1]])
+    px = torch.tensor([[0.5, 0.0], [1.0, 0.0], [0.0, 1.3], [1.0, 0.0], [0.5, 1.5], [5.0, 1.5]])
+    dep = torch.tensor([5.0, 3.0, 6.5, 2.0, 0.5, 0.7])
+    want = torch.tensor([[-10.0, -11.25, 5.0], [-5.25, -6.75, 3.0], [-14.625, -10.4, 6.5], [-3.5, -4.5, 2.0],
+                         [-1.0, -0.75, 0.5], [0.175, -1.05, 0.7]])
+    torch.testing.assert_close(dense_ba.pixel2point(px, dep, K), want)
+    x = torch.tensor([[0.5, 0.2, 1.0], [3.0, 0.0, 1.0], [0.1, 0.1, 0.05]])
+    p, m = dense_ba.proj(x, return_mask=True)
+    assert m.tolist() == [True, False, False] and torch.equal(p[1], torch.zeros(3))
+    mask = torch.zeros(2, 8, 10, dtype=torch.bool)
+    mask[0, 2:6, 3:7] = True
+    mask[1, 0, 0] = True
+    kp = dense_ba.sample_keypoints(mask, 6, torch.Generator().manual_seed(0))
+    assert kp.shape == (2, 6, 2)
+    assert mask[0][kp[0, :, 1].long(), kp[0, :, 0].long()].all() and len({tuple(r) for r in kp[0].tolist()}) == 6
+    assert (kp[1] == 0).all()

@@ -274,3 +274,43 @@ def test_scale_oracle_recovers_known_scale():
     s, zz, mask, dmask, _ = oscale.scale_from_disp_flow(disp[None], flow, direction, fx, fy, cx, cy, base, None, 1.0)
     assert mask.sum() > 500
     np.testing.assert_allclose(s, np.linalg.norm(motion[:3]), rtol=2e-3)
+
+
+def test_reprojection_factor_oracle():
+    """5th PVGO residual (pvgo.py:53-61, dense_ba.py:276-305): analytic left-perturbation Jacobian vs central differences,
+    dense == banded LM, the in-place `motion[0] = 0.1` quirk, and the known-answer vector of dense_ba.py:29-47."""
+    from oracle import reproj as orp
+    from tests.helpers import chain_problem, reproj_inputs
+    # the only golden vector the reference holds on this path: the pixel2point docstring example (dense_ba.py:29-47)
+    px = np.array([[0.5, 0.0], [1.0, 0.0], [0.0, 1.3], [1.0, 0.0], [0.5, 1.5], [5.0, 1.5]])
+    dep = np.array([5.0, 3.0, 6.5, 2.0, 0.5, 0.7])
+    want = np.array([[-10.0, -11.25, 5.0], [-5.25, -6.75, 3.0], [-14.625, -10.4, 6.5], [-3.5, -4.5, 2.0], [-1.0, -0.75, 0.5],
+                     [0.175, -1.05, 0.7]])
+    np.testing.assert_allclose(orp.pixel2point(px, dep, (2.0, 2.0, 4.5, 4.5)), want, atol=1e-12)
+
+    F, K = 9, 24
+    prob, tr = chain_problem(F)
+    R = orp.SparseReprojection(**reproj_inputs(tr, K, [0.1, -0.05, 0.02, 0.5, -0.5, 0.5, -0.5]))
+    nodes = prob['init_nodes']
+    for compat in (True, False):
+        J = orp.jac_link(R, nodes, compat)
+        eps = 1e-6
+        for k in (0, 4):
+            for node, sign in ((k + 1, 1.0), (k, -1.0)):
+                Jn = np.zeros((2 * K, 6))
+                for a in range(6):
+                    d = np.zeros(6)
+                    d[a] = eps
+                    hi, lo = nodes.copy(), nodes.copy()
+                    hi[node] = lie.se3_mul(lie.se3_exp(d), nodes[node])
+                    lo[node] = lie.se3_mul(lie.se3_exp(-d), nodes[node])
+                    Jn[:, a] = (orp.residual(R, hi, compat)[k] - orp.residual(R, lo, compat)[k]) / (2 * eps)
+                np.testing.assert_allclose(Jn, sign * J[k], atol=2e-7 * max(np.abs(J[k]).max(), 1.0))
+        if compat:
+            assert np.all(J[0] == 0) and np.abs(orp.residual(R, nodes, True)[0]).max() > 1.0
+    lw = (1, 0.1, 10, 0.1, 2.0)
+    d = opvgo.run_pvgo(**prob, loss_weight=lw, mode='dense', reproj=R, return_optimizer=True)
+    b = opvgo.run_pvgo(**prob, loss_weight=lw, mode='banded', reproj=R, return_optimizer=True)
+    assert [t[2] for t in d[5].trace] == [t[2] for t in b[5].trace]
+    np.testing.assert_allclose(d[2], b[2], atol=1e-9)
+    np.testing.assert_allclose(d[4]['reproj'], (lw[4] / K) ** 2)

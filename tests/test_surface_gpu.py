@@ -44,12 +44,12 @@ def test_run_pvgo_surface_matches_oracle(cuda):
 
 
 def test_run_pvgo_rejects_what_is_not_built(cuda):
-    from islam_amd.pvgo import UnsupportedGraphError, run_pvgo
+    from islam_amd.pvgo import run_pvgo
     prob, _ = chain_problem(5)
     args = [torch.tensor(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions')]
     rest = [torch.tensor(prob[k]) for k in ('dts', 'imu_drots', 'imu_dtrans', 'imu_dvels')]
-    with pytest.raises(UnsupportedGraphError):
-        run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cuda', reproj=object())
+    with pytest.raises(AttributeError):          # like the reference: a reproj object without .N fails at pvgo.py:131
+        run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cuda', loss_weight=(1, 1, 1, 1, 1), reproj=object())
     with pytest.raises(RuntimeError):
         run_pvgo(*args, torch.tensor(prob['links']), *rest, device='cpu')
 
