@@ -211,6 +211,15 @@ int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx
  * path (islam_amd/pvgo_dense.py). */
 int islam_pvgo_linearize_edges(const double* nodes, const int64_t* edges, const double* poses, int E, double* out,
                                void* stream);
+/* General-topology normal equations without ever forming J: A (9N x 9N row-major, fully written) and rhs (9N) from
+ *   - the block-tridiagonal IMU part Hd, Ho (N,9,9), rhs_chain (N,9)  (islam_pvgo_build_normal with w[0] = 0, no clamp),
+ *   - the VO factors of arbitrary edges `vo` (24,E) from islam_pvgo_linearize_edges, weight w0.
+ * node_ptr (N+1), node_adj (2E) = CSR of the edge ends per node, entry = 2*edge + end (end 0 = i, 1 = j), so every
+ * diagonal block and right-hand side is summed in a fixed order (bit-reproducible); off-diagonal VO blocks are added
+ * with one atomic per entry.  Replaces PyPose's dense J^T W J (pp.optim.LM) on the loop-closure path. */
+int islam_pvgo_assemble_dense(const double* Hd, const double* Ho, const double* rhs_chain, const double* vo,
+                              const int64_t* edges, const int64_t* node_ptr, const int64_t* node_adj, double w0,
+                              int N, int E, double* A, double* rhs, void* stream);
 /* vo_loss forward/backward (pvgo.py:67-78 with PyPose's left-tangent gradient convention).
  * fwd: e (E,6) = Log(P^-1 Xi^-1 Xj); trans_loss, rot_loss (E).  bwd: grad_poses (E,7), last column 0. */
 int islam_pvgo_vo_loss_fwd(const double* nodes, const int64_t* edges, const double* poses, int E,

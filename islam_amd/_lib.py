@@ -77,6 +77,7 @@ SIGNATURES = {
     'islam_pvgo_trial': (c_int, [c_void_p] * 9 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_retract': (c_int, [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 3),
     'islam_pvgo_linearize_edges': (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_void_p]),
+    'islam_pvgo_assemble_dense': (c_int, [c_void_p] * 7 + [c_double, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'islam_pvgo_vo_loss_fwd': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_vo_loss_bwd': (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 2),
     'islam_pvgo_align': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3),

@@ -1013,6 +1013,109 @@ __global__ __launch_bounds__(64) void vo_edge_linearize_kernel(const double* __r
     for (int c = 0; c < 24; ++c) out[(size_t)c * E + e] = rec[c];
 }
 
+// ---- general topology: dense A from block pieces (no dense J) ----
+struct EdgeNormal { M3<double> Srr, Srp, Spp; V3<double> gr, gp; };
+
+__device__ __forceinline__ EdgeNormal edge_normal(const double* __restrict__ vo, int E, int e) {
+    double rec[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) rec[c] = vo[(size_t)c * E + e];
+    const V3<double> er{rec[0], rec[1], rec[2]}, ep{rec[3], rec[4], rec[5]};
+    const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15);
+    const M3<double> Gt = transpose(G), Ct = transpose(C);
+    EdgeNormal o;
+    o.Srr = Gt * G;
+    o.Srp = Gt * C;
+    o.Spp = Ct * C + o.Srr;
+    o.gr = Gt * er;
+    o.gp = Ct * er + Gt * ep;
+    return o;
+}
+
+// one lane per node: diagonal block + right-hand side (fixed summation order over the node's edge ends), chain coupling
+__global__ __launch_bounds__(64) void dense_nodes_kernel(const double* __restrict__ Hd, const double* __restrict__ Ho,
+                                                          const double* __restrict__ rhs_chain, const double* __restrict__ vo,
+                                                          const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ node_adj,
+                                                          double w0, int N, int E, double* __restrict__ A, double* __restrict__ rhs) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= N) return;
+    const size_t ld = (size_t)9 * N;
+    const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    M3<double> Srr = Z, Srp = Z, Spp = Z;
+    V3<double> gr{0, 0, 0}, gp{0, 0, 0};
+    for (int64_t a = node_ptr[k]; a < node_ptr[k + 1]; ++a) {
+        const int64_t code = node_adj[a];
+        const EdgeNormal en = edge_normal(vo, E, (int)(code >> 1));
+        Srr = Srr + en.Srr; Srp = Srp + en.Srp; Spp = Spp + en.Spp;
+        if (code & 1) { gr = gr + en.gr; gp = gp + en.gp; } else { gr = gr - en.gr; gp = gp - en.gp; }
+    }
+    double blk[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) blk[i] = Hd[(size_t)k * 81 + i];
+    double add[36];
+    m3_store(w0 * Srr, add); m3_store(w0 * Srp, add + 9); m3_store(w0 * Spp, add + 18); m3_store(w0 * transpose(Srp), add + 27);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            blk[r * 9 + c] += add[r * 3 + c];
+            blk[r * 9 + 3 + c] += add[9 + r * 3 + c];
+            blk[(3 + r) * 9 + c] += add[27 + r * 3 + c];
+            blk[(3 + r) * 9 + 3 + c] += add[18 + r * 3 + c];
+        }
+    double* d = A + (size_t)9 * k * ld + 9 * k;
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) d[r * ld + c] = blk[r * 9 + c];
+    const double* rc = rhs_chain + (size_t)k * 9;
+    double* b = rhs + (size_t)k * 9;
+    b[0] = rc[0] - w0 * gr.x; b[1] = rc[1] - w0 * gr.y; b[2] = rc[2] - w0 * gr.z;
+    b[3] = rc[3] - w0 * gp.x; b[4] = rc[4] - w0 * gp.y; b[5] = rc[5] - w0 * gp.z;
+    b[6] = rc[6]; b[7] = rc[7]; b[8] = rc[8];
+    if (k < N - 1) {
+        double* up = A + (size_t)9 * k * ld + 9 * (k + 1);
+        double* lo = A + (size_t)9 * (k + 1) * ld + 9 * k;
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double v = Ho[(size_t)k * 81 + r * 9 + c];
+                up[r * ld + c] = v;
+                lo[c * ld + r] = v;
+            }
+    }
+}
+
+// one lane per edge: the two off-diagonal blocks -w0 S (and its transpose) of an arbitrary edge (i, j)
+__global__ __launch_bounds__(64) void dense_edges_kernel(const double* __restrict__ vo, const int64_t* __restrict__ edges, double w0,
+                                                          int N, int E, double* __restrict__ A) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    const int64_t i = edges[2 * e], j = edges[2 * e + 1];
+    if (i == j) return;
+    const EdgeNormal en = edge_normal(vo, E, e);
+    double S[36];       // row-major 6x6 [[Srr, Srp],[Srp^T, Spp]]
+    const M3<double> Spr = transpose(en.Srp);
+    double t[9];
+    m3_store(en.Srr, t);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S[r * 6 + c] = t[r * 3 + c];
+    m3_store(en.Srp, t);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S[r * 6 + 3 + c] = t[r * 3 + c];
+    m3_store(Spr, t);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S[(3 + r) * 6 + c] = t[r * 3 + c];
+    m3_store(en.Spp, t);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S[(3 + r) * 6 + 3 + c] = t[r * 3 + c];
+    const size_t ld = (size_t)9 * N;
+    double* ij = A + (size_t)9 * i * ld + 9 * j;
+    double* ji = A + (size_t)9 * j * ld + 9 * i;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            atomicAdd(&ij[r * ld + c], -w0 * S[r * 6 + c]);
+            atomicAdd(&ji[c * ld + r], -w0 * S[r * 6 + c]);
+        }
+}
+
 __global__ __launch_bounds__(64) void vo_loss_fwd_kernel(const double* __restrict__ nodes, const int64_t* __restrict__ edges,
                                                           const double* __restrict__ poses, int E, double* __restrict__ err6,
                                                           double* __restrict__ tl, double* __restrict__ rl) {
@@ -1423,6 +1526,19 @@ int islam_pvgo_linearize_edges(const double* nodes, const int64_t* edges, const 
                                void* stream) {
     if (E < 1) return fail(ISLAM_EARG, "islam_pvgo_linearize_edges: E=%d < 1", E);
     hipLaunchKernelGGL(vo_edge_linearize_kernel, dim3((E + 63) / 64), dim3(64), 0, as_stream(stream), nodes, edges, poses, E, out);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_pvgo_assemble_dense(const double* Hd, const double* Ho, const double* rhs_chain, const double* vo,
+                              const int64_t* edges, const int64_t* node_ptr, const int64_t* node_adj, double w0, int N, int E,
+                              double* A, double* rhs, void* stream) {
+    if (N < 2 || E < 0) return fail(ISLAM_EARG, "islam_pvgo_assemble_dense: N=%d E=%d", N, E);
+    hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(A, 0, (size_t)81 * N * N * sizeof(double), s));
+    hipLaunchKernelGGL(dense_nodes_kernel, dim3((N + 63) / 64), dim3(64), 0, s, Hd, Ho, rhs_chain, vo, node_ptr, node_adj, w0, N, E, A,
+                       rhs);
+    if (E > 0) hipLaunchKernelGGL(dense_edges_kernel, dim3((E + 63) / 64), dim3(64), 0, s, vo, edges, w0, N, E, A);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

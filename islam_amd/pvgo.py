@@ -59,8 +59,8 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
         res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm, reproj=rp)
     else:                # loop closures / arbitrary links: dense formulation on the device (islam_amd/pvgo_dense.py)
         from .pvgo_dense import run_lm_dense
-        if N > 4000:
-            raise UnsupportedGraphError('dense general-topology path is sized for N <= 4000 nodes (got %d)' % N)
+        if N > 12000:
+            raise UnsupportedGraphError('dense general-topology path is sized for N <= 12000 nodes, (9N)^2 doubles (got %d)' % N)
         nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
 
     if target == 'vo':

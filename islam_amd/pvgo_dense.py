@@ -1,16 +1,24 @@
 """General-topology PVGO (arbitrary ``links``: loop closures, skipped frames) on the GPU -- SURVEY.md section 8f rank 4.
 
 The chain fast path (islam_amd/csrc/pvgo.hip) needs links[k] = [k, k+1].  For any other edge set this module runs the
-same LM (pp.optim.LM + TrustRegion + StopOnPlateau as constructed at pvgo.py:169-172) the way PyPose does it -- dense
-Jacobian, dense J^T W J, dense Cholesky -- but with every O(rows) piece on the device: residuals and Jacobian blocks from
-the HIP kernels (islam_pvgo_linearize_edges for the VO factors, islam_pvgo_linearize for the IMU factors, which always
-couple consecutive nodes), the fp64 GEMM / POTRF / POTRS from rocBLAS / rocSOLVER (fp64 MFMA), the retraction from
-islam_pvgo_retract.  Sized for N up to a few thousand nodes (the dense matrix is (9N)^2 doubles)."""
+same LM (pp.optim.LM + Cholesky + TrustRegion + StopOnPlateau as constructed at pvgo.py:169-172) with the same dense
+normal matrix PyPose factorises, but never forms the Jacobian PyPose multiplies (rows x 10N):
+
+  * residuals and Jacobian blocks per factor from the HIP kernels (islam_pvgo_linearize_edges for the VO factors on
+    arbitrary edges, islam_pvgo_linearize for the IMU factors, which always couple consecutive nodes);
+  * A = J^T W J (9N x 9N) and b = -J^T W r assembled block by block on the device (islam_pvgo_assemble_dense):
+    O(E) work instead of the 2*rows*cols^2 dense product;
+  * fp64 POTRF / POTRS from rocSOLVER (the only O(N^3) piece; its trailing updates are fp64 MFMA GEMMs);
+  * retraction, trial residuals and the trust-region term (J D)^T (2R + J D) from the per-factor blocks.
+Sized by the dense matrix: (9N)^2 doubles (N = 5001: 16 GB of the 288 GB)."""
+import numpy as np
 import torch
 
 from . import ops
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import c_double, check, lib, ptr, stream_ptr
 from .lm_control import LMControl
+
+_NOCLAMP = 1e300
 
 
 def _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy_poses):
@@ -21,46 +29,43 @@ def _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy_poses
     return vo, lin
 
 
-def _residual_vector(vo, lin):
-    # model output order (pvgo.py:64): pgerr (6E) | adjvelerr (3M) | imuroterr (3M) | transvelerr (3M)
-    return torch.cat([vo[0:6].t().reshape(-1), lin[36:39].t().reshape(-1), lin[24:27].t().reshape(-1), lin[39:42].t().reshape(-1)])
+def _loss(vo, lin):
+    """Unweighted sum of squares over the model outputs (pvgo.py:64): pgerr | adjvelerr | imuroterr | transvelerr."""
+    return (vo[0:6] ** 2).sum() + (lin[36:39] ** 2).sum() + (lin[24:27] ** 2).sum() + (lin[39:42] ** 2).sum()
 
 
-def _dense_jacobian(N, edges, vo, lin, dts):
-    """Rows as _residual_vector, columns node-major [rho phi v] (the always-zero pad column of PyPose's 7-slot pose is dropped)."""
-    dev = vo.device
-    E, M = edges.shape[0], N - 1
-    rows = 6 * E + 9 * M
-    J = torch.zeros((rows, 9 * N), dtype=torch.float64, device=dev)
+def _node_adjacency(edges_host, N):
+    """CSR of edge ends per node, entry = 2*edge + end, ascending: fixes the summation order of the diagonal blocks."""
+    E = edges_host.shape[0]
+    node = edges_host.reshape(-1)                          # entry index = 2*e + end
+    order = np.argsort(node, kind='stable')
+    ptr_ = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(ptr_, node + 1, 1)
+    return np.cumsum(ptr_), order.astype(np.int64)
+
+
+def _quality_term(vo, lin, edges, dts, D):
+    """(J D)^T (2 R + J D) with the unweighted J, R of the linearisation point, factor by factor."""
+    D6, Dv = D[:, :6], D[:, 6:]
+    E = edges.shape[0]
+    dp = D6[edges[:, 1]] - D6[edges[:, 0]]
     G = vo[6:15].t().reshape(E, 3, 3)
     C = vo[15:24].t().reshape(E, 3, 3)
-    A = torch.zeros((E, 6, 6), dtype=torch.float64, device=dev)
-    A[:, :3, :3], A[:, :3, 3:], A[:, 3:, 3:] = G, C, G
-    ar6 = torch.arange(6, device=dev)
-    r = (6 * torch.arange(E, device=dev)[:, None, None] + ar6[None, :, None]).expand(E, 6, 6)
-    for col, sign in ((edges[:, 1], 1.0), (edges[:, 0], -1.0)):
-        c = (9 * col[:, None, None] + ar6[None, None, :]).expand(E, 6, 6)
-        J.index_put_((r, c), sign * A, accumulate=True)
-    ar3 = torch.arange(3, device=dev)
-    k = torch.arange(M, device=dev)
-    I3 = torch.eye(3, dtype=torch.float64, device=dev).expand(M, 3, 3)
+    mv = lambda M, v: (M @ v[:, :, None])[:, :, 0]
+    j0 = mv(G, dp[:, :3]) + mv(C, dp[:, 3:])
+    j1 = mv(G, dp[:, 3:])
+    dc = D6[1:] - D6[:-1]
+    M = dc.shape[0]
     B = lin[27:36].t().reshape(M, 3, 3)
-
-    def put(row0, node, off, block):
-        rr = (row0 + 3 * k[:, None, None] + ar3[None, :, None]).expand(M, 3, 3)
-        cc = (9 * node[:, None, None] + off + ar3[None, None, :]).expand(M, 3, 3)
-        J.index_put_((rr, cc), block, accumulate=True)
-    r0 = 6 * E
-    put(r0, k + 1, 6, -I3)                       # adjvelerr = dv - (v_{k+1} - v_k)
-    put(r0, k, 6, I3)
-    r1 = r0 + 3 * M
-    put(r1, k + 1, 3, B)                         # imuroterr
-    put(r1, k, 3, -B)
-    r2 = r1 + 3 * M
-    put(r2, k + 1, 0, I3)                        # transvelerr (raw-slice translation Jacobian, SURVEY F11)
-    put(r2, k, 0, -I3)
-    put(r2, k, 6, -dts[:, None, None] * I3)
-    return J
+    j2 = Dv[:-1] - Dv[1:]
+    j3 = mv(B, dc[:, 3:])
+    j4 = dc[:, :3] - dts[:, None] * Dv[:-1]
+    R0, R1 = vo[0:3].t(), vo[3:6].t()
+    R2, R3, R4 = lin[36:39].t(), lin[24:27].t(), lin[39:42].t()
+    q = 0.0
+    for j, r in ((j0, R0), (j1, R1), (j2, R2), (j3, R3), (j4, R4)):
+        q = q + (j * (2 * r + j)).sum()
+    return q
 
 
 def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, max_steps=10, patience=3,
@@ -70,38 +75,38 @@ def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weig
     if E != M:
         raise ValueError('PoseVelGraph needs as many VO edges as IMU intervals (dts broadcasts over both, pvgo.py:51): E=%d, N-1=%d' % (E, M))
     dev = nodes.device
-    w = torch.cat([torch.full((6 * E,), float(loss_weight[0]) ** 2), torch.full((3 * M,), float(loss_weight[1]) ** 2),
-                   torch.full((3 * M,), float(loss_weight[2]) ** 2), torch.full((3 * M,), float(loss_weight[3]) ** 2)]).to(dev, torch.float64)
+    w = [float(x) ** 2 for x in loss_weight[:4]]
     dummy = torch.zeros((M, 7), dtype=torch.float64, device=dev)
     dummy[:, 6] = 1.0
+    nptr, nadj = _node_adjacency(edges.cpu().numpy(), N)
+    nptr, nadj = torch.from_numpy(nptr).to(dev), torch.from_numpy(nadj).to(dev)
+    A = torch.empty((9 * N, 9 * N), dtype=torch.float64, device=dev)
+    b = torch.empty((9 * N,), dtype=torch.float64, device=dev)
     ctl = LMControl(radius=radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
     trials = 0
     while ctl.continual:
         vo, lin = _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
-        R = _residual_vector(vo, lin)
-        J = _dense_jacobian(N, edges, vo, lin, dts)
         if not ctl.has_loss:
-            ctl.set_initial_loss(float((R * R).sum()))
+            ctl.set_initial_loss(float(_loss(vo, lin)))
         ctl.begin_step()
-        JTW = J.t() * w[None, :]
-        A = JTW @ J
-        b = -(JTW @ R)
-        d = A.diagonal().clamp(vmin, vmax).clone()
+        Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w[1], w[2], w[3]), -_NOCLAMP, _NOCLAMP)     # IMU factors
+        check(lib().islam_pvgo_assemble_dense(ptr(Hd), ptr(Ho), ptr(rhs), ptr(vo), ptr(edges), ptr(nptr), ptr(nadj),
+                                              c_double(w[0]), N, E, ptr(A), ptr(b), stream_ptr(dev)))
+        d = A.diagonal().clamp(vmin, vmax).clone()                    # A.diagonal().clamp_(min, max)
         while True:
             d = d + d * ctl.damping                                   # cumulative, like A.diagonal().add_(...)
             A.diagonal().copy_(d)
             L, info = torch.linalg.cholesky_ex(A)
             trials += 1
-            if int(info) != 0 or not bool(torch.isfinite(L).all()):
+            if int(info) != 0 or not bool(torch.isfinite(L.diagonal()).all()):
                 print('Linear solver failed. Breaking optimization step...')
                 ctl.solver_failed()
                 break
-            D = torch.cholesky_solve(b[:, None], L)[:, 0]
-            nt, vt = ops.pvgo_retract(nodes, vels, D.view(N, 9).contiguous(), 1.0)
+            D = torch.cholesky_solve(b[:, None], L)[:, 0].view(N, 9).contiguous()
+            del L
+            nt, vt = ops.pvgo_retract(nodes, vels, D, 1.0)
             vo_t, lin_t = _linearize(nt, vt, edges, poses, drots, dtrans, dvels, dts, dummy)
-            Rt = _residual_vector(vo_t, lin_t)
-            JD = J @ D
-            s, q = torch.stack([(Rt * Rt).sum(), (JD * (2 * R + JD)).sum()]).tolist()
+            s, q = torch.stack([_loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)]).tolist()
             if ctl.after_trial(s, q):
                 nodes, vels = nt, vt
                 break

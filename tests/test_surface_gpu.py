@@ -187,3 +187,50 @@ def test_run_pvgo_general_topology_matches_oracle(cuda):
     assert (err / ref).max() < 1e-6
     np.testing.assert_allclose(vels.numpy(), ov, atol=1e-7)
     np.testing.assert_allclose(tl.cpu().numpy(), otl, rtol=1e-6, atol=1e-10)
+
+
+def test_dense_assembly_matches_dense_jacobian_product(cuda):
+    """islam_pvgo_assemble_dense (block assembly, no J) == J^T W J / -J^T W r of the oracle's dense Jacobian, node-major."""
+    from islam_amd import ops, pvgo_dense
+    from islam_amd._lib import c_double, check, lib, ptr, stream_ptr
+    F = 17
+    prob, tr = chain_problem(F)
+    links = prob['links'].copy()
+    links[2], links[9], links[13] = (0, 7), (12, 3), (16, 1)
+    links[5] = (5, 6)
+    N, E, M = F, F - 1, F - 1
+    res = opvgo.residuals(prob['init_nodes'], prob['init_vels'], links, prob['vo_motions'], prob['imu_drots'], prob['imu_dtrans'],
+                          prob['imu_dvels'], prob['dts'])
+    Ae, Bk = opvgo.jac_blocks(prob['init_nodes'], links, prob['vo_motions'], prob['imu_drots'], res[0], res[2])
+    J10 = opvgo.jacobian_dense(N, links, Ae, Bk, prob['dts'])
+    cols = np.concatenate([np.concatenate([7 * k + np.arange(6), 7 * N + 3 * k + np.arange(3)]) for k in range(N)])
+    J = J10[:, cols]
+    w = opvgo.weight_vector(E, M, LW, np.float64)
+    A_ref = (J.T * w) @ J
+    b_ref = -(J.T * w) @ np.concatenate([r.reshape(-1) for r in res])
+
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=cuda)
+    nodes, vels, poses = t(prob['init_nodes']), t(prob['init_vels']), t(prob['vo_motions'])
+    drots, dtrans, dvels, dts = t(prob['imu_drots']), t(prob['imu_dtrans']), t(prob['imu_dvels']), t(prob['dts'])
+    edges = torch.tensor(links, device=cuda)
+    dummy = torch.zeros((M, 7), dtype=torch.float64, device=cuda)
+    dummy[:, 6] = 1.0
+    vo, lin = pvgo_dense._linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
+    w2 = [x ** 2 for x in LW]
+    Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w2[1], w2[2], w2[3]), -1e300, 1e300)
+    nptr, nadj = pvgo_dense._node_adjacency(links, N)
+    A = torch.full((9 * N, 9 * N), float('nan'), dtype=torch.float64, device=cuda)
+    b = torch.empty(9 * N, dtype=torch.float64, device=cuda)
+    check(lib().islam_pvgo_assemble_dense(ptr(Hd), ptr(Ho), ptr(rhs), ptr(vo), ptr(edges), ptr(torch.from_numpy(nptr).to(cuda)),
+                                          ptr(torch.from_numpy(nadj).to(cuda)), c_double(w2[0]), N, E, ptr(A), ptr(b),
+                                          stream_ptr(cuda)))
+    scale = np.abs(A_ref).max()
+    np.testing.assert_allclose(A.cpu().numpy(), A_ref, atol=1e-12 * scale)
+    np.testing.assert_allclose(b.cpu().numpy(), b_ref, atol=1e-11 * np.abs(b_ref).max())
+    D = t(np.random.default_rng(0).normal(size=(N, 9)) * 0.01)
+    q = float(pvgo_dense._quality_term(vo, lin, edges, dts, D))
+    D10 = np.zeros(10 * N)
+    D10[cols] = D.cpu().numpy().reshape(-1)
+    JD = J10 @ D10
+    R = np.concatenate([r.reshape(-1) for r in res])
+    assert q == pytest.approx(float(JD @ (2 * R + JD)), rel=1e-10)
