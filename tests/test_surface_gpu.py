@@ -218,11 +218,10 @@ def test_dense_assembly_matches_dense_jacobian_product(cuda):
     vo, lin = pvgo_dense._linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
     w2 = [x ** 2 for x in LW]
     Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w2[1], w2[2], w2[3]), -1e300, 1e300)
-    nptr, nadj = pvgo_dense._node_adjacency(links, N)
+    nptr, nadj = [torch.from_numpy(a).to(cuda) for a in pvgo_dense._node_adjacency(links, N)]
     A = torch.full((9 * N, 9 * N), float('nan'), dtype=torch.float64, device=cuda)
     b = torch.empty(9 * N, dtype=torch.float64, device=cuda)
-    check(lib().islam_pvgo_assemble_dense(ptr(Hd), ptr(Ho), ptr(rhs), ptr(vo), ptr(edges), ptr(torch.from_numpy(nptr).to(cuda)),
-                                          ptr(torch.from_numpy(nadj).to(cuda)), c_double(w2[0]), N, E, ptr(A), ptr(b),
+    check(lib().islam_pvgo_assemble_dense(ptr(Hd), ptr(Ho), ptr(rhs), ptr(vo), ptr(edges), ptr(nptr), ptr(nadj), c_double(w2[0]), N, E, ptr(A), ptr(b),
                                           stream_ptr(cuda)))
     scale = np.abs(A_ref).max()
     np.testing.assert_allclose(A.cpu().numpy(), A_ref, atol=1e-12 * scale)
