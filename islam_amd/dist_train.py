@@ -52,3 +52,93 @@ class TrajectoryParallel:
     def end_epoch(self):
         allreduce_gradients(self.loop.vo.vonet.flowPoseNet.parameters(), self.group, self.average)
         self.loop.end_epoch()
+
+
+class ShardedBatchNorm2d(torch.nn.BatchNorm2d):
+    """BatchNorm2d whose batch statistics span the frames of ALL ranks.
+
+    The "frozen" stereo network of the reference still normalises with train-mode statistics over the (2B, C, H, W)
+    left/right-stacked batch (TartanVO.py:90-91).  When the B frames of a window are sharded over ranks (frame b on
+    rank b mod P) each rank only sees 2B/P of them, so every layer all-reduces ONE packed vector [sum | sum of squares |
+    count] (2C+1 values, <= 1 KB for C <= 128) and normalises with the global moments -- the result equals the
+    un-sharded forward.  Forward-only: the stereo net is never differentiated on this path (fix_parts, TartanVO.py:109);
+    with requires-grad inputs it raises instead of returning a wrong gradient."""
+
+    group = None
+
+    def forward(self, x):
+        if not self.training or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return super().forward(x)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise RuntimeError('ShardedBatchNorm2d is forward-only (frozen stereo net); got a tensor that requires grad')
+        C = x.shape[1]
+        xf = x.float()
+        stat = torch.cat([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3)), xf.new_tensor([x.numel() / C])]).double()
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=self.group)
+        n = stat[-1]
+        mean = stat[:C] / n
+        var = (stat[C:2 * C] / n - mean * mean).clamp_(min=0.0)
+        if self.track_running_stats:
+            m = self.momentum if self.momentum is not None else 0.1
+            with torch.no_grad():
+                self.running_mean.mul_(1 - m).add_(m * mean.to(self.running_mean.dtype))
+                self.running_var.mul_(1 - m).add_(m * (var * n / (n - 1)).to(self.running_var.dtype))
+                self.num_batches_tracked += 1
+        scale = (self.weight.double() / torch.sqrt(var + self.eps)).to(x.dtype)
+        shift = (self.bias.double() - mean * self.weight.double() / torch.sqrt(var + self.eps)).to(x.dtype)
+        return x * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)
+
+
+def shard_batchnorm(module, group=None):
+    """Swap every BatchNorm2d under ``module`` for a ShardedBatchNorm2d sharing its parameters and buffers."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.BatchNorm2d) and not isinstance(child, ShardedBatchNorm2d):
+            new = ShardedBatchNorm2d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+            new.weight, new.bias = child.weight, child.bias
+            new.running_mean, new.running_var, new.num_batches_tracked = child.running_mean, child.running_var, child.num_batches_tracked
+            new.group = group
+            new.train(child.training)
+            setattr(module, name, new)
+        else:
+            shard_batchnorm(child, group)
+    return module
+
+
+class FrameParallelVO(torch.nn.Module):
+    """Front-end sharded over the frames of one window: rank r runs frames r, r+P, ... of the sample through TartanVO
+    (PWC, pose head and the scale kernel are per-frame independent; the stereo net's BatchNorm layers are synchronised,
+    see ShardedBatchNorm2d), then the (B,7) motions are all-gathered (28 B per frame) because PVGO needs the window."""
+
+    def __init__(self, tartanvo, group=None):
+        super().__init__()
+        self.vo, self.group = tartanvo, group
+        shard_batchnorm(tartanvo.vonet.stereoNet, group)
+
+    @staticmethod
+    def shard_sample(sample, rank, world):
+        out = {}
+        for k, v in sample.items():
+            if isinstance(v, torch.Tensor) and v.dim() >= 1:
+                out[k] = v[rank::world].contiguous()
+            elif isinstance(v, (list, tuple)):
+                out[k] = list(v[rank::world])
+            else:
+                out[k] = v
+        return out
+
+    def forward(self, sample, **kw):
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        B = sample['img0'].shape[0]
+        if B % world:
+            raise ValueError('window of %d frames does not split over %d ranks' % (B, world))
+        res = self.vo(self.shard_sample(sample, rank, world), **kw)
+        from . import lietensor as pp
+        local = res['motion'].tensor() if isinstance(res['motion'], pp.LieTensor) else res['motion']
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.detach().contiguous(), group=self.group)
+        parts[rank] = local                                    # keep this rank's rows differentiable
+        full = torch.stack(parts, 1).reshape(B, local.shape[-1])          # frame b = parts[b % P][b // P]
+        res = dict(res)
+        res['motion_local'] = res['motion']
+        res['motion'] = pp.SE3(full)
+        return res

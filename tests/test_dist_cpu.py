@@ -135,3 +135,70 @@ def test_gradient_allreduce_gloo(tmp_path):
             if p == 3:
                 continue                                       # frozen parameter: untouched
             torch.testing.assert_close(got, want)
+
+
+class _StubFrontEnd(torch.nn.Module):
+    """A TartanVO stand-in: a BN'd 'stereo' branch and a per-frame 'pose' that depends on it."""
+
+    class _V(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            from islam_amd import nets
+            self.stereoNet = nets.StereoNet7()
+            self.flowPoseNet = torch.nn.Linear(1, 7)
+
+    def __init__(self):
+        super().__init__()
+        self.vonet = self._V()
+
+    def forward(self, sample):
+        disp = self.vonet.stereoNet(torch.cat([sample['img0_norm'], sample['img0_r_norm']], 1))[0]
+        feat = disp.mean((1, 2, 3)).reshape(-1, 1)
+        return {'motion': self.vonet.flowPoseNet(feat), 'disp': disp}
+
+
+def _sample(B, H=256, W=256):
+    g = torch.Generator().manual_seed(3)
+    return {'img0': torch.rand(B, 3, H, W, generator=g), 'img0_norm': torch.randn(B, 3, H, W, generator=g),
+            'img0_r_norm': torch.randn(B, 3, H, W, generator=g), 'datatype': ['kitti'] * B}
+
+
+def _frontend_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from islam_amd.dist_train import FrameParallelVO, ShardedBatchNorm2d
+    torch.manual_seed(0)
+    vo = _StubFrontEnd()
+    keys = list(vo.vonet.state_dict().keys())
+    fp = FrameParallelVO(vo)
+    assert list(vo.vonet.state_dict().keys()) == keys                   # checkpoint layout unchanged
+    assert sum(isinstance(m, ShardedBatchNorm2d) for m in vo.modules()) == 34          # SURVEY F4: 34 BN layers
+    vo.train()
+    with torch.no_grad():
+        res = fp(_sample(4))
+    rm = vo.vonet.stereoNet.state_dict()
+    bn = {k: v.clone() for k, v in rm.items() if 'running_' in k}
+    torch.save({'motion': res['motion'].tensor().clone(), 'disp': res['disp'].clone(), 'bn': bn}, os.path.join(out_dir, 'f%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_parallel_frontend_gloo(tmp_path):
+    """Section 8e row 3: frames sharded over 2 ranks with synchronised BatchNorm statistics == the un-sharded forward
+    (outputs, all-gathered motions, and the running statistics that end up in the checkpoint)."""
+    port = _free_port()
+    mp.spawn(_frontend_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), 'f%d.pt' % r)) for r in range(2)]
+    torch.manual_seed(0)
+    vo = _StubFrontEnd()
+    vo.train()
+    with torch.no_grad():
+        ref = vo(_sample(4))
+    for r in range(2):
+        torch.testing.assert_close(outs[r]['motion'], ref['motion'], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(outs[r]['disp'], ref['disp'][r::2], rtol=2e-3, atol=2e-4)
+        for k, v in outs[r]['bn'].items():
+            torch.testing.assert_close(v, vo.vonet.stereoNet.state_dict()[k], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0]['motion'], outs[1]['motion'], rtol=0, atol=0)
