@@ -46,6 +46,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+#ifdef ISLAM_PROBE
+__device__ long long islam_probe_buf[512];
+#define PROBE_AT(cond, slot) do { __builtin_amdgcn_sched_barrier(0); if (cond) islam_probe_buf[(slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROBE_AT(cond, slot) do { } while (0)
+#endif
+
 // XCD-aware work mapping.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, dispatch section; speed
 // only, never correctness).  Every kernel of the LM loop splits its node / link / segment range into 8 CONTIGUOUS parts,
 // part x handled by the workgroups with b % 8 == x, so data produced for a stretch of the chain stays in the L2 of the XCD
@@ -64,6 +71,12 @@ __device__ __forceinline__ double bcast(double v, int src) {   // src must be wa
     hi = __builtin_amdgcn_readlane(hi, src);
     return __hiloint2double(hi, lo);
 }
+
+// Run-ahead gate.  The host enqueues LM iteration t+1 before it knows the outcome of trial t, assuming "accepted,
+// continue".  Every kernel of an iteration carries the epoch it was enqueued under; the deciding lane bumps the device
+// epoch (state[14]) on any other outcome, which turns the already-queued kernels into no-ops.
+struct Gate { const double* ctl; double epoch; };
+__device__ __forceinline__ bool gate_closed(const Gate& g) { return g.ctl != nullptr && g.ctl[14] != g.epoch; }
 
 // ------------------------------------------------------------------------------------------
 // residuals of one link (pvgo.py:36-51); also returns what the Jacobian needs
@@ -219,10 +232,10 @@ constexpr int RP_NSUM = 28;
 
 // one workgroup per link, lanes stride over the keypoints; fixed-order reduction (bit-reproducible)
 __global__ __launch_bounds__(256) void reproj_reduce_kernel(const double* __restrict__ nodes, const double* __restrict__ dx,
-                                                             int M, ReprojDev rp, double* __restrict__ red) {
+                                                             int M, ReprojDev rp, double* __restrict__ red, Gate gate) {
     __shared__ double sw[4][RP_NSUM];
     const int L = xcd_index(blockIdx.x, M);
-    if (L < 0) return;
+    if (L < 0 || gate_closed(gate)) return;
     SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
     if (dx) {
         const double* di = dx + (size_t)L * 9;
@@ -318,107 +331,169 @@ __device__ __forceinline__ ReprojLink reproj_link(const double* __restrict__ rec
 // first one is a halo shared with the previous workgroup), hands the weighted per-link pieces over through LDS and builds
 // the blocks of its 63 nodes.  Same arithmetic as linearize_kernel + build_normal_kernel, one launch, no re-read of `lin`.
 constexpr int LB_NODES = 63;
+constexpr int LB_THREADS = 256;       // wave 0 linearises the links; waves 0-2 build Hd / Ho / rhs; all four copy out
+constexpr int LB_DYN_BYTES = (2 * LB_NODES * 81 + LB_NODES * 9) * (int)sizeof(double);
 constexpr int LB_REC = 41;          // Srr 9 | Srp 9 | Spp 9 | gr 3 | gp 3 | rv 3 | rt 3 | dt 1, +1 pad
 
-__global__ __launch_bounds__(64) void linbuild_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
-                                                       const double* __restrict__ poses, const double* __restrict__ drots,
-                                                       const double* __restrict__ dtrans, const double* __restrict__ dvels,
-                                                       const double* __restrict__ dts, int N, double w0, double w1, double w2,
-                                                       double w3, double vmin, double vmax, double* __restrict__ lin,
-                                                       double* __restrict__ loss_part, double* __restrict__ Hd,
-                                                       double* __restrict__ Ho, double* __restrict__ rhs,
-                                                       const double* __restrict__ red, ReprojDev rp) {
-    __shared__ double sl[64][LB_REC];
+struct LinWeights { double w0, w1, w2, w3, vmin, vmax; };
+
+// Jacobian blocks of one link at its residuals: d pgerr / d delta_j = [[G, C],[0, G]], d imuroterr / d phi_j = B
+__device__ __forceinline__ void link_jacobians(const LinkRes& r, M3<double>& G, M3<double>& C, M3<double>& B) {
+    const M3<double> Ji = so3_Jl_inv(r.ephi);
+    const M3<double> R = qmat(r.pre.q);
+    G = Ji * R;
+    C = Ji * (skew(r.pre.t) * R - se3_Q(r.erho, r.ephi) * G);
+    B = so3_Jl_inv(r.er) * qmat(r.rpre);
+}
+
+// lin record of link L (component-major) + the weighted per-link pieces handed to the node builders through LDS
+__device__ __forceinline__ void link_emit(const LinkRes& r, const M3<double>& G, const M3<double>& C, const M3<double>& B,
+                                          double dt, int L, int M, bool owns, const LinWeights& W, double* __restrict__ lin,
+                                          double* __restrict__ o, const double* __restrict__ red, const ReprojDev& rp,
+                                          SE3<double> Xi) {
+    if (owns) {                                               // the halo link belongs to the previous workgroup
+        double rec[LIN_C];
+        rec[0] = r.erho.x; rec[1] = r.erho.y; rec[2] = r.erho.z;
+        rec[3] = r.ephi.x; rec[4] = r.ephi.y; rec[5] = r.ephi.z;
+        m3_store(G, rec + 6);
+        m3_store(C, rec + 15);
+        rec[24] = r.er.x; rec[25] = r.er.y; rec[26] = r.er.z;
+        m3_store(B, rec + 27);
+        rec[36] = r.rv.x; rec[37] = r.rv.y; rec[38] = r.rv.z;
+        rec[39] = r.rt.x; rec[40] = r.rt.y; rec[41] = r.rt.z;
+#pragma unroll
+        for (int c = 0; c < LIN_C; ++c) lin[(size_t)c * M + L] = rec[c];
+    }
+    const M3<double> Gt = transpose(G), Ct = transpose(C), Bt = transpose(B);
+    const M3<double> GtG = Gt * G;
+    M3<double> Srr = W.w0 * GtG + W.w3 * m3_identity<double>();
+    M3<double> Srp = W.w0 * (Gt * C);
+    M3<double> Spp = W.w0 * (Ct * C + GtG) + W.w2 * (Bt * B);
+    V3<double> gr = W.w0 * (Gt * r.erho) + W.w3 * r.rt;
+    V3<double> gp = W.w0 * (Ct * r.erho + Gt * r.ephi) + W.w2 * (Bt * r.er);
+    if (red) {                                                // 5th residual: same +/- coupling pattern as the VO factor
+        const ReprojLink q = reproj_link(red + (size_t)L * RP_REC, rp, Xi);
+        Srr = Srr + rp.weight * q.Arr; Srp = Srp + rp.weight * q.Arp; Spp = Spp + rp.weight * q.App;
+        gr = gr + rp.weight * q.gr; gp = gp + rp.weight * q.gp;
+    }
+    m3_store(Srr, o);
+    m3_store(Srp, o + 9);
+    m3_store(Spp, o + 18);
+    o[27] = gr.x; o[28] = gr.y; o[29] = gr.z; o[30] = gp.x; o[31] = gp.y; o[32] = gp.z;
+    o[33] = r.rv.x; o[34] = r.rv.y; o[35] = r.rv.z; o[36] = r.rt.x; o[37] = r.rt.y; o[38] = r.rt.z; o[39] = dt;
+}
+
+// After the link pieces are in `sl` (workgroup barrier done by the caller): waves 0-2 build Hd / Ho / rhs of the
+// workgroup's 63 nodes in LDS (node k = links k-1 in slot lane and k in slot lane+1), then all waves copy the three
+// contiguous ranges out with lane-contiguous addresses (a lane-per-node store of a 9x9 block touches 64 cache lines).
+__device__ __forceinline__ void nodes_build_copy(const double (*sl)[LB_REC], double* __restrict__ lb_out, int blk, int N,
+                                                 const LinWeights& W, double* __restrict__ Hd, double* __restrict__ Ho,
+                                                 double* __restrict__ rhs) {
+    double* const oHd = lb_out;
+    double* const oHo = lb_out + LB_NODES * 81;
+    double* const oR = lb_out + 2 * LB_NODES * 81;
     const int M = N - 1;
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blk * LB_NODES + lane;
+    const int cnt = min(LB_NODES, N - blk * LB_NODES);             // nodes of this workgroup
+    const double w1 = W.w1, w3 = W.w3;
+    if (lane < cnt && wave < 3) {
+        const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const M3<double> I = m3_identity<double>();
+        const double* a0 = sl[lane];
+        const double* a1 = sl[lane + 1];
+        if (wave == 0) {                                            // Hd
+            M3<double> Hrr = Z, Hrp = Z, Hpp = Z;
+            double hvv = 0.0, hrv = 0.0;
+            if (k > 0) {
+                Hrr = Hrr + m3_load(a0); Hrp = Hrp + m3_load(a0 + 9); Hpp = Hpp + m3_load(a0 + 18);
+                hvv += w1;
+            }
+            if (k < M) {
+                const double dt = a1[39];
+                Hrr = Hrr + m3_load(a1); Hrp = Hrp + m3_load(a1 + 9); Hpp = Hpp + m3_load(a1 + 18);
+                hvv += w1 + w3 * dt * dt;
+                hrv = w3 * dt;
+            }
+            double h[81];
+            put3x3(h, 0, 0, Hrr); put3x3(h, 0, 3, Hrp); put3x3(h, 0, 6, hrv * I);
+            put3x3(h, 3, 0, transpose(Hrp)); put3x3(h, 3, 3, Hpp); put3x3(h, 3, 6, Z);
+            put3x3(h, 6, 0, hrv * I); put3x3(h, 6, 3, Z); put3x3(h, 6, 6, hvv * I);
+#pragma unroll
+            for (int d = 0; d < 9; ++d) h[d * 10] = fmin(fmax(h[d * 10], W.vmin), W.vmax);   // A.diagonal().clamp_(min, max)
+#pragma unroll
+            for (int e = 0; e < 81; ++e) oHd[lane * 81 + e] = h[e];
+        } else if (wave == 1) {                                     // Ho (coupling k -> k+1); the last node has none
+            if (k < M) {
+                const M3<double> Srr = m3_load(a1), Srp = m3_load(a1 + 9), Spp = m3_load(a1 + 18);
+                const double dt = a1[39];
+                double o[81];
+                put3x3(o, 0, 0, -1.0 * Srr); put3x3(o, 0, 3, -1.0 * Srp); put3x3(o, 0, 6, Z);
+                put3x3(o, 3, 0, -1.0 * transpose(Srp)); put3x3(o, 3, 3, -1.0 * Spp); put3x3(o, 3, 6, Z);
+                put3x3(o, 6, 0, (-w3 * dt) * I); put3x3(o, 6, 3, Z); put3x3(o, 6, 6, (-w1) * I);
+#pragma unroll
+                for (int e = 0; e < 81; ++e) oHo[lane * 81 + e] = o[e];
+            }
+        } else {                                                    // rhs = -J^T W r
+            V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
+            if (k > 0) {
+                gr = gr + ld3(a0 + 27); gp = gp + ld3(a0 + 30);
+                gv = gv - w1 * ld3(a0 + 33);
+            }
+            if (k < M) {
+                const double dt = a1[39];
+                gr = gr - ld3(a1 + 27); gp = gp - ld3(a1 + 30);
+                gv = gv + w1 * ld3(a1 + 33) - (w3 * dt) * ld3(a1 + 36);
+            }
+            double* bb = oR + lane * 9;
+            bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
+            bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
+        }
+    }
+    __syncthreads();
+    const size_t node0 = (size_t)blk * LB_NODES;
+    const int nHd = cnt * 81, nHo = min(cnt, M - blk * LB_NODES) * 81, nR = cnt * 9;
+    for (int e = threadIdx.x; e < nHd; e += LB_THREADS) Hd[node0 * 81 + e] = oHd[e];
+    for (int e = threadIdx.x; e < nHo; e += LB_THREADS) Ho[node0 * 81 + e] = oHo[e];
+    for (int e = threadIdx.x; e < nR; e += LB_THREADS) rhs[node0 * 9 + e] = oR[e];
+}
+
+__global__ __launch_bounds__(LB_THREADS) void linbuild_kernel(const double* __restrict__ nodes, const double* __restrict__ vels,
+                                                               const double* __restrict__ poses, const double* __restrict__ drots,
+                                                               const double* __restrict__ dtrans, const double* __restrict__ dvels,
+                                                               const double* __restrict__ dts, int N, LinWeights W,
+                                                               double* __restrict__ lin, double* __restrict__ loss_part,
+                                                               double* __restrict__ Hd, double* __restrict__ Ho,
+                                                               double* __restrict__ rhs, const double* __restrict__ red,
+                                                               ReprojDev rp) {
+    __shared__ double sl[64][LB_REC];
+    extern __shared__ __attribute__((aligned(16))) double lb_out[];   // staged Hd (63x81) | Ho (63x81) | rhs (63x9)
+    const int M = N - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blk = xcd_index(blockIdx.x, (N + LB_NODES - 1) / LB_NODES);
     if (blk < 0) return;
-    const int L = blk * LB_NODES - 1 + lane;                  // link handled by this lane
-    double sq = 0.0;
-    if (L >= 0 && L < M) {
-        SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
-        const double dt = dts[L];
-        LinkRes r = link_residuals(Xi, Xj, ld3(vels + 3 * L), ld3(vels + 3 * (L + 1)), se3_load(poses + 7 * L),
-                                   ld4(drots + 4 * L), ld3(dtrans + 3 * L), ld3(dvels + 3 * L), dt);
-        M3<double> Ji = so3_Jl_inv(r.ephi);
-        M3<double> R = qmat(r.pre.q);
-        M3<double> G = Ji * R;
-        M3<double> C = Ji * (skew(r.pre.t) * R - se3_Q(r.erho, r.ephi) * G);
-        M3<double> B = so3_Jl_inv(r.er) * qmat(r.rpre);
-        if (lane > 0 || blk == 0) {                           // the halo link belongs to the previous workgroup
-            double rec[LIN_C];
-            rec[0] = r.erho.x; rec[1] = r.erho.y; rec[2] = r.erho.z;
-            rec[3] = r.ephi.x; rec[4] = r.ephi.y; rec[5] = r.ephi.z;
-            m3_store(G, rec + 6);
-            m3_store(C, rec + 15);
-            rec[24] = r.er.x; rec[25] = r.er.y; rec[26] = r.er.z;
-            m3_store(B, rec + 27);
-            rec[36] = r.rv.x; rec[37] = r.rv.y; rec[38] = r.rv.z;
-            rec[39] = r.rt.x; rec[40] = r.rt.y; rec[41] = r.rt.z;
-#pragma unroll
-            for (int c = 0; c < LIN_C; ++c) lin[(size_t)c * M + L] = rec[c];
-            sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
-            if (red) sq += red[(size_t)L * RP_REC + 27];
+    const int L = blk * LB_NODES - 1 + lane;                  // link handled by this lane (wave 0)
+    if (wave == 0) {
+        double sq = 0.0;
+        if (L >= 0 && L < M) {
+            const SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
+            const double dt = dts[L];
+            const LinkRes r = link_residuals(Xi, Xj, ld3(vels + 3 * L), ld3(vels + 3 * (L + 1)), se3_load(poses + 7 * L),
+                                             ld4(drots + 4 * L), ld3(dtrans + 3 * L), ld3(dvels + 3 * L), dt);
+            M3<double> G, C, B;
+            link_jacobians(r, G, C, B);
+            const bool owns = lane > 0 || blk == 0;
+            if (owns) {
+                sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+                if (red) sq += red[(size_t)L * RP_REC + 27];
+            }
+            link_emit(r, G, C, B, dt, L, M, owns, W, lin, sl[lane], red, rp, Xi);
         }
-        M3<double> Gt = transpose(G), Ct = transpose(C), Bt = transpose(B);
-        M3<double> GtG = Gt * G;
-        double* o = sl[lane];
-        M3<double> Srr = w0 * GtG + w3 * m3_identity<double>();
-        M3<double> Srp = w0 * (Gt * C);
-        M3<double> Spp = w0 * (Ct * C + GtG) + w2 * (Bt * B);
-        V3<double> gr = w0 * (Gt * r.erho) + w3 * r.rt;
-        V3<double> gp = w0 * (Ct * r.erho + Gt * r.ephi) + w2 * (Bt * r.er);
-        if (red) {                                            // 5th residual: same +/- coupling pattern as the VO factor
-            const ReprojLink q = reproj_link(red + (size_t)L * RP_REC, rp, Xi);
-            Srr = Srr + rp.weight * q.Arr; Srp = Srp + rp.weight * q.Arp; Spp = Spp + rp.weight * q.App;
-            gr = gr + rp.weight * q.gr; gp = gp + rp.weight * q.gp;
-        }
-        m3_store(Srr, o);
-        m3_store(Srp, o + 9);
-        m3_store(Spp, o + 18);
-        o[27] = gr.x; o[28] = gr.y; o[29] = gr.z; o[30] = gp.x; o[31] = gp.y; o[32] = gp.z;
-        o[33] = r.rv.x; o[34] = r.rv.y; o[35] = r.rv.z; o[36] = r.rt.x; o[37] = r.rt.y; o[38] = r.rt.z; o[39] = dt;
+        sq = wave_sum(sq);
+        if (lane == 0) loss_part[blk] = sq;
     }
-    sq = wave_sum(sq);
-    if (lane == 0) loss_part[blk] = sq;
     __syncthreads();
-    const int k = blk * LB_NODES + lane;               // node built by this lane: links k-1 (slot lane), k (slot lane+1)
-    if (lane >= LB_NODES || k >= N) return;
-    const M3<double> Z{0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const M3<double> I = m3_identity<double>();
-    M3<double> Hrr = Z, Hrp = Z, Hpp = Z;
-    V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
-    double hvv = 0.0, hrv = 0.0;
-    if (k > 0) {
-        const double* a = sl[lane];
-        Hrr = Hrr + m3_load(a); Hrp = Hrp + m3_load(a + 9); Hpp = Hpp + m3_load(a + 18);
-        gr = gr + ld3(a + 27); gp = gp + ld3(a + 30);
-        gv = gv - w1 * ld3(a + 33);
-        hvv += w1;
-    }
-    double* o = Ho + (size_t)k * 81;
-    if (k < M) {
-        const double* a = sl[lane + 1];
-        const M3<double> Srr = m3_load(a), Srp = m3_load(a + 9), Spp = m3_load(a + 18);
-        const double dt = a[39];
-        Hrr = Hrr + Srr; Hrp = Hrp + Srp; Hpp = Hpp + Spp;
-        gr = gr - ld3(a + 27); gp = gp - ld3(a + 30);
-        gv = gv + w1 * ld3(a + 33) - (w3 * dt) * ld3(a + 36);
-        hvv += w1 + w3 * dt * dt;
-        hrv = w3 * dt;
-        put3x3(o, 0, 0, -1.0 * Srr); put3x3(o, 0, 3, -1.0 * Srp); put3x3(o, 0, 6, Z);
-        put3x3(o, 3, 0, -1.0 * transpose(Srp)); put3x3(o, 3, 3, -1.0 * Spp); put3x3(o, 3, 6, Z);
-        put3x3(o, 6, 0, (-w3 * dt) * I); put3x3(o, 6, 3, Z); put3x3(o, 6, 6, (-w1) * I);
-    }
-    double* h = Hd + (size_t)k * 81;
-    put3x3(h, 0, 0, Hrr); put3x3(h, 0, 3, Hrp); put3x3(h, 0, 6, hrv * I);
-    put3x3(h, 3, 0, transpose(Hrp)); put3x3(h, 3, 3, Hpp); put3x3(h, 3, 6, Z);
-    put3x3(h, 6, 0, hrv * I); put3x3(h, 6, 3, Z); put3x3(h, 6, 6, hvv * I);
-#pragma unroll
-    for (int d = 0; d < 9; ++d) h[d * 10] = fmin(fmax(h[d * 10], vmin), vmax);   // A.diagonal().clamp_(min, max)
-    double* bb = rhs + (size_t)k * 9;
-    bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
-    bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
+    nodes_build_copy(sl, lb_out, blk, N, W, Hd, Ho, rhs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -508,7 +583,6 @@ __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s
 }
 
 #ifdef ISLAM_PROBE
-__device__ long long islam_probe_buf[512];
 #define PROBE(slot) do { if (lane == 0 && p == 1 && src.level0) islam_probe_buf[(slot)] = clock64(); } while (0)
 #else
 #define PROBE(slot) do { } while (0)
@@ -769,10 +843,10 @@ extern "C" int islam_probe_read(long long* out) {
 
 // one wavefront per workgroup, one segment per workgroup (the large levels)
 __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
-                                                           int nseg) {
+                                                           int nseg, Gate gate) {
     __shared__ __attribute__((aligned(16))) double lds[LDS_PER_WAVE];
     const int p = xcd_index(blockIdx.x, nseg);
-    if (p < 0) return;
+    if (p < 0 || gate_closed(gate)) return;
     eliminate_segment(src, dst, n, m, p + seg0, flags, threadIdx.x, lds);
 }
 
@@ -805,8 +879,9 @@ struct TopArgs {
     int nl;
 };
 
-__global__ __launch_bounds__(512) void bt_top_kernel(TopArgs a, int* flags) {
+__global__ __launch_bounds__(512) void bt_top_kernel(TopArgs a, int* flags, Gate gate) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    if (gate_closed(gate)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* lds = lds_all + wave * LDS_PER_WAVE;
     for (int l = 0; l < a.nl; ++l) {
@@ -829,9 +904,9 @@ __global__ __launch_bounds__(512) void bt_top_kernel(TopArgs a, int* flags) {
 // expand the solution of the separators (xsep, from the next level) into this level's interior nodes
 __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict__ fac, const double* __restrict__ inv,
                                                          const double* __restrict__ xsep, double* __restrict__ x, int n,
-                                                         int m, int seg0, int nseg) {
+                                                         int m, int seg0, int nseg, Gate gate) {
     const int p = xcd_index(blockIdx.x, nseg);
-    if (p < 0) return;
+    if (p < 0 || gate_closed(gate)) return;
     backsub_level_segment(fac, inv, xsep, x, n, m, p + seg0, threadIdx.x);
 }
 
@@ -839,7 +914,21 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 // state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
 //        [8] reject_count [9] accepted [10] error [11] has_loss
 // report (host-visible copy written after every trial): same slots as seen by the step that just ran, [15] = sequence number
-struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; };
+//        [12] optimizer steps [13] plateau patience count [14] run-ahead epoch (Gate)
+// report[12] = verdict: 0 accepted & continue, 1 rejected (retry with more damping), 2 accepted & stop, 3 solver failed &
+// continue (same iterate, new linearisation), 4 solver failed & stop;  report[13] = optimizer steps so far
+struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; int max_steps, patience; double decreasing; };
+
+// StopOnPlateau.step(loss) after a finished optimizer.step() (pvgo.py:172,177-180): returns 1 when the loop must stop
+__device__ __forceinline__ int scheduler_step(double* __restrict__ st, const TRParams& tr, double last, double loss, double rejects) {
+    int stop = 0;
+    st[12] += 1.0;
+    if (st[12] >= (double)tr.max_steps) stop = 1;
+    if ((last - loss) < tr.decreasing) st[13] += 1.0; else st[13] = 0.0;
+    if (st[13] >= (double)tr.patience) stop = 1;
+    if (rejects >= (double)tr.reject) stop = 1;
+    return stop;
+}
 
 // pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
 __device__ void lm_control(double s, double q, double* __restrict__ st, int* flags, const TRParams& tr,
@@ -850,7 +939,9 @@ __device__ void lm_control(double s, double q, double* __restrict__ st, int* fla
     if (flags[0] != 0) {                 // solver failed: PyPose prints and breaks the step, nothing changes
         flags[0] = 0;
         rep[0] = st[0]; rep[1] = st[1]; rep[2] = st[2]; rep[8] = st[8]; rep[10] = 1.0;
+        rep[12] = scheduler_step(st, tr, st[1], st[0], st[8]) ? 4.0 : 3.0;
         st[8] = 0.0;
+        st[14] += 1.0;
     } else {
         const double last = st[1];
         const double quality = (last - s) / (-q);
@@ -866,13 +957,19 @@ __device__ void lm_control(double s, double q, double* __restrict__ st, int* fla
             st[0] = last;
             st[8] += 1.0;
             rep[0] = last; rep[8] = st[8]; rep[9] = 0.0;
+            rep[12] = 1.0;
+            st[14] += 1.0;
         } else {                                           // step kept (also when the reject limit is exhausted)
             rep[0] = s; rep[8] = st[8]; rep[9] = 1.0;
+            const int stop = scheduler_step(st, tr, last, s, st[8]);
+            rep[12] = stop ? 2.0 : 0.0;
+            if (stop) st[14] += 1.0;
             st[0] = s;
             st[1] = s;                                     // next optimizer.step(): self.last = self.loss
             st[8] = 0.0;
         }
     }
+    rep[13] = st[12];
     if (report) {
 #pragma unroll
         for (int i = 0; i < 15; ++i) report[i] = rep[i];
@@ -896,6 +993,8 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     const int blk = xcd_index(blockIdx.x, nblk);
     int k = blk * 64 + threadIdx.x;
     double sq = 0.0, qd = 0.0;
+    const bool pr = threadIdx.x == 0 && blk == 1;
+    PROBE_AT(pr, 200);
     if (blk >= 0 && k < M) {
         const double* di = dx + (size_t)k * 9;
         const double* dj = dx + (size_t)(k + 1) * 9;
@@ -905,8 +1004,10 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
         SE3<double> Xj = se3_mul(se3_exp(drj, dpj), se3_load(nodes + 7 * (k + 1)));
         V3<double> vi = ld3(vels + 3 * k) + dvi, vj = ld3(vels + 3 * (k + 1)) + dvj;
         double dt = dts[k];
+        PROBE_AT(pr, 201);
         LinkRes r = link_residuals(Xi, Xj, vi, vj, se3_load(poses + 7 * k), ld4(drots + 4 * k), ld3(dtrans + 3 * k),
                                    ld3(dvels + 3 * k), dt);
+        PROBE_AT(pr, 202);
         sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
         se3_store(Xi, nodes_t + 7 * k);
         vels_t[3 * k] = vi.x; vels_t[3 * k + 1] = vi.y; vels_t[3 * k + 2] = vi.z;
@@ -939,9 +1040,11 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
             qd += dot(ua, 2.0 * ba + sa) + dot(ub, 2.0 * bb + sb);
         }
     }
+    PROBE_AT(pr, 203);
     sq = wave_sum(sq);
     qd = wave_sum(qd);
     if (threadIdx.x == 0 && blk >= 0) { part[2 * blk] = sq; part[2 * blk + 1] = qd; }
+    PROBE_AT(pr, 204);
     if (st == nullptr) return;           // stage-level call: no control
     // ---- last block takes the decision
     int last_block = 0;
@@ -950,7 +1053,9 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
         last_block = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
     }
     last_block = __builtin_amdgcn_readfirstlane(last_block);
+    PROBE_AT(pr, 205);
     if (!last_block) return;
+    PROBE_AT(threadIdx.x == 0, 206);
     __threadfence();                                                  // acquire the other blocks' partials
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 64) {
@@ -963,6 +1068,118 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
         *ticket = 0u;
         lm_control(s, q, st, flags, tr, report, seq);
     }
+    PROBE_AT(threadIdx.x == 0, 207);
+}
+
+// The LM loop's trial step and the NEXT step's linearisation in one launch (the trial point is the next linearisation
+// point whenever the trial is accepted -- the common case; after a reject the output buffer is simply overwritten).
+// Wave 0: one lane per link (lane 0 = halo link shared with the previous workgroup): retraction, residuals at the trial
+// point, loss / trust-region partials, ticket.  The decision is taken as soon as the last partial is in -- by wave 1 of
+// the workgroup that drew the last ticket, concurrently with wave 0's Jacobian work -- so the host learns it while the
+// linearisation is still being written.  Then as linbuild_kernel: Jacobians, weighted pieces, node blocks, coalesced copy.
+__global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
+    const double* __restrict__ nodes, const double* __restrict__ vels, const double* __restrict__ dx,
+    const double* __restrict__ poses, const double* __restrict__ drots, const double* __restrict__ dtrans,
+    const double* __restrict__ dvels, const double* __restrict__ dts, const double* __restrict__ lin, int N,
+    double* __restrict__ nodes_t, double* __restrict__ vels_t, double* part, double* st, int* flags, unsigned* ticket,
+    TRParams tr, double* report, double seq, const double* __restrict__ red_lin, const double* __restrict__ red_trial,
+    ReprojDev rp, LinWeights W, double* __restrict__ lin_o, double* __restrict__ Hd_o, double* __restrict__ Ho_o,
+    double* __restrict__ rhs_o, Gate gate) {
+    __shared__ double sl[64][LB_REC];
+    __shared__ int s_last;
+    extern __shared__ __attribute__((aligned(16))) double lb_out[];
+    const int M = N - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    const int blk = xcd_index(blockIdx.x, nlb);
+    if (blk < 0 || gate_closed(gate)) return;
+    const int L = blk * LB_NODES - 1 + lane;
+    const bool valid = L >= 0 && L < M;
+    const bool owns = valid && (lane > 0 || blk == 0);
+    SE3<double> Xi{}, Xj{};
+    V3<double> vi{}, vj{};
+    LinkRes r{};
+    double dt = 0.0;
+    if (wave == 0) {
+        double sq = 0.0, qd = 0.0;
+        if (valid) {
+            const double* di = dx + (size_t)L * 9;
+            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+            Xi = se3_mul(se3_exp(dri, dpi), se3_load(nodes + 7 * L));                      // LieTensor.add_
+            Xj = se3_mul(se3_exp(drj, dpj), se3_load(nodes + 7 * (L + 1)));
+            vi = ld3(vels + 3 * L) + dvi;
+            vj = ld3(vels + 3 * (L + 1)) + dvj;
+            dt = dts[L];
+            r = link_residuals(Xi, Xj, vi, vj, se3_load(poses + 7 * L), ld4(drots + 4 * L), ld3(dtrans + 3 * L),
+                               ld3(dvels + 3 * L), dt);
+            if (owns) {
+                sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+                // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
+                double rec[LIN_C];
+#pragma unroll
+                for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + L];
+                const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+                const V3<double> ddr = drj - dri, ddp = dpj - dpi;
+                const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dt * dvi;
+                const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+                    R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+                qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+                     dot(j4, 2.0 * R4 + j4);
+                if (red_lin) {       // reprojection rows: u^T (2 b + S u), u = Ad(C^-1 X_i^-1)(d_j - d_i)
+                    sq += red_trial[(size_t)L * RP_REC + 27];
+                    double u[RP_NSUM];
+#pragma unroll
+                    for (int i = 0; i < RP_NSUM; ++i) u[i] = red_lin[(size_t)L * RP_REC + i];
+                    M3<double> Ra, Ta;
+                    reproj_adjoint(rp, se3_load(nodes + 7 * L), Ra, Ta);
+                    const V3<double> ua = Ra * ddr + Ta * ddp, ub = Ra * ddp;
+                    const V3<double> sa = sym_from(u, 0, 0) * ua + sym_from(u, 0, 3) * ub;
+                    const V3<double> sb = tmul(sym_from(u, 0, 3), ua) + sym_from(u, 3, 3) * ub;
+                    const V3<double> ba{u[21], u[22], u[23]}, bb{u[24], u[25], u[26]};
+                    qd += dot(ua, 2.0 * ba + sa) + dot(ub, 2.0 * bb + sb);
+                }
+            }
+        }
+        sq = wave_sum(sq);
+        qd = wave_sum(qd);
+        if (lane == 0) {
+            part[2 * blk] = sq;
+            part[2 * blk + 1] = qd;
+            __threadfence();                                          // publish this workgroup's partial
+            s_last = (atomicAdd(ticket, 1u) == (unsigned)(nlb - 1)) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (wave == 1 && s_last) {                                        // the decision, concurrently with wave 0 below
+        __threadfence();                                              // acquire the other workgroups' partials
+        double ssum = 0.0, qsum = 0.0;
+        for (int i = lane; i < nlb; i += 64) {
+            ssum += __hip_atomic_load(&part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qsum += __hip_atomic_load(&part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ssum = wave_sum(ssum);
+        qsum = wave_sum(qsum);
+        if (lane == 0) {
+            *ticket = 0u;
+            lm_control(ssum, qsum, st, flags, tr, report, seq);
+        }
+    }
+    if (wave == 0 && valid) {
+        if (owns) {
+            se3_store(Xi, nodes_t + 7 * L);
+            vels_t[3 * L] = vi.x; vels_t[3 * L + 1] = vi.y; vels_t[3 * L + 2] = vi.z;
+            if (L == M - 1) {
+                se3_store(Xj, nodes_t + 7 * (L + 1));
+                vels_t[3 * L + 3] = vj.x; vels_t[3 * L + 4] = vj.y; vels_t[3 * L + 5] = vj.z;
+            }
+        }
+        M3<double> G, C, B;
+        link_jacobians(r, G, C, B);
+        link_emit(r, G, C, B, dt, L, M, owns, W, lin_o, sl[lane], red_trial, rp, Xi);
+    }
+    __syncthreads();
+    nodes_build_copy(sl, lb_out, blk, N, W, Hd_o, Ho_o, rhs_o);
 }
 
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
@@ -975,6 +1192,8 @@ __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restr
         st[1] = s;                                         // self.last = self.loss
         st[8] = 0.0;
         st[11] = 1.0;
+        st[12] = 0.0;
+        st[13] = 0.0;
         flags[0] = 0;
     }
 }
@@ -1227,8 +1446,9 @@ Workspace carve(void* base, int N) {
     const int M = std::max(N - 1, 1);
     const int nblk = (M + 63) / 64;
     w.lin = take((size_t)LIN_C * M);
-    w.loss_part = take(nblk + 2);
-    w.part = take(2 * (size_t)nblk);
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;     // workgroups of linbuild / trial_lin (>= nblk)
+    w.loss_part = take(std::max(nblk, nlb) + 2);
+    w.part = take(2 * (size_t)std::max(nblk, nlb) + 2);
     w.Hd = take((size_t)N * 81);
     w.Ho = take((size_t)N * 81);
     w.rhs = take((size_t)N * 9);
@@ -1279,7 +1499,7 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
 // Enqueue levels [lbegin, nl): `first` describes the source of level lbegin (level-0 arrays, or the level-0 products when
 // lbegin == 1), xout receives the solution of level lbegin.  Big levels: one launch each way; levels >= sp.top: one launch.
 int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const LevelSrc& first, const LevelBufs* first_prev,
-                   double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev) {
+                   double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev, Gate gate = Gate{nullptr, 0.0}) {
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)bt_top_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1297,7 +1517,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
     auto x_of = [&](int l) { return l == lbegin ? xout : w.lv[l].x; };
     for (int l = lbegin; l < top; ++l) {
         hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, src_of(l), level_dst(w.lv[l], x_of(l)),
-                           sp.lv[l].n, sp.lv[l].m, flags, 0, sp.lv[l].P);
+                           sp.lv[l].n, sp.lv[l].m, flags, 0, sp.lv[l].P, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     {
@@ -1311,12 +1531,12 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             a.n[i] = sp.lv[l].n; a.m[i] = sp.lv[l].m; a.P[i] = sp.lv[l].P;
             maxP = std::max(maxP, sp.lv[l].P);
         }
-        hipLaunchKernelGGL(bt_top_kernel, dim3(1), dim3(64 * maxP), maxP * LDS_PER_WAVE * sizeof(double), s, a, flags);
+        hipLaunchKernelGGL(bt_top_kernel, dim3(1), dim3(64 * maxP), maxP * LDS_PER_WAVE * sizeof(double), s, a, flags, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     for (int l = top - 1; l >= lbegin; --l) {
         hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1),
-                           x_of(l), sp.lv[l].n, sp.lv[l].m, 0, sp.lv[l].P);
+                           x_of(l), sp.lv[l].n, sp.lv[l].m, 0, sp.lv[l].P, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     if (nev) *nev = ne;
@@ -1327,12 +1547,12 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
 // enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
 int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
                   double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
-                  int* nev = nullptr) {
+                  int* nev = nullptr, Gate gate = Gate{nullptr, 0.0}) {
     SolvePlan sp;
     plan_levels(N, seg_len, sp);
     LevelSrc src{};
     src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = state; src.damping_override = damping;
-    return enqueue_levels(w, sp, 0, src, nullptr, dx, w.flags, s, evs, nev);
+    return enqueue_levels(w, sp, 0, src, nullptr, dx, w.flags, s, evs, nev, gate);
 }
 
 }  // namespace
@@ -1469,7 +1689,7 @@ int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, 
     dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
     dst.x = nullptr;
     hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m,
-                       flags, seg0, nseg);
+                       flags, seg0, nseg, Gate{nullptr, 0.0});
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -1495,7 +1715,8 @@ int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double*
     const LevelPlan* plan = sp.lv;
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
     hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
-                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0, nseg);
+                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0, nseg,
+                       Gate{nullptr, 0.0});
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -1580,9 +1801,10 @@ static int reproj_dev(const islam_pvgo_reproj* r, ReprojDev& d) {
     return ISLAM_OK;
 }
 
-static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s) {
+static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s,
+                                  Gate gate = Gate{nullptr, 0.0}) {
     const int waves = std::min(4, std::max(1, (rp.K + 127) / 128));
-    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 0, s, nodes, dx, M, rp, red);
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 0, s, nodes, dx, M, rp, red, gate);
 }
 
 int islam_pvgo_reproj_reduce(const double* nodes, const double* dx, int N, const islam_pvgo_reproj* reproj, double* red,
@@ -1620,115 +1842,128 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
     const int M = N - 1, nblk = (M + 63) / 64;
-    // status block in pinned, device-visible host memory: the deciding block of trial_kernel writes it, the host polls
-    // its sequence number (no stream synchronisation, no copy on the critical path)
+    // status blocks in pinned, device-visible host memory: the deciding wave of trial_lin_kernel writes one per trial
+    // (two slots, alternating with the trial number), the host polls its sequence number (no stream synchronisation,
+    // no copy on the critical path)
     static thread_local double* host_state = nullptr;
-    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 16 * sizeof(double), hipHostMallocMapped));
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped));
     double* report = nullptr;
     ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
-    volatile double* hs = host_state;
-    hs[15] = 0.0;
+    volatile double* hs_all = host_state;
+    hs_all[15] = 0.0;
+    hs_all[31] = 0.0;
 
     double init[16] = {0};
     init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
     init[3] = prm->radius;
     init[4] = prm->down;
+    init[14] = 1.0;                // run-ahead epoch
     ISLAM_HIP_CHECK(hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, s));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));       // flags[0] solver error, flags[2] ticket
     unsigned* ticket = reinterpret_cast<unsigned*>(w.flags + 2);
-    TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject};
+    TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
+                prm->max_steps, prm->patience, prm->decreasing};
 
-    double* cur_n = nodes;  double* cur_v = vels;      // current iterate (caller's buffers)
-    double* tri_n = w.nodes_t; double* tri_v = w.vels_t;
-    int steps = 0, trials = 0, patience_count = 0, status = ISLAM_OK;
-    bool continual = true;
-    double loss = 0.0, damping = init[2];
-    // Two linearisation buffers: while the host waits for the decision of trial t, the GPU already linearises at the
-    // trial point (the next optimizer.step() if the trial is accepted -- the common case); on a reject the old buffer
-    // (with its cumulatively damped diagonal) is simply kept.
+    // Two linearisation buffers: trial_lin_kernel linearises at the trial point into the other buffer (the next
+    // optimizer.step() if the trial is accepted -- the common case); on a reject the old buffer (with its cumulatively
+    // damped diagonal) is simply kept.
     double* LIN[2] = {w.lin, w.lin2};
     double* HD[2] = {w.Hd, w.Hd2};
     double* HO[2] = {w.Ho, w.Ho2};
     double* RH[2] = {w.rhs, w.rhs2};
-    const int nlb = (N + LB_NODES - 1) / LB_NODES;
     double* RED[2] = {w.red, w.red2};
-    // red_ready: RED[b] already holds the reduction at (xn): the trial pass computed it for the accept test
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    static bool lb_attr_set = false;
+    if (!lb_attr_set) {
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)linbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
+        lb_attr_set = true;
+    }
+    const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
+    // red_ready: RED[b] already holds the reduction at (xn)
     auto enqueue_linbuild = [&](const double* xn, const double* xv, int b, bool red_ready) {
         if (reproj && !red_ready) enqueue_reproj_reduce(xn, nullptr, M, rp, RED[b], s);
-        hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(64), 0, s, xn, xv, poses, drots, dtrans, dvels, dts, N, prm->w[0],
-                           prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax, LIN[b], w.loss_part, HD[b], HO[b], RH[b],
-                           reproj ? RED[b] : (const double*)nullptr, rp);
+        hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, xn, xv, poses, drots, dtrans, dvels,
+                           dts, N, W, LIN[b], w.loss_part, HD[b], HO[b], RH[b], reproj ? RED[b] : (const double*)nullptr, rp);
     };
-    int pb = 0;
-    enqueue_linbuild(cur_n, cur_v, pb, false);
+    // one pass of PyPose's inner `while self.last <= self.loss`: damped solve on buffer pb, then trial + linearisation at
+    // the trial point into buffer 1-pb; every kernel is gated on `epoch`
+    struct IterCfg { int pb; double *cur_n, *cur_v, *tri_n, *tri_v; };
+    auto enqueue_iter = [&](const IterCfg& c, double seq, double epoch) -> int {
+        const Gate gate{w.state, epoch};
+        int rc = enqueue_solve(w, HD[c.pb], HO[c.pb], RH[c.pb], w.state, 0.0, N, prm->seg_len, w.dx, s, nullptr, nullptr, gate);
+        if (rc != ISLAM_OK) return rc;
+        // reprojection factor at the trial point Exp(dx)*cur: its r^T r joins the trial loss, and it IS the reduction of
+        // the next linearisation if the trial is accepted
+        if (reproj) enqueue_reproj_reduce(c.cur_n, w.dx, M, rp, RED[1 - c.pb], s, gate);
+        double* rep_slot = report + 16 * ((long long)seq & 1);
+        hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses, drots,
+                           dtrans, dvels, dts, LIN[c.pb], N, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot, seq,
+                           reproj ? RED[c.pb] : (const double*)nullptr, reproj ? RED[1 - c.pb] : (const double*)nullptr, rp, W,
+                           LIN[1 - c.pb], HD[1 - c.pb], HO[1 - c.pb], RH[1 - c.pb], gate);
+        ISLAM_LAUNCH_CHECK();
+        return ISLAM_OK;
+    };
+
+    IterCfg A{0, nodes, vels, w.nodes_t, w.vels_t};       // the iteration whose verdict is awaited
+    int steps = 0, trials = 0, status = ISLAM_OK;
+    double loss = 0.0, damping = init[2];
+    double epoch = 1.0;
+    enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
-    bool speculate = true;
-    while (continual) {
-        // ---- optimizer.step()   (its linearisation is already enqueued)
-        int reject_count = 0;
-        double last = 0.0;
-        bool broke = false;
-        for (;;) {           // while self.last <= self.loss
-            int rc = enqueue_solve(w, HD[pb], HO[pb], RH[pb], w.state, 0.0, N, prm->seg_len, w.dx, s);
-            if (rc != ISLAM_OK) return rc;
-            const double seq = (double)(trials + 1);
-            // reprojection factor at the trial point Exp(dx)*cur: its r^T r joins the trial loss, and it IS the reduction
-            // of the next linearisation if the trial is accepted
-            if (reproj) enqueue_reproj_reduce(cur_n, w.dx, M, rp, RED[1 - pb], s);
-            hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid(nblk)), dim3(64), 0, s, cur_n, cur_v, w.dx, poses, drots, dtrans, dvels,
-                               dts, LIN[pb], M, tri_n, tri_v, w.part, w.state, w.flags, ticket, tr, report, seq,
-                               reproj ? RED[pb] : (const double*)nullptr, reproj ? RED[1 - pb] : (const double*)nullptr, rp);
-            if (speculate) enqueue_linbuild(tri_n, tri_v, 1 - pb, true);
-            ISLAM_LAUNCH_CHECK();
-            // wait for the decision (poll the pinned status block; fall back to a stream sync after ~2 s)
-            {
-                unsigned long spins = 0;
-                while (hs[15] != seq) {
-                    if (++spins > 400000000ul) {
-                        ISLAM_HIP_CHECK(hipStreamSynchronize(s));
-                        if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: no status from the device (trial %d)", trials + 1);
-                    }
+    int rc = enqueue_iter(A, 1.0, epoch);
+    if (rc != ISLAM_OK) return rc;
+    for (;;) {
+        const double seq = (double)(trials + 1);
+        // run ahead: the next iteration under the assumption "trial accepted, loop continues"
+        const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
+        rc = enqueue_iter(B, seq + 1.0, epoch);
+        if (rc != ISLAM_OK) return rc;
+        // wait for the verdict (poll the pinned status block; fall back to a stream sync after ~2 s)
+        volatile double* hs = hs_all + 16 * ((long long)seq & 1);
+        {
+            unsigned long spins = 0;
+            while (hs[15] != seq) {
+                if (++spins > 400000000ul) {
+                    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                    if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: no status from the device (trial %d)", trials + 1);
                 }
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
             }
-            ++trials;
-            last = hs[1];
-            damping = hs[2];
-            if (hs[10] != 0.0) {      // "Linear solver failed. Breaking optimization step..."
-                status = ISLAM_ENOTPD;
-                loss = hs[0];
-                reject_count = (int)hs[8];
-                broke = true;
-                break;
-            }
-            const bool accepted = hs[9] != 0.0;
-            if (trace && trials <= trace_cap) {
-                trace[3 * (trials - 1)] = hs[6];
-                trace[3 * (trials - 1) + 1] = damping;
-                trace[3 * (trials - 1) + 2] = accepted ? 1.0 : 0.0;
-            }
-            loss = hs[0];
-            reject_count = (int)hs[8];
-            if (accepted) {
-                std::swap(cur_n, tri_n); std::swap(cur_v, tri_v);
-                if (!speculate) enqueue_linbuild(cur_n, cur_v, 1 - pb, true);
-                pb = 1 - pb;
-                speculate = true;
-                break;
-            }
-            speculate = false;        // after a reject: linearise the next step only once a trial is accepted
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
-        ++steps;
-        // ---- scheduler.step(loss)   (StopOnPlateau)
-        if (steps >= prm->max_steps) continual = false;
-        if ((last - loss) < prm->decreasing) ++patience_count; else patience_count = 0;
-        if (patience_count >= prm->patience) continual = false;
-        if (reject_count >= prm->reject) continual = false;
-        if (broke) {
-            // PyPose keeps looping through the scheduler (the plateau counter stops it): same iterate, new linearisation
-            if (continual) { enqueue_linbuild(cur_n, cur_v, pb, true); speculate = true; }
+        ++trials;
+        const int verdict = (int)hs[12];
+        damping = hs[2];
+        loss = hs[0];
+        steps = (int)hs[13];
+        if (trace && trials <= trace_cap && verdict < 3) {
+            trace[3 * (trials - 1)] = hs[6];
+            trace[3 * (trials - 1) + 1] = damping;
+            trace[3 * (trials - 1) + 2] = (verdict == 1) ? 0.0 : 1.0;
         }
+        if (verdict == 0) {               // accepted, continue: B is the iteration now in flight
+            A = B;
+            continue;
+        }
+        epoch += 1.0;                     // any other verdict bumped the device epoch: B's kernels are no-ops
+        if (verdict == 1) {               // rejected: same iterate, same (cumulatively damped) linearisation
+            rc = enqueue_iter(A, seq + 1.0, epoch);
+            if (rc != ISLAM_OK) return rc;
+            continue;
+        }
+        if (verdict == 2) {               // accepted, StopOnPlateau says stop
+            A = B;
+            break;
+        }
+        status = ISLAM_ENOTPD;            // "Linear solver failed. Breaking optimization step..."
+        if (verdict == 4) break;
+        // PyPose keeps looping through the scheduler (the plateau counter stops it): same iterate, new linearisation
+        enqueue_linbuild(A.cur_n, A.cur_v, A.pb, true);
+        rc = enqueue_iter(A, seq + 1.0, epoch);
+        if (rc != ISLAM_OK) return rc;
     }
+    double* cur_n = A.cur_n;
+    double* cur_v = A.cur_v;
     if (cur_n != nodes) {
         ISLAM_HIP_CHECK(hipMemcpyAsync(nodes, cur_n, (size_t)N * 7 * sizeof(double), hipMemcpyDeviceToDevice, s));
         ISLAM_HIP_CHECK(hipMemcpyAsync(vels, cur_v, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
