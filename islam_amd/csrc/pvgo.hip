@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -49,8 +50,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifdef ISLAM_PROBE
 __device__ long long islam_probe_buf[512];
 #define PROBE_AT(cond, slot) do { __builtin_amdgcn_sched_barrier(0); if (cond) islam_probe_buf[(slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROBE_WALL(cond, slot) do { __builtin_amdgcn_sched_barrier(0); if (cond) islam_probe_buf[(slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PROBE_AT(cond, slot) do { } while (0)
+#define PROBE_WALL(cond, slot) do { } while (0)
 #endif
 
 // XCD-aware work mapping.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, dispatch section; speed
@@ -70,6 +73,16 @@ __device__ __forceinline__ double bcast(double v, int src) {   // src must be wa
     lo = __builtin_amdgcn_readlane(lo, src);
     hi = __builtin_amdgcn_readlane(hi, src);
     return __hiloint2double(hi, lo);
+}
+
+// Agent-coherent accesses (global_store / global_load with sc1: written through to / read from the level every XCD
+// sees).  Data handed from one workgroup to another INSIDE a launch goes through these, so that publishing needs no
+// release fence: an agent-scope release is a write-back walk of the XCD's whole L2 (microseconds when many waves do it).
+__device__ __forceinline__ void st_coherent(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_coherent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Run-ahead gate.  The host enqueues LM iteration t+1 before it knows the outcome of trial t, assuming "accepted,
@@ -635,14 +648,27 @@ __device__ __forceinline__ void load_facrow(const double* __restrict__ fac, cons
     o.iv = inv[(size_t)c * 9 + r];
 }
 
+__device__ __forceinline__ void backsub_run(const double* __restrict__ fac, const double* __restrict__ inv,
+                                            double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
+                                            const double (&xL)[9], FacRow& cur);
+
 // Back-substitution through one segment (nodes c0 .. c0+cnt-1), right to left; the factor rows of node c-1 are
 // fetched while node c is being solved.  xn = solution right of the segment (0 if none), xL = left separator's (0 if none).
 __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, const double* __restrict__ inv,
                                                 double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
                                                 const double (&xL)[9]) {
     const int r = lane < 9 ? lane : 8;
-    FacRow cur, nxt;
+    FacRow cur;
     load_facrow(fac, inv, c0 + cnt - 1, r, cur);
+    backsub_run(fac, inv, x, c0, cnt, lane, xn, xL, cur);
+}
+
+// the same with the factor rows of the segment's last node already requested (they do not depend on xn / xL)
+__device__ __forceinline__ void backsub_run(const double* __restrict__ fac, const double* __restrict__ inv,
+                                            double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
+                                            const double (&xL)[9], FacRow& cur) {
+    const int r = lane < 9 ? lane : 8;
+    FacRow nxt;
     for (int c = c0 + cnt - 1; c >= c0; --c) {
         load_facrow(fac, inv, max(c - 1, c0), r, nxt);       // unconditional (clamped): same memory ops on every path
         __builtin_amdgcn_sched_barrier(0);
@@ -662,7 +688,7 @@ __device__ __forceinline__ void backsub_segment(const double* __restrict__ fac, 
 #pragma unroll
             for (int i = 0; i < 9; ++i)
                 if (i == lane) mine = xn[i];
-            x[(size_t)c * 9 + lane] = mine;
+            st_coherent(&x[(size_t)c * 9 + lane], mine);
         }
         // the rows of node c-1 were requested at the top of this iteration; make their arrival an explicit event HERE
         // (empty asm with in/out operands), so the next iteration's arithmetic carries no loop-carried memory wait
@@ -850,6 +876,44 @@ __global__ __launch_bounds__(64) void bt_eliminate_kernel(LevelSrc src, LevelDst
     eliminate_segment(src, dst, n, m, p + seg0, flags, threadIdx.x, lds);
 }
 
+// Segment of at most BS_PAR_MAX nodes: lane t*9 + r owns row r of node c0+t, so the factor rows of ALL nodes are requested
+// at once (one memory round trip instead of one per node) and the left-separator term y - F~ xL of every node is formed in
+// parallel; only U~ x_{t+1} and the 9-step triangular solve remain sequential (pivot lane broadcast with v_readlane).
+constexpr int BS_PAR_MAX = 7;
+
+__device__ __forceinline__ void backsub_par_load(const double* __restrict__ fac, const double* __restrict__ inv, int c0,
+                                                 int cnt, int lane, FacRow& row) {
+    const int t = min(lane / 9, cnt - 1);           // lanes past the segment duplicate its last node (valid memory, unused)
+    load_facrow(fac, inv, c0 + t, lane - (lane / 9) * 9, row);
+}
+
+__device__ __forceinline__ void backsub_par_run(double* __restrict__ x, int c0, int cnt, int lane, double (&xn)[9],
+                                                const double (&xL)[9], const FacRow& row) {
+    const int t = lane / 9, r = lane - t * 9;
+    double wF = row.y;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wF = fma(-row.f[q], xL[q], wF);
+    for (int tt = cnt - 1; tt >= 0; --tt) {
+        double w = wF;                                // meaningful on the nine lanes of node tt
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w = fma(-row.u[q], xn[q], w);
+        const int base = tt * 9;
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            const double xi = bcast(w * row.iv, base + i);
+            xn[i] = xi;
+            w = fma(-row.lt[i], xi, w);
+        }
+        if (t == tt) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i == r) mine = xn[i];
+            st_coherent(&x[(size_t)(c0 + tt) * 9 + r], mine);
+        }
+    }
+}
+
 __device__ __forceinline__ void backsub_level_segment(const double* __restrict__ fac, const double* __restrict__ inv,
                                                       const double* __restrict__ xsep, double* __restrict__ x, int n, int m,
                                                       int p, int lane) {
@@ -866,7 +930,13 @@ __device__ __forceinline__ void backsub_level_segment(const double* __restrict__
         xn[q] = has_right ? xsep[(size_t)p * 9 + q] : 0.0;
     }
     if (has_right && lane < 9) x[(size_t)sR * 9 + lane] = xsep[(size_t)p * 9 + lane];
-    backsub_segment(fac, inv, x, c0, cnt, lane, xn, xL);
+    if (m <= BS_PAR_MAX) {
+        FacRow row;
+        backsub_par_load(fac, inv, c0, cnt, lane, row);
+        backsub_par_run(x, c0, cnt, lane, xn, xL, row);
+    } else {
+        backsub_segment(fac, inv, x, c0, cnt, lane, xn, xL);
+    }
 }
 
 // The small top of the level tree in ONE launch: a single workgroup of up to 8 wavefronts runs every remaining level
@@ -908,6 +978,124 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
     const int p = xcd_index(blockIdx.x, nseg);
     if (p < 0 || gate_closed(gate)) return;
     backsub_level_segment(fac, inv, xsep, x, n, m, p + seg0, threadIdx.x);
+}
+
+// Root solve + the whole down-sweep in ONE launch.  Workgroup 0 eliminates and solves the root level; every other
+// workgroup owns one segment of one level (upper levels first in workgroup order).  A segment requests the factor rows
+// of its last node (they do not depend on the solution above), waits until the one or two segments of the level above
+// that hold its separators have published their part of the solution (a per-segment word set to this solve's serial
+// number after an agent-scope release fence), back-substitutes, publishes.  The waits replace four kernel boundaries and
+// overlap the first factor loads with the dependency.  Workgroups are dispatched in index order, so a waiting workgroup
+// only ever waits for lower-indexed ones (already resident or finished); the spin is bounded all the same.
+struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride; };
+struct SweepArgs {
+    LevelSrc root_src;
+    LevelDst root_dst;
+    int root_n;
+    SweepLevel lv[ISLAM_PVGO_MAX_LEVELS];      // lv[0] = the level just below the root ... lv[nl-1] = the largest level
+    int first_block[ISLAM_PVGO_MAX_LEVELS + 1];   // workgroup index where lv[i] starts (first_block[0] == 8)
+    int nl;
+    int* ready;               // per-segment words; ready[flag0 + p] == serial once segment p of that level is solved
+    int serial;
+};
+
+constexpr int READY_STRIDE = 32;      // ints between two ready words: one 128-byte line each (polled words spread over L2 channels)
+
+__device__ __forceinline__ void wait_ready(const int* f, int serial, int* flags, int lane) {
+    if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) { atomicOr(flags, 2); break; }     // never observed; keeps a logic error from hanging the GPU
+        }
+    }
+    asm volatile("" ::: "memory");      // what was published is read with ld_coherent AFTER this point: no acquire fence
+}
+
+__device__ __forceinline__ void publish_ready(int* f, int serial, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the wave's st_coherent stores have completed
+    if (lane == 0) __hip_atomic_store(f, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_PER_WAVE];
+    if (gate_closed(gate)) return;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b == 0) {                                   // root: eliminate + solve
+        PROBE_WALL(lane == 0, 300);
+        eliminate_segment(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, lane, lds);
+        PROBE_WALL(lane == 0, 301);
+        double xn[9], xL[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
+        if (a.root_n <= BS_PAR_MAX) {
+            FacRow row;
+            backsub_par_load(a.root_dst.fac, a.root_dst.inv, 0, a.root_n, lane, row);
+            backsub_par_run(a.root_dst.x, 0, a.root_n, lane, xn, xL, row);
+        } else {
+            backsub_segment(a.root_dst.fac, a.root_dst.inv, a.root_dst.x, 0, a.root_n, lane, xn, xL);
+        }
+        PROBE_WALL(lane == 0, 302);
+        publish_ready(a.ready, a.serial, lane);     // ready[0] = the root
+        PROBE_WALL(lane == 0, 303);
+        return;
+    }
+    if (b < a.first_block[0]) return;               // padding so that every level starts at a multiple of 8 (XCD mapping)
+    int li = 0;
+    while (li + 1 < a.nl && b >= a.first_block[li + 1]) ++li;
+    const SweepLevel L = a.lv[li];
+    const int p = xcd_index(b - a.first_block[li], L.P);   // blocks of a level are padded to a multiple of 8
+    if (p < 0) return;
+    const int stride = L.m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(L.m, L.n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + L.m;
+    const bool has_right = sR < L.n;
+    const bool pr = lane == 0 && (p == 1 || p == L.P / 2 || p == L.P - 1);
+    const int po = (p == 1 ? 0 : p == L.P / 2 ? 50 : 100);
+    PROBE_WALL(pr, po + 310 + 10 * li);
+    const bool par = L.m <= BS_PAR_MAX;
+    FacRow cur;
+    if (par) backsub_par_load(L.fac, L.inv, c0, cnt, lane, cur);
+    else load_facrow(L.fac, L.inv, c0 + cnt - 1, lane < 9 ? lane : 8, cur);
+    // address-translation warm-up: touch the pages this wave will read (separators) and write (its part of x) while it
+    // has nothing else to do; with hundreds of waves starting at once the page walks otherwise land on the critical path
+    double warm0 = L.xsep[(size_t)(has_left ? p - 1 : p) * 9 + (lane & 7)];
+    double warm1 = L.x[(size_t)c0 * 9 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
+    // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times)
+    for (int i = 0; i <= li; ++i) __builtin_amdgcn_s_sleep(48);
+    asm volatile("" ::"v"(warm0), "v"(warm1));
+    // separators p-1 and p are nodes of the level above; node q there is published by its segment q / up_stride
+    PROBE_WALL(pr, po + 315 + 10 * li);
+    if (has_left) wait_ready(a.ready + (size_t)(L.up_flag0 + (p - 1) / L.up_stride) * READY_STRIDE, a.serial, flags, lane);
+    PROBE_WALL(pr, po + 316 + 10 * li);
+    if (has_right && (!has_left || p / L.up_stride != (p - 1) / L.up_stride))
+        wait_ready(a.ready + (size_t)(L.up_flag0 + p / L.up_stride) * READY_STRIDE, a.serial, flags, lane);
+    PROBE_WALL(pr, po + 311 + 10 * li);
+    // one load per lane (lanes 0-8: left separator, 9-17: right separator), then lane broadcasts
+    double sv = 0.0;
+    if (lane < 9 ? has_left : (lane < 18 && has_right)) sv = ld_coherent(&L.xsep[(size_t)(p - 1) * 9 + lane]);
+#ifdef ISLAM_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PROBE_WALL(pr, po + 317 + 10 * li);
+#endif
+    double xn[9], xL[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        xL[q] = bcast(sv, q);
+        xn[q] = bcast(sv, 9 + q);
+    }
+    if (has_right && lane >= 9 && lane < 18) st_coherent(&L.x[(size_t)sR * 9 + lane - 9], sv);
+    PROBE_WALL(pr, po + 312 + 10 * li);
+    if (par) backsub_par_run(L.x, c0, cnt, lane, xn, xL, cur);
+    else backsub_run(L.fac, L.inv, L.x, c0, cnt, lane, xn, xL, cur);
+    PROBE_WALL(pr, po + 313 + 10 * li);
+    if (li + 1 < a.nl) publish_ready(a.ready + (size_t)(L.flag0 + p) * READY_STRIDE, a.serial, lane);
+    PROBE_WALL(pr, po + 314 + 10 * li);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1433,6 +1621,8 @@ struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
     double *lin2, *Hd2, *Ho2, *rhs2;          // second linearisation buffer (speculative next step)
     double *red, *red2;                       // reprojection factor: per-link reductions (same double buffering)
+    int* ready;                               // down-sweep: one word per segment of every level (+ the root)
+    size_t ready_bytes;
     int* flags;
     LevelBufs lv[MAXL];
     size_t bytes;
@@ -1463,6 +1653,8 @@ Workspace carve(void* base, int N) {
     w.vels_t = take((size_t)N * 3);
     w.state = take(16);
     w.flags = (int*)take(2);
+    w.ready_bytes = align_up(((size_t)N / 3 + 64 * MAXL) * READY_STRIDE * sizeof(int));   // segments of all levels < N/4 + ...
+    w.ready = (int*)take(w.ready_bytes / sizeof(double));
     int n = N;
     for (int l = 0; l < MAXL; ++l) {
         LevelBufs& b = w.lv[l];
@@ -1520,7 +1712,36 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
                            sp.lv[l].n, sp.lv[l].m, flags, 0, sp.lv[l].P, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
-    {
+    const bool sweep = (top == nl - 1) && (top > lbegin);      // root alone in the top kernel, at least one level below
+    if (sweep) {
+        static std::atomic<int> g_serial{0};
+        int serial = ++g_serial;
+        if (serial == 0) serial = ++g_serial;                 // 0 is the reset value of the ready words
+        SweepArgs a{};
+        a.root_src = src_of(top);
+        a.root_dst = level_dst(w.lv[top], x_of(top));
+        a.root_n = sp.lv[top].n;
+        a.ready = w.ready;
+        a.serial = serial;
+        a.nl = top - lbegin;
+        int flag = 1, blk = 8;
+        for (int i = 0; i < a.nl; ++i) {
+            const int l = top - 1 - i;
+            SweepLevel& L = a.lv[i];
+            L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
+            L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
+            L.flag0 = flag;
+            L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
+            L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
+            a.first_block[i] = blk;
+            flag += L.P;
+            blk += xcd_grid(L.P);
+        }
+        a.first_block[a.nl] = blk;
+        if ((size_t)flag * READY_STRIDE * sizeof(int) > w.ready_bytes) return fail(ISLAM_EARG, "pvgo: ready-flag buffer too small (%d words)", flag);
+        hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(64), 0, s, a, flags, gate);
+        if (evs) (void)hipEventRecord(evs[ne++], s);
+    } else {
         TopArgs a{};
         a.nl = nl - top;
         int maxP = 1;
@@ -1533,11 +1754,11 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         }
         hipLaunchKernelGGL(bt_top_kernel, dim3(1), dim3(64 * maxP), maxP * LDS_PER_WAVE * sizeof(double), s, a, flags, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
-    }
-    for (int l = top - 1; l >= lbegin; --l) {
-        hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1),
-                           x_of(l), sp.lv[l].n, sp.lv[l].m, 0, sp.lv[l].P, gate);
-        if (evs) (void)hipEventRecord(evs[ne++], s);
+        for (int l = top - 1; l >= lbegin; --l) {
+            hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1),
+                               x_of(l), sp.lv[l].n, sp.lv[l].m, 0, sp.lv[l].P, gate);
+            if (evs) (void)hipEventRecord(evs[ne++], s);
+        }
     }
     if (nev) *nev = ne;
     ISLAM_LAUNCH_CHECK();
@@ -1606,6 +1827,7 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
     ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     int rc = enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, s);
     if (rc != ISLAM_OK) return rc;
     int flag = 0;
@@ -1625,6 +1847,7 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_solve_chain_timed: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     hipEvent_t evs[2 * MAXL + 2];
     for (auto& e : evs) ISLAM_HIP_CHECK(hipEventCreate(&e));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
@@ -1702,6 +1925,7 @@ int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2]
     if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: single-level problem");
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, as_stream(stream)));
     LevelBufs pb{};
     products_view(const_cast<double*>(products), sp.lv[0].P, pb);
     return enqueue_levels(w, sp, 1, level_src_from(pb, sp.lv[0].P), &pb, x1, flags, as_stream(stream), nullptr, nullptr);
@@ -1841,6 +2065,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
                     islam_pvgo_workspace_bytes(N));
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     const int M = N - 1, nblk = (M + 63) / 64;
     // status blocks in pinned, device-visible host memory: the deciding wave of trial_lin_kernel writes one per trial
     // (two slots, alternating with the trial number), the host polls its sequence number (no stream synchronisation,

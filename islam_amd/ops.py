@@ -254,8 +254,11 @@ def pvgo_solve_chain_timed(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None)
                                              ptr(dx), ms, plan, ctypes.byref(nl), stream_ptr(Hd.device)))
     levels = [(plan[3 * l], plan[3 * l + 1], plan[3 * l + 2]) for l in range(_lib.MAX_LEVELS) if plan[3 * l] > 0]
     top = plan[3 * _lib.MAX_LEVELS]
-    names = ['eliminate_L%d' % l for l in range(top)] + ['top_L%d-%d' % (top, len(levels) - 1)] + \
-        ['backsub_L%d' % l for l in range(top - 1, -1, -1)]
+    if nl.value == top + 1:         # root solve + whole down-sweep in one launch (bt_downsweep_kernel)
+        names = ['eliminate_L%d' % l for l in range(top)] + ['root_L%d+downsweep' % top]
+    else:
+        names = ['eliminate_L%d' % l for l in range(top)] + ['top_L%d-%d' % (top, len(levels) - 1)] + \
+            ['backsub_L%d' % l for l in range(top - 1, -1, -1)]
     return dx, dict(zip(names, [ms[i] for i in range(nl.value)])), levels
 
 
