@@ -1160,9 +1160,9 @@ __device__ void lm_control(double s, double q, double* __restrict__ st, int* fla
     rep[13] = st[12];
     if (report) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) report[i] = rep[i];
-        __threadfence_system();
-        __hip_atomic_store(&report[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = 0; i < 15; ++i) __hip_atomic_store(&report[i], rep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // payload written through before the sequence number
+        __hip_atomic_store(&report[15], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1332,19 +1332,19 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
         sq = wave_sum(sq);
         qd = wave_sum(qd);
         if (lane == 0) {
-            part[2 * blk] = sq;
-            part[2 * blk + 1] = qd;
-            __threadfence();                                          // publish this workgroup's partial
+            // write-through stores + completion wait instead of a release fence (an agent-scope release walks the L2)
+            st_coherent(&part[2 * blk], sq);
+            st_coherent(&part[2 * blk + 1], qd);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_last = (atomicAdd(ticket, 1u) == (unsigned)(nlb - 1)) ? 1 : 0;
         }
     }
     __syncthreads();
     if (wave == 1 && s_last) {                                        // the decision, concurrently with wave 0 below
-        __threadfence();                                              // acquire the other workgroups' partials
         double ssum = 0.0, qsum = 0.0;
         for (int i = lane; i < nlb; i += 64) {
-            ssum += __hip_atomic_load(&part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            qsum += __hip_atomic_load(&part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ssum += ld_coherent(&part[2 * i]);
+            qsum += ld_coherent(&part[2 * i + 1]);
         }
         ssum = wave_sum(ssum);
         qsum = wave_sum(qsum);
