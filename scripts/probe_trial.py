@@ -1,5 +1,4 @@
-"""Per-phase shader-clock probes of trial_kernel / linbuild_kernel inside the LM loop.
-Build: hipcc -DISLAM_PROBE (scripts/build_probe.sh) -> islam_amd/lib/libislam_probe.so; run on the GPU box."""
+"""Wall-clock (100 MHz) probes of trial_lin_kernel inside the LM loop (libislam_probe.so, scripts/build_probe.sh)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import islam_amd._lib as L
@@ -19,12 +18,9 @@ buf = (ctypes.c_longlong * 512)()
 L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
 assert L.lib().islam_probe_read(buf) == 0
 b = list(buf)
-print('clock64 ticks (100 MHz constant clock on gfx950: 1 tick = 10 ns)' )
-names = {200: 'entry', 201: 'loads+retract', 202: 'link_residuals', 203: 'quality', 204: 'wave_sum+part', 205: 'ticket', 206: 'lastblk entry', 207: 'control done'}
-for a in range(201, 208):
-    print('trial   %-16s +%6d' % (names[a], b[a] - b[a - 1]))
-print('trial block1 total', b[205] - b[200], ' last block tail', b[207] - b[206])
-names = {221: 'loads+residuals', 222: 'jacobians', 223: 'products+LDS', 224: 'sum+barrier', 225: 'node build+stores'}
-for a in range(221, 226):
-    print('linbuild %-18s +%6d' % (names[a], b[a] - b[a - 1]))
-print('linbuild total', b[225] - b[220])
+t0 = b[400]
+us = lambda x: (x - t0) / 100.0
+names = ['entry', 'loads+retract', 'residuals', 'quality', 'sum+ticket', 'barrier1', 'node stores', 'jacobians', 'emit(lin+LDS)', 'barrier2', 'build+copy']
+for i, nm in enumerate(names):
+    print('block 40  %-14s %.2f us' % (nm, us(b[400 + i])))
+print('deciding wave: start %.2f  done %.2f us (relative to block 40 entry)' % (us(b[420]), us(b[421])))

@@ -2,7 +2,7 @@
 import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-names = {'linearize': 'lin', 'build_normal': 'build', 'bt_eliminate': 'elim', 'bt_top': 'top', 'bt_backsub': 'bsub', 'trial_lin': 'trial', 'trial_kernel': 'trial', 'linbuild': 'linb', 'control_begin': 'cbeg'}
+names = {'bt_downsweep': 'sweep', 'linearize': 'lin', 'build_normal': 'build', 'bt_eliminate': 'elim', 'bt_top': 'top', 'bt_backsub': 'bsub', 'trial_lin': 'trial', 'trial_kernel': 'trial', 'linbuild': 'linb', 'control_begin': 'cbeg'}
 seq = []
 for r in rows:
     n = r['Kernel_Name']
