@@ -816,7 +816,7 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
         if (lane < 28) {
             double* f = dst.fac + (size_t)c * FAC + lane * 9;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) f[r] = mcol[r];
+            for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);   // streamed out: not left dirty in the L2s for the end-of-kernel write-back
         }
         if (lane == 0) {
             double* iv = dst.inv + (size_t)c * 9;
