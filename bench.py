@@ -182,9 +182,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get('ISLAM_FORCE_SHARDED') == '1'   # 1-GPU self-test of the N>1 code path (RCCL, world 1)
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('ISLAM_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' only for 1-GPU self-tests
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -196,7 +200,7 @@ def main():
     N = prob['init_nodes'].shape[0]
     prm = ops.pvgo_default_params(LOSS_WEIGHT, radius=1e4)
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         ws = ops.pvgo_workspace(N, device)
         nodes = torch.empty_like(prob['init_nodes'])
         vels = torch.empty_like(prob['init_vels'])
