@@ -1284,6 +1284,10 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     const int L = blk * LB_NODES - 1 + lane;
     const bool valid = L >= 0 && L < M;
     const bool owns = valid && (lane > 0 || blk == 0);
+#ifdef ISLAM_PROBE
+    const bool pr = threadIdx.x == 0 && blk == nlb / 2;
+#endif
+    PROBE_WALL(pr, 400);
     SE3<double> Xi{}, Xj{};
     V3<double> vi{}, vj{};
     LinkRes r{};
@@ -1299,8 +1303,10 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
             vi = ld3(vels + 3 * L) + dvi;
             vj = ld3(vels + 3 * (L + 1)) + dvj;
             dt = dts[L];
+            PROBE_WALL(pr, 401);
             r = link_residuals(Xi, Xj, vi, vj, se3_load(poses + 7 * L), ld4(drots + 4 * L), ld3(dtrans + 3 * L),
                                ld3(dvels + 3 * L), dt);
+            PROBE_WALL(pr, 402);
             if (owns) {
                 sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
                 // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
@@ -1329,6 +1335,7 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
                 }
             }
         }
+        PROBE_WALL(pr, 403);
         sq = wave_sum(sq);
         qd = wave_sum(qd);
         if (lane == 0) {
@@ -1339,7 +1346,9 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
             s_last = (atomicAdd(ticket, 1u) == (unsigned)(nlb - 1)) ? 1 : 0;
         }
     }
+    PROBE_WALL(pr, 404);
     __syncthreads();
+    PROBE_WALL(wave == 1 && lane == 0 && s_last, 420);
     if (wave == 1 && s_last) {                                        // the decision, concurrently with wave 0 below
         double ssum = 0.0, qsum = 0.0;
         for (int i = lane; i < nlb; i += 64) {
@@ -1352,7 +1361,9 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
             *ticket = 0u;
             lm_control(ssum, qsum, st, flags, tr, report, seq);
         }
+        PROBE_WALL(lane == 0, 421);
     }
+    PROBE_WALL(pr, 405);
     if (wave == 0 && valid) {
         if (owns) {
             se3_store(Xi, nodes_t + 7 * L);
@@ -1362,12 +1373,17 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
                 vels_t[3 * L + 3] = vj.x; vels_t[3 * L + 4] = vj.y; vels_t[3 * L + 5] = vj.z;
             }
         }
+        PROBE_WALL(pr, 406);
         M3<double> G, C, B;
         link_jacobians(r, G, C, B);
+        PROBE_WALL(pr, 407);
         link_emit(r, G, C, B, dt, L, M, owns, W, lin_o, sl[lane], red_trial, rp, Xi);
+        PROBE_WALL(pr, 408);
     }
     __syncthreads();
+    PROBE_WALL(pr, 409);
     nodes_build_copy(sl, lb_out, blk, N, W, Hd_o, Ho_o, rhs_o);
+    PROBE_WALL(pr, 410);
 }
 
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
