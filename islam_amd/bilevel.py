@@ -45,10 +45,13 @@ class BilevelLoop:
         T_IL = self.T_IL.to(motions.device)
         motions = T_IL @ motions @ T_IL.Inv()                                                   # train.py:214-215
         sync(); t1 = time.perf_counter()
-        T0 = torch.as_tensor(self.pgo_poses[-1])
-        poses_vo = motion2pose_pypose(motions[:bs], torch.as_tensor(self.vo_poses[-1]))
-        self.vo_motions.extend(motions.detach().cpu().numpy())
-        self.vo_poses.extend(poses_vo.detach().cpu().numpy()[1:])
+        # VO-only dead reckoning is book-keeping (train.py:219-228 keeps it for the plots): no gradient flows through it,
+        # so the 8 sequential SE3 products run on the host copy instead of ~160 tiny device launches
+        motions_host = pp.SE3(motions.detach().tensor().cpu())
+        with torch.no_grad():
+            poses_vo = motion2pose_pypose(motions_host[:bs], torch.as_tensor(self.vo_poses[-1]).to(motions_host.dtype))
+        self.vo_motions.extend(motions_host.tensor().numpy())
+        self.vo_poses.extend(poses_vo.tensor().numpy()[1:])
 
         st, end = self.current_idx, self.current_idx + bs
         imu_trans, imu_rots, _, imu_vels = self.imu.integrate(st, end, self.init_state, motion_mode=False)

@@ -51,27 +51,38 @@ class IMUModule:
             self.use_est_cov = use_est_cov
 
     def integrate(self, st, end, init=None, motion_mode=False):
-        """imu_integrator.py:69-164.  world mode: (end-st+1) rows incl. the initial state; motion mode: (end-st) rows."""
-        init_pos, init_rot, init_vel = prase_init(init, motion_mode, self.device, self.dtype)
+        """imu_integrator.py:69-164.  world mode: (end-st+1) rows incl. the initial state; motion mode: (end-st) rows.
+        Host traffic per call: one H2D of the 10 initial-state values, one of the frame offsets, one D2H of the packed
+        result (the reference: 3 D2H copies per frame)."""
         b0 = int(self.rgb2imu_sync[st])
         b1 = int(self.rgb2imu_sync[end]) + 1
-        dts = self.dts[b0:b1, 0].clone()
-        gyros = self.gyros[b0:b1].clone()
-        accels = self.accels[b0:b1].clone()
+        dts = self.dts[b0:b1, 0]                    # contiguous views of the stream; only written to through new tensors
+        gyros = self.gyros[b0:b1]
+        accels = self.accels[b0:b1]
         if self.optm_bias:
             if self.denoise_accel:
-                accels -= self.accel_bias.view(1, 3)
+                accels = accels - self.accel_bias.view(1, 3)
             if self.denoise_gyro:
-                gyros -= self.gyro_bias.view(1, 3)
+                gyros = gyros - self.gyro_bias.view(1, 3)
         if self.use_denoise_model and b1 - b0 >= 10:
             d_acc, d_gyro, _, _ = self.denoiser({'acc': accels.float(), 'gyro': gyros.float()}, eval=True)
             if self.denoise_accel:
                 accels = d_acc.to(self.dtype)
             if self.denoise_gyro:
                 gyros = d_gyro.to(self.dtype)
+        # prase_init (imu_integrator.py:11-28) packed into one transfer: [pos(3) | rot(4) | vel(3)]
+        np_dt = {torch.float32: np.float32, torch.float64: np.float64}[self.dtype]
+        i10 = np.zeros(10, dtype=np_dt)
+        i10[6] = 1.0
+        if init is not None:
+            i10[3:7] = np.asarray(init['rot'], dtype=np_dt)
+            if not motion_mode:
+                i10[0:3] = np.asarray(init['pos'], dtype=np_dt)
+                i10[7:10] = np.asarray(init['vel'], dtype=np_dt)
+        i10 = torch.from_numpy(i10).to(self.device)
         seg_host = np.ascontiguousarray(self.rgb2imu_sync[st:end + 1] - b0, dtype=np.int64)
         seg = torch.from_numpy(seg_host).to(self.device)
         pos, rot, vel = ops.imu_preint(dts.contiguous(), gyros.contiguous(), accels.contiguous(), seg, seg_host,
-                                       init_pos.contiguous(), init_rot.tensor().contiguous(), init_vel.contiguous(),
-                                       self.gravity, motion_mode)
-        return pos.cpu(), pp.SO3(rot.cpu()), [], vel.cpu()
+                                       i10[0:3], i10[3:7], i10[7:10], self.gravity, motion_mode)
+        out = torch.cat((pos, rot, vel), 1).cpu()
+        return out[:, 0:3].contiguous(), pp.SO3(out[:, 3:7].contiguous()), [], out[:, 7:10].contiguous()

@@ -122,6 +122,23 @@ class _PSMBlock(nn.Module):
         return y + (x if self.downsample is None else self.downsample(x))
 
 
+def _block_mean(x, k):
+    """AvgPool2d((k, k), stride=(k, k)) (floor mode, no padding) as a reshape + mean: one pass over x."""
+    B, C, H, W = x.shape
+    h, w = H // k, W // k
+    return x[:, :, :h * k, :w * k].reshape(B, C, h, k, w, k).mean((3, 5))
+
+
+def _spp_pools(x):
+    """The four non-overlapping average pools of the SPP branches (kernels 8/16/32/64, submodule.py:103-122): the 8x8
+    pool reads x once, every coarser pool is the 2x2 mean of the previous one (identical blocks: floor mode drops the same
+    rows / columns either way).  torch's avg_pool2d kernel takes ~0.4 ms per call on these shapes."""
+    p8 = _block_mean(x, 8)
+    p16 = _block_mean(p8, 2)
+    p32 = _block_mean(p16, 2)
+    return {8: p8, 16: p16, 32: p32, 64: _block_mean(p32, 2)}
+
+
 class feature_extraction(nn.Module):
     def __init__(self, last_planes=32, bigger=False, middleblock=16):
         super().__init__()
@@ -153,7 +170,9 @@ class feature_extraction(nn.Module):
         raw = self.layer2(o0)
         skip = self.layer4(self.layer3(raw))
         hw = [skip.shape[2], skip.shape[3]]
-        br = [F.interpolate(getattr(self, 'branch%d' % i)(skip), hw, mode='bilinear', align_corners=True) for i in (4, 3, 2, 1)]
+        pools = _spp_pools(skip)
+        br = [F.interpolate(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, mode='bilinear', align_corners=True)
+              for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))]
         feat = torch.cat([raw, skip] + br, 1)
         if self.bigger:
             feat = torch.cat((F.interpolate(feat, [hw[0] * 2, hw[1] * 2], mode='bilinear', align_corners=True), o0), 1)
@@ -211,7 +230,9 @@ class SSP(nn.Module):
 
     def forward(self, x):
         hw = [x.shape[2], x.shape[3]]
-        return torch.cat([x] + [F.interpolate(getattr(self, 'branch%d' % i)(x), hw, mode='bilinear') for i in (4, 3, 2, 1)], 1)
+        pools = _spp_pools(x)
+        return torch.cat([x] + [F.interpolate(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, mode='bilinear')
+                                for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))], 1)
 
 
 class StereoNet7(nn.Module):
