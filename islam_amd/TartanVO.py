@@ -52,7 +52,7 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th):
 
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
-                 device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None):
+                 device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -61,7 +61,7 @@ class TartanVO(nn.Module):
         self.use_kitti_coord = use_kitti_coord
         self.pose_std = torch.tensor([0.13, 0.13, 0.13, 0.013, 0.013, 0.013]).cuda(self.device_id)
         self.vonet = VONet(fix_parts=fix_parts)
-        self.vonet.set_frozen_dtype(frozen_dtype)
+        self.vonet.set_frozen_dtype(frozen_dtype, flow_dtype)
         for name, part in ((vo_model_name, self.vonet), (flow_model_name, self.vonet.flowNet),
                            (pose_model_name, self.vonet.flowPoseNet), (stereo_model_name, self.vonet.stereoNet)):
             if name is not None and name != '':

@@ -148,3 +148,29 @@ def test_warp_backward_matches_torch_autograd(cuda, C, H, W, scale):
     (out * m).backward(go)
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(fl.grad, fr.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_frozen_stereo_net_bf16_execution_copy(cuda):
+    """BASELINE config 2 ("bf16 nets"): the frozen stereo net runs through a bf16 channels_last execution copy whose weights
+    are cast once; the fp32 master keeps the checkpoint, train-mode BatchNorm statistics still land in it, and a
+    weight change (load_state_dict) is picked up."""
+    from islam_amd import nets
+    torch.manual_seed(0)
+    net = nets.VONet(fix_parts=('flow', 'stereo')).to(cuda).train()
+    x = torch.randn(2, 6, 256, 320, device=cuda)
+    run = lambda: net._run_frozen('stereo', net.stereoNet, net.frozen_dtype, x)[0].float()
+    with torch.no_grad():
+        d0 = run()
+    rm0 = net.stereoNet.state_dict()['feature_extraction.firstconv.0.1.running_mean'].clone()
+    net.set_frozen_dtype(torch.bfloat16)
+    with torch.no_grad():
+        d1 = run()
+    assert all(v.dtype == torch.float32 for v in net.state_dict().values() if v.is_floating_point())
+    assert float((d1 - d0).abs().max()) <= 0.05 * float(d0.abs().max()) + 1e-3
+    rm1 = net.stereoNet.state_dict()['feature_extraction.firstconv.0.1.running_mean']
+    assert not torch.equal(rm1, rm0)                                     # statistics updated through the shared buffers
+    copy_a = net._exec['stereo'].module()
+    assert copy_a is net._exec['stereo'].module()                        # cached
+    sd = {k: (v * 0.5 if k.endswith('conv_c13.weight') else v) for k, v in net.stereoNet.state_dict().items()}
+    net.stereoNet.load_state_dict(sd)
+    assert net._exec['stereo'].module() is not copy_a                    # re-cast after the master changed
