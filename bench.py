@@ -128,7 +128,7 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     from islam_amd.bilevel import BilevelLoop
     from islam_amd.imu_integrator import IMUModule
     torch.manual_seed(0)
-    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, frozen_dtype=torch.bfloat16)
+    vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16)
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
         vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
@@ -154,7 +154,7 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tm = loop.timing
-    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo', 'nets': 'stereo net bf16 NHWC (77 % of the FLOPs), flow net + pose head fp32 (MIOpen runs the flow net fastest in fp32)',
+    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo', 'nets': 'stereo net: bf16 NHWC execution copy on MIOpen (77 % of the FLOPs); flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, fp32 accumulate and activations); pose head fp32 (trainable)',
             'ms_per_batch': el / steps * 1e3, 'stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
             'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic'}
 

@@ -65,6 +65,18 @@ int islam_warp_mask(const float* x, const float* flow, float scale, float* out, 
 int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const float* gout, float* gx, float* gflow,
                         int B, int C, int H, int W, void* stream);
 
+/* 3x3 convolution (+ bias + LeakyReLU) of the frozen flow network on the matrix cores (implicit GEMM, bf16 operands,
+ * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:20-25 `conv()` (Conv2d k=3, padding = dilation, then
+ * LeakyReLU(0.1)) for inference:  y[b, coff+n, ho, wo] = act(bias[n] + sum w[n,c,r,s] x[b, c, ho*stride + (r-1)*dil,
+ * wo*stride + (s-1)*dil]),  act(v) = v >= 0 ? v : slope*v  (slope = 1: no activation).
+ * x: channels [xoff, xoff+Cin) of a (B,xtot,H,W) fp32 NCHW buffer; y: channels [coff, coff+Cout) of a (B,ytot,Ho,Wo) fp32
+ * NCHW buffer, Ho = (H-1)/stride+1 -- the DenseNet-style torch.cat of PWCNet.py:237-292 without a copy; bias (Cout) or NULL.
+ * wpacked: bf16 bits, [9][CoutP][CinP] (tap = 3r+s; CoutP = Cout rounded up to 64, CinP = Cin rounded up to 16, zero padded),
+ * islam_conv3x3_packed_elems(Cin, Cout) elements.  stride 1 or 2, dilation 1..8. */
+size_t islam_conv3x3_packed_elems(int Cin, int Cout);
+int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bias, float* y, int B, int Cin, int H, int W,
+                       int Cout, int stride, int dilation, int xoff, int xtot, int coff, int ytot, float slope, void* stream);
+
 /* ---------------------------------------------------------------- stereo scale recovery */
 
 /* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176

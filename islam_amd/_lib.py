@@ -48,6 +48,8 @@ SIGNATURES = {
     'islam_corr81_bwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     'islam_warp_mask': (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 4 + [c_void_p]),
     'islam_warp_mask_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    'islam_conv3x3_packed_elems': (c_size_t, [c_int, c_int]),
+    'islam_conv3x3_mfma': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_float, c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
     'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +

@@ -1,0 +1,216 @@
+// conv_mfma.hip -- 3x3 convolution of the frozen PWC-Net flow network as an implicit GEMM on the CDNA4 matrix cores.
+//
+// Replaces, for the frozen (inference-only) flow network, what the reference runs through cuDNN
+// (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d(k=3, padding=dilation) + LeakyReLU(0.1), :208-292 the network):
+//   y[b, coff+n, ho, wo] = act( bias[n] + sum_{c,r,s} w[n,c,r,s] * x[b, c, ho*S + r*D - D, wo*S + s*D - D] )
+// x, y stay fp32 NCHW (the layout of the correlation / warp kernels and of torch.cat); operands are rounded to bf16 when
+// they are staged in LDS and accumulated in fp32 (v_mfma_f32_32x32x16_bf16) -- BASELINE config 2 "bf16 nets".  Bias and
+// LeakyReLU are fused; `xoff`/`xtot` and `coff`/`ytot` let a layer read and write channel slices of the DenseNet-style
+// concatenation buffer directly (no torch.cat).
+//
+// GEMM view per image: M = Cout (A operand: weights), N = pixels (B operand: im2col of x), K = 9*Cin; computing it this way
+// round makes the accumulator's lane index the pixel x, so output stores are 128-byte rows of one channel.
+// Workgroup: 256 threads, tile 32 x 8 output pixels x TN output channels; wave w owns pixel rows 2w, 2w+1.  K is walked in
+// chunks of 16 input channels: the halo tile of the chunk ([y][x][16 ch] bf16, 48-byte pixel stride: conflict-free 16-byte
+// operand reads) and the nine weight taps are staged in LDS once and feed 9 * 2 * TN/32 MFMAs per wave; the next chunk's
+// global loads are in flight (registers) while the current chunk is multiplied.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include "../../include/islam_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace islam;
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TW = 32, TH = 8, KC = 16, PS = 24;     // PS: bf16 elements per LDS pixel / weight row (16 + 8 pad = 48 bytes)
+constexpr int THREADS = 256;
+constexpr int MAX_IN_PER_THREAD = 48;                // halo-tile (pixel, channel-pair) items a thread prefetches per chunk (large dilations / stride 2)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    // round-to-nearest-even, as torch's .to(bfloat16)
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+template <int TN, int NPRE>
+__global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                                const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                                int CinP, int H, int W, int Cout, int CoutP, int Ho, int Wo,
+                                                                int S, int D, int coff, int ytot, float slope, int tiles_x, int xoff,
+                                                                int xtot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    const int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
+    unsigned short* lin = lds;                               // [IH][IW][PS]
+    unsigned short* lw = lds + (size_t)IH * IW * PS;         // [9][TN][PS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int wo0 = tx * TW, ho0 = ty * TH, n0 = blockIdx.y * TN, b = blockIdx.z;
+    const float* xb = x + ((size_t)b * xtot + xoff) * H * W;
+    const int gx0 = wo0 * S - D, gy0 = ho0 * S - D;
+    const int npix = IH * IW;
+    const int nitems = npix * (KC / 2);                      // (channel pair, pixel) items of one chunk, pixel fastest
+    constexpr int NT = TN / 32;
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][p][i] = 0.0f;
+
+    float pre0[NPRE], pre1[NPRE];                            // fully unrolled below: stays in registers
+    uint4 prew[(9 * TN * 2 + THREADS - 1) / THREADS];
+    constexpr int NW = (9 * TN * 2 + THREADS - 1) / THREADS;
+
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int it = tid + k * THREADS;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (it < nitems) {
+                const int cp = it / npix, pix = it - cp * npix;
+                const int yy = pix / IW, xx = pix - yy * IW;
+                const int gy = gy0 + yy, gx = gx0 + xx, c = c0 + 2 * cp;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const float* p = xb + ((size_t)c * H + gy) * W + gx;
+                    if (c < Cin) v0 = p[0];
+                    if (c + 1 < Cin) v1 = p[(size_t)H * W];
+                }
+            }
+            pre0[k] = v0;
+            pre1[k] = v1;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int it = tid + k * THREADS;                // 16-byte vector index: ((tap*TN + n)*2 + half)
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (it < 9 * TN * 2) {
+                const int half = it & 1, row = it >> 1, tap = row / TN, n = row - tap * TN;
+                v = *reinterpret_cast<const uint4*>(wp + ((size_t)tap * CoutP + n0 + n) * CinP + c0 + 8 * half);
+            }
+            prew[k] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int it = tid + k * THREADS;
+            if (it < nitems) {
+                const int cp = it / npix, pix = it - cp * npix;
+                *reinterpret_cast<unsigned*>(lin + (size_t)pix * PS + 2 * cp) = pack_bf16(pre0[k], pre1[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int it = tid + k * THREADS;
+            if (it < 9 * TN * 2) {
+                const int half = it & 1, row = it >> 1;
+                *reinterpret_cast<uint4*>(lw + (size_t)row * PS + 8 * half) = prew[k];
+            }
+        }
+    };
+
+    const int kg = lane >> 5, li = lane & 31;
+    fetch(0);
+    for (int c0 = 0; c0 < CinP; c0 += KC) {
+        __syncthreads();                                     // the previous chunk's operand reads are done
+        stage();
+        __syncthreads();
+        if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, s = tap - r * 3;
+            bf16x8 bfrag[2], afrag[NT];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int yy = (2 * wave + p) * S + r * D, xx = li * S + s * D;
+                bfrag[p] = *reinterpret_cast<const bf16x8*>(lin + ((size_t)yy * IW + xx) * PS + 8 * kg);
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+                afrag[a] = *reinterpret_cast<const bf16x8*>(lw + ((size_t)tap * TN + a * 32 + li) * PS + 8 * kg);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[a], bfrag[p], acc[a][p], 0, 0, 0);
+        }
+    }
+    // epilogue: D row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel x) = lane&31
+    float* yb = y + ((size_t)b * ytot + coff) * Ho * Wo;
+    const int wo = wo0 + li;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ho = ho0 + 2 * wave + p;
+            if (ho >= Ho || wo >= Wo) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = n0 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                if (n < Cout) {
+                    float v = acc[a][p][reg] + (bias ? bias[n] : 0.0f);
+                    v = v >= 0.0f ? v : v * slope;
+                    yb[((size_t)n * Ho + ho) * Wo + wo] = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t islam_conv3x3_packed_elems(int Cin, int Cout) {
+    const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 63) / 64 * 64;
+    return (size_t)9 * CoutP * CinP;
+}
+
+int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bias, float* y, int B, int Cin, int H, int W,
+                       int Cout, int stride, int dilation, int xoff, int xtot, int coff, int ytot, float slope, void* stream) {
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_conv3x3_mfma: bad shape");
+    if (stride != 1 && stride != 2) return fail(ISLAM_EARG, "islam_conv3x3_mfma: stride %d (1 or 2)", stride);
+    if (dilation < 1 || dilation > 16) return fail(ISLAM_EARG, "islam_conv3x3_mfma: dilation %d (1..16)", dilation);
+    const int S = stride, D = dilation;
+    const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+    if (xoff < 0 || xoff + Cin > xtot) return fail(ISLAM_EARG, "islam_conv3x3_mfma: input slice %d+%d > %d", xoff, Cin, xtot);
+    if (coff < 0 || coff + Cout > ytot) return fail(ISLAM_EARG, "islam_conv3x3_mfma: channel slice %d+%d > %d", coff, Cout, ytot);
+    const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 63) / 64 * 64;
+    const int IH = (TH - 1) * S + 2 * D + 1, IW = (TW - 1) * S + 2 * D + 1;
+    if ((IH * IW * (KC / 2) + THREADS - 1) / THREADS > MAX_IN_PER_THREAD)
+        return fail(ISLAM_EARG, "islam_conv3x3_mfma: halo tile %dx%d too large", IH, IW);
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipStream_t s = (hipStream_t)stream;
+    const int TN = Cout > 32 ? 64 : 32;
+    const int nper = (IH * IW * (KC / 2) + THREADS - 1) / THREADS;
+    const size_t lds = ((size_t)IH * IW * PS + (size_t)9 * TN * PS) * sizeof(unsigned short);
+    dim3 grid(tiles_x * tiles_y, (Cout + TN - 1) / TN, B);
+#define ISLAM_CONV_LAUNCH(TN_, NPRE_)                                                                                          \
+    do {                                                                                                                       \
+        static size_t maxlds = 0;                                                                                              \
+        if (lds > maxlds) {                                                                                                    \
+            ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<TN_, NPRE_>,                                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+            maxlds = lds;                                                                                                      \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<TN_, NPRE_>), grid, dim3(THREADS), lds, s, x, wpacked, bias, y, Cin, CinP, H, W, \
+                           Cout, CoutP, Ho, Wo, S, D, coff, ytot, slope, tiles_x, xoff, xtot);                                             \
+    } while (0)
+    if (TN == 64) {
+        if (nper <= 12) ISLAM_CONV_LAUNCH(64, 12); else ISLAM_CONV_LAUNCH(64, MAX_IN_PER_THREAD);
+    } else {
+        if (nper <= 12) ISLAM_CONV_LAUNCH(32, 12); else ISLAM_CONV_LAUNCH(32, MAX_IN_PER_THREAD);
+    }
+#undef ISLAM_CONV_LAUNCH
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // extern "C"

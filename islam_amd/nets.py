@@ -103,6 +103,77 @@ class PWCDCNet(nn.Module):
         flow2 = flow2 + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
         return (flow2, flows[3], flows[4], flows[5], flows[6]), (None, None, None, None, None)
 
+    # ---- inference path on the HIP matrix-core convolution (frozen flow net, BASELINE config 2 "bf16 nets") ----
+    def _packed(self, name):
+        """bf16 tap-major weights of a 3x3 conv for islam_conv3x3_mfma, re-packed when the fp32 master changes."""
+        mod = getattr(self, name)
+        conv = mod[0] if isinstance(mod, nn.Sequential) else mod
+        cache = self.__dict__.setdefault('_mfma_cache', {})
+        key = (conv.weight._version, conv.weight.data_ptr())
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, ops.pack_conv3x3_weight(conv.weight), conv.bias.detach(), conv)
+        return hit[1], hit[2], hit[3]
+
+    def _c(self, name, x, out=None, coff=0, xoff=0):
+        """One `conv()` block (PWCNet.py:20-25).  Stride-1 layers with dilation <= 2 and >= 16 input channels run on the HIP
+        kernel (2-2.8x MIOpen's fp32 Winograd there); the stride-2 pyramid heads and the widely dilated context layers, where
+        the halo tile outweighs the outputs, stay on MIOpen."""
+        packed, bias, conv = self._packed(name)
+        act = isinstance(getattr(self, name), nn.Sequential)
+        if conv.stride[0] == 1 and conv.dilation[0] <= 2 and conv.in_channels >= 16:
+            return ops.conv3x3_mfma(x, packed, bias, conv.out_channels, 1, conv.dilation[0], 0.1 if act else 1.0, out, coff, xoff)
+        xin = x if xoff == 0 else x[:, xoff:]
+        y = conv(xin)
+        y = F.leaky_relu(y, 0.1) if act else y
+        if out is None:
+            return y
+        out[:, coff:coff + y.shape[1]].copy_(y)
+        return out
+
+    def _dense_mfma(self, l, pieces):
+        """The DenseNet block of one level without torch.cat: the buffer holds [conv4 | conv3 | conv2 | conv1 | conv0 |
+        input] (PWCNet.py:237-292 prepend the newest features); every layer reads a suffix and writes the slice before it."""
+        od = sum(p.shape[1] for p in pieces)
+        B, _, H, W = pieces[0].shape
+        tot = od + sum(self.DENSE)
+        buf = torch.empty((B, tot, H, W), dtype=torch.float32, device=pieces[0].device)
+        o = tot - od
+        for p in pieces:
+            buf[:, o:o + p.shape[1]].copy_(p)
+            o += p.shape[1]
+        off = tot - od
+        for i, w in enumerate(self.DENSE):
+            self._c('conv%d_%d' % (l, i), buf, out=buf, coff=off - w, xoff=off)
+            off -= w
+        return buf
+
+    def forward_mfma(self, x):
+        """Same network as forward(), no autograd: both images go through the pyramid as one batch, convolutions through
+        _c(), concatenations through channel slices.  fp32 activations; bf16-rounded operands inside the convolutions."""
+        B = x.shape[0]
+        x = x.float()
+        f, feats = torch.cat((x[:, 0:3], x[:, 3:6]), 0).contiguous(), []
+        for l in range(1, 7):
+            for s in (('a', 'aa', 'b') if l < 6 else ('aa', 'a', 'b')):
+                f = self._c('conv%d%s' % (l, s), f)
+            feats.append(f)
+        p1, p2 = [t[:B] for t in feats], [t[B:] for t in feats]
+        lrelu = lambda t: F.leaky_relu(t, 0.1)
+        x = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
+        flows = {}
+        for l in range(5, 1, -1):
+            flows[l + 1] = self._c('predict_flow%d' % (l + 1), x)
+            up_flow = getattr(self, 'deconv%d' % (l + 1))(flows[l + 1])
+            up_feat = getattr(self, 'upfeat%d' % (l + 1))(x)
+            a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
+            warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
+            x = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
+        flow2 = self._c('predict_flow2', x)
+        x = self._c('dc_conv4', self._c('dc_conv3', self._c('dc_conv2', self._c('dc_conv1', x))))
+        flow2 = flow2 + self._c('dc_conv7', self._c('dc_conv6', self._c('dc_conv5', x)))
+        return (flow2, flows[3], flows[4], flows[5], flows[6]), (None, None, None, None, None)
+
 
 # ------------------------------------------------------------------------------------------ StereoNet7
 def _convbn(cin, cout, k, stride, pad, dilation):
@@ -346,8 +417,8 @@ class VONet(nn.Module):
         # BASELINE config 2 ("bf16 nets"): the frozen nets run through a reduced-precision channels_last EXECUTION COPY
         # (_HalfExec) whose conv weights are cast once; autocast re-casts ~150 weight tensors and as many activations per
         # forward and keeps interpolate / cat in fp32.  The fp32 master modules keep the checkpoint (765 keys, fp32).
-        self.frozen_dtype = None        # stereo net (77 % of the FLOPs)
-        self.flow_dtype = None          # flow net
+        self.frozen_dtype = None        # stereo net (77 % of the FLOPs): bf16 execution copy on MIOpen
+        self.flow_dtype = None          # flow net: not None -> PWCDCNet.forward_mfma (HIP implicit-GEMM convolutions)
         self._exec = {}
 
     def set_frozen_dtype(self, dtype, flow_dtype=None):
@@ -357,6 +428,9 @@ class VONet(nn.Module):
     def _run_frozen(self, name, master, dtype, x):
         if dtype is None or any(p.requires_grad for p in master.parameters()):
             return master(x)                 # trainable parts keep their fp32 autograd path
+        if name == 'flow':                   # fp32 activations, bf16 operands inside the HIP matrix-core convolutions
+            with torch.no_grad():
+                return master.forward_mfma(x)
         ex = self._exec.get(name)
         if ex is None or ex.dtype != dtype:
             ex = self._exec[name] = _HalfExec(master, dtype)

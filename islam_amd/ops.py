@@ -119,6 +119,35 @@ def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th):
     return scale, z, mask.bool(), dmask.bool(), sums
 
 
+# --------------------------------------------------------------------------- 3x3 convolution on the matrix cores
+def pack_conv3x3_weight(w):
+    """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages."""
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    assert tuple(w.shape[2:]) == (3, 3)
+    CinP, CoutP = (Cin + 15) // 16 * 16, (Cout + 63) // 64 * 64
+    p = torch.zeros((9, CoutP, CinP), dtype=torch.bfloat16, device=w.device)
+    p[:, :Cout, :Cin] = w.detach().permute(2, 3, 0, 1).reshape(9, Cout, Cin).to(torch.bfloat16)
+    assert p.numel() == lib().islam_conv3x3_packed_elems(Cin, Cout)
+    return p.contiguous()
+
+
+def conv3x3_mfma(x, packed, bias, cout, stride=1, dilation=1, slope=0.1, out=None, coff=0, xoff=0, cin=None):
+    """y = LeakyReLU_slope(conv3x3(x[:, xoff:xoff+cin]) + bias) with padding = dilation (slope=1.0: linear).
+    ``out`` (B, Ctot, Ho, Wo) fp32: the result goes to channels [coff, coff+cout); with ``xoff`` the input is a channel slice
+    of a larger buffer -- together a DenseNet block needs no torch.cat.  Inference only (no autograd)."""
+    require_cuda(x, packed)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, xtot, H, W = x.shape
+    cin = xtot - xoff if cin is None else cin
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == B and tuple(out.shape[2:]) == (Ho, Wo)
+    check(lib().islam_conv3x3_mfma(ptr(x), ptr(packed), ptr(bias), ptr(out), B, int(cin), H, W, int(cout), int(stride), int(dilation),
+                                   int(xoff), int(xtot), int(coff), int(out.shape[1]), ctypes.c_float(slope), stream_ptr(x.device)))
+    return out
+
+
 # --------------------------------------------------------------------------- IMU
 def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
     """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,

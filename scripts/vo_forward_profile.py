@@ -8,7 +8,7 @@ from islam_amd.TartanVO import TartanVO
 dev = torch.device('cuda:0')
 B = 8
 torch.manual_seed(0)
-vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, frozen_dtype=torch.bfloat16)
+vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16)
 with torch.no_grad():
     vo.vonet.stereoNet.conv_c13.weight.zero_(); vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
 s = synthetic.stereo_batch(B, seed=100)

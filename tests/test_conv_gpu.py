@@ -1,0 +1,60 @@
+"""3x3 convolution on the matrix cores (islam_conv3x3_mfma) vs torch: the kernel rounds its operands to bf16 and accumulates
+in fp32, so the reference is F.conv2d in fp32 on bf16-rounded inputs and weights (only the summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Cin, H, W, Cout, stride, dilation
+    (2, 6, 64, 96, 16, 2, 1),          # conv1a: first pyramid layer
+    (2, 16, 32, 48, 16, 1, 1),
+    (1, 117, 28, 40, 128, 1, 1),       # conv2_0-like: odd channel count
+    (2, 245, 14, 20, 128, 1, 1),
+    (1, 533, 7, 10, 32, 1, 1),
+    (1, 565, 28, 40, 2, 1, 1),         # predict_flow: 2 output channels, no activation
+    (1, 128, 28, 40, 128, 1, 2),       # context network: dilated
+    (1, 128, 28, 40, 96, 1, 8),
+    (1, 96, 37, 53, 196, 2, 1),        # ragged sizes, stride 2
+    (3, 32, 9, 70, 64, 1, 4),
+]
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,S,D', CASES)
+def test_conv3x3_mfma_matches_torch(cuda, B, Cin, H, W, Cout, S, D):
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    slope = 1.0 if Cout == 2 else 0.1
+    y = ops.conv3x3_mfma(x, ops.pack_conv3x3_weight(w), b, Cout, stride=S, dilation=D, slope=slope)
+    xr, wr = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    ref = F.conv2d(xr.double(), wr.double(), b.double(), stride=S, padding=D, dilation=D)
+    ref = torch.where(ref >= 0, ref, ref * slope).float()
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-5 * float(ref.abs().max()))
+    # against the unrounded fp32 convolution: bf16 operand rounding only (~2^-9 relative per product)
+    full = F.conv2d(x, w, b, stride=S, padding=D, dilation=D)
+    full = torch.where(full >= 0, full, full * slope)
+    assert float((y - full).abs().max()) < 2e-2 * float(full.abs().max())
+
+
+def test_conv3x3_mfma_writes_into_a_channel_slice(cuda):
+    """`coff`: the DenseNet-style concatenation of PWCNet.py:237-292 without torch.cat."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 48, 20, 36, generator=g).to(cuda)
+    w = (torch.randn(40, 48, 3, 3, generator=g) * 0.05).to(cuda)
+    buf = torch.full((2, 100, 20, 36), 7.0, device=cuda)
+    ops.conv3x3_mfma(x, ops.pack_conv3x3_weight(w), None, 40, out=buf, coff=25)
+    ref = F.leaky_relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), padding=1), 0.1)
+    torch.testing.assert_close(buf[:, 25:65], ref, rtol=1e-4, atol=1e-4)
+    assert bool((buf[:, :25] == 7.0).all()) and bool((buf[:, 65:] == 7.0).all())
+    # input slice: the suffix [60, 100) of the buffer (here: 5 conv channels + 35 untouched ones) as a 40-channel input
+    w2 = (torch.randn(8, 40, 3, 3, generator=g) * 0.05).to(cuda)
+    src = buf.clone()
+    ops.conv3x3_mfma(src, ops.pack_conv3x3_weight(w2), None, 8, out=buf, coff=52, xoff=60)
+    ref2 = F.leaky_relu(F.conv2d(src[:, 60:].to(torch.bfloat16).float(), w2.to(torch.bfloat16).float(), padding=1), 0.1)
+    torch.testing.assert_close(buf[:, 52:60], ref2, rtol=1e-4, atol=1e-3)

@@ -174,3 +174,25 @@ def test_frozen_stereo_net_bf16_execution_copy(cuda):
     sd = {k: (v * 0.5 if k.endswith('conv_c13.weight') else v) for k, v in net.stereoNet.state_dict().items()}
     net.stereoNet.load_state_dict(sd)
     assert net._exec['stereo'].module() is not copy_a                    # re-cast after the master changed
+
+
+def test_flow_net_on_the_matrix_core_convolution(cuda):
+    """PWCDCNet.forward_mfma (HIP implicit-GEMM convolutions, slice-written DenseNet blocks, batched pyramid) against the
+    plain fp32 forward of the same weights: all five flow outputs agree to bf16-operand accuracy."""
+    from islam_amd import nets
+    torch.manual_seed(0)
+    net = nets.PWCDCNet().to(cuda).eval()
+    x = torch.rand(2, 6, 192, 256, device=cuda)
+    with torch.no_grad():
+        ref, _ = net(x)
+        got, _ = net.forward_mfma(x)
+    for r, g in zip(ref, got):
+        assert r.shape == g.shape
+        assert float((r - g).abs().max()) < 3e-2 * float(r.abs().max()) + 1e-3
+    # the weights are re-packed when the fp32 master changes
+    with torch.no_grad():
+        net.conv2_0[0].weight.mul_(0.5)
+        ref2, _ = net(x)
+        got2, _ = net.forward_mfma(x)
+    assert float((ref2[0] - got2[0]).abs().max()) < 3e-2 * float(ref2[0].abs().max()) + 1e-3
+    assert float((ref2[0] - ref[0]).abs().max()) > 1e-3 * float(ref[0].abs().max())
