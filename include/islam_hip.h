@@ -77,6 +77,12 @@ size_t islam_conv3x3_packed_elems(int Cin, int Cout);
 int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bias, float* y, int B, int Cin, int H, int W,
                        int Cout, int stride, int dilation, int xoff, int xtot, int coff, int ytot, float slope, void* stream);
 
+/* Bilinear resize of a channels-last (NHWC) bf16 tensor: the F.upsample / F.interpolate calls of the frozen stereo network
+ * (Network/PSM/submodule.py:124-155 SPP branches, Network/StereoNet7.py:100-146), ATen's upsample_bilinear2d arithmetic.
+ * x (B,Hi,Wi,C), y (B,Ho,Wo,C) bf16 bits, C a multiple of 8; align_corners as in torch. */
+int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                    int align_corners, void* stream);
+
 /* ---------------------------------------------------------------- stereo scale recovery */
 
 /* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176

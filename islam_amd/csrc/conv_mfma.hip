@@ -214,3 +214,72 @@ int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bia
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Bilinear resize of a channels-last bf16 tensor (the SPP branches and decoder up/down-samplings of the frozen stereo
+// network, Network/PSM/submodule.py:124-155 / StereoNet7.py:100-146 F.upsample / F.interpolate).  One thread per output
+// pixel and group of 8 channels (16 bytes): the four taps are 16-byte reads of a source that lives in L2, the store is
+// lane-contiguous.  Arithmetic as ATen's upsample_bilinear2d (fp32 interpolation weights and accumulation).
+namespace {
+
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8,
+                                                                        int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                                        int align, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % C8);
+    long long p = i / C8;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float fy, fx;
+    if (align) {
+        fy = sh * oy;
+        fx = sw * ox;
+    } else {
+        fy = fmaxf(sh * (oy + 0.5f) - 0.5f, 0.0f);
+        fx = fmaxf(sw * (ox + 0.5f) - 0.5f, 0.0f);
+    }
+    const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const uint4* base = x + (size_t)b * Hi * Wi * C8 + cg;
+    const uint4 a = base[((size_t)y0 * Wi + x0) * C8], bq = base[((size_t)y0 * Wi + x1) * C8];
+    const uint4 c = base[((size_t)y1 * Wi + x0) * C8], d = base[((size_t)y1 * Wi + x1) * C8];
+    auto mix = [&](unsigned va, unsigned vb, unsigned vc, unsigned vd) {
+        const float lo = hy * (hx * bf16_lo(va) + lx * bf16_lo(vb)) + ly * (hx * bf16_lo(vc) + lx * bf16_lo(vd));
+        const float hi = hy * (hx * bf16_hi(va) + lx * bf16_hi(vb)) + ly * (hx * bf16_hi(vc) + lx * bf16_hi(vd));
+        return pack_bf16(lo, hi);
+    };
+    uint4 o;
+    o.x = mix(a.x, bq.x, c.x, d.x);
+    o.y = mix(a.y, bq.y, c.y, d.y);
+    o.z = mix(a.z, bq.z, c.z, d.z);
+    o.w = mix(a.w, bq.w, c.w, d.w);
+    y[i] = o;
+}
+
+}  // namespace
+
+extern "C" int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                               int align_corners, void* stream) {
+    if (B < 1 || C < 8 || (C & 7) || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1)
+        return fail(ISLAM_EARG, "islam_resize_bilinear_nhwc_bf16: bad shape (C=%d must be a multiple of 8)", C);
+    float sh, sw;
+    if (align_corners) {
+        sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+        sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    } else {
+        sh = (float)Hi / (float)Ho;
+        sw = (float)Wi / (float)Wo;
+    }
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(resize_bilinear_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, Hi, Wi, Ho, Wo, sh, sw, align_corners, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}

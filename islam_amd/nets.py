@@ -242,11 +242,11 @@ class feature_extraction(nn.Module):
         skip = self.layer4(self.layer3(raw))
         hw = [skip.shape[2], skip.shape[3]]
         pools = _spp_pools(skip)
-        br = [F.interpolate(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, mode='bilinear', align_corners=True)
+        br = [ops.resize_bilinear(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, align_corners=True)
               for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))]
         feat = torch.cat([raw, skip] + br, 1)
         if self.bigger:
-            feat = torch.cat((F.interpolate(feat, [hw[0] * 2, hw[1] * 2], mode='bilinear', align_corners=True), o0), 1)
+            feat = torch.cat((ops.resize_bilinear(feat, [hw[0] * 2, hw[1] * 2], align_corners=True), o0), 1)
         return self.lastconv(feat)
 
 
@@ -302,7 +302,7 @@ class SSP(nn.Module):
     def forward(self, x):
         hw = [x.shape[2], x.shape[3]]
         pools = _spp_pools(x)
-        return torch.cat([x] + [F.interpolate(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, mode='bilinear')
+        return torch.cat([x] + [ops.resize_bilinear(getattr(self, 'branch%d' % i)[1:](pools[k]), hw)
                                 for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))], 1)
 
 

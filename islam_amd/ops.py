@@ -148,6 +148,20 @@ def conv3x3_mfma(x, packed, bias, cout, stride=1, dilation=1, slope=0.1, out=Non
     return out
 
 
+def resize_bilinear(x, size, align_corners=False):
+    """F.interpolate(x, size, mode='bilinear', align_corners=...) -- on the HIP kernel for channels-last bf16 inference
+    tensors (the frozen stereo net's execution copy), through torch otherwise."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and not x.requires_grad
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        B, C, Hi, Wi = x.shape
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        check(lib().islam_resize_bilinear_nhwc_bf16(ptr(x), ptr(y), B, C, Hi, Wi, Ho, Wo, int(bool(align_corners)),
+                                                    stream_ptr(x.device)))
+        return y
+    return torch.nn.functional.interpolate(x, [Ho, Wo], mode='bilinear', align_corners=align_corners)
+
+
 # --------------------------------------------------------------------------- IMU
 def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
     """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,

@@ -58,3 +58,20 @@ def test_conv3x3_mfma_writes_into_a_channel_slice(cuda):
     ops.conv3x3_mfma(src, ops.pack_conv3x3_weight(w2), None, 8, out=buf, coff=52, xoff=60)
     ref2 = F.leaky_relu(F.conv2d(src[:, 60:].to(torch.bfloat16).float(), w2.to(torch.bfloat16).float(), padding=1), 0.1)
     torch.testing.assert_close(buf[:, 52:60], ref2, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('Hi,Wi,Ho,Wo,align', [(1, 2, 112, 160, True), (3, 5, 112, 160, True), (14, 20, 112, 160, True),
+                                               (56, 80, 112, 160, True), (3, 5, 28, 40, False), (7, 10, 56, 80, False),
+                                               (64, 96, 32, 48, False)])
+def test_resize_bilinear_nhwc_bf16_matches_torch(cuda, Hi, Wi, Ho, Wo, align):
+    """The SPP / decoder resizes of the frozen stereo net: ATen's upsample_bilinear2d arithmetic on channels-last bf16."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(Hi * 7 + Wo)
+    x = torch.randn(3, 32, Hi, Wi, generator=g).to(cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = ops.resize_bilinear(x, (Ho, Wo), align)
+    ref = F.interpolate(x.float(), [Ho, Wo], mode='bilinear', align_corners=align)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y.float(), ref, rtol=8e-3, atol=8e-3)           # one bf16 rounding of the result
+    # other dtypes / layouts fall through to torch
+    z = ops.resize_bilinear(x.float(), (Ho, Wo), align)
+    torch.testing.assert_close(z, ref)
