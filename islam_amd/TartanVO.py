@@ -25,11 +25,12 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th):
     ds = (dMw - s dMM)/MM is a linear functional of (a, R) whose coefficients are sums over the masked pixels
     (islam_amd/csrc/scale_ls.hip); it is re-attached through the same LieTensor ops the reference differentiates
     (T.Inv().rotation() acting on points, T.Inv().translation(), dense_ba.py:142-166)."""
-    s, z, mask, dmask, sums = ops.scale_ls(disp, flow, pose_enu.tensor(), intr4, baseline, edge, disp_th)
+    s, z, mask, dmask, sums = ops.scale_ls(disp, flow, pose_enu.tensor().detach().to(disp.device), intr4, baseline, edge, disp_th)
     if not pose_enu.requires_grad:
         return s, z, mask, dmask
-    dev, dt = s.device, pose_enu.dtype
-    sums = sums.to(dt)
+    dev, dt = pose_enu.device, pose_enu.dtype          # the (B,6)-sized gradient glue runs where the pose lives (host or device)
+    sums = sums.to(dev, dt)
+    s = s.to(dev)
     intr4 = intr4.to(dev, dt)
     fx, fy, cx, cy = intr4.unbind(-1)
     MM = sums[:, 0]
@@ -52,7 +53,8 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th):
 
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
-                 device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None):
+                 device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
+                 host_glue=False):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -62,6 +64,10 @@ class TartanVO(nn.Module):
         self.pose_std = torch.tensor([0.13, 0.13, 0.13, 0.013, 0.013, 0.013]).cuda(self.device_id)
         self.vonet = VONet(fix_parts=fix_parts)
         self.vonet.set_frozen_dtype(frozen_dtype, flow_dtype)
+        # host_glue: the (B,6)->(B,7) pose algebra after the networks (unit rescale, frame changes, scale re-attachment:
+        # ~150 tiny tensor ops and as many autograd nodes) runs in float64 on the host instead of one device launch per op;
+        # res['motion'] is still returned on the device, res['motion_host'] is the same LieTensor on the host
+        self.host_glue = host_glue
         for name, part in ((vo_model_name, self.vonet), (flow_model_name, self.vonet.flowNet),
                            (pose_model_name, self.vonet.flowPoseNet), (stereo_model_name, self.vonet.stereoNet)):
             if name is not None and name != '':
@@ -100,11 +106,14 @@ class TartanVO(nn.Module):
             precalc_flow = sample['flow'] if 'flow' in sample else None
 
             flow, disp, pose = self.vonet(img0, img1, img0_norm, img0_r_norm, intrinsic)
-            pose = pose * self.pose_std
+            if self.host_glue:
+                pose = pose.double().cpu() * self.pose_std.double().cpu()
+            else:
+                pose = pose * self.pose_std
             flow, disp = flow.detach(), disp.detach()
             res = {}
             if given_scale is not None:
-                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * given_scale.view(-1, 1)
+                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * given_scale.to(pose.device, pose.dtype).view(-1, 1)
                 pose = torch.cat([trans, pose[:, 3:]], dim=1)
             elif not self.correct_scale:
                 flow = flow * 5 if precalc_flow is None else precalc_flow.cuda(dev)     # pixels at 1/4 res
@@ -116,11 +125,15 @@ class TartanVO(nn.Module):
                 scale, depth, mask, depth_mask = stereo_scale(disp, flow, pose_enu, intr4, baseline.float(), edge, th)
                 res.update(flow=flow, disp=disp, mask=mask, depth=depth, depth_mask=depth_mask, baseline=baseline[0],
                            intrinsic=intrinsic_calib[0] / 4)
-                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * scale.view(-1, 1)
+                trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * scale.to(pose.device, pose.dtype).view(-1, 1)
                 pose = torch.cat([trans, pose[:, 3:]], dim=1)
             else:
-                scale = torch.norm(sample['motion'][:, :3], dim=1).cuda(dev)
+                scale = torch.norm(sample['motion'][:, :3], dim=1).to(pose.device, pose.dtype)
                 trans = torch.nn.functional.normalize(pose[:, :3], dim=1) * scale.view(-1, 1)
                 pose = torch.cat([trans, pose[:, 3:]], dim=1)
-            res['motion'] = tartan2kitti_pypose(pose) if self.use_kitti_coord else cvtSE3_pypose(pose)
+            motion = tartan2kitti_pypose(pose) if self.use_kitti_coord else cvtSE3_pypose(pose)
+            if self.host_glue:
+                res['motion_host'] = motion
+                motion = pp.SE3(motion.tensor().float().cuda(dev))
+            res['motion'] = motion
             return res

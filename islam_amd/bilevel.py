@@ -41,8 +41,8 @@ class BilevelLoop:
         sync = torch.cuda.synchronize
         t0 = time.perf_counter()
         res = self.vo(sample)
-        motions = res['motion']
-        T_IL = self.T_IL.to(motions.device)
+        motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
+        T_IL = self.T_IL.to(motions.device).to(motions.dtype)
         motions = T_IL @ motions @ T_IL.Inv()                                                   # train.py:214-215
         sync(); t1 = time.perf_counter()
         # VO-only dead reckoning is book-keeping (train.py:219-228 keeps it for the plots): no gradient flows through it,

@@ -233,3 +233,27 @@ def test_dense_assembly_matches_dense_jacobian_product(cuda):
     JD = J10 @ D10
     R = np.concatenate([r.reshape(-1) for r in res])
     assert q == pytest.approx(float(JD @ (2 * R + JD)), rel=1e-10)
+
+
+def test_host_glue_matches_device_glue(cuda):
+    """TartanVO(host_glue=True): the post-network pose algebra in float64 on the host gives the same motions and the same
+    gradients to the pose head as the per-op device path."""
+    from islam_amd.TartanVO import TartanVO
+    outs = []
+    sample = synthetic.stereo_batch(2, seed=3)
+    for host in (False, True):
+        torch.manual_seed(0)
+        vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, host_glue=host)
+        with torch.no_grad():
+            vo.vonet.stereoNet.conv_c13.weight.zero_()
+            vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+        res = vo(sample)
+        m = res['motion']
+        assert m.tensor().is_cuda and m.tensor().dtype == torch.float32
+        w = torch.linspace(0.5, 1.5, 7, device=m.tensor().device)
+        (res.get('motion_host', m).tensor().to(m.tensor().device).float() * w).sum().backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in vo.vonet.flowPoseNet.parameters() if p.grad is not None])
+        outs.append((m.tensor().detach().clone(), grads.clone(), 'motion_host' in res))
+    assert outs[1][2] and not outs[0][2]
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=2e-3, atol=1e-6 + 1e-3 * float(outs[0][1].abs().max()))
