@@ -68,53 +68,62 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
     float pre0[NPRE], pre1[NPRE];                            // fully unrolled below: stays in registers
     uint4 prew[(9 * TN * 2 + THREADS - 1) / THREADS];
     constexpr int NW = (9 * TN * 2 + THREADS - 1) / THREADS;
+    // the (pixel, channel pair) items a thread stages are the same for every chunk: decode them once
+    int goff[NPRE];                                          // offset inside the chunk's first channel plane, -1 = zero
+    int loff[NPRE];                                          // LDS element offset, -1 = no item
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int it = tid + k * THREADS;
+        goff[k] = -1;
+        loff[k] = -1;
+        if (it < nitems) {
+            const int cp = it / npix, pix = it - cp * npix;
+            const int yy = pix / IW, xx = pix - yy * IW;
+            const int gy = gy0 + yy, gx = gx0 + xx;
+            loff[k] = pix * PS + 2 * cp;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (2 * cp * H + gy) * W + gx;
+        }
+    }
+    int woff[NW], wlds[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int it = tid + k * THREADS;                    // 16-byte vector index: ((tap*TN + n)*2 + half)
+        woff[k] = -1;
+        wlds[k] = 0;
+        if (it < 9 * TN * 2) {
+            const int half = it & 1, row = it >> 1, tap = row / TN, n = row - tap * TN;
+            woff[k] = (tap * CoutP + n0 + n) * CinP + 8 * half;
+            wlds[k] = row * PS + 8 * half;
+        }
+    }
 
     auto fetch = [&](int c0) {
+        const float* xc = xb + (size_t)c0 * plane;
+        const int rem = Cin - c0;                            // channels left: pair cp is valid if 2cp < rem (second: 2cp+1 < rem)
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
-            const int it = tid + k * THREADS;
             float v0 = 0.0f, v1 = 0.0f;
-            if (it < nitems) {
-                const int cp = it / npix, pix = it - cp * npix;
-                const int yy = pix / IW, xx = pix - yy * IW;
-                const int gy = gy0 + yy, gx = gx0 + xx, c = c0 + 2 * cp;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    const float* p = xb + ((size_t)c * H + gy) * W + gx;
-                    if (c < Cin) v0 = p[0];
-                    if (c + 1 < Cin) v1 = p[(size_t)H * W];
-                }
+            if (goff[k] >= 0) {
+                const int c = 2 * ((tid + k * THREADS) / npix);
+                const float* p = xc + goff[k];
+                if (c < rem) v0 = p[0];
+                if (c + 1 < rem) v1 = p[plane];
             }
             pre0[k] = v0;
             pre1[k] = v1;
         }
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int it = tid + k * THREADS;                // 16-byte vector index: ((tap*TN + n)*2 + half)
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (it < 9 * TN * 2) {
-                const int half = it & 1, row = it >> 1, tap = row / TN, n = row - tap * TN;
-                v = *reinterpret_cast<const uint4*>(wp + ((size_t)tap * CoutP + n0 + n) * CinP + c0 + 8 * half);
-            }
-            prew[k] = v;
-        }
+        for (int k = 0; k < NW; ++k)
+            prew[k] = woff[k] >= 0 ? *reinterpret_cast<const uint4*>(wp + (size_t)woff[k] + c0) : make_uint4(0, 0, 0, 0);
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int it = tid + k * THREADS;
-            if (it < nitems) {
-                const int cp = it / npix, pix = it - cp * npix;
-                *reinterpret_cast<unsigned*>(lin + (size_t)pix * PS + 2 * cp) = pack_bf16(pre0[k], pre1[k]);
-            }
-        }
+        for (int k = 0; k < NPRE; ++k)
+            if (loff[k] >= 0) *reinterpret_cast<unsigned*>(lin + loff[k]) = pack_bf16(pre0[k], pre1[k]);
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int it = tid + k * THREADS;
-            if (it < 9 * TN * 2) {
-                const int half = it & 1, row = it >> 1;
-                *reinterpret_cast<uint4*>(lw + (size_t)row * PS + 8 * half) = prew[k];
-            }
-        }
+        for (int k = 0; k < NW; ++k)
+            if (woff[k] >= 0) *reinterpret_cast<uint4*>(lw + wlds[k]) = prew[k];
     };
 
     const int kg = lane >> 5, li = lane & 31;

@@ -116,12 +116,12 @@ class PWCDCNet(nn.Module):
         return hit[1], hit[2], hit[3]
 
     def _c(self, name, x, out=None, coff=0, xoff=0):
-        """One `conv()` block (PWCNet.py:20-25).  Stride-1 layers with dilation <= 2 and >= 16 input channels run on the HIP
-        kernel (2-2.8x MIOpen's fp32 Winograd there); the stride-2 pyramid heads and the widely dilated context layers, where
-        the halo tile outweighs the outputs, stay on MIOpen."""
+        """One `conv()` block (PWCNet.py:20-25).  Stride-1 layers with dilation <= 8 and >= 16 input channels run on the HIP
+        kernel (1.3-4.5x MIOpen's fp32 Winograd there, scripts/conv_bench.py); the stride-2 pyramid heads and the dilation-16
+        context layer (its halo tile does not fit the prefetch registers) stay on MIOpen."""
         packed, bias, conv = self._packed(name)
         act = isinstance(getattr(self, name), nn.Sequential)
-        if conv.stride[0] == 1 and conv.dilation[0] <= 2 and conv.in_channels >= 16:
+        if conv.stride[0] == 1 and conv.dilation[0] <= 8 and conv.in_channels >= 16:
             return ops.conv3x3_mfma(x, packed, bias, conv.out_channels, 1, conv.dilation[0], 0.1 if act else 1.0, out, coff, xoff)
         xin = x if xoff == 0 else x[:, xoff:]
         y = conv(xin)

@@ -16,7 +16,8 @@ def timeit(fn, reps=20, warm=5):
 shapes = [(6, 448, 640, 16, 2, 1), (16, 224, 320, 16, 1, 1), (16, 224, 320, 32, 2, 1), (32, 112, 160, 32, 1, 1),
           (117, 112, 160, 128, 1, 1), (245, 112, 160, 128, 1, 1), (373, 112, 160, 96, 1, 1), (469, 112, 160, 64, 1, 1),
           (533, 112, 160, 32, 1, 1), (565, 112, 160, 128, 1, 1), (128, 112, 160, 128, 1, 2), (128, 112, 160, 128, 1, 4),
-          (128, 112, 160, 96, 1, 8), (181, 56, 80, 128, 1, 1), (565, 56, 80, 128, 1, 1)]
+          (128, 112, 160, 96, 1, 8), (181, 56, 80, 128, 1, 1), (565, 56, 80, 128, 1, 1), (32, 112, 160, 64, 2, 1),
+          (64, 56, 80, 96, 2, 1), (96, 28, 40, 128, 2, 1), (64, 56, 80, 64, 1, 1), (96, 28, 40, 96, 1, 1), (529, 7, 10, 32, 1, 1)]
 tot_h = tot_m = 0
 for Cin, H, W, Cout, S, D in shapes:
     x = torch.randn(B, Cin, H, W, device=dev)
