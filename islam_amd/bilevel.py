@@ -35,12 +35,16 @@ class BilevelLoop:
         self.current_idx = 0
         self.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
 
-    def step(self, sample, target='vo'):
-        """One pass of train.py:200-299 over one batch of ``batch_size`` frames."""
+    def step(self, sample, target='vo', next_sample=None):
+        """One pass of train.py:200-299 over one batch of ``batch_size`` frames.  ``next_sample``: the following batch;
+        its frozen flow / disparity forward is started on a side stream as soon as this batch's pose head is enqueued
+        (TartanVO.prefetch) and overlaps with this batch's IMU / PVGO / backward."""
         bs, dev = self.bs, self.device
-        sync = torch.cuda.synchronize
+        sync = (lambda: torch.cuda.current_stream().synchronize()) if next_sample is not None else torch.cuda.synchronize
         t0 = time.perf_counter()
         res = self.vo(sample)
+        if next_sample is not None and hasattr(self.vo, 'prefetch'):
+            self.vo.prefetch(next_sample)
         motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
         T_IL = self.T_IL.to(motions.device).to(motions.dtype)
         motions = T_IL @ motions @ T_IL.Inv()                                                   # train.py:214-215

@@ -436,11 +436,16 @@ class VONet(nn.Module):
             ex = self._exec[name] = _HalfExec(master, dtype)
         return ex.module()(x.to(dtype).contiguous(memory_format=torch.channels_last))
 
-    def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic):
+    def frozen_forward(self, img0, img1, img0_norm, img0_r_norm):
+        """Flow + disparity (Network/VONet.py:28-34).  With both nets frozen this part carries no autograd state, so
+        TartanVO.prefetch can run it for the NEXT batch on a side stream while the current batch is optimised."""
         flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0]
         disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1))[0]
         flow, disp = flow.float().contiguous(), disp.float().contiguous()
-        disp = F.interpolate(disp, scale_factor=0.25, mode='nearest')
+        return flow, F.interpolate(disp, scale_factor=0.25, mode='nearest')
+
+    def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic, frozen=None):
+        flow, disp = frozen if frozen is not None else self.frozen_forward(img0, img1, img0_norm, img0_r_norm)
         pose = self.flowPoseNet(torch.cat([flow, intrinsic], 1))
         return flow, disp, pose
 

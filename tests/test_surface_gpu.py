@@ -257,3 +257,30 @@ def test_host_glue_matches_device_glue(cuda):
     assert outs[1][2] and not outs[0][2]
     torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=2e-3, atol=1e-6 + 1e-3 * float(outs[0][1].abs().max()))
+
+
+def test_prefetched_frozen_forward_is_identical(cuda):
+    """TartanVO.prefetch (frozen nets of the next batch on a side stream) changes the schedule, not the result."""
+    from islam_amd.TartanVO import TartanVO
+    torch.manual_seed(0)
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True)
+    with torch.no_grad():
+        vo.vonet.stereoNet.conv_c13.weight.zero_()
+        vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+    vo.vonet.stereoNet.eval()                       # keep BatchNorm statistics fixed so both passes see the same network
+    a, b = synthetic.stereo_batch(2, seed=3), synthetic.stereo_batch(2, seed=4)
+    ref = [vo(s, is_train=False)['motion'].tensor().clone() for s in (a, b)]
+    assert vo.prefetch(a, is_train=False)
+    got_a = vo(a, is_train=False)['motion'].tensor().clone()
+    assert vo.prefetch(b, is_train=False)
+    _ = torch.randn(512, 512, device=cuda) @ torch.randn(512, 512, device=cuda)      # unrelated work on the main stream
+    got_b = vo(b, is_train=False)['motion'].tensor().clone()
+    tol = dict(rtol=1e-5, atol=1e-6)                # MIOpen's split-K convolutions are not bit-reproducible run to run
+    torch.testing.assert_close(got_a, ref[0], **tol)
+    torch.testing.assert_close(got_b, ref[1], **tol)
+    assert float((ref[0] - ref[1]).abs().max()) > 1e-4                                # the two batches do differ
+    # a sample that was not prefetched is computed inline; a trainable flow net refuses to prefetch
+    torch.testing.assert_close(vo(a, is_train=False)['motion'].tensor(), ref[0], **tol)
+    for p in vo.vonet.flowNet.parameters():
+        p.requires_grad_(True)
+    assert vo.prefetch(a) is False
