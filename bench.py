@@ -285,7 +285,7 @@ def main():
         out = {
             'metric': 'pvgo_lm_iters_per_sec', 'value': value, 'unit': 'LM iters/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[3]: synthetic %d-frame KITTI-shape chain graph (N=%d nodes, E=%d links), '
                                    'full run_pvgo LM loop per step' % (N - 1, N, N - 1),
                        'loss_weight': list(LOSS_WEIGHT), 'radius': 1e4, 'parallelism': 'graph sharded over %d GPU(s)' % world},
