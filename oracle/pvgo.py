@@ -251,9 +251,10 @@ class LM:
     """pp.optim.LM with Cholesky solver + TrustRegion strategy, as constructed at pvgo.py:169-171."""
 
     def __init__(self, nodes, vels, radius=1e4, vmin=1e-4, vmax=1e32, reject=16, mode='dense',
-                 true_translation_jacobian=False, reproj=None, compat_first_motion=True):
+                 true_translation_jacobian=False, reproj=None, compat_first_motion=True, info_scalars=None):
         self.nodes, self.vels = nodes.copy(), vels.copy()
         self.reproj, self.compat_first = reproj, compat_first_motion
+        self.info_scalars = info_scalars      # tests only: the four information scalars directly (may be indefinite)
         self.strategy = TrustRegion(radius=radius)
         self.min, self.max, self.reject = vmin, vmax, reject
         self.reject_count = 0
@@ -282,7 +283,8 @@ class LM:
         if self.mode == 'dense':
             lin = _DenseLin(self.nodes, inp, res, A_e, B_k, weight_vector(E, M, loss_weight, dt, n_rp), self.ttj, J_rp)
         else:
-            lin = _BandedLin(self.nodes, inp, res, A_e, B_k, [x ** 2 for x in loss_weight[:4]], self.ttj, J_rp,
+            w4 = [x ** 2 for x in loss_weight[:4]] if self.info_scalars is None else list(self.info_scalars)
+            lin = _BandedLin(self.nodes, inp, res, A_e, B_k, w4, self.ttj, J_rp,
                              (loss_weight[4] / n_rp) ** 2 if n_rp else 0.0)
         if self.loss is None:
             self.loss = loss_unweighted(res)
@@ -371,14 +373,15 @@ def align_to(nodes, vels, target, idx=0):
 def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtrans, imu_dvels,
              radius=1e4, loss_weight=(1, 1, 1, 1), target='vo', mode='dense', dtype=np.float64,
              true_translation_jacobian=False, max_steps=10, return_optimizer=False, reproj=None,
-             compat_first_motion=True):
+             compat_first_motion=True, info_scalars=None):
     """pvgo.py:122-205 on numpy arrays.  Returns (trans_loss, rot_loss, nodes, vels, covs[, optimizer])."""
     c = lambda a: np.ascontiguousarray(np.asarray(a), dtype=dtype)
     init_nodes, init_vels, vo_motions = c(init_nodes), c(init_vels), c(vo_motions)
     dts, imu_drots, imu_dtrans, imu_dvels = c(dts), c(imu_drots), c(imu_dtrans), c(imu_dvels)
     links = np.asarray(links, dtype=np.int64)
     opt = LM(init_nodes, init_vels, radius=radius, vmin=1e-4, mode=mode,
-             true_translation_jacobian=true_translation_jacobian, reproj=reproj, compat_first_motion=compat_first_motion)
+             true_translation_jacobian=true_translation_jacobian, reproj=reproj, compat_first_motion=compat_first_motion,
+             info_scalars=info_scalars)
     sched = StopOnPlateau(opt, steps=max_steps, patience=3, decreasing=1e-3)
     inp = (links, vo_motions, imu_drots, imu_dtrans, imu_dvels, dts)
     while sched.continual():

@@ -180,3 +180,75 @@ def test_vo_loss_and_align(cuda):
     on, ov = opvgo.align_to(prob['init_nodes'], prob['init_vels'], tgt)
     np.testing.assert_allclose(an.cpu().numpy(), on, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(av.cpu().numpy(), ov, rtol=1e-10, atol=1e-12)
+
+
+def _noisy_problem(F, seed, sig):
+    """Dead-reckoning init perturbed hard enough that LM has to reject trials (the run-ahead / epoch-gate paths)."""
+    prob, _ = chain_problem(F)
+    rng = np.random.default_rng(seed)
+    n = prob['init_nodes'].copy()
+    n[:, :3] += rng.normal(0, sig, (F, 3))
+    n = lie.se3_mul(lie.se3_exp(np.concatenate([np.zeros((F, 3)), rng.normal(0, sig * 0.2, (F, 3))], 1)), n)
+    return dict(prob, init_nodes=n)
+
+
+@pytest.mark.parametrize('F,seed,sig,pattern', [(33, 1, 1.5, '00000011110'), (65, 8, 1.5, '0000000010'),
+                                               (65, 2, 1.0, None)])
+def test_lm_with_rejected_trials_matches_oracle(cuda, F, seed, sig, pattern):
+    """Rejected trials (more damping on the same linearisation, the pre-enqueued run-ahead iteration cancelled by the
+    epoch gate) and the reject limit (16 rejects, then the step is kept and the scheduler stops): same accept / reject
+    sequence, losses, dampings and final iterate as the oracle."""
+    from islam_amd import ops
+    prob = _noisy_problem(F, seed, sig)
+    out = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True)
+    opt = out[5]
+    rej = ''.join(str(int(not t[2])) for t in opt.trace)
+    if pattern is not None:
+        assert rej == pattern, 'the oracle problem changed: %s' % rej
+    else:
+        assert rej.count('1') >= 16                    # reject limit reached
+    nodes, vels, poses, drots, dtrans, dvels, dts = _dev(prob, cuda)
+    prm = ops.pvgo_default_params(LW, radius=1e4)
+    res, trace = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, prm, trace_cap=256)
+    ot = np.array([(l, d, float(a)) for l, d, a in opt.trace])
+    assert res.trials == len(ot)
+    np.testing.assert_array_equal(trace[:, 2], ot[:, 2])
+    np.testing.assert_allclose(trace[:, 0], ot[:, 0], rtol=1e-7)
+    np.testing.assert_allclose(trace[:, 1], ot[:, 1], rtol=1e-12)
+    assert res.loss == pytest.approx(opt.loss, rel=1e-7)
+    err = se3_log_err(nodes.cpu().numpy(), opt.nodes)
+    ref = np.maximum(np.linalg.norm(lie.se3_log(opt.nodes), axis=-1), 1e-6)
+    assert (err / ref).max() < 1e-6
+    np.testing.assert_allclose(vels.cpu().numpy(), opt.vels, rtol=1e-6, atol=1e-7)
+    # a second run on the same workspace (stale ready words, cancelled kernels still draining) gives the same answer
+    n2, v2 = _dev(prob, cuda)[:2]
+    res2, _ = ops.pvgo_run_chain(n2, v2, poses, drots, dtrans, dvels, dts, prm)
+    assert res2.trials == res.trials and res2.steps == res.steps
+    torch.testing.assert_close(n2, nodes, rtol=0, atol=0)
+
+
+def test_lm_solver_failure_breaks_the_step_like_pypose(cuda):
+    """An indefinite normal matrix (a negative information scalar) makes the Cholesky factorisation fail: PyPose prints
+    "Linear solver failed. Breaking optimization step..." and keeps looping through the scheduler until the plateau counter
+    stops it (3 steps, one failed solve each); the iterate must not move."""
+    from islam_amd import ops
+    prob, _ = chain_problem(33)
+    info = (1.0, -0.5, 100.0, 0.01)
+    out = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True, info_scalars=info)
+    opt = out[5]
+    assert len(opt.trace) == 0 and np.array_equal(opt.nodes, prob['init_nodes'])      # every solve failed, nothing moved
+    nodes, vels, poses, drots, dtrans, dvels, dts = _dev(prob, cuda)
+    n0 = nodes.clone()
+    prm = ops.pvgo_default_params(LW, radius=1e4)
+    for i in range(4):
+        prm.w[i] = info[i]
+    res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, prm)
+    assert res.status == -3                                     # ISLAM_ENOTPD
+    assert res.steps == 3 and res.trials == 3                   # StopOnPlateau(patience=3): no decrease three times
+    assert res.loss == pytest.approx(opt.loss, rel=1e-9)
+    torch.testing.assert_close(nodes, n0, rtol=0, atol=0)
+    # the workspace is reusable afterwards
+    prm2 = ops.pvgo_default_params(LW, radius=1e4)
+    res2, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, prm2)
+    ref = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True)[5]
+    assert res2.status == 0 and res2.trials == len(ref.trace)
