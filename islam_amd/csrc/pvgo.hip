@@ -2156,10 +2156,13 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     if (rc != ISLAM_OK) return rc;
     for (;;) {
         const double seq = (double)(trials + 1);
-        // run ahead: the next iteration under the assumption "trial accepted, loop continues"
+        // run ahead: the next iteration under the assumption "trial accepted, loop continues" -- unless an accepted trial
+        // would be the last optimizer step anyway (StopOnPlateau's step limit): nothing can follow it
         const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
-        rc = enqueue_iter(B, seq + 1.0, epoch);
-        if (rc != ISLAM_OK) return rc;
+        if (steps + 1 < prm->max_steps) {
+            rc = enqueue_iter(B, seq + 1.0, epoch);
+            if (rc != ISLAM_OK) return rc;
+        }
         // wait for the verdict (poll the pinned status block; fall back to a stream sync after ~2 s)
         volatile double* hs = hs_all + 16 * ((long long)seq & 1);
         {
