@@ -246,7 +246,7 @@ constexpr int RP_NSUM = 28;
 // one workgroup per link, lanes stride over the keypoints; fixed-order reduction (bit-reproducible)
 __global__ __launch_bounds__(256) void reproj_reduce_kernel(const double* __restrict__ nodes, const double* __restrict__ dx,
                                                              int M, ReprojDev rp, double* __restrict__ red, Gate gate) {
-    __shared__ double sw[4][RP_NSUM];
+    extern __shared__ __attribute__((aligned(16))) double sw[];   // blockDim.x rows of RP_NSUM + 1 doubles
     const int L = xcd_index(blockIdx.x, M);
     if (L < 0 || gate_closed(gate)) return;
     SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
@@ -288,17 +288,16 @@ __global__ __launch_bounds__(256) void reproj_reduce_kernel(const double* __rest
         for (int a = 0; a < 6; ++a) acc[21 + a] += ju[a] * ru + jv[a] * rv;
         acc[27] += ru * ru + rv * rv;
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    // 28 sums over the workgroup through LDS (row stride 29: conflict-free), added in thread order by 28 lanes: a shuffle
+    // reduction of a double is two ds_bpermute per step -- 28 x 6 x 2 of them cost more than the keypoint loop
 #pragma unroll
-    for (int i = 0; i < RP_NSUM; ++i) {
-        const double s = wave_sum(acc[i]);
-        if (lane == 0) sw[wave][i] = s;
-    }
+    for (int i = 0; i < RP_NSUM; ++i) sw[threadIdx.x * (RP_NSUM + 1) + i] = acc[i];
     __syncthreads();
     if (threadIdx.x < RP_REC) {
         double s = 0.0;
         if (threadIdx.x < RP_NSUM) {
-            for (int w2 = 0; w2 < nw; ++w2) s += sw[w2][threadIdx.x];
+            const int nt = blockDim.x;
+            for (int t = 0; t < nt; ++t) s += sw[t * (RP_NSUM + 1) + threadIdx.x];
             if (frozen && threadIdx.x < 27) s = 0.0;            // a constant residual: no Jacobian
         }
         red[(size_t)L * RP_REC + threadIdx.x] = s;
@@ -2044,7 +2043,8 @@ static int reproj_dev(const islam_pvgo_reproj* r, ReprojDev& d) {
 static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s,
                                   Gate gate = Gate{nullptr, 0.0}) {
     const int waves = std::min(4, std::max(1, (rp.K + 127) / 128));
-    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 0, s, nodes, dx, M, rp, red, gate);
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 64 * waves * (RP_NSUM + 1) * sizeof(double), s, nodes,
+                       dx, M, rp, red, gate);
 }
 
 int islam_pvgo_reproj_reduce(const double* nodes, const double* dx, int N, const islam_pvgo_reproj* reproj, double* red,
