@@ -289,7 +289,9 @@ class Hourglass(nn.Module):
 
     def forward(self, x):
         u = self.up1(x)
-        return u + self.up2(self.low3(self.low2(self.pool1(u))))
+        low = self.low3(self.low2(self.pool1(u)))
+        # self.up2 = nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False); HIP kernel for bf16 channels-last
+        return u + ops.resize_bilinear(low, (low.shape[2] * 2, low.shape[3] * 2), align_corners=False)
 
 
 class SSP(nn.Module):
