@@ -83,6 +83,13 @@ int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bia
 int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                     int align_corners, void* stream);
 
+/* In-place epilogue of a bias-free convolution on a channels-last bf16 tensor: y <- act(bf16(y + bias[c]) [+ res]),
+ * act = ReLU (relu != 0) or identity; res NULL or a tensor of y's shape.  One pass for the bias add, activation and residual
+ * add around the convolutions of Network/PSM/hourglass.py:6-40 (Residual) and Network/StereoNet7.py:100-146.
+ * y, res: (pixels, C) bf16 bits, C a multiple of 8; bias (C) fp32. */
+int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, const uint16_t* res, long long pixels, int C, int relu,
+                                 void* stream);
+
 /* ---------------------------------------------------------------- stereo scale recovery */
 
 /* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176

@@ -292,3 +292,48 @@ extern "C" int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, i
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Epilogue of a bias-free MIOpen convolution of the frozen stereo net's execution copy, in place on channels-last bf16:
+//   y <- act( bf16(y + bias[c]) [+ res] )      act = ReLU or identity
+// One pass instead of ATen's broadcast add + clamp (+ residual add) kernels (Network/PSM/hourglass.py:6-40 Residual,
+// StereoNet7.py:100-146).  Same roundings as the separate ops: bf16 after the bias, bf16 after the residual.
+namespace {
+
+__global__ __launch_bounds__(256) void bias_act_add_nhwc_bf16_kernel(uint4* __restrict__ y, const float* __restrict__ bias,
+                                                                     const uint4* __restrict__ res, int C8, int relu, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % C8) * 8;
+    const uint4 v = y[i];
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (res) r = res[i];
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+    auto one = [&](unsigned yv, unsigned rv, float blo, float bhi) {
+        unsigned t = pack_bf16(bf16_lo(yv) + blo, bf16_hi(yv) + bhi);
+        if (res) t = pack_bf16(bf16_lo(t) + bf16_lo(rv), bf16_hi(t) + bf16_hi(rv));
+        if (relu) {
+            if (t & 0x8000u) t &= 0xffff0000u;          // negative low half -> +0
+            if (t & 0x80000000u) t &= 0x0000ffffu;      // negative high half -> +0
+        }
+        return t;
+    };
+    uint4 o;
+    o.x = one(v.x, r.x, b0.x, b0.y);
+    o.y = one(v.y, r.y, b0.z, b0.w);
+    o.z = one(v.z, r.z, b1.x, b1.y);
+    o.w = one(v.w, r.w, b1.z, b1.w);
+    y[i] = o;
+}
+
+}  // namespace
+
+extern "C" int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, const uint16_t* res, long long pixels, int C, int relu,
+                                            void* stream) {
+    if (pixels < 1 || C < 8 || (C & 7)) return fail(ISLAM_EARG, "islam_bias_act_add_nhwc_bf16: C=%d must be a multiple of 8", C);
+    const long long total = pixels * (C / 8);
+    hipLaunchKernelGGL(bias_act_add_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint4*>(y), bias, reinterpret_cast<const uint4*>(res), C / 8, relu, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}

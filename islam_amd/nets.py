@@ -260,6 +260,17 @@ class _HGConv(nn.Module):
         assert x.shape[1] == self.inp_dim, '{} {}'.format(x.shape[1], self.inp_dim)
         return self.conv(x)
 
+    def run(self, x, relu=False, res=None):
+        """act(conv(x) + bias [+ res]) with the bias add, ReLU and residual add in ONE in-place pass over the bias-free
+        MIOpen convolution's output (frozen bf16 channels-last execution copy only; see _HGResidual.forward)."""
+        c = self.conv
+        b = self.__dict__.get('_b32')
+        key = (c.bias._version, c.bias.data_ptr())
+        if b is None or b[0] != key:
+            b = self.__dict__['_b32'] = (key, c.bias.detach().float().contiguous())
+        y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        return ops.bias_act_add_(y, b[1], res, relu)
+
 
 class _HGResidual(nn.Module):
     def __init__(self, cin, cout):
@@ -271,6 +282,10 @@ class _HGResidual(nn.Module):
         self.need_skip = cin != cout
 
     def forward(self, x):
+        if ops.fusable_nhwc_bf16(x, self.conv1.conv.out_channels) and self.conv3.conv.out_channels % 8 == 0:
+            res = self.skip_layer.run(x) if self.need_skip else x
+            y = self.conv2.run(self.conv1.run(self.relu(x), relu=True), relu=True)
+            return self.conv3.run(y, relu=False, res=res)
         res = self.skip_layer(x) if self.need_skip else x
         y = self.conv3(self.relu(self.conv2(self.relu(self.conv1(self.relu(x))))))
         return y + res

@@ -162,6 +162,23 @@ def resize_bilinear(x, size, align_corners=False):
     return torch.nn.functional.interpolate(x, [Ho, Wo], mode='bilinear', align_corners=align_corners)
 
 
+def fusable_nhwc_bf16(x, channels):
+    """True for the tensors the channels-last bf16 epilogue / resize kernels take (frozen execution copies, no autograd)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and channels % 8 == 0 and not x.requires_grad
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def bias_act_add_(y, bias32, res=None, relu=False):
+    """In place on a channels-last bf16 conv output: y <- act(bf16(y + bias) [+ res]) (islam_bias_act_add_nhwc_bf16)."""
+    B, C, H, W = y.shape
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last) and bias32.dtype == torch.float32
+    if res is not None:
+        assert res.shape == y.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
+    check(lib().islam_bias_act_add_nhwc_bf16(ptr(y), ptr(bias32), ptr(res), ctypes.c_longlong(B * H * W), C, int(bool(relu)),
+                                             stream_ptr(y.device)))
+    return y
+
+
 # --------------------------------------------------------------------------- IMU
 def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
     """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,

@@ -75,3 +75,33 @@ def test_resize_bilinear_nhwc_bf16_matches_torch(cuda, Hi, Wi, Ho, Wo, align):
     # other dtypes / layouts fall through to torch
     z = ops.resize_bilinear(x.float(), (Ho, Wo), align)
     torch.testing.assert_close(z, ref)
+
+
+@pytest.mark.parametrize('relu,with_res', [(True, False), (False, True), (True, True), (False, False)])
+def test_bias_act_add_epilogue_matches_torch(cuda, relu, with_res):
+    """One-pass epilogue of the bias-free convolutions in the stereo net's execution copy vs the separate ATen ops."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: torch.randn(3, 64, 19, 27, generator=g).to(cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y, res = mk(), (mk() if with_res else None)
+    bias = torch.randn(64, generator=g).to(cuda).to(torch.bfloat16)
+    ref = y + bias.view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res
+    if relu:
+        ref = torch.relu(ref)
+    got = ops.bias_act_add_(y.clone(memory_format=torch.channels_last), bias.float(), res, relu)
+    assert torch.equal(got.float(), ref.float())
+
+
+def test_hourglass_residual_fused_path_matches_plain(cuda):
+    from islam_amd import nets
+    torch.manual_seed(0)
+    for cin, cout in ((64, 64), (64, 128)):
+        m = nets._HGResidual(cin, cout).to(cuda).to(torch.bfloat16).to(memory_format=torch.channels_last)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        x = torch.randn(2, cin, 24, 40, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        fused = m(x)
+        plain = m(x.contiguous())                    # NCHW-contiguous input: the unfused ATen path
+        torch.testing.assert_close(fused.float(), plain.float(), rtol=2e-2, atol=2e-2)
