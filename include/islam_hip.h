@@ -10,7 +10,8 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch tensors' data_ptr()),
  *     contiguous, row-major / NCHW; the library never frees or retains them;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it;
- *     only islam_pvgo_run_chain() synchronises (it reads one 128-byte status block per LM trial);
+ *     islam_pvgo_run_chain[_reproj]() polls one 128-byte verdict per LM trial in pinned host memory (no stream
+ *     synchronisation), islam_pvgo_solve_chain_timed() synchronises the stream; nothing else waits on the device;
  *   - return 0 on success, <0 on error: -1 bad argument, -2 HIP runtime error, -3 non-positive
  *     pivot in the block Cholesky (PyPose: "Linear solver failed. Breaking optimization step"),
  *     -4 unsupported graph topology;  islam_last_error() returns a thread-local message;

@@ -14,15 +14,21 @@
 //   1. linearise per link (one lane per link, everything in registers),
 //   2. build the 9x9 diagonal / coupling blocks per node (gather from the two adjacent links,
 //      no atomics, deterministic),
-//   3. factor with a partitioned ("spike") block Cholesky: the chain is cut into segments, one
-//      wavefront eliminates each segment's interior onto its two separator nodes, the separators
-//      form a ~20x smaller chain that is reduced the same way, the last level is solved by one
-//      wavefront, and two back-substitution sweeps expand the solution.  Inside a wavefront one
+//   3. factor with a partitioned ("spike") block LDL^T: the chain is cut into segments, one
+//      wavefront eliminates each segment's interior onto its two separator nodes (bt_eliminate_kernel,
+//      one launch per level), the separators form a ~6x smaller chain that is reduced the same way;
+//      the root solve and the whole back-substitution run in ONE launch (bt_downsweep_kernel) with
+//      per-segment ready words and write-through hand-off between levels.  Inside a wavefront one
 //      lane owns one column of the augmented 9 x 28 matrix [S | U | F^T | g]; pivots are broadcast
 //      with v_readlane, the 19x19 Schur update runs over all 64 lanes from an LDS copy,
-//   4. apply the step on a trial copy, re-evaluate the loss and the trust-region ratio per link,
-//   5. take the accept/reject decision in a one-wave control kernel; the host reads back one
-//      128-byte status block per trial.
+//   4. apply the step on a trial copy, re-evaluate the loss and the trust-region ratio per link AND
+//      linearise at the trial point for the next step in the same launch (trial_lin_kernel); the
+//      workgroup that draws the last ticket takes the LM / TrustRegion / StopOnPlateau decision and
+//      writes a 128-byte verdict to pinned host memory,
+//   5. the host enqueues one iteration ahead (every kernel is gated on an epoch the deciding lane
+//      bumps on any verdict other than "accepted, continue") and only polls the verdicts.
+// linearize_kernel / build_normal_kernel / trial_kernel / bt_top_kernel / bt_backsub_kernel are the
+// stage-level versions behind the islam_pvgo_* entry points the sharded driver and the tests call.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1634,7 +1640,7 @@ struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill,
 
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
-    double *lin2, *Hd2, *Ho2, *rhs2;          // second linearisation buffer (speculative next step)
+    double *lin2, *Hd2, *Ho2, *rhs2;          // second linearisation buffer (the trial point = the next step, if accepted)
     double *red, *red2;                       // reprojection factor: per-link reductions (same double buffering)
     int* ready;                               // down-sweep: one word per segment of every level (+ the root)
     size_t ready_bytes;
