@@ -1058,8 +1058,8 @@ __global__ __launch_bounds__(64) void bt_downsweep_kernel(SweepArgs a, int* flag
     const bool has_left = p > 0;
     const int sR = c0 + L.m;
     const bool has_right = sR < L.n;
-    const bool pr = lane == 0 && (p == 1 || p == L.P / 2 || p == L.P - 1);
-    const int po = (p == 1 ? 0 : p == L.P / 2 ? 50 : 100);
+    [[maybe_unused]] const bool pr = lane == 0 && (p == 1 || p == L.P / 2 || p == L.P - 1);     // probe build only
+    [[maybe_unused]] const int po = (p == 1 ? 0 : p == L.P / 2 ? 50 : 100);
     PROBE_WALL(pr, po + 310 + 10 * li);
     const bool par = L.m <= BS_PAR_MAX;
     FacRow cur;
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     const int blk = xcd_index(blockIdx.x, nblk);
     int k = blk * 64 + threadIdx.x;
     double sq = 0.0, qd = 0.0;
-    const bool pr = threadIdx.x == 0 && blk == 1;
+    [[maybe_unused]] const bool pr = threadIdx.x == 0 && blk == 1;     // probe build only
     PROBE_AT(pr, 200);
     if (blk >= 0 && k < M) {
         const double* di = dx + (size_t)k * 9;
@@ -2088,7 +2088,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
-    const int M = N - 1, nblk = (M + 63) / 64;
+    const int M = N - 1;
     // status blocks in pinned, device-visible host memory: the deciding wave of trial_lin_kernel writes one per trial
     // (two slots, alternating with the trial number), the host polls its sequence number (no stream synchronisation,
     // no copy on the critical path)
