@@ -110,7 +110,7 @@ def test_solver_reports_non_positive_definite(cuda):
     assert e.value.code == -3
 
 
-@pytest.mark.parametrize('F', [9, 33, 257])
+@pytest.mark.parametrize('F', [2, 3, 9, 12, 13, 14, 33, 63, 64, 65, 127, 257])
 def test_lm_matches_oracle(cuda, F):
     """Whole LM loop: same accept/reject trace, same poses (<= 1e-4 rel on the SE3 log; here ~1e-9)."""
     from islam_amd import ops
