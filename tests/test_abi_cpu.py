@@ -112,3 +112,25 @@ def test_product_fails_loudly_without_gpu():
                  torch.zeros(2, 4), torch.zeros(2, 3), torch.zeros(2, 3), device='cpu')
     with pytest.raises(RuntimeError):
         IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/bench_r01_final.json is the last `python bench.py` line measured on the MI355X: one JSON object with the
+    driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = open(os.path.join(root, 'profiles', 'bench_r01_final.json')).read().strip().split('\n')[-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['metric'] == 'pvgo_lm_iters_per_sec' and d['unit'] == 'LM iters/s' and d['higher_is_better'] is True
+    assert d['vs_baseline'] is None and d['dtype'] == 'f64' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert not any(k in d['config'] for k in ('model', 'seq_len', 'global_batch'))
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
+    assert abs(d['value'] * d['ms_per_step'] / 1e3 - d['lm_iters_per_step']) < 1e-6 * d['lm_iters_per_step'] + 1e-9
