@@ -298,7 +298,7 @@ def main():
                 out['stereo_vio'] = vio_frames_per_sec(device)
             except Exception as e:           # the headline metric must still be reported
                 out['stereo_vio'] = {'error': repr(e)[:300]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             host = {k: v.cpu().numpy() for k, v in (('init_nodes', prob['init_nodes']), ('init_vels', prob['init_vels']),
                                                      ('vo_motions', prob['vo']), ('imu_drots', prob['drots']),
                                                      ('imu_dtrans', prob['dtrans']), ('imu_dvels', prob['dvels']),
