@@ -91,6 +91,17 @@ int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C
 int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, const uint16_t* res, long long pixels, int C, int relu,
                                  void* stream);
 
+/* Train-mode BatchNorm2d (+ ReLU, + residual add) on a channels-last bf16 tensor -- the BatchNorm layers of the "frozen"
+ * stereo feature extractor, which the reference still runs with batch statistics (TartanVO.py:90-91; Network/PSM/
+ * submodule.py:10-43):  y = act(bf16(x*scale[c] + shift[c]) [+ res]), scale = weight*rsqrt(var_biased + eps),
+ * shift = bias - mean*scale; running_mean / running_var (unbiased) / num_batches_tracked updated as nn.BatchNorm2d does
+ * (pass NULL to skip).  x, y, res: (pixels, C) bf16 bits (y may alias x), C = 8 * (a divisor of 256); weight, bias, running_*:
+ * fp32 (C); scratch: islam_bn_scratch_floats(C) floats.  Deterministic (fixed-order reduction). */
+size_t islam_bn_scratch_floats(int C);
+int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* weight, const float* bias,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, double momentum,
+                             double eps, int relu, long long pixels, int C, float* scratch, void* stream);
+
 /* ---------------------------------------------------------------- stereo scale recovery */
 
 /* Replaces the per-sample Python loop TartanVO.py:159-167 around dense_ba.py:88-176

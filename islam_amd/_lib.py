@@ -52,6 +52,8 @@ SIGNATURES = {
     'islam_conv3x3_mfma': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_float, c_void_p]),
     'islam_resize_bilinear_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'islam_bias_act_add_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
+    'islam_bn_scratch_floats': (c_size_t, [c_int]),
+    'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
     'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +

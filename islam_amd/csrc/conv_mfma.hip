@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
+#include <algorithm>
+
 #include "../../include/islam_hip.h"
 #include "common.h"
 
@@ -334,6 +336,147 @@ extern "C" int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, cons
     const long long total = pixels * (C / 8);
     hipLaunchKernelGGL(bias_act_add_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<uint4*>(y), bias, reinterpret_cast<const uint4*>(res), C / 8, relu, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Train-mode BatchNorm2d (+ ReLU, + residual add) on a channels-last bf16 tensor, for the "frozen" stereo feature extractor
+// that the reference still runs with batch statistics (TartanVO.py:90-91; Network/PSM/submodule.py:10-43):
+//   y = act( bf16(x * scale[c] + shift[c]) [+ res] ),  scale = w * rsqrt(var_b + eps),  shift = b - mean * scale,
+// mean / var_b (biased) over all pixels; running_mean / running_var (unbiased) / num_batches_tracked updated like
+// nn.BatchNorm2d.  Three launches (MIOpen: three for the normalisation alone, ATen two more for ReLU and the residual add):
+// per-workgroup partial sums -> one workgroup finalises in a fixed order (deterministic, double) -> one apply pass.
+namespace {
+
+constexpr int BN_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const uint4* __restrict__ x, int C8, long long pixels,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[256][17];
+    const int tid = threadIdx.x;
+    const int cg = tid % C8, pl = tid / C8, ppb = 256 / C8;         // C8 divides 256 (C = 8, 16, 32, 64, 128 ...)
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
+    if (pl < ppb)
+        for (long long p = (long long)blockIdx.x * ppb + pl; p < pixels; p += (long long)gridDim.x * ppb) {
+            const uint4 v = x[p * C8 + cg];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = bf16_lo(w[i]), b = bf16_hi(w[i]);
+                s[2 * i] += a; q[2 * i] = fmaf(a, a, q[2 * i]);
+                s[2 * i + 1] += b; q[2 * i + 1] = fmaf(b, b, q[2 * i + 1]);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[tid][i] = s[i]; red[tid][8 + i] = q[i]; }
+    __syncthreads();
+    // thread (cg, j<16) adds the ppb pixel lanes of its channel group in lane order
+    const int C = C8 * 8;
+    for (int o = tid; o < C8 * 16; o += 256) {
+        const int g = o / 16, j = o - g * 16;
+        float acc = 0.0f;
+        for (int l = 0; l < ppb; ++l) acc += red[l * C8 + g][j];
+        const int c = g * 8 + (j & 7);
+        partial[((size_t)blockIdx.x * 2 + (j >> 3)) * C + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                          const float* __restrict__ weight, const float* __restrict__ bias,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ num_batches, double momentum, double eps,
+                                                          float* __restrict__ scale_shift) {
+    // 256 threads = (256 / C) slices of the partial blocks x C channels (C <= 256); slices are combined in slice order
+    __shared__ double ls[256], lq[256];
+    const int nsl = 256 / C, c = threadIdx.x % C, sl = threadIdx.x / C;
+    double s = 0.0, q = 0.0;
+    if (sl < nsl) {
+        const int per = (nblk + nsl - 1) / nsl, b0 = sl * per, b1 = min(nblk, b0 + per);
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {                     // four independent loads in flight per accumulator pair
+            const float s0 = partial[((size_t)b * 2) * C + c], q0 = partial[((size_t)b * 2 + 1) * C + c];
+            const float s1 = partial[((size_t)b * 2 + 2) * C + c], q1 = partial[((size_t)b * 2 + 3) * C + c];
+            const float s2 = partial[((size_t)b * 2 + 4) * C + c], q2 = partial[((size_t)b * 2 + 5) * C + c];
+            const float s3 = partial[((size_t)b * 2 + 6) * C + c], q3 = partial[((size_t)b * 2 + 7) * C + c];
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; b < b1; ++b) {
+            s += (double)partial[((size_t)b * 2) * C + c];
+            q += (double)partial[((size_t)b * 2 + 1) * C + c];
+        }
+    }
+    ls[threadIdx.x] = s;
+    lq[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        s = 0.0;
+        q = 0.0;
+        for (int j = 0; j < nsl; ++j) { s += ls[j * C + c]; q += lq[j * C + c]; }
+        const double mean = s / count;
+        const double var = fmax(q / count - mean * mean, 0.0);
+        const double sc = (double)weight[c] / sqrt(var + eps);
+        scale_shift[c] = (float)sc;
+        scale_shift[C + c] = (float)((double)bias[c] - mean * sc);
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    }
+    if (threadIdx.x == 0 && num_batches) *num_batches += 1;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const uint4* __restrict__ res,
+                                                       const float* __restrict__ scale_shift, int C8, int relu, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int C = C8 * 8, c0 = (int)(i % C8) * 8;
+    const uint4 v = x[i];
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (res) r = res[i];
+    const float4 s0 = *reinterpret_cast<const float4*>(scale_shift + c0), s1 = *reinterpret_cast<const float4*>(scale_shift + c0 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(scale_shift + C + c0), h1 = *reinterpret_cast<const float4*>(scale_shift + C + c0 + 4);
+    auto one = [&](unsigned xv, unsigned rv, float slo, float shi, float hlo, float hhi) {
+        unsigned t = pack_bf16(fmaf(bf16_lo(xv), slo, hlo), fmaf(bf16_hi(xv), shi, hhi));
+        if (res) t = pack_bf16(bf16_lo(t) + bf16_lo(rv), bf16_hi(t) + bf16_hi(rv));
+        if (relu) {
+            if (t & 0x8000u) t &= 0xffff0000u;
+            if (t & 0x80000000u) t &= 0x0000ffffu;
+        }
+        return t;
+    };
+    uint4 o;
+    o.x = one(v.x, r.x, s0.x, s0.y, h0.x, h0.y);
+    o.y = one(v.y, r.y, s0.z, s0.w, h0.z, h0.w);
+    o.z = one(v.z, r.z, s1.x, s1.y, h1.x, h1.y);
+    o.w = one(v.w, r.w, s1.z, s1.w, h1.z, h1.w);
+    y[i] = o;
+}
+
+}  // namespace
+
+extern "C" size_t islam_bn_scratch_floats(int C) { return (size_t)BN_BLOCKS * 2 * C + 2 * (size_t)C; }
+
+extern "C" int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* weight, const float* bias,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked, double momentum,
+                                        double eps, int relu, long long pixels, int C, float* scratch, void* stream) {
+    if (pixels < 1 || C < 8 || (C & 7) || 256 % (C / 8) != 0)
+        return fail(ISLAM_EARG, "islam_bn_train_nhwc_bf16: C=%d must be 8 * a divisor of 256", C);
+    hipStream_t s = (hipStream_t)stream;
+    const int C8 = C / 8, ppb = 256 / C8;
+    const int nblk = (int)std::min<long long>(BN_BLOCKS, (pixels + ppb - 1) / ppb);
+    float* partial = scratch;
+    float* scale_shift = scratch + (size_t)BN_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const uint4*>(x), C8, pixels, partial);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, C, (double)pixels, weight, bias, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, scale_shift);
+    const long long total = pixels * C8;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4*>(x),
+                       reinterpret_cast<uint4*>(y), reinterpret_cast<const uint4*>(res), scale_shift, C8, relu, total);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

@@ -181,6 +181,23 @@ def _convbn(cin, cout, k, stride, pad, dilation):
                          nn.BatchNorm2d(cout))
 
 
+def _cbn(convbn, x, relu=False, res=None):
+    """A `convbn` block (Conv2d, BatchNorm2d; submodule.py:10-13) together with the residual add and / or ReLU that follows
+    it.  On the frozen bf16 channels-last execution copy in training mode the BatchNorm (batch statistics, running-stat
+    update), the add and the ReLU are ONE HIP op on the convolution's output (ops.bn_train_); everywhere else plain torch."""
+    conv, bn = convbn[0], convbn[1]
+    y = conv(x)
+    c = y.shape[1]
+    if bn.training and bn.weight.dtype == torch.float32 and ops.fusable_nhwc_bf16(y, c) and 256 % (c // 8) == 0:
+        if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
+            res = res.contiguous(memory_format=torch.channels_last)
+        return ops.bn_train_(y, bn, relu, res)
+    y = bn(y)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
 class _PSMBlock(nn.Module):
     def __init__(self, cin, cout, stride, downsample):
         super().__init__()
@@ -189,8 +206,9 @@ class _PSMBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.conv2(self.conv1(x))
-        return y + (x if self.downsample is None else self.downsample(x))
+        y = _cbn(self.conv1[0], x, relu=True)
+        res = x if self.downsample is None else _cbn(self.downsample, x)
+        return _cbn(self.conv2, y, res=res)
 
 
 def _block_mean(x, k):
@@ -237,17 +255,20 @@ class feature_extraction(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        o0 = self.layer1(self.firstconv(x))
+        f = x
+        for i in (0, 2, 4):                                  # firstconv = (convbn, ReLU) x 3
+            f = _cbn(self.firstconv[i], f, relu=True)
+        o0 = self.layer1(f)
         raw = self.layer2(o0)
         skip = self.layer4(self.layer3(raw))
         hw = [skip.shape[2], skip.shape[3]]
         pools = _spp_pools(skip)
-        br = [ops.resize_bilinear(getattr(self, 'branch%d' % i)[1:](pools[k]), hw, align_corners=True)
+        br = [ops.resize_bilinear(_cbn(getattr(self, 'branch%d' % i)[1], pools[k], relu=True), hw, align_corners=True)
               for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))]
         feat = torch.cat([raw, skip] + br, 1)
         if self.bigger:
             feat = torch.cat((ops.resize_bilinear(feat, [hw[0] * 2, hw[1] * 2], align_corners=True), o0), 1)
-        return self.lastconv(feat)
+        return self.lastconv[2](_cbn(self.lastconv[0], feat, relu=True))
 
 
 class _HGConv(nn.Module):

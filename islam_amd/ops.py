@@ -179,6 +179,24 @@ def bias_act_add_(y, bias32, res=None, relu=False):
     return y
 
 
+def bn_train_(x, bn, relu=False, res=None):
+    """nn.BatchNorm2d in training mode on a channels-last bf16 conv output, IN PLACE, with the ReLU and / or residual add
+    that follows it folded in (islam_bn_train_nhwc_bf16).  ``bn``: the fp32 BatchNorm2d module (weight, bias, running
+    statistics, momentum, eps); its buffers are updated like nn.BatchNorm2d would."""
+    B, C, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
+    scratch = torch.empty(lib().islam_bn_scratch_floats(C), dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    check(lib().islam_bn_train_nhwc_bf16(ptr(x), ptr(x), ptr(res), ptr(bn.weight), ptr(bn.bias),
+                                         ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                         ptr(bn.num_batches_tracked) if track else None, c_double(mom), c_double(bn.eps),
+                                         int(bool(relu)), ctypes.c_longlong(B * H * W), C, ptr(scratch), stream_ptr(x.device)))
+    return x
+
+
 # --------------------------------------------------------------------------- IMU
 def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
     """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,

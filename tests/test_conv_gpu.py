@@ -105,3 +105,36 @@ def test_hourglass_residual_fused_path_matches_plain(cuda):
         fused = m(x)
         plain = m(x.contiguous())                    # NCHW-contiguous input: the unfused ATen path
         torch.testing.assert_close(fused.float(), plain.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('C,relu,with_res', [(32, True, False), (64, False, True), (128, True, False), (32, False, False)])
+def test_fused_batchnorm_train_matches_torch(cuda, C, relu, with_res):
+    """islam_bn_train_nhwc_bf16 vs nn.BatchNorm2d in training mode (+ add, + ReLU): output to bf16 accuracy, running
+    statistics and the batch counter like torch's."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C)
+    mk = lambda: (torch.randn(4, C, 37, 53, generator=g) * 1.7 + 0.3).to(cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x, res = mk(), (mk() if with_res else None)
+    ref_bn = torch.nn.BatchNorm2d(C).to(cuda).train()
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ref_bn.bias.copy_(torch.randn(C, generator=g))
+    import copy
+    hip_bn = copy.deepcopy(ref_bn)
+    ref = ref_bn(x.float())
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    got = ops.bn_train_(x.clone(memory_format=torch.channels_last), hip_bn, relu, res)
+    assert got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(hip_bn.running_mean, ref_bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hip_bn.running_var, ref_bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(hip_bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    # deterministic
+    hip2 = copy.deepcopy(ref_bn)
+    hip2.load_state_dict({k: v for k, v in torch.nn.BatchNorm2d(C).state_dict().items()}, strict=False)
+    a = ops.bn_train_(x.clone(memory_format=torch.channels_last), copy.deepcopy(hip_bn), relu, res)
+    b = ops.bn_train_(x.clone(memory_format=torch.channels_last), copy.deepcopy(hip_bn), relu, res)
+    assert torch.equal(a, b)
