@@ -55,21 +55,17 @@ def build_problem(device, n_frames=N_FRAMES):
 
 
 def eliminate_l0_burst(ops, Hd, Ho, rhs, N, levels, device, launches=40):
-    """Average period (us) of back-to-back launches of bt_eliminate_kernel on level 0 (all segments), HIP events on the
-    stream the kernel is launched on (torch's current stream, the one islam_amd passes to the C ABI)."""
-    import ctypes
-    from islam_amd._lib import c_double, c_int, check, lib, ptr, stream_ptr
-    P0 = levels[0][2]
-    products = torch.zeros(351 * P0, dtype=torch.float64, device=device)
-    fac = torch.empty((N, 252), dtype=torch.float64, device=device)
-    inv = torch.empty((N, 9), dtype=torch.float64, device=device)
-    flags = torch.zeros(4, dtype=torch.int32, device=device)
+    """Average period (us) of back-to-back launches of the level-0 up-sweep kernel (all segments; the launch
+    islam_pvgo_solve_chain makes, through islam_pvgo_eliminate_level0), HIP events on the stream the kernel is launched on
+    (torch's current stream, the one islam_amd passes to the C ABI)."""
+    from islam_amd._lib import c_double, c_int, c_size_t, check, lib, ptr, stream_ptr
+    ws, nbytes = ops.pvgo_workspace(N, device)
     sl = (c_int * 2)(0, 0)
     Hd = Hd.clone()
 
     def launch():
-        check(lib().islam_pvgo_shard_eliminate(ptr(Hd), ptr(Ho), ptr(rhs), c_double(0.0), N, sl, 0, 0, P0, ptr(products), ptr(fac),
-                                               ptr(inv), ptr(flags), stream_ptr(device)))
+        check(lib().islam_pvgo_eliminate_level0(ptr(Hd), ptr(Ho), ptr(rhs), c_double(0.0), N, sl, ptr(ws), c_size_t(nbytes),
+                                                stream_ptr(device)))
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -276,7 +272,7 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic_eliminate_L0.json')
         if os.path.exists(tpath) and N == N_FRAMES:
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
-        roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+        roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_tw_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': elim0_s * 1e6,
                     'solve_launch_us': kern, 'levels_n_m_P': levels,

@@ -218,6 +218,10 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
 int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                                  const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx,
                                  float* ms, int* plan, int* nlaunch, void* stream);
+/* Measurement hook: exactly the level-0 up-sweep launch of islam_pvgo_solve_chain (same kernel, grid, arguments) and
+ * nothing else -- bench.py times a burst of these for the roofline figure.  Hd's diagonal is damped in place. */
+int islam_pvgo_eliminate_level0(double* Hd, const double* Ho, const double* rhs, double damping, int N,
+                                const int seg_len[2], void* workspace, size_t workspace_bytes, void* stream);
 /* ---- multi-GPU building blocks (islam_amd/dist_pvgo.py; no reference counterpart: the reference is single-GPU).
  * plan9 (3*ISLAM_PVGO_MAX_LEVELS+1 ints) receives (nodes, segment length, segments) per level (unused = 0) and, last,
  * the first level that runs inside the single-workgroup top kernel; returns the level count. */

@@ -74,6 +74,8 @@ SIGNATURES = {
     'islam_pvgo_solve_chain_timed': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                               c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int),
                                                               ctypes.POINTER(c_int), c_void_p]),
+    'islam_pvgo_eliminate_level0': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
+                                                             c_void_p]),
     'islam_pvgo_plan': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'islam_pvgo_shard_eliminate': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int] +
                                    [c_void_p] * 5),

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -866,6 +867,257 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     if (bad && lane == 0) atomicOr(flags, 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// Twisted (two-sided) elimination of a segment by TWO wavefronts.  Wave A sweeps the interior nodes left -> right exactly
+// like eliminate_segment (spike = coupling to the left separator), wave B sweeps right -> left over the mirrored chain
+// (its "next node" is c-1, its spike is the coupling to the RIGHT separator); they meet at the middle node c0+h, which A
+// eliminates last with the Schur contributions of both sides: a segment of cnt interior nodes costs h+1 = cnt/2+1
+// dependent node steps instead of cnt.  The products handed to the next level (cL, cR, fill, cgL, cgR, Dsep, rsep) and
+// the factor layout per node are those of eliminate_segment; a B-side node's U~ couples to the node on its LEFT and its
+// F~ to the right separator (backsub_twisted).  Segments with fewer than 3 interior nodes run one-sided on wave A.
+__device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) {
+    LaneSrc L = lane_source(s, lane);
+    if (L.isU) {                                    // U' column cu of node k = coupling (k rows, k-1 col cu) = row cu of the
+        const int cu = lane - 9;                    // block that couples k-1 -> k
+        L.A = (s.level0 ? s.Ho - 81 : s.fill) + cu * 9;
+        L.sa = 1;
+    }
+    return L;
+}
+
+__device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, double damping,
+                                                 const RawCols& raw, double (&m)[9]) {
+    if (s.level0) {
+        const bool zeroU = L.isU && k <= 0;
+        double dg = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = zeroU ? 0.0 : raw.a[r];
+            if (r == lane) { v = v + v * damping; dg = v; }
+            m[r] = v;
+        }
+        if (lane < 9) s.Hd[(size_t)k * 81 + lane * 10] = dg;
+    } else {
+        const bool ua = L.isS || L.isG || (L.isU && k > 0);
+        const bool ub = L.isS || L.isG;
+        const bool uc = ub && (k + 1) < s.Pprev;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) m[r] = (ua ? raw.a[r] : 0.0) - (ub ? raw.b[r] : 0.0) - (uc ? raw.c[r] : 0.0);
+    }
+}
+
+constexpr int TW_ACC = 9 * 10;                                  // wave B's accumulation onto the right separator: [a][b], b = 9: g
+constexpr int LDS_TWISTED = 2 * LDS_PER_WAVE + TW_ACC + 2;      // doubles per workgroup
+
+// One directed sweep.  REV = false: nodes first, first+1, ...; REV = true: first, first-1, ...
+//   count      nodes eliminated by this wave
+//   has_spike  an outer separator exists (left for forward, right for reverse)
+//   merge_t    (forward only) after node step merge_t the next node is the MIDDLE node: wait for wave B and fold its
+//              contributions in (-1: one-sided)
+//   last_next  (forward only) node whose columns follow the last eliminated node (the right separator), -1: none
+template <bool REV>
+__device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDst& dst, int n, int p, int first, int count,
+                                              bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
+                                              double* __restrict__ lds, const double* __restrict__ TnB,
+                                              double* __restrict__ accB) {
+    double* Xa = lds;
+    double* Xb = lds + 19 * XS;
+    double* Tn = lds + 2 * 19 * XS;
+    const double damping = src.state ? src.state[2] : src.damping_override;
+    const int tr = lane % 9, tg = lane / 9;
+    const bool t_on = tg < 7;
+    const bool t_third = t_on && (tg + 14) < 19;
+    const int pa = lane < 45 ? kPairA[lane] : lane - 45;
+    const int pb = lane < 45 ? kPairB[lane] : 9;
+    const bool acc_on = has_spike && lane < 54;
+    const bool use_nb = lane < 18 || lane == 27;
+    const bool use_tn = lane < 9 || lane == 27 || (has_spike && lane >= 18 && lane < 27);
+    const int tn_off = (lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
+    const LaneSrc LS = REV ? lane_source_rev(src, lane) : lane_source(src, lane);
+    const bool level0 = src.level0 != 0;
+    auto clampi = [&](int k) { return min(max(k, 0), n - 1); };
+    double mcol[9], nb[9];
+    RawCols raw;
+    issue_cols(LS, level0, first, raw);
+    double spike[9];
+    {
+        const int jj = (lane >= 18 && lane < 27) ? lane - 18 : 0;
+        if (!REV) {         // coupling (left separator rows, first cols), transposed
+            const int cl = has_spike ? first : 1;
+            const double* O = src.level0 ? (src.Ho + (size_t)(cl - 1) * 81) : (src.fill + (size_t)cl * 81);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) spike[r] = O[jj * 9 + r];
+        } else {            // coupling (first rows, right separator cols)
+            const int cl = has_spike ? first : 0;
+            const double* O = src.level0 ? (src.Ho + (size_t)cl * 81) : (src.fill + (size_t)(cl + 1) * 81);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) spike[r] = O[r * 9 + jj];
+        }
+    }
+    if (REV) combine_cols_rev(LS, src, first, lane, damping, raw, mcol);
+    else combine_cols(LS, src, first, n, lane, damping, raw, mcol);
+    if (lane >= 18 && lane < 27) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) mcol[r] = has_spike ? spike[r] : 0.0;
+    }
+    double accL = 0.0;
+    int bad = 0;
+    for (int t = 0; t < count; ++t) {
+        const int c = REV ? first - t : first + t;
+        const bool last = (t == count - 1);
+        const int nxt = REV ? c - 1 : ((last && last_next >= 0) ? last_next : c + 1);
+        issue_cols(LS, level0, clampi(nxt), raw);
+        __builtin_amdgcn_sched_barrier(0);
+        double ipv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double piv = bcast(mcol[i], i);
+            bad |= !(piv > 0.0);
+            const double ip = rcp_nr(piv);
+            ipv[i] = ip;
+            const double f = mcol[i] * ip;
+#pragma unroll
+            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
+        }
+        if (lane >= 9 && lane < 28) {
+            double* xa = Xa + (lane - 9) * XS;
+            double* xb = Xb + (lane - 9) * XS;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
+        }
+        lds_sync();
+        if (t_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + tr * XS, ca);
+            ldcol(Xb + tg * XS, cbv);
+            Tn[tg * XS + tr] = dot9r(ca, cbv);
+            ldcol(Xb + (tg + 7) * XS, cbv);
+            Tn[(tg + 7) * XS + tr] = dot9r(ca, cbv);
+            if (t_third) {
+                ldcol(Xb + (tg + 14) * XS, cbv);
+                Tn[(tg + 14) * XS + tr] = dot9r(ca, cbv);
+            }
+        }
+        if (acc_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + (9 + pa) * XS, ca);
+            ldcol(Xb + (9 + pb) * XS, cbv);
+            accL += dot9r(ca, cbv);
+        }
+        lds_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        // the next node's own columns; wave B never forms the middle node's (wave A does: its diagonal is damped once)
+        const bool want_next = REV ? !last : (nxt >= 0 && nxt < n && (!last || last_next >= 0));
+        if (want_next) {
+            if (REV) combine_cols_rev(LS, src, nxt, lane, damping, raw, nb);
+            else combine_cols(LS, src, nxt, n, lane, damping, raw, nb);
+        }
+        if (lane < 28) {
+            double* f = dst.fac + (size_t)c * FAC + lane * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);
+        }
+        if (lane == 0) {
+            double* iv = dst.inv + (size_t)c * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+        }
+        if (!last) {
+            double tcol[9];
+            ldcol(Tn + tn_off, tcol);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) mcol[r] = (use_nb ? nb[r] : 0.0) - (use_tn ? tcol[r] : 0.0);
+            if (!REV && t == merge_t) {
+                // the node just formed is the middle node: fold wave B's side in.  T_B(r, cb): r = middle unknown, cb < 9
+                // middle unknown (S update), cb = 9+j right-separator unknown j (its negative IS the coupling middle -> R,
+                // i.e. this wave's U columns), cb = 18 right-hand side
+                __syncthreads();
+                double tb[9];
+                const int off = (lane < 9 ? lane : lane < 18 ? lane : 18) * XS;       // U lane 9+cu reads column 9+cu
+                ldcol(TnB + off, tb);
+                if (lane < 9 || lane == 27) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) mcol[r] -= tb[r];
+                } else if (lane >= 9 && lane < 18) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) mcol[r] = has_right ? -tb[r] : 0.0;
+                }
+            }
+        } else if (!REV) {
+            if (has_right) {
+                const bool addB = merge_t >= 0;               // wave B accumulated onto the right separator as well
+                for (int e = lane; e < 81; e += 64) {
+                    const int r = e / 9, cc = e - r * 9;
+                    dst.cR[(size_t)p * 81 + e] = Tn[cc * XS + r] + (addB ? accB[r * 10 + cc] : 0.0);
+                    dst.fill[(size_t)p * 81 + e] = has_spike ? -Tn[(9 + r) * XS + cc] : 0.0;
+                }
+                if (lane < 9) {
+                    dst.cgR[(size_t)p * 9 + lane] = Tn[18 * XS + lane] + (addB ? accB[lane * 10 + 9] : 0.0);
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) dst.Dsep[(size_t)p * 81 + r * 9 + lane] = nb[r];
+                }
+                if (lane == 27) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
+                }
+            }
+        }
+        lds_sync();
+    }
+    if (!REV) {
+        if (has_spike) {
+            if (lane < 45) {
+                dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
+                dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
+            } else if (lane < 54) {
+                dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
+            }
+        }
+    } else {
+        // wave B: its last Tn stays in LDS for wave A; the accumulation onto the right separator goes next to it
+        if (lane < 45) {
+            accB[pa * 10 + pb] = has_spike ? accL : 0.0;
+            accB[pb * 10 + pa] = has_spike ? accL : 0.0;
+        } else if (lane < 54) {
+            accB[(lane - 45) * 10 + 9] = has_spike ? accL : 0.0;
+        }
+        __syncthreads();
+    }
+    if (bad && lane == 0) atomicOr(flags, 1);
+}
+
+// middle index of a segment with cnt interior nodes (wave A: nodes 0..h incl. the middle, wave B: cnt-1 .. h+1)
+__host__ __device__ __forceinline__ int twisted_mid(int cnt) { return cnt >= 3 ? cnt / 2 : cnt - 1; }
+
+__device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
+                                                  int wave, int lane, double* __restrict__ lds_wg) {
+    const int stride = m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(m, n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + m;
+    const bool has_right = sR < n;
+    const bool tw = cnt >= 3;
+    const int h = twisted_mid(cnt);
+    double* ldsA = lds_wg;
+    double* ldsB = lds_wg + LDS_PER_WAVE;
+    double* accB = lds_wg + 2 * LDS_PER_WAVE;
+    if (wave == 0) {
+        twisted_sweep<false>(src, dst, n, p, c0, tw ? h + 1 : cnt, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags,
+                             lane, ldsA, ldsB + 2 * 19 * XS, accB);
+    } else if (tw) {
+        twisted_sweep<true>(src, dst, n, p, c0 + cnt - 1, cnt - 1 - h, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB);
+    }
+}
+
+__global__ __launch_bounds__(128) void bt_eliminate_tw_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
+                                                              int nseg, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
+    const int p = xcd_index(blockIdx.x, nseg);
+    if (p < 0 || gate_closed(gate)) return;
+    eliminate_twisted(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds);
+}
+
 #ifdef ISLAM_PROBE
 extern "C" int islam_probe_read(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_probe_buf), sizeof(long long) * 512) == hipSuccess ? 0 : -2;
@@ -915,6 +1167,66 @@ __device__ __forceinline__ void backsub_par_run(double* __restrict__ x, int c0, 
             for (int i = 0; i < 9; ++i)
                 if (i == r) mine = xn[i];
             st_coherent(&x[(size_t)(c0 + tt) * 9 + r], mine);
+        }
+    }
+}
+
+// Back-substitution of a segment factored by eliminate_twisted: the middle node first (its U~ couples to the right
+// separator), then both halves at once -- the nodes left of the middle right-to-left (U~ couples to the node on the right,
+// F~ to the left separator) and the nodes right of it left-to-right (U~ couples to the node on the LEFT, F~ to the right
+// separator): h+1 dependent node steps instead of cnt.  xR / xL = solution at the right / left separator (0 if none).
+__device__ __forceinline__ void backsub_par_run_tw(double* __restrict__ x, int c0, int cnt, int lane, const double (&xR)[9],
+                                                   const double (&xL)[9], const FacRow& row) {
+    const int t = lane / 9, r = lane - t * 9;
+    const int h = twisted_mid(cnt);
+    const bool sideB = t > h;
+    double wF = row.y;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wF = fma(-row.f[q], sideB ? xR[q] : xL[q], wF);
+    double xn[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) xn[q] = xR[q];
+    {
+        double w = wF;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w = fma(-row.u[q], xn[q], w);
+        const int base = h * 9;
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            const double xi = bcast(w * row.iv, base + i);
+            xn[i] = xi;
+            w = fma(-row.lt[i], xi, w);
+        }
+        if (t == h) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i == r) mine = xn[i];
+            st_coherent(&x[(size_t)(c0 + h) * 9 + r], mine);
+        }
+    }
+    const int steps = max(h, cnt - 1 - h);
+    for (int j = 1; j <= steps; ++j) {
+        const int tA = h - j, tB = h + j;
+        double w = wF;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w = fma(-row.u[q], xn[q], w);
+        const int baseA = max(tA, 0) * 9, baseB = min(tB, cnt - 1) * 9;
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            const double v = w * row.iv;
+            const double xa = bcast(v, baseA + i);
+            const double xb = bcast(v, baseB + i);
+            const double xi = sideB ? xb : xa;
+            xn[i] = xi;
+            w = fma(-row.lt[i], xi, w);
+        }
+        if ((t == tA && tA >= 0) || (t == tB && tB < cnt)) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i == r) mine = xn[i];
+            st_coherent(&x[(size_t)(c0 + t) * 9 + r], mine);
         }
     }
 }
@@ -1002,6 +1314,8 @@ struct SweepArgs {
     int nl;
     int* ready;               // per-segment words; ready[flag0 + p] == serial once segment p of that level is solved
     int serial;
+    int twisted;              // levels below the root were factored by bt_eliminate_tw_kernel
+    int root_twisted;         // the root is eliminated by both wavefronts of workgroup 0 (root_n <= BS_PAR_MAX)
 };
 
 constexpr int READY_STRIDE = 32;      // ints between two ready words: one 128-byte line each (polled words spread over L2 channels)
@@ -1022,19 +1336,29 @@ __device__ __forceinline__ void publish_ready(int* f, int serial, int lane) {
     if (lane == 0) __hip_atomic_store(f, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
-    __shared__ __attribute__((aligned(16))) double lds[LDS_PER_WAVE];
+// 128 threads: the second wavefront only helps workgroup 0 with a twisted root elimination and exits everywhere else.
+__global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
     if (gate_closed(gate)) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
+    if (threadIdx.x >= 64) {
+        if (b == 0 && a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 1, lane, lds);
+        return;
+    }
     if (b == 0) {                                   // root: eliminate + solve
         PROBE_WALL(lane == 0, 300);
-        eliminate_segment(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, lane, lds);
+        if (a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 0, lane, lds);
+        else eliminate_segment(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, lane, lds);
         PROBE_WALL(lane == 0, 301);
         double xn[9], xL[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
-        if (a.root_n <= BS_PAR_MAX) {
+        if (a.root_twisted) {
+            FacRow row;
+            backsub_par_load(a.root_dst.fac, a.root_dst.inv, 0, a.root_n, lane, row);
+            backsub_par_run_tw(a.root_dst.x, 0, a.root_n, lane, xn, xL, row);
+        } else if (a.root_n <= BS_PAR_MAX) {
             FacRow row;
             backsub_par_load(a.root_dst.fac, a.root_dst.inv, 0, a.root_n, lane, row);
             backsub_par_run(a.root_dst.x, 0, a.root_n, lane, xn, xL, row);
@@ -1096,7 +1420,8 @@ __global__ __launch_bounds__(64) void bt_downsweep_kernel(SweepArgs a, int* flag
     }
     if (has_right && lane >= 9 && lane < 18) st_coherent(&L.x[(size_t)sR * 9 + lane - 9], sv);
     PROBE_WALL(pr, po + 312 + 10 * li);
-    if (par) backsub_par_run(L.x, c0, cnt, lane, xn, xL, cur);
+    if (a.twisted) backsub_par_run_tw(L.x, c0, cnt, lane, xn, xL, cur);      // (twisted levels always have m <= BS_PAR_MAX)
+    else if (par) backsub_par_run(L.x, c0, cnt, lane, xn, xL, cur);
     else backsub_run(L.fac, L.inv, L.x, c0, cnt, lane, xn, xL, cur);
     PROBE_WALL(pr, po + 313 + 10 * li);
     if (li + 1 < a.nl) publish_ready(a.ready + (size_t)(L.flag0 + p) * READY_STRIDE, a.serial, lane);
@@ -1600,7 +1925,10 @@ __global__ __launch_bounds__(64) void align_kernel(const double* __restrict__ no
 struct LevelPlan { int n, m, P, nsep; };
 constexpr int MAXL = ISLAM_PVGO_MAX_LEVELS;
 constexpr int TOPW = 1;                        // wavefronts of the top kernel's workgroup (see plan_levels)
-struct SolvePlan { LevelPlan lv[MAXL]; int nl; int top; };   // levels >= top run inside bt_top_kernel
+struct SolvePlan { LevelPlan lv[MAXL]; int nl; int top; int twisted; };   // levels >= top run inside bt_top_kernel
+
+// dependent node steps of one segment of m interior nodes
+static inline int segment_steps(int m, bool twisted) { return (twisted && m >= 3) ? m / 2 + 1 : m; }
 
 // Level tree.  The critical path is a chain of dependent node steps (~2.3 us each: eliminate + back-substitute) plus
 // ~4 us per level boundary (launch + the first dependent loads of data another CU just wrote), so many short levels
@@ -1608,29 +1936,45 @@ struct SolvePlan { LevelPlan lv[MAXL]; int nl; int top; };   // levels >= top ru
 // the rest of the tree inside ONE workgroup (bt_top_kernel); measured on MI355X this only pays for the root level
 // (the inter-level latency is memory round trips, not launch overhead), hence TOPW = 1.
 // seg_len[0..1] > 0 pin the segment length of levels 0 / 1 (tests, tuning).
-int plan_levels(int N, const int seg_len[2], SolvePlan& best) {
+// twisted: plan for the two-sided elimination (a segment of m nodes costs m/2+1 steps; odd lengths, at most BS_PAR_MAX,
+// waste nothing).  The plan is marked twisted only if every level below the root qualifies; the sharded entry points
+// always plan one-sided (their level-0 factor is consumed by bt_backsub_kernel).
+int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = false) {
     const double t_node = 2.3, t_launch = 4.0;
     double best_cost = 1e300;
     best.nl = 0;
+    best.twisted = 0;
     for (int depth = 1; depth <= MAXL; ++depth) {
-        const int m_auto = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
+        int m_auto = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
+        if (twisted) {
+            if (m_auto > BS_PAR_MAX && depth < MAXL) continue;          // a deeper tree reaches a length the twisted path handles
+            if (m_auto % 2 == 0 && m_auto + 1 <= BS_PAR_MAX) ++m_auto;
+        }
         SolvePlan c;
         c.nl = 0;
         int n = N;
+        bool tw = twisted;
         for (int l = 0; l < MAXL; ++l) {
             LevelPlan L;
             L.n = n;
             int m = m_auto;
             if (seg_len && l < 2 && seg_len[l] > 0) m = std::max(seg_len[l], 4);
-            if (l == MAXL - 1 || l >= depth - 1 || m + 1 >= n || n <= 12) { L.m = n; L.P = 1; L.nsep = 0; c.lv[c.nl++] = L; break; }
+            if (l == MAXL - 1 || l >= depth - 1 || m + 1 >= n || n <= (twisted ? BS_PAR_MAX : 12)) { L.m = n; L.P = 1; L.nsep = 0; c.lv[c.nl++] = L; break; }
+            if (m > BS_PAR_MAX) tw = false;
             L.m = m; L.P = (n + m) / (m + 1); L.nsep = n / (m + 1);
             c.lv[c.nl++] = L;
             n = L.nsep;
         }
         c.top = c.nl - 1;
         while (c.top > 0 && c.lv[c.top - 1].P <= TOPW && (c.nl - (c.top - 1)) <= MAXTOP) --c.top;
+        if (c.nl < 2 || c.top != c.nl - 1) tw = false;                  // twisted levels exist only on the down-sweep path
+        c.twisted = tw ? 1 : 0;
         double cost = t_launch;
-        for (int l = 0; l < c.nl; ++l) cost += c.lv[l].m * t_node + (l < c.top ? 2 * t_launch : 0.0);
+        for (int l = 0; l < c.nl; ++l) {
+            const bool root = l == c.nl - 1;
+            const bool ltw = tw && (!root || c.lv[l].n <= BS_PAR_MAX);
+            cost += segment_steps(c.lv[l].m, ltw) * t_node + (l < c.top ? 2 * t_launch : 0.0);
+        }
         if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
     }
     return best.nl;
@@ -1709,6 +2053,15 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
     return s;
 }
 
+// the up-sweep launch of one level below the root: one workgroup per segment (two wavefronts when twisted)
+static void launch_eliminate(const LevelPlan& L, bool tw, const LevelSrc& src, const LevelDst& dst, int* flags, hipStream_t s,
+                             Gate gate) {
+    if (tw)
+        hipLaunchKernelGGL(bt_eliminate_tw_kernel, dim3(xcd_grid(L.P)), dim3(128), 0, s, src, dst, L.n, L.m, flags, 0, L.P, gate);
+    else
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(L.P)), dim3(64), 0, s, src, dst, L.n, L.m, flags, 0, L.P, gate);
+}
+
 // Enqueue levels [lbegin, nl): `first` describes the source of level lbegin (level-0 arrays, or the level-0 products when
 // lbegin == 1), xout receives the solution of level lbegin.  Big levels: one launch each way; levels >= sp.top: one launch.
 int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const LevelSrc& first, const LevelBufs* first_prev,
@@ -1728,12 +2081,12 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         return level_src_from(pb, sp.lv[l - 1].P);
     };
     auto x_of = [&](int l) { return l == lbegin ? xout : w.lv[l].x; };
+    const bool sweep = (top == nl - 1) && (top > lbegin);      // root alone in the top kernel, at least one level below
+    const bool tw = sp.twisted && sweep && lbegin == 0;
     for (int l = lbegin; l < top; ++l) {
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(sp.lv[l].P)), dim3(64), 0, s, src_of(l), level_dst(w.lv[l], x_of(l)),
-                           sp.lv[l].n, sp.lv[l].m, flags, 0, sp.lv[l].P, gate);
+        launch_eliminate(sp.lv[l], tw, src_of(l), level_dst(w.lv[l], x_of(l)), flags, s, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
-    const bool sweep = (top == nl - 1) && (top > lbegin);      // root alone in the top kernel, at least one level below
     if (sweep) {
         static std::atomic<int> g_serial{0};
         int serial = ++g_serial;
@@ -1744,6 +2097,8 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         a.root_n = sp.lv[top].n;
         a.ready = w.ready;
         a.serial = serial;
+        a.twisted = tw ? 1 : 0;
+        a.root_twisted = (tw && sp.lv[top].n <= BS_PAR_MAX) ? 1 : 0;
         a.nl = top - lbegin;
         int flag = 1, blk = 8;
         for (int i = 0; i < a.nl; ++i) {
@@ -1760,7 +2115,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         }
         a.first_block[a.nl] = blk;
         if ((size_t)flag * READY_STRIDE * sizeof(int) > w.ready_bytes) return fail(ISLAM_EARG, "pvgo: ready-flag buffer too small (%d words)", flag);
-        hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(64), 0, s, a, flags, gate);
+        hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(128), 0, s, a, flags, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     } else {
         TopArgs a{};
@@ -1786,12 +2141,18 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
     return ISLAM_OK;
 }
 
+// single-GPU solves use the twisted elimination; ISLAM_PVGO_ONESIDED=1 keeps the one-sided path (A/B measurements)
+static bool solve_twisted() {
+    static const bool tw = [] { const char* e = std::getenv("ISLAM_PVGO_ONESIDED"); return !(e && e[0] == '1'); }();
+    return tw;
+}
+
 // enqueue one damped solve: Hd.diag += Hd.diag*damping; dx = A^-1 rhs
 int enqueue_solve(const Workspace& w, double* Hd, const double* Ho, const double* rhs, const double* state,
                   double damping, int N, const int seg_len[2], double* dx, hipStream_t s, hipEvent_t* evs = nullptr,
                   int* nev = nullptr, Gate gate = Gate{nullptr, 0.0}) {
     SolvePlan sp;
-    plan_levels(N, seg_len, sp);
+    plan_levels(N, seg_len, sp, solve_twisted());
     LevelSrc src{};
     src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = state; src.damping_override = damping;
     return enqueue_levels(w, sp, 0, src, nullptr, dx, w.flags, s, evs, nev, gate);
@@ -1879,7 +2240,7 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     for (int i = 0; i + 1 < ne; ++i) ISLAM_HIP_CHECK(hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
     for (auto& e : evs) (void)hipEventDestroy(e);
     SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
+    const int nl = plan_levels(N, seg_len, sp, solve_twisted());
     for (int l = 0; l < MAXL; ++l) {
         plan_out[3 * l] = l < nl ? sp.lv[l].n : 0;
         plan_out[3 * l + 1] = l < nl ? sp.lv[l].m : 0;
@@ -1887,6 +2248,22 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     }
     plan_out[3 * MAXL] = sp.top;
     *nlaunch = ne - 1;
+    return ISLAM_OK;
+}
+
+// Measurement hook (bench.py's roofline leg): exactly the level-0 up-sweep launch of islam_pvgo_solve_chain -- same
+// kernel, grid and arguments -- and nothing else.  Hd's diagonal is damped in place like in a solve.
+int islam_pvgo_eliminate_level0(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_eliminate_level0: N=%d < 1", N);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_eliminate_level0: workspace too small");
+    SolvePlan sp;
+    if (plan_levels(N, seg_len, sp, solve_twisted()) < 2) return fail(ISLAM_EARG, "islam_pvgo_eliminate_level0: single-level problem");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    LevelSrc src{};
+    src.level0 = 1; src.Hd = Hd; src.Ho = Ho; src.rhs0 = rhs; src.state = nullptr; src.damping_override = damping;
+    launch_eliminate(sp.lv[0], sp.twisted != 0, src, level_dst(w.lv[0], w.lv[0].x), w.flags, as_stream(stream), Gate{nullptr, 0.0});
+    ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 
