@@ -248,6 +248,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # ---- N > 1 only: the same graph solved independently on every GPU (one trajectory per GPU, SURVEY 8(e) row 4: no
+    # data-path collective), reported NEXT to the headline sharded-graph figure, never instead of it
+    replicas = None
+    if dist is not None:
+        try:
+            ws_r = ops.pvgo_workspace(N, device)
+            n_r, v_r = torch.empty_like(prob['init_nodes']), torch.empty_like(prob['init_vels'])
+
+            def step_r():
+                n_r.copy_(prob['init_nodes'])
+                v_r.copy_(prob['init_vels'])
+                res, _ = ops.pvgo_run_chain(n_r, v_r, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'],
+                                            prm, workspace=ws_r)
+                return res.trials
+            for _ in range(args.warmup):
+                step_r()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            tr_r = 0
+            for _ in range(args.steps):
+                tr_r += step_r()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0, float(tr_r)], dtype=torch.float64, device=device)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            replicas = {'value': t[1].item() / tmax[0].item(), 'unit': 'LM iters/s', 'scaling': 'weak',
+                        'what': 'every rank runs the fused single-GPU LM loop on its own copy of the N=%d graph '
+                                '(independent trajectories, no collective); all ranks\' iterations / max-over-ranks time' % N}
+        except Exception as e:           # the headline metric must still be reported
+            replicas = {'error': repr(e)[:300]}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
@@ -289,6 +323,8 @@ def main():
             'us_per_lm_iter': elapsed / trials * 1e6,
             'roofline': roofline,
         }
+        if replicas is not None:
+            out['independent_graphs'] = replicas
         if not args.no_frontend and world == 1:
             try:
                 out['stereo_vio'] = vio_frames_per_sec(device)
@@ -302,10 +338,17 @@ def main():
             host['links'] = tr['links']
             out['cpu_baseline'] = cpu_baseline(host)
             out['speedup_vs_cpu_port'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL's banner goes through C stdio (block-buffered on a pipe): flush it first so the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
