@@ -611,11 +611,13 @@ __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s
 // compiler must be kept from reordering; no vmcnt wait (global prefetches and stores stay in flight).
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// pairs (a <= b) of the symmetric 9x9 accumulation F~^T F~ handled by lanes 0..44
-__constant__ unsigned char kPairA[45] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2,
-                                         2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8};
-__constant__ unsigned char kPairB[45] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7,
-                                         8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
+// pairs (a <= b) of the symmetric 9x9 accumulation F~^T F~ handled by lanes 0..44, row-major over the upper triangle
+// (row a starts at index 9a - a(a-1)/2).  Computed, not tabulated: a table in memory is a dependent load in the prologue
+// of every launch, ahead of the first node's column loads in the in-order vmcnt queue.
+__device__ __forceinline__ void pair_of(int idx, int& a, int& b) {
+    a = (idx >= 9) + (idx >= 17) + (idx >= 24) + (idx >= 30) + (idx >= 35) + (idx >= 39) + (idx >= 42) + (idx >= 44);
+    b = idx - (9 * a - ((a * (a - 1)) >> 1)) + a;
+}
 
 // LDS column (9 doubles, 16-byte aligned) -> registers with four 16-byte reads and one 8-byte read
 __device__ __forceinline__ void ldcol(const double* p, double (&c)[9]) {
@@ -731,8 +733,9 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     const int tr = lane % 9, tg = lane / 9;                         // lanes 0..62 (g <= 6); lane 63 idles
     const bool t_on = tg < 7;
     const bool t_third = t_on && (tg + 14) < 19;
-    const int pa = lane < 45 ? kPairA[lane] : lane - 45;            // left-separator accumulation F-^T D^-1 [F- | y-]
-    const int pb = lane < 45 ? kPairB[lane] : 9;
+    int pa, pb;                                                     // left-separator accumulation F-^T D^-1 [F- | y-]
+    pair_of(lane, pa, pb);
+    if (lane >= 45) { pa = lane - 45; pb = 9; }
     const bool acc_on = has_left && lane < 54;
     // role of this lane when the next node's columns are formed: S columns and g take (next - update), U columns take
     // the next node's coupling unchanged, spike columns take -(update) (0 without a left separator)
@@ -919,7 +922,7 @@ template <bool REV>
 __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDst& dst, int n, int p, int first, int count,
                                               bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
                                               double* __restrict__ lds, const double* __restrict__ TnB,
-                                              double* __restrict__ accB) {
+                                              double* __restrict__ accB, const Gate& gate) {
     double* Xa = lds;
     double* Xb = lds + 19 * XS;
     double* Tn = lds + 2 * 19 * XS;
@@ -927,8 +930,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
     const int tr = lane % 9, tg = lane / 9;
     const bool t_on = tg < 7;
     const bool t_third = t_on && (tg + 14) < 19;
-    const int pa = lane < 45 ? kPairA[lane] : lane - 45;
-    const int pb = lane < 45 ? kPairB[lane] : 9;
+    int pa, pb;                                                     // left-separator accumulation F-^T D^-1 [F- | y-]
+    pair_of(lane, pa, pb);
+    if (lane >= 45) { pa = lane - 45; pb = 9; }
     const bool acc_on = has_spike && lane < 54;
     const bool use_nb = lane < 18 || lane == 27;
     const bool use_tn = lane < 9 || lane == 27 || (has_spike && lane >= 18 && lane < 27);
@@ -954,6 +958,11 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             for (int r = 0; r < 9; ++r) spike[r] = O[r * 9 + jj];
         }
     }
+    // the run-ahead gate is looked at only now: the first node's loads are already in flight (a cancelled launch has read
+    // valid memory and writes nothing), so the gate word's round trip overlaps them instead of preceding them.  The epoch
+    // cannot change while this kernel runs (it is bumped by the previous iteration's trial kernel), so both wavefronts of
+    // the workgroup take the same branch.
+    if (gate_closed(gate)) return;
     if (REV) combine_cols_rev(LS, src, first, lane, damping, raw, mcol);
     else combine_cols(LS, src, first, n, lane, damping, raw, mcol);
     if (lane >= 18 && lane < 27) {
@@ -1090,7 +1099,8 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
 __host__ __device__ __forceinline__ int twisted_mid(int cnt) { return cnt >= 3 ? cnt / 2 : cnt - 1; }
 
 __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
-                                                  int wave, int lane, double* __restrict__ lds_wg) {
+                                                  int wave, int lane, double* __restrict__ lds_wg,
+                                                  const Gate& gate = Gate{nullptr, 0.0}) {
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -1104,9 +1114,9 @@ __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const Lev
     double* accB = lds_wg + 2 * LDS_PER_WAVE;
     if (wave == 0) {
         twisted_sweep<false>(src, dst, n, p, c0, tw ? h + 1 : cnt, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags,
-                             lane, ldsA, ldsB + 2 * 19 * XS, accB);
+                             lane, ldsA, ldsB + 2 * 19 * XS, accB, gate);
     } else if (tw) {
-        twisted_sweep<true>(src, dst, n, p, c0 + cnt - 1, cnt - 1 - h, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB);
+        twisted_sweep<true>(src, dst, n, p, c0 + cnt - 1, cnt - 1 - h, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB, gate);
     }
 }
 
@@ -1114,8 +1124,8 @@ __global__ __launch_bounds__(128) void bt_eliminate_tw_kernel(LevelSrc src, Leve
                                                               int nseg, Gate gate) {
     __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
     const int p = xcd_index(blockIdx.x, nseg);
-    if (p < 0 || gate_closed(gate)) return;
-    eliminate_twisted(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds);
+    if (p < 0) return;
+    eliminate_twisted(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
 }
 
 #ifdef ISLAM_PROBE
