@@ -118,6 +118,11 @@ int islam_scale_ls(const float* disp, const float* flow, const float* pose7, con
                    const float* baseline, const uint8_t* edge, const float* disp_th,
                    float* scale, float* z, uint8_t* mask, uint8_t* dmask, double* sums, double* partial,
                    int B, int H, int W, void* stream);
+/* Same with a depth map in place of the disparity (dense_ba.py:125-131, `depth=` argument of scale_from_disp_flow):
+ * depth_mask = 0 < depth <= fx*baseline, z = depth there. */
+int islam_scale_ls_depth(const float* depth, const float* flow, const float* pose7, const float* intr4,
+                         const float* baseline, const uint8_t* edge, float* scale, float* z, uint8_t* mask,
+                         uint8_t* dmask, double* sums, double* partial, int B, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------- IMU pre-integration */
 

@@ -18,14 +18,15 @@ from .transformation import cvtSE3_pypose, tartan2kitti_pypose
 DISP_TH = {'kitti': 5, 'tartanair': 1, 'euroc': 1}          # TartanVO.py:161
 
 
-def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th):
+def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_input=False):
     """Batched dense_ba.scale_from_disp_flow (dense_ba.py:88-176), differentiable w.r.t. ``pose_enu`` (SE3 LieTensor).
 
     Value: the HIP reduction.  Gradient: s = Mw/MM with M linear in a = K t^ and w linear in R, so
     ds = (dMw - s dMM)/MM is a linear functional of (a, R) whose coefficients are sums over the masked pixels
     (islam_amd/csrc/scale_ls.hip); it is re-attached through the same LieTensor ops the reference differentiates
     (T.Inv().rotation() acting on points, T.Inv().translation(), dense_ba.py:142-166)."""
-    s, z, mask, dmask, sums = ops.scale_ls(disp, flow, pose_enu.tensor().detach().to(disp.device), intr4, baseline, edge, disp_th)
+    s, z, mask, dmask, sums = ops.scale_ls(disp, flow, pose_enu.tensor().detach().to(disp.device), intr4, baseline, edge, disp_th,
+                                           depth_input=depth_input)
     if not pose_enu.requires_grad:
         return s, z, mask, dmask
     dev, dt = pose_enu.device, pose_enu.dtype          # the (B,6)-sized gradient glue runs where the pose lives (host or device)

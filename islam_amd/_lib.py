@@ -55,6 +55,7 @@ SIGNATURES = {
     'islam_bn_scratch_floats': (c_size_t, [c_int]),
     'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
+    'islam_scale_ls_depth': (c_int, [c_void_p] * 12 + [c_int] * 3 + [c_void_p]),
     'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +
                          [c_void_p] * 4 + [c_int, c_void_p]),

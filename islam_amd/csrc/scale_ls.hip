@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void scale_partial_kernel(const float* __restr
                                                              const float* __restrict__ baseline, const uint8_t* __restrict__ edge,
                                                              const float* __restrict__ disp_th, float* __restrict__ z,
                                                              uint8_t* __restrict__ mask, uint8_t* __restrict__ dmask,
-                                                             double* __restrict__ partial, int H, int W) {
+                                                             double* __restrict__ partial, int H, int W, int depth_input) {
     const int b = blockIdx.y;
     const int HW = H * W;
     const float fx = intr4[4 * b], fy = intr4[4 * b + 1], cx = intr4[4 * b + 2], cy = intr4[4 * b + 3];
@@ -63,10 +63,17 @@ __global__ __launch_bounds__(256) void scale_partial_kernel(const float* __restr
         const bool inside = fu >= 0.f && fu <= (float)W && fv >= 0.f && fv <= (float)H;     // inclusive upper bound (Q6)
         bool m = inside && (sqrtf(flx * flx + fly * fly) > 0.f);
         if (edge) m = m && (edge[(size_t)b * HW + i] != 0);
-        const float du = -d + uf;
-        const bool dm = du >= 0.f && du <= (float)W && d >= dth;
+        bool dm;
+        float zz;
+        if (depth_input) {                 // dense_ba.py:125-131: `disp` holds depth, valid up to fx*baseline (disparity >= 1)
+            dm = d <= fx * bl && d > 0.f;
+            zz = dm ? d : 0.f;
+        } else {                           // dense_ba.py:115-123
+            const float du = -d + uf;
+            dm = du >= 0.f && du <= (float)W && d >= dth;
+            zz = dm ? fx * bl / d : 0.f;
+        }
         m = m && dm;
-        const float zz = dm ? fx * bl / d : 0.f;
         z[(size_t)b * HW + i] = zz;
         mask[(size_t)b * HW + i] = m ? 1 : 0;
         dmask[(size_t)b * HW + i] = dm ? 1 : 0;
@@ -118,14 +125,29 @@ __global__ void scale_final_kernel(const double* __restrict__ partial, double* _
 
 }  // namespace
 
-extern "C" int islam_scale_ls(const float* disp, const float* flow, const float* pose7, const float* intr4,
-                              const float* baseline, const uint8_t* edge, const float* disp_th, float* scale, float* z,
-                              uint8_t* mask, uint8_t* dmask, double* sums, double* partial, int B, int H, int W, void* stream) {
+static int scale_ls_launch(const float* disp, const float* flow, const float* pose7, const float* intr4, const float* baseline,
+                           const uint8_t* edge, const float* disp_th, float* scale, float* z, uint8_t* mask, uint8_t* dmask,
+                           double* sums, double* partial, int B, int H, int W, int depth_input, void* stream) {
     if (B < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_scale_ls: bad shape (%d,%d,%d)", B, H, W);
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(scale_partial_kernel, dim3(NBLK, B), dim3(256), 0, s, disp, flow, pose7, intr4, baseline, edge, disp_th,
-                       z, mask, dmask, partial, H, W);
+                       z, mask, dmask, partial, H, W, depth_input);
     hipLaunchKernelGGL(scale_final_kernel, dim3(B), dim3(64), 0, s, partial, sums, scale, B);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+extern "C" int islam_scale_ls(const float* disp, const float* flow, const float* pose7, const float* intr4,
+                              const float* baseline, const uint8_t* edge, const float* disp_th, float* scale, float* z,
+                              uint8_t* mask, uint8_t* dmask, double* sums, double* partial, int B, int H, int W, void* stream) {
+    return scale_ls_launch(disp, flow, pose7, intr4, baseline, edge, disp_th, scale, z, mask, dmask, sums, partial, B, H, W, 0,
+                           stream);
+}
+
+// the depth-input branch of scale_from_disp_flow (dense_ba.py:125-131): `depth` replaces the disparity map
+extern "C" int islam_scale_ls_depth(const float* depth, const float* flow, const float* pose7, const float* intr4,
+                                    const float* baseline, const uint8_t* edge, float* scale, float* z, uint8_t* mask,
+                                    uint8_t* dmask, double* sums, double* partial, int B, int H, int W, void* stream) {
+    return scale_ls_launch(depth, flow, pose7, intr4, baseline, edge, baseline /* unused */, scale, z, mask, dmask, sums, partial,
+                           B, H, W, 1, stream);
 }

@@ -54,9 +54,6 @@ def scale_from_disp_flow(disp, flow, motion, fx, fy, cx, cy, baseline, depth=Non
     """dense_ba.py:88-176 for ONE sample: disp (1,H,W) or (H,W), flow (2,H,W), motion SE3 (7) or se3 (6).
     Returns (s (1,), z (H,W), mask (H,W), depth_mask (H,W)); differentiable w.r.t. ``motion``."""
     from .TartanVO import stereo_scale
-    if depth is not None:
-        raise NotImplementedError('scale_from_disp_flow(depth=...) (dense_ba.py:125-131) is not on the TartanVO path '
-                                  '(TartanVO.py:162 passes disparity); only the disparity branch is built')
     dev = flow.device
     if isinstance(motion, pp.LieTensor):
         T = motion if motion.shape[-1] == 7 else motion.Exp()
@@ -67,7 +64,11 @@ def scale_from_disp_flow(disp, flow, motion, fx, fy, cx, cy, baseline, depth=Non
     f32 = lambda v: torch.as_tensor(v, dtype=torch.float32).reshape(-1)
     intr = torch.cat([f32(fx), f32(fy), f32(cx), f32(cy)]).reshape(1, 4)
     edge = None if mask is None else mask.reshape(1, H, W)
-    s, z, m, dm = stereo_scale(disp.reshape(1, 1, H, W), flow.reshape(1, 2, H, W), T, intr, f32(baseline), edge, f32(disp_th))
+    if depth is not None:        # dense_ba.py:125-131: a depth map replaces the disparity, valid where 0 < depth <= fx*baseline
+        s, z, m, dm = stereo_scale(depth.reshape(1, 1, H, W), flow.reshape(1, 2, H, W), T, intr, f32(baseline), edge, None,
+                                   depth_input=True)
+    else:
+        s, z, m, dm = stereo_scale(disp.reshape(1, 1, H, W), flow.reshape(1, 2, H, W), T, intr, f32(baseline), edge, f32(disp_th))
     if int(m.sum()) < 500:
         print('Warning! mask contains too less points!', int(m.sum()))          # dense_ba.py:133-134
     return s.reshape(1), z[0], m[0], dm[0]

@@ -94,9 +94,10 @@ def warp_mask(x, flow, scale=1.0):
 
 
 # --------------------------------------------------------------------------- scale recovery
-def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th):
+def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th, depth_input=False):
     """Batched dense_ba.scale_from_disp_flow (dense_ba.py:88-176).  Returns scale (B), z (B,H,W),
-    mask, depth_mask (B,H,W) bool, sums (B,18) float64."""
+    mask, depth_mask (B,H,W) bool, sums (B,18) float64.  depth_input: ``disp`` holds a depth map (the ``depth=`` branch,
+    dense_ba.py:125-131; disp_th unused)."""
     require_cuda(disp, flow, pose7)
     dev = disp.device
     disp, flow = _f32c(disp), _f32c(flow)
@@ -104,7 +105,7 @@ def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th):
     pose7 = _f32c(pose7.detach())
     intr4 = _f32c(intr4.to(dev))
     baseline = _f32c(baseline.to(dev))
-    disp_th = _f32c(disp_th.to(dev))
+    disp_th = None if depth_input else _f32c(disp_th.to(dev))
     if edge is not None:
         edge = edge.to(dev).to(torch.uint8).contiguous()
     scale = torch.empty(B, dtype=torch.float32, device=dev)
@@ -113,9 +114,13 @@ def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th):
     dmask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     sums = torch.empty((B, _lib.SCALE_NSUM), dtype=torch.float64, device=dev)
     partial = torch.empty((B, _lib.SCALE_NBLK, _lib.SCALE_NSUM), dtype=torch.float64, device=dev)
-    check(lib().islam_scale_ls(ptr(disp), ptr(flow), ptr(pose7), ptr(intr4), ptr(baseline), ptr(edge), ptr(disp_th),
-                               ptr(scale), ptr(z), ptr(mask), ptr(dmask), ptr(sums), ptr(partial), B, H, W,
-                               stream_ptr(dev)))
+    if depth_input:
+        check(lib().islam_scale_ls_depth(ptr(disp), ptr(flow), ptr(pose7), ptr(intr4), ptr(baseline), ptr(edge), ptr(scale),
+                                         ptr(z), ptr(mask), ptr(dmask), ptr(sums), ptr(partial), B, H, W, stream_ptr(dev)))
+    else:
+        check(lib().islam_scale_ls(ptr(disp), ptr(flow), ptr(pose7), ptr(intr4), ptr(baseline), ptr(edge), ptr(disp_th),
+                                   ptr(scale), ptr(z), ptr(mask), ptr(dmask), ptr(sums), ptr(partial), B, H, W,
+                                   stream_ptr(dev)))
     return scale, z, mask.bool(), dmask.bool(), sums
 
 

@@ -1,17 +1,18 @@
 """Oracle (test infrastructure): stereo scale recovery.
 
 numpy restatement of reference dense_ba.py:88-176 (scale_from_disp_flow) with is_inside_image*
-(:65-72, inclusive upper bound -- SURVEY Q6), disparity branch only (depth=None as TartanVO.py:163
-calls it).  float32 arithmetic like the reference; the 1-DoF normal equations are accumulated in
+(:65-72, inclusive upper bound -- SURVEY Q6); ``depth`` selects the depth-input branch (:125-131), otherwise the
+disparity branch TartanVO.py:163 uses.  float32 arithmetic like the reference; the 1-DoF normal equations are accumulated in
 float64 (the HIP kernel reduces in a different order, tests use a tolerance)."""
 import numpy as np
 
 from . import lie
 
 
-def scale_from_disp_flow(disp, flow, motion7, fx, fy, cx, cy, baseline, edge_mask=None, disp_th=1.0):
+def scale_from_disp_flow(disp, flow, motion7, fx, fy, cx, cy, baseline, edge_mask=None, disp_th=1.0, depth=None):
     f32 = np.float32
-    disp = np.asarray(disp, f32).reshape(disp.shape[-2:])
+    if depth is None:
+        disp = np.asarray(disp, f32).reshape(disp.shape[-2:])
     flow = np.asarray(flow, f32)
     H, W = flow.shape[-2:]
     fx, fy, cx, cy, baseline = f32(fx), f32(fy), f32(cx), f32(cy), f32(baseline)
@@ -22,10 +23,16 @@ def scale_from_disp_flow(disp, flow, motion7, fx, fy, cx, cy, baseline, edge_mas
     mask = np.logical_and(np.logical_and(inside(fu, W), inside(fv, H)), flow_norm > 0)
     if edge_mask is not None:
         mask = np.logical_and(mask, np.asarray(edge_mask, bool))
-    disp_mask = np.logical_and(inside(-disp + u, W), disp >= f32(disp_th))
-    mask = np.logical_and(disp_mask, mask)
-    with np.errstate(divide='ignore', invalid='ignore'):
-        z = np.where(disp_mask, fx * baseline / disp, f32(0)).astype(f32)
+    if depth is None:
+        disp_mask = np.logical_and(inside(-disp + u, W), disp >= f32(disp_th))
+        mask = np.logical_and(disp_mask, mask)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            z = np.where(disp_mask, fx * baseline / disp, f32(0)).astype(f32)
+    else:                                   # dense_ba.py:125-131
+        depth = np.asarray(depth, f32).reshape(depth.shape[-2:])
+        disp_mask = np.logical_and(depth <= fx * baseline, depth > 0)      # the reference calls it depth_mask
+        mask = np.logical_and(disp_mask, mask)
+        z = np.where(disp_mask, depth, f32(0)).astype(f32)
     # back-projection P = z * K^-1 [u v 1]
     Px = z * ((u - cx) / fx)
     Py = z * ((v - cy) / fy)

@@ -113,6 +113,36 @@ def test_scale_ls(cuda, with_edge):
     assert sums[:, 17].cpu().numpy().tolist() == m.reshape(B, -1).sum(1).cpu().numpy().tolist()
 
 
+def test_scale_ls_depth_input(cuda):
+    """The depth= branch of scale_from_disp_flow (dense_ba.py:125-131) through islam_scale_ls_depth and the dense_ba surface."""
+    from islam_amd import dense_ba, ops
+    B, H, W = 2, 96, 128
+    rng = np.random.default_rng(11)
+    depth = rng.uniform(-1.0, 160.0, (B, 1, H, W)).astype(np.float32)       # negatives, zeros and beyond fx*baseline are masked
+    depth[:, :, :3, :3] = 0.0
+    flow = rng.normal(0, 3.0, (B, 2, H, W)).astype(np.float32)
+    q = rng.normal(size=(B, 4)) * 0.05
+    q[:, 3] = 1.0
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pose = np.concatenate([rng.normal(size=(B, 3)), q], 1).astype(np.float32)
+    intr = np.tile(np.array([[214.7, 214.7, 64.0, 48.0]], np.float32), (B, 1))
+    base = np.array([0.54, 0.25], np.float32)
+    t = lambda a: torch.tensor(a, device=cuda)
+    s, z, m, dm, sums = ops.scale_ls(t(depth), t(flow), t(pose), t(intr), t(base), None, None, depth_input=True)
+    for b in range(B):
+        so, zo, mo, dmo, (MM, Mw) = oscale.scale_from_disp_flow(None, flow[b], pose[b], *intr[b], base[b], None, depth=depth[b])
+        assert 0.1 < dmo.mean() < 0.95
+        assert (m[b].cpu().numpy() != mo).mean() < 1e-4
+        np.testing.assert_array_equal(dm[b].cpu().numpy(), dmo)
+        np.testing.assert_array_equal(z[b].cpu().numpy(), zo)
+        np.testing.assert_allclose(sums[b, 0].item(), MM, rtol=1e-4)
+        np.testing.assert_allclose(s[b].item(), so, rtol=2e-4, atol=1e-6)
+    s1, z1, m1, dm1 = dense_ba.scale_from_disp_flow(None, t(flow[0]), t(pose[0]), *[float(v) for v in intr[0]], float(base[0]),
+                                                    depth=t(depth[0, 0]))
+    np.testing.assert_allclose(s1.item(), s[0].item(), rtol=1e-6)
+    assert torch.equal(z1, z[0]) and torch.equal(dm1, dm[0])
+
+
 def test_scale_ls_empty_mask_is_nan(cuda):
     from islam_amd import ops
     B, H, W = 1, 16, 16

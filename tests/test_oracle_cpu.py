@@ -274,6 +274,11 @@ def test_scale_oracle_recovers_known_scale():
     s, zz, mask, dmask, _ = oscale.scale_from_disp_flow(disp[None], flow, direction, fx, fy, cx, cy, base, None, 1.0)
     assert mask.sum() > 500
     np.testing.assert_allclose(s, np.linalg.norm(motion[:3]), rtol=2e-3)
+    # depth-input branch (dense_ba.py:125-131): the same scene handed over as depth gives the same answer
+    s2, zz2, mask2, dmask2, _ = oscale.scale_from_disp_flow(None, flow, direction, fx, fy, cx, cy, base, None, depth=z)
+    np.testing.assert_allclose(s2, s, rtol=1e-4)
+    np.testing.assert_allclose(zz2[dmask2], z[dmask2].astype(np.float32))
+    assert dmask2.all()                                     # every depth is within (0, fx*baseline = 50]
 
 
 def test_reprojection_factor_oracle():
