@@ -73,7 +73,9 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
  * x: channels [xoff, xoff+Cin) of a (B,xtot,H,W) fp32 NCHW buffer; y: channels [coff, coff+Cout) of a (B,ytot,Ho,Wo) fp32
  * NCHW buffer, Ho = (H-1)/stride+1 -- the DenseNet-style torch.cat of PWCNet.py:237-292 without a copy; bias (Cout) or NULL.
  * wpacked: bf16 bits, [9][CoutP][CinP] (tap = 3r+s; CoutP = Cout rounded up to 64, CinP = Cin rounded up to 16, zero padded),
- * islam_conv3x3_packed_elems(Cin, Cout) elements.  stride 1 or 2, dilation 1..8. */
+ * islam_conv3x3_packed_elems(Cin, Cout) elements.  When Cin > 16 is not a multiple of 16 the LAST group of 16 channel slots holds
+ * channels Cin-16 .. Cin-1 (the kernel's last chunk reads the last 16 channels of x), with zeros in the slots of channels the
+ * previous group already holds; Cin <= 16 or a multiple of 16: slot c = channel c.  stride 1 or 2, dilation 1..16. */
 size_t islam_conv3x3_packed_elems(int Cin, int Cout);
 int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bias, float* y, int B, int Cin, int H, int W,
                        int Cout, int stride, int dilation, int xoff, int xtot, int coff, int ytot, float slope, void* stream);

@@ -70,15 +70,18 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
     float pre0[NPRE], pre1[NPRE];                            // fully unrolled below: stays in registers
     uint4 prew[(9 * TN * 2 + THREADS - 1) / THREADS];
     constexpr int NW = (9 * TN * 2 + THREADS - 1) / THREADS;
-    // the (pixel, channel pair) items a thread stages are the same for every chunk: decode them once
-    int goff[NPRE];                                          // offset inside the chunk's first channel plane, -1 = zero
-    int loff[NPRE];                                          // LDS element offset, -1 = no item
+    // The (pixel, channel pair) items a thread stages are the same for every chunk: decode them once.  Everything in the
+    // channel loop is branch-free: an item outside the image reads a valid address and is zeroed by a select, a thread
+    // without an item writes to a dummy LDS slot behind the two tiles.
+    int goff[NPRE];                                          // offset inside the chunk's first channel plane, -1 outside the image
+    int loff[NPRE];                                          // LDS element offset
     const size_t plane = (size_t)H * W;
+    const int dummy = (IH * IW + 9 * TN) * PS;               // 16 bytes of scratch behind lin and lw
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
         const int it = tid + k * THREADS;
         goff[k] = -1;
-        loff[k] = -1;
+        loff[k] = dummy;
         if (it < nitems) {
             const int cp = it / npix, pix = it - cp * npix;
             const int yy = pix / IW, xx = pix - yy * IW;
@@ -91,8 +94,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int it = tid + k * THREADS;                    // 16-byte vector index: ((tap*TN + n)*2 + half)
-        woff[k] = -1;
-        wlds[k] = 0;
+        woff[k] = 0;
+        wlds[k] = dummy;
         if (it < 9 * TN * 2) {
             const int half = it & 1, row = it >> 1, tap = row / TN, n = row - tap * TN;
             woff[k] = (tap * CoutP + n0 + n) * CinP + 8 * half;
@@ -100,58 +103,73 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
         }
     }
 
+    // Raw loads only: nothing here consumes a loaded value (the zero padding is applied when the chunk is staged), so the
+    // loads stay in flight behind the MFMAs of the current chunk.  A last chunk with fewer than 16 channels left reads the
+    // LAST 16 channels of the tensor instead (all exist); ops.pack_conv3x3_weight lays that chunk's weights out to match,
+    // with zeros for the channels the previous chunk has already covered.  Cin < 16: channels past the end are read from
+    // the last existing channel (finite data) and meet zero weights.
     auto fetch = [&](int c0) {
-        const float* xc = xb + (size_t)c0 * plane;
-        const int rem = Cin - c0;                            // channels left: pair cp is valid if 2cp < rem (second: 2cp+1 < rem)
+        const int rem = Cin - c0;
+        if (rem >= KC || Cin >= KC) {                        // (uniform)
+            const float* xc = xb + (size_t)min(c0, Cin - KC) * plane;
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            float v0 = 0.0f, v1 = 0.0f;
-            if (goff[k] >= 0) {
-                const int c = 2 * ((tid + k * THREADS) / npix);
-                const float* p = xc + goff[k];
-                if (c < rem) v0 = p[0];
-                if (c + 1 < rem) v1 = p[plane];
+            for (int k = 0; k < NPRE; ++k) {
+                const float* p = xc + max(goff[k], 0);       // outside the image: any valid address, zeroed when staged
+                pre0[k] = p[0];
+                pre1[k] = p[plane];
             }
-            pre0[k] = v0;
-            pre1[k] = v1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int c = 2 * ((tid + k * THREADS) / npix);
+                const float* p = xb + (goff[k] < 0 ? (size_t)0 : goff[k] - (size_t)c * plane);
+                pre0[k] = p[(size_t)min(c, rem - 1) * plane];
+                pre1[k] = p[(size_t)min(c + 1, rem - 1) * plane];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < NW; ++k)
-            prew[k] = woff[k] >= 0 ? *reinterpret_cast<const uint4*>(wp + (size_t)woff[k] + c0) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < NW; ++k) {
+            const uint4* q = reinterpret_cast<const uint4*>(wp + (size_t)woff[k] + c0);
+            prew[k] = make_uint4(q->x, q->y, q->z, q->w);
+        }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int k = 0; k < NPRE; ++k)
-            if (loff[k] >= 0) *reinterpret_cast<unsigned*>(lin + loff[k]) = pack_bf16(pre0[k], pre1[k]);
+            *reinterpret_cast<unsigned*>(lin + loff[k]) = pack_bf16(pre0[k], pre1[k]) & ~(unsigned)(goff[k] >> 31);   // zero padding
 #pragma unroll
-        for (int k = 0; k < NW; ++k)
-            if (woff[k] >= 0) *reinterpret_cast<uint4*>(lw + wlds[k]) = prew[k];
+        for (int k = 0; k < NW; ++k) *reinterpret_cast<uint4*>(lw + wlds[k]) = prew[k];
     };
 
     const int kg = lane >> 5, li = lane & 31;
+    // operand addresses of tap (r, s): B = halo pixel rows of this wave's two output rows, A = the tap's weight rows
+    const unsigned short* bbase = lin + ((size_t)(2 * wave * S) * IW + li * S) * PS + 8 * kg;
+    const unsigned short* abase = lw + (size_t)li * PS + 8 * kg;
+    auto load_tap = [&](int tap, bf16x8 (&bf)[2], bf16x8 (&af)[NT]) {
+        const int r = tap / 3, s = tap - r * 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(bbase + ((size_t)(p * S + r * D) * IW + s * D) * PS);
+#pragma unroll
+        for (int a = 0; a < NT; ++a) af[a] = *reinterpret_cast<const bf16x8*>(abase + ((size_t)tap * TN + a * 32) * PS);
+    };
     fetch(0);
     for (int c0 = 0; c0 < CinP; c0 += KC) {
         __syncthreads();                                     // the previous chunk's operand reads are done
         stage();
         __syncthreads();
         if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
+        // software pipeline over the nine taps: the operands of tap t+1 are requested before the MFMAs of tap t issue
+        bf16x8 bq[2][2], aq[2][NT];
+        load_tap(0, bq[0], aq[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int r = tap / 3, s = tap - r * 3;
-            bf16x8 bfrag[2], afrag[NT];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int yy = (2 * wave + p) * S + r * D, xx = li * S + s * D;
-                bfrag[p] = *reinterpret_cast<const bf16x8*>(lin + ((size_t)yy * IW + xx) * PS + 8 * kg);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-                afrag[a] = *reinterpret_cast<const bf16x8*>(lw + ((size_t)tap * TN + a * 32 + li) * PS + 8 * kg);
+            const int cur = tap & 1;
+            if (tap + 1 < 9) load_tap(tap + 1, bq[cur ^ 1], aq[cur ^ 1]);
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
-                    acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[a], bfrag[p], acc[a][p], 0, 0, 0);
+                    acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cur][a], bq[cur][p], acc[a][p], 0, 0, 0);
         }
     }
     // epilogue: D row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel x) = lane&31
@@ -201,7 +219,7 @@ int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bia
     hipStream_t s = (hipStream_t)stream;
     const int TN = Cout > 32 ? 64 : 32;
     const int nper = (IH * IW * (KC / 2) + THREADS - 1) / THREADS;
-    const size_t lds = ((size_t)IH * IW * PS + (size_t)9 * TN * PS) * sizeof(unsigned short);
+    const size_t lds = ((size_t)IH * IW * PS + (size_t)9 * TN * PS + 8) * sizeof(unsigned short);   // + 16-byte dummy slot
     dim3 grid(tiles_x * tiles_y, (Cout + TN - 1) / TN, B);
 #define ISLAM_CONV_LAUNCH(TN_, NPRE_)                                                                                          \
     do {                                                                                                                       \

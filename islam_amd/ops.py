@@ -126,12 +126,21 @@ def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th, depth_input=Fals
 
 # --------------------------------------------------------------------------- 3x3 convolution on the matrix cores
 def pack_conv3x3_weight(w):
-    """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages."""
+    """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages.
+    The kernel walks the input channels in chunks of 16; when Cin > 16 is not a multiple of 16 its last chunk reads the LAST
+    16 channels of the tensor (all exist), so that chunk's 16 weight slots hold channels Cin-16 .. Cin-1, zero for the ones
+    the previous chunk already covered (include/islam_hip.h, islam_conv3x3_mfma)."""
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     assert tuple(w.shape[2:]) == (3, 3)
     CinP, CoutP = (Cin + 15) // 16 * 16, (Cout + 63) // 64 * 64
     p = torch.zeros((9, CoutP, CinP), dtype=torch.bfloat16, device=w.device)
-    p[:, :Cout, :Cin] = w.detach().permute(2, 3, 0, 1).reshape(9, Cout, Cin).to(torch.bfloat16)
+    wt = w.detach().permute(2, 3, 0, 1).reshape(9, Cout, Cin).to(torch.bfloat16)
+    full = Cin // 16 * 16
+    if Cin == full or Cin < 16:
+        p[:, :Cout, :Cin] = wt
+    else:
+        p[:, :Cout, :full] = wt[:, :, :full]
+        p[:, :Cout, CinP - (Cin - full):] = wt[:, :, full:]
     assert p.numel() == lib().islam_conv3x3_packed_elems(Cin, Cout)
     return p.contiguous()
 

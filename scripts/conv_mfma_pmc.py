@@ -1,24 +1,31 @@
-"""Summarise the PMC pass of scripts/conv_mfma_pmc.sh: per (grid size) dispatch group of conv3x3_mfma_kernel, the average
-counter values and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 SIMDs * 256 CUs)
-(MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, 32 per v_mfma_f32_32x32x16_bf16 and SIMD)."""
-import csv, glob, os, sys, collections
+"""Summarise the PMC pass of scripts/conv_mfma_pmc.sh for conv3x3_mfma_kernel, grouped by (template instance, grid):
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs)   [MI355X_MICROARCH.md:
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles, 32 per v_mfma_f32_32x32x16_bf16 on its SIMD; the counter is summed over the chip],
+with the duration taken from the same pass (dispatch start/end timestamps of the counter rows), and the MFMA count
+= busy / 32 as a cross-check against 2*B*H*W*Cout*9*Cin / 32768 flops per instruction."""
+import csv, glob, os, re, sys, collections
 root = sys.argv[1]
 f = glob.glob(os.path.join(root, 'pmc', '**', '*counter_collection.csv'), recursive=True)
 if not f:
     sys.exit('no counter_collection.csv under %s' % root)
-rows = list(csv.DictReader(open(f[0])))
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in rows:
-    name = r.get('Kernel_Name', '')
+disp = {}
+for r in csv.DictReader(open(f[0])):
+    name = r['Kernel_Name']
     if 'conv3x3_mfma_kernel' not in name:
         continue
-    key = (name.split('(')[0][-40:], r.get('Grid_Size', ''), r.get('Dispatch_Id', ''))
-    acc[(key[0], key[1])][r['Counter_Name']].append(float(r['Counter_Value']))
-print('conv3x3_mfma_kernel dispatch groups (same template instance and grid): counters averaged over dispatches')
-print('%-42s %10s %6s %14s %14s %14s %9s' % ('kernel', 'grid', 'n', 'MFMA_BUSY_CYC', 'GUI_ACTIVE', 'MFMA_MOPS_BF16', 'MfmaUtil'))
-for (k, g), c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get('SQ_VALU_MFMA_BUSY_CYCLES', [0]))):
-    avg = {n: sum(v) / len(v) for n, v in c.items()}
-    busy, act = avg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0), avg.get('GRBM_GUI_ACTIVE', 0.0)
-    util = busy / (act * 4 * 256) if act else float('nan')
-    print('%-42s %10s %6d %14.0f %14.0f %14.0f %8.1f%%' % (k, g, len(c.get('SQ_VALU_MFMA_BUSY_CYCLES', [])), busy, act,
-                                                          avg.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.0), 100 * util))
+    m = re.search(r'conv3x3_mfma_kernel<(\d+), (\d+)>', name)
+    d = disp.setdefault(r['Dispatch_Id'], {'k': 'conv3x3_mfma<%s,%s>' % (m.group(1), m.group(2)) if m else 'conv3x3_mfma',
+                                           'grid': int(r['Grid_Size']),
+                                           'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
+    d[r['Counter_Name']] = float(r['Counter_Value'])
+groups = collections.defaultdict(list)
+for d in disp.values():
+    groups[(d['k'], d['grid'])].append(d)
+print('%-24s %9s %5s %10s %14s %12s %9s' % ('kernel', 'grid', 'n', 'avg_us', 'MFMA_BUSY_CYC', 'MFMAs', 'MfmaUtil'))
+tb = tt = 0.0
+for (k, g), ds in sorted(groups.items(), key=lambda kv: -sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) for d in kv[1])):
+    busy = sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for d in ds) / len(ds)
+    ns = sum(d['ns'] for d in ds) / len(ds)
+    tb += busy * len(ds); tt += ns * len(ds)
+    print('%-24s %9d %5d %10.1f %14.0f %12.0f %8.1f%%' % (k, g, len(ds), ns / 1e3, busy, busy / 32, 100 * busy / (ns * 2.4 * 1024)))
+print('all conv3x3_mfma dispatches: MfmaUtil %.1f%% (time-weighted)' % (100 * tb / (tt * 2.4 * 1024)))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Where conv3x3_mfma_kernel's wave cycles go (SQ counters, own PMC pass).  bash scripts/conv_pmc_detail.sh
+OUT=$GRAFT_REPO_ROOT/gpurun_out/conv_pmc_detail
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
+    --kernel-trace --output-format csv -d $OUT/pmc -o conv -- python3 $GRAFT_REPO_ROOT/scripts/conv_one.py > $OUT/pmc.log 2>&1
+tail -1 $OUT/pmc.log
+python3 - <<PY
+import csv, glob, collections
+f = glob.glob('$OUT/pmc/**/*counter_collection.csv', recursive=True)[0]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if 'conv3x3_mfma_kernel' in r['Kernel_Name']:
+        acc[r['Counter_Name']].append(float(r['Counter_Value']))
+wc = sum(acc['SQ_WAVE_CYCLES']) / len(acc['SQ_WAVE_CYCLES'])
+for k, v in sorted(acc.items()):
+    a = sum(v) / len(v)
+    print('%-24s %16.0f  %6.1f%% of SQ_WAVE_CYCLES' % (k, a, 100 * a / wc))
+PY
