@@ -55,10 +55,16 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_inp
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
                  device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
-                 host_glue=False):
+                 host_glue=False, miopen_find=False):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
+        # miopen_find: let MIOpen time its candidate kernels for every convolution shape the first time it is seen
+        # (torch.backends.cudnn.benchmark, process-wide) instead of trusting its heuristics: the first forward + backward take
+        # ~1-2 minutes longer, the stereo net then runs ~25 % faster (the heuristics pick split-K kernels that need
+        # zero-fill and cast passes around them)
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
         self.device_id = device_id
         self.correct_scale = correct_scale
         self.use_kitti_coord = use_kitti_coord

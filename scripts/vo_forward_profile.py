@@ -7,6 +7,9 @@ from islam_amd import synthetic
 from islam_amd.TartanVO import TartanVO
 dev = torch.device('cuda:0')
 B = 8
+if os.environ.get('BENCHMARK') == '1':          # MIOpen exhaustive find instead of its heuristics / find-db
+    torch.backends.cudnn.benchmark = True
+TOP = int(os.environ.get('TOP', 45))
 torch.manual_seed(0)
 vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16)
 with torch.no_grad():
@@ -30,5 +33,5 @@ for e in prof.key_averages():
         tot += t / reps / 1e3
 rows.sort(reverse=True)
 print('total GPU ms per forward: %.2f' % tot)
-for t, n, k in rows[:45]:
+for t, n, k in rows[:TOP]:
     print('%7.3f ms  n=%-4d %s' % (t, n, k[:110]))
