@@ -55,7 +55,7 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_inp
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
                  device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
-                 host_glue=False, miopen_find=False):
+                 host_glue=False, miopen_find=False, pose_channels_last=False):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -80,6 +80,8 @@ class TartanVO(nn.Module):
             if name is not None and name != '':
                 self.load_model(part, name)
         self.vonet = self.vonet.cuda(self.device_id)
+        if pose_channels_last:
+            self.vonet.set_pose_channels_last(True)
 
     def load_model(self, model, modelname):
         """TartanVO.py:49-87: suffix matching of state-dict keys with a size check."""

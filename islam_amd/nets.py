@@ -437,7 +437,7 @@ class VOFlowRes(nn.Module):
 
     def forward(self, x, extrinsic=None):
         x = self.feat_net(x)
-        x = x.view(x.shape[0], -1)
+        x = x.reshape(x.shape[0], -1)          # (= .view for the reference's NCHW activations; channels_last ones are re-laid out)
         return torch.cat((self.voflow_trans(x), self.voflow_rot(x)), 1)
 
 
@@ -458,6 +458,14 @@ class VONet(nn.Module):
         self.frozen_dtype = None        # stereo net (77 % of the FLOPs): bf16 execution copy on MIOpen
         self.flow_dtype = None          # flow net: not None -> PWCDCNet.forward_mfma (HIP implicit-GEMM convolutions)
         self._exec = {}
+        self.pose_channels_last = False
+
+    def set_pose_channels_last(self, on=True):
+        """Run the trainable pose head on channels_last (NHWC) fp32 tensors: MIOpen's fp32 implicit-GEMM kernels are NHWC
+        and otherwise wrap every convolution (forward, data- and weight-gradient) in layout-transposing launches
+        (~270 per step).  Same parameters, same state dict, same arithmetic up to MIOpen's kernel choice."""
+        self.pose_channels_last = bool(on)
+        self.flowPoseNet.to(memory_format=torch.channels_last if on else torch.contiguous_format)
 
     def set_frozen_dtype(self, dtype, flow_dtype=None):
         self.frozen_dtype, self.flow_dtype = dtype, flow_dtype
@@ -484,7 +492,10 @@ class VONet(nn.Module):
 
     def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic, frozen=None):
         flow, disp = frozen if frozen is not None else self.frozen_forward(img0, img1, img0_norm, img0_r_norm)
-        pose = self.flowPoseNet(torch.cat([flow, intrinsic], 1))
+        x = torch.cat([flow, intrinsic], 1)
+        if self.pose_channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        pose = self.flowPoseNet(x)
         return flow, disp, pose
 
 

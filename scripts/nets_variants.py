@@ -13,10 +13,10 @@ def timeit(fn, reps=8, warm=3):
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
 
-for bench in (False,):
+for bench in ((False, True) if os.environ.get('BOTH') else (False,)):
     torch.backends.cudnn.benchmark = bench
     for cl in (True,):
-        for dt in (None, torch.bfloat16, torch.float16):
+        for dt in (None, torch.bfloat16):
             st = nets.StereoNet7().to(dev).train()
             pw = nets.PWCDCNet().to(dev).train()
             a, b = x2, x1

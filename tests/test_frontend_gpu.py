@@ -226,3 +226,36 @@ def test_flow_net_on_the_matrix_core_convolution(cuda):
         got2, _ = net.forward_mfma(x)
     assert float((ref2[0] - got2[0]).abs().max()) < 3e-2 * float(ref2[0].abs().max()) + 1e-3
     assert float((ref2[0] - ref[0]).abs().max()) > 1e-3 * float(ref[0].abs().max())
+
+
+def test_pose_head_channels_last_is_the_same_function(cuda):
+    """VONet.set_pose_channels_last: same parameters, same pose and same gradients as the NCHW pose head (MIOpen may pick
+    other kernels, hence a tolerance)."""
+    from islam_amd import nets
+    torch.manual_seed(5)
+    vn = nets.VONet(fix_parts=('flow', 'stereo'))
+    head = vn.flowPoseNet.to(cuda)
+    B = 2
+    flow = torch.randn(B, 2, 112, 160, device=cuda)
+    intr = torch.rand(B, 2, 112, 160, device=cuda)
+    frozen = (flow, torch.zeros(B, 1, 112, 160, device=cuda))
+
+    def run():
+        for p in head.parameters():
+            p.grad = None
+        _, _, pose = vn(None, None, None, None, intr, frozen=frozen)
+        (pose * torch.arange(1, 7, device=cuda)).sum().backward()
+        return pose.detach().clone(), [p.grad.detach().clone() for p in head.parameters()]
+    p0, g0 = run()
+    keys0 = list(head.state_dict().keys())
+    vn.set_pose_channels_last(True)
+    p1, g1 = run()
+    assert list(head.state_dict().keys()) == keys0
+    assert any(p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() for p in head.parameters())
+    torch.testing.assert_close(p1, p0, rtol=1e-3, atol=1e-5)
+    for a, b in zip(g1, g0):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=2e-3 * float(b.abs().max()) + 1e-8)   # fp32 sums in another order
+    vn.set_pose_channels_last(False)
+    p2, _ = run()
+    torch.testing.assert_close(p2, p0, rtol=1e-3, atol=1e-5)
