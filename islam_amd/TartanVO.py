@@ -55,7 +55,7 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_inp
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
                  device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
-                 host_glue=False, miopen_find=False, pose_channels_last=False):
+                 host_glue=False, miopen_find=False, pose_channels_last=False, graph_frozen=False):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -82,6 +82,8 @@ class TartanVO(nn.Module):
         self.vonet = self.vonet.cuda(self.device_id)
         if pose_channels_last:
             self.vonet.set_pose_channels_last(True)
+        if graph_frozen:        # the frozen flow + disparity forward replays from a HIP graph (VONet.set_graph_frozen)
+            self.vonet.set_graph_frozen(True)
 
     def load_model(self, model, modelname):
         """TartanVO.py:49-87: suffix matching of state-dict keys with a size check."""
@@ -99,6 +101,8 @@ class TartanVO(nn.Module):
                 print('! [load_model] Key {} in model but not in {}!'.format(kk, modelname))
         own.update(picked)
         model.load_state_dict(own)
+        if hasattr(self, 'vonet'):
+            self.vonet.reset_graphs()          # captured graphs hold the old frozen weights
         return model
 
     def prefetch(self, sample, is_train=True):

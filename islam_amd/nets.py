@@ -458,6 +458,8 @@ class VONet(nn.Module):
         self.frozen_dtype = None        # stereo net (77 % of the FLOPs): bf16 execution copy on MIOpen
         self.flow_dtype = None          # flow net: not None -> PWCDCNet.forward_mfma (HIP implicit-GEMM convolutions)
         self._exec = {}
+        self._graphs = {}
+        self.graph_frozen = False
         self.pose_channels_last = False
 
     def set_pose_channels_last(self, on=True):
@@ -470,6 +472,7 @@ class VONet(nn.Module):
     def set_frozen_dtype(self, dtype, flow_dtype=None):
         self.frozen_dtype, self.flow_dtype = dtype, flow_dtype
         self._exec = {}
+        self._graphs = {}
 
     def _run_frozen(self, name, master, dtype, x):
         if dtype is None or any(p.requires_grad for p in master.parameters()):
@@ -482,9 +485,45 @@ class VONet(nn.Module):
             ex = self._exec[name] = _HalfExec(master, dtype)
         return ex.module()(x.to(dtype).contiguous(memory_format=torch.channels_last))
 
+    def set_graph_frozen(self, on=True):
+        """Replay the frozen flow + disparity forward (~750 launches) from a captured HIP graph instead of enqueueing it
+        launch by launch: same kernels and results, the host is free during the replay.  Graphs are keyed by input shape and
+        train / eval mode and dropped by reset_graphs() (call it after changing frozen weights: the graph holds the bf16
+        execution copies and packed weights it was captured with)."""
+        self.graph_frozen = bool(on)
+        self.reset_graphs()
+
+    def reset_graphs(self):
+        self._graphs = {}
+
+    def _frozen_graphed(self, imgs):
+        key = (tuple(imgs[0].shape), imgs[0].device, self.stereoNet.training, self.flowNet.training, self.frozen_dtype, self.flow_dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            static_in = [t.detach().clone() for t in imgs]
+            with torch.no_grad():
+                for _ in range(2):                      # MIOpen's kernel search, lazy initialisation: outside the capture
+                    self._frozen_eager(*static_in)
+            torch.cuda.synchronize(imgs[0].device)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                static_out = self._frozen_eager(*static_in)
+            st = self._graphs[key] = (g, static_in, static_out)
+        g, static_in, static_out = st
+        for d, t in zip(static_in, imgs):
+            d.copy_(t, non_blocking=True)
+        g.replay()
+        return tuple(t.clone() for t in static_out)
+
     def frozen_forward(self, img0, img1, img0_norm, img0_r_norm):
         """Flow + disparity (Network/VONet.py:28-34).  With both nets frozen this part carries no autograd state, so
         TartanVO.prefetch can run it for the NEXT batch on a side stream while the current batch is optimised."""
+        if getattr(self, 'graph_frozen', False) and self.frozen_dtype is not None and self.flow_dtype is not None and \
+                not any(p.requires_grad for n in (self.flowNet, self.stereoNet) for p in n.parameters()):
+            return self._frozen_graphed((img0, img1, img0_norm, img0_r_norm))
+        return self._frozen_eager(img0, img1, img0_norm, img0_r_norm)
+
+    def _frozen_eager(self, img0, img1, img0_norm, img0_r_norm):
         flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0]
         disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1))[0]
         flow, disp = flow.float().contiguous(), disp.float().contiguous()

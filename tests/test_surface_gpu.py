@@ -284,3 +284,48 @@ def test_prefetched_frozen_forward_is_identical(cuda):
     for p in vo.vonet.flowNet.parameters():
         p.requires_grad_(True)
     assert vo.prefetch(a) is False
+
+
+def test_graph_replay_of_the_frozen_forward(cuda):
+    """VONet.set_graph_frozen: the frozen flow + disparity forward replayed from a captured HIP graph gives what the
+    launch-by-launch forward gives -- for new inputs, from a side stream (prefetch), and train-mode BatchNorm statistics
+    keep being updated by the replays."""
+    from islam_amd.TartanVO import TartanVO
+    torch.manual_seed(0)
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, frozen_dtype=torch.bfloat16,
+                  flow_dtype=torch.bfloat16)
+    with torch.no_grad():
+        vo.vonet.stereoNet.conv_c13.weight.zero_()
+        vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+    a, b = synthetic.stereo_batch(2, seed=3), synthetic.stereo_batch(2, seed=4)
+    imgs = lambda s: [s[k].to(cuda) for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm')]
+    vo.vonet.eval()
+    with torch.no_grad():
+        ref = [tuple(t.clone() for t in vo.vonet.frozen_forward(*imgs(s))) for s in (a, b)]
+    vo.vonet.set_graph_frozen(True)
+    with torch.no_grad():
+        got_a = vo.vonet.frozen_forward(*imgs(a))           # captures
+        got_b = vo.vonet.frozen_forward(*imgs(b))           # replays with other inputs
+        got_a2 = vo.vonet.frozen_forward(*imgs(a))
+    assert len(vo.vonet._graphs) == 1
+    tol = dict(rtol=2e-2, atol=2e-2)                        # bf16 nets; MIOpen's kernels are not bit-reproducible run to run
+    for g, r in ((got_a, ref[0]), (got_b, ref[1]), (got_a2, ref[0])):
+        torch.testing.assert_close(g[0], r[0], **tol)
+        torch.testing.assert_close(g[1], r[1], **tol)
+    assert float((ref[0][0] - ref[1][0]).abs().max()) > 0.05         # the two batches do differ
+    assert got_a[0].data_ptr() != got_a2[0].data_ptr()               # results are copies, not the graph's static buffers
+    # through prefetch on the side stream, and the whole forward
+    ref_motion = vo(a, is_train=False)['motion'].tensor().clone()
+    assert vo.prefetch(a, is_train=False)
+    torch.testing.assert_close(vo(a, is_train=False)['motion'].tensor(), ref_motion, rtol=1e-3, atol=1e-4)
+    # train mode is a different graph; its replays update the running statistics of the master's BatchNorm layers
+    bn = vo.vonet.stereoNet.feature_extraction.firstconv[0][1]
+    vo.vonet.train()
+    with torch.no_grad():
+        vo.vonet.frozen_forward(*imgs(a))
+        before = bn.running_mean.clone()
+        vo.vonet.frozen_forward(*imgs(b))
+    assert len(vo.vonet._graphs) == 2
+    assert float((bn.running_mean - before).abs().max()) > 0
+    vo.vonet.reset_graphs()
+    assert len(vo.vonet._graphs) == 0
