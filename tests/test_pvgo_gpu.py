@@ -60,7 +60,11 @@ def test_linearize_and_normal_equations(cuda, F):
 
 @pytest.mark.parametrize('N,seg', [(1, (0, 0)), (2, (0, 0)), (9, (0, 0)), (40, (0, 0)), (41, (0, 0)), (64, (4, 4)),
                                    (65, (7, 4)), (100, (9, 0)), (257, (0, 0)), (1000, (0, 0)), (1000, (4, 4)),
-                                   (5001, (0, 0)), (5001, (19, 15)), (5003, (24, 6))])
+                                   (5001, (0, 0)), (5001, (19, 15)), (5003, (24, 6)),
+                                   # twisted (two-wavefront) elimination: roots of 2..7 nodes and above, pinned odd / even segment
+                                   # lengths, a tree of six levels, and a chain too long for it (one-sided fallback)
+                                   (13, (0, 0)), (23, (0, 0)), (47, (0, 0)), (57, (5, 5)), (64, (7, 7)), (500, (6, 5)),
+                                   (5001, (7, 5)), (30011, (0, 0)), (300007, (0, 0))])
 def test_block_tridiagonal_solver(cuda, N, seg):
     """Partitioned block-Cholesky vs a dense/banded CPU solve on a random SPD block-tridiagonal system."""
     from islam_amd import ops
