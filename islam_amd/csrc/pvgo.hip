@@ -22,9 +22,9 @@
 //      lane owns one column of the augmented 9 x 28 matrix [S | U | F^T | g]; pivots are broadcast
 //      with v_readlane, the 19x19 Schur update runs over all 64 lanes from an LDS copy,
 //   4. apply the step on a trial copy, re-evaluate the loss and the trust-region ratio per link AND
-//      linearise at the trial point for the next step in the same launch (trial_lin_kernel); the
-//      workgroup that draws the last ticket takes the LM / TrustRegion / StopOnPlateau decision and
-//      writes a 128-byte verdict to pinned host memory,
+//      linearise at the trial point for the next step in the same launch (trial_lin_kernel); one
+//      extra workgroup waits for all partial sums, takes the LM / TrustRegion / StopOnPlateau decision
+//      and writes a 128-byte verdict to pinned host memory,
 //   5. the host enqueues one iteration ahead (every kernel is gated on an epoch the deciding lane
 //      bumps on any verdict other than "accepted, continue") and only polls the verdicts.
 // linearize_kernel / build_normal_kernel / trial_kernel / bt_top_kernel / bt_backsub_kernel are the
@@ -1602,9 +1602,11 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
 // The LM loop's trial step and the NEXT step's linearisation in one launch (the trial point is the next linearisation
 // point whenever the trial is accepted -- the common case; after a reject the output buffer is simply overwritten).
 // Wave 0: one lane per link (lane 0 = halo link shared with the previous workgroup): retraction, residuals at the trial
-// point, loss / trust-region partials, ticket.  The decision is taken as soon as the last partial is in -- by wave 1 of
-// the workgroup that drew the last ticket, concurrently with wave 0's Jacobian work -- so the host learns it while the
-// linearisation is still being written.  Then as linbuild_kernel: Jacobians, weighted pieces, node blocks, coalesced copy.
+// point, partial sum of the loss.  Wave 1, concurrently: the trust-region term (J D)^T (2R + J D) of the same links (it
+// needs the step and the OLD linearisation only); after the workgroup barrier its lane 0 publishes both partial sums and
+// bumps the ticket without waiting for it.  The decision is taken by one extra workgroup that polls the ticket -- on
+// nobody's critical path -- so the host learns the verdict while the linearisation is still being written.
+// Then as linbuild_kernel: Jacobians, weighted pieces, node blocks, coalesced copy.
 __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     const double* __restrict__ nodes, const double* __restrict__ vels, const double* __restrict__ dx,
     const double* __restrict__ poses, const double* __restrict__ drots, const double* __restrict__ dtrans,
@@ -1614,11 +1616,40 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     ReprojDev rp, LinWeights W, double* __restrict__ lin_o, double* __restrict__ Hd_o, double* __restrict__ Ho_o,
     double* __restrict__ rhs_o, Gate gate) {
     __shared__ double sl[64][LB_REC];
-    __shared__ int s_last;
+    __shared__ double s_sq;
     extern __shared__ __attribute__((aligned(16))) double lb_out[];
     const int M = N - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    if (blockIdx.x == gridDim.x - 1) {
+        // The deciding workgroup (one extra workgroup behind the grid, dispatched last): waits until every workgroup has
+        // published its partial sums (ticket == nlb), adds them in index order (deterministic) and takes the LM decision --
+        // on nobody's critical path: the other workgroups go straight on to the next linearisation.
+        if (wave != 0 || gate_closed(gate)) return;
+        PROBE_WALL(lane == 0, 420);
+        __builtin_amdgcn_s_sleep(64);                  // the sums cannot be there before the residuals are evaluated (~2 us)
+        if (lane == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nlb) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { atomicOr(flags, 2); break; }     // never observed; a logic error must not hang the GPU
+            }
+        }
+        asm volatile("" ::: "memory");                 // the partial sums are read with ld_coherent after this point
+        double ssum = 0.0, qsum = 0.0;
+        for (int i = lane; i < nlb; i += 64) {
+            ssum += ld_coherent(&part[2 * i]);
+            qsum += ld_coherent(&part[2 * i + 1]);
+        }
+        ssum = wave_sum(ssum);
+        qsum = wave_sum(qsum);
+        if (lane == 0) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lm_control(ssum, qsum, st, flags, tr, report, seq);
+        }
+        PROBE_WALL(lane == 0, 421);
+        return;
+    }
     const int blk = xcd_index(blockIdx.x, nlb);
     if (blk < 0 || gate_closed(gate)) return;
     const int L = blk * LB_NODES - 1 + lane;
@@ -1632,8 +1663,9 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     V3<double> vi{}, vj{};
     LinkRes r{};
     double dt = 0.0;
-    if (wave == 0) {
-        double sq = 0.0, qd = 0.0;
+    double qd = 0.0;
+    if (wave == 0) {                                   // the trial point and its residuals
+        double sq = 0.0;
         if (valid) {
             const double* di = dx + (size_t)L * 9;
             const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
@@ -1649,59 +1681,54 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
             PROBE_WALL(pr, 402);
             if (owns) {
                 sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
-                // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
-                double rec[LIN_C];
-#pragma unroll
-                for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + L];
-                const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
-                const V3<double> ddr = drj - dri, ddp = dpj - dpi;
-                const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dt * dvi;
-                const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
-                    R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
-                qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
-                     dot(j4, 2.0 * R4 + j4);
-                if (red_lin) {       // reprojection rows: u^T (2 b + S u), u = Ad(C^-1 X_i^-1)(d_j - d_i)
-                    sq += red_trial[(size_t)L * RP_REC + 27];
-                    double u[RP_NSUM];
-#pragma unroll
-                    for (int i = 0; i < RP_NSUM; ++i) u[i] = red_lin[(size_t)L * RP_REC + i];
-                    M3<double> Ra, Ta;
-                    reproj_adjoint(rp, se3_load(nodes + 7 * L), Ra, Ta);
-                    const V3<double> ua = Ra * ddr + Ta * ddp, ub = Ra * ddp;
-                    const V3<double> sa = sym_from(u, 0, 0) * ua + sym_from(u, 0, 3) * ub;
-                    const V3<double> sb = tmul(sym_from(u, 0, 3), ua) + sym_from(u, 3, 3) * ub;
-                    const V3<double> ba{u[21], u[22], u[23]}, bb{u[24], u[25], u[26]};
-                    qd += dot(ua, 2.0 * ba + sa) + dot(ub, 2.0 * bb + sb);
-                }
+                if (red_lin) sq += red_trial[(size_t)L * RP_REC + 27];
             }
         }
         PROBE_WALL(pr, 403);
         sq = wave_sum(sq);
-        qd = wave_sum(qd);
-        if (lane == 0) {
-            // write-through stores + completion wait instead of a release fence (an agent-scope release walks the L2)
-            st_coherent(&part[2 * blk], sq);
-            st_coherent(&part[2 * blk + 1], qd);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_last = (atomicAdd(ticket, 1u) == (unsigned)(nlb - 1)) ? 1 : 0;
+        if (lane == 0) s_sq = sq;
+    } else if (wave == 1) {
+        // concurrently: -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update);
+        // it needs the step and the old linearisation only, not the trial residuals
+        if (owns) {
+            const double* di = dx + (size_t)L * 9;
+            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+            const double dtl = dts[L];
+            double rec[LIN_C];
+#pragma unroll
+            for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + L];
+            const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+            const V3<double> ddr = drj - dri, ddp = dpj - dpi;
+            const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
+            const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+                R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+            qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+                 dot(j4, 2.0 * R4 + j4);
+            if (red_lin) {       // reprojection rows: u^T (2 b + S u), u = Ad(C^-1 X_i^-1)(d_j - d_i)
+                double u[RP_NSUM];
+#pragma unroll
+                for (int i = 0; i < RP_NSUM; ++i) u[i] = red_lin[(size_t)L * RP_REC + i];
+                M3<double> Ra, Ta;
+                reproj_adjoint(rp, se3_load(nodes + 7 * L), Ra, Ta);
+                const V3<double> ua = Ra * ddr + Ta * ddp, ub = Ra * ddp;
+                const V3<double> sa = sym_from(u, 0, 0) * ua + sym_from(u, 0, 3) * ub;
+                const V3<double> sb = tmul(sym_from(u, 0, 3), ua) + sym_from(u, 3, 3) * ub;
+                const V3<double> ba{u[21], u[22], u[23]}, bb{u[24], u[25], u[26]};
+                qd += dot(ua, 2.0 * ba + sa) + dot(ub, 2.0 * bb + sb);
+            }
         }
+        qd = wave_sum(qd);
     }
     PROBE_WALL(pr, 404);
     __syncthreads();
-    PROBE_WALL(wave == 1 && lane == 0 && s_last, 420);
-    if (wave == 1 && s_last) {                                        // the decision, concurrently with wave 0 below
-        double ssum = 0.0, qsum = 0.0;
-        for (int i = lane; i < nlb; i += 64) {
-            ssum += ld_coherent(&part[2 * i]);
-            qsum += ld_coherent(&part[2 * i + 1]);
-        }
-        ssum = wave_sum(ssum);
-        qsum = wave_sum(qsum);
-        if (lane == 0) {
-            *ticket = 0u;
-            lm_control(ssum, qsum, st, flags, tr, report, seq);
-        }
-        PROBE_WALL(lane == 0, 421);
+    if (wave == 1 && lane == 0) {
+        // publish: write-through stores + completion wait instead of a release fence (an agent-scope release walks the
+        // L2), then the ticket -- fire and forget, nobody in this workgroup waits for it
+        st_coherent(&part[2 * blk], s_sq);
+        st_coherent(&part[2 * blk + 1], qd);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PROBE_WALL(pr, 405);
     if (wave == 0 && valid) {
@@ -2531,7 +2558,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
         // the next linearisation if the trial is accepted
         if (reproj) enqueue_reproj_reduce(c.cur_n, w.dx, M, rp, RED[1 - c.pb], s, gate);
         double* rep_slot = report + 16 * ((long long)seq & 1);
-        hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses, drots,
+        hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb) + 1), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses, drots,
                            dtrans, dvels, dts, LIN[c.pb], N, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot, seq,
                            reproj ? RED[c.pb] : (const double*)nullptr, reproj ? RED[1 - c.pb] : (const double*)nullptr, rp, W,
                            LIN[1 - c.pb], HD[1 - c.pb], HO[1 - c.pb], RH[1 - c.pb], gate);
