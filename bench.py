@@ -172,8 +172,8 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)       # one step = one full run_pvgo LM loop (~0.8 ms on one MI355X)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--frames', type=int, default=N_FRAMES)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-frontend', action='store_true')
