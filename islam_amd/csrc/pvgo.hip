@@ -926,6 +926,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
     double* Xa = lds;
     double* Xb = lds + 19 * XS;
     double* Tn = lds + 2 * 19 * XS;
+    [[maybe_unused]] const bool prb = lane == 0 && p == 1 && !src.level0 && src.Pprev > 500;      // probe build: level 1, segment 1
+    [[maybe_unused]] const int pbase = REV ? 470 : 440;
+    PROBE_WALL(prb, pbase);
     const double damping = src.state ? src.state[2] : src.damping_override;
     const int tr = lane % 9, tg = lane / 9;
     const bool t_on = tg < 7;
@@ -963,6 +966,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
     // cannot change while this kernel runs (it is bumped by the previous iteration's trial kernel), so both wavefronts of
     // the workgroup take the same branch.
     if (gate_closed(gate)) return;
+    PROBE_WALL(prb, pbase + 1);
     if (REV) combine_cols_rev(LS, src, first, lane, damping, raw, mcol);
     else combine_cols(LS, src, first, n, lane, damping, raw, mcol);
     if (lane >= 18 && lane < 27) {
@@ -974,6 +978,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
     for (int t = 0; t < count; ++t) {
         const int c = REV ? first - t : first + t;
         const bool last = (t == count - 1);
+        PROBE_WALL(prb, pbase + 2 + 5 * t);
         const int nxt = REV ? c - 1 : ((last && last_next >= 0) ? last_next : c + 1);
         issue_cols(LS, level0, clampi(nxt), raw);
         __builtin_amdgcn_sched_barrier(0);
@@ -981,13 +986,14 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const double piv = bcast(mcol[i], i);
-            bad |= !(piv > 0.0);
+            bad |= !(piv > 0.0);                 // off the critical path; a non-positive pivot only poisons this solve
             const double ip = rcp_nr(piv);
             ipv[i] = ip;
             const double f = mcol[i] * ip;
 #pragma unroll
             for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
         }
+        PROBE_WALL(prb, pbase + 3 + 5 * t);
         if (lane >= 9 && lane < 28) {
             double* xa = Xa + (lane - 9) * XS;
             double* xb = Xb + (lane - 9) * XS;
@@ -1014,6 +1020,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             accL += dot9r(ca, cbv);
         }
         lds_sync();
+        PROBE_WALL(prb, pbase + 4 + 5 * t);
         __builtin_amdgcn_sched_barrier(0);
         // the next node's own columns; wave B never forms the middle node's (wave A does: its diagonal is damped once)
         const bool want_next = REV ? !last : (nxt >= 0 && nxt < n && (!last || last_next >= 0));
@@ -1031,6 +1038,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
 #pragma unroll
             for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
         }
+        PROBE_WALL(prb, pbase + 5 + 5 * t);
         if (!last) {
             double tcol[9];
             ldcol(Tn + tn_off, tcol);
@@ -1072,6 +1080,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             }
         }
         lds_sync();
+        PROBE_WALL(prb, pbase + 6 + 5 * t);
     }
     if (!REV) {
         if (has_spike) {
@@ -1092,6 +1101,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
         }
         __syncthreads();
     }
+    PROBE_WALL(prb, pbase + 29);
     if (bad && lane == 0) atomicOr(flags, 1);
 }
 
