@@ -14,9 +14,11 @@
 //   1. linearise per link (one lane per link, everything in registers),
 //   2. build the 9x9 diagonal / coupling blocks per node (gather from the two adjacent links,
 //      no atomics, deterministic),
-//   3. factor with a partitioned ("spike") block LDL^T: the chain is cut into segments, one
-//      wavefront eliminates each segment's interior onto its two separator nodes (bt_eliminate_kernel,
-//      one launch per level), the separators form a ~6x smaller chain that is reduced the same way;
+//   3. factor with a partitioned ("spike") block LDL^T: the chain is cut into segments, each
+//      segment's interior is eliminated onto its two separator nodes -- by two wavefronts that start
+//      at the two ends and meet at the middle node (bt_eliminate_tw_kernel, "twisted"; the one-sided
+//      bt_eliminate_kernel serves the sharded entry points) -- one launch per level; the separators
+//      form a ~6x smaller chain that is reduced the same way;
 //      the root solve and the whole back-substitution run in ONE launch (bt_downsweep_kernel) with
 //      per-segment ready words and write-through hand-off between levels.  Inside a wavefront one
 //      lane owns one column of the augmented 9 x 28 matrix [S | U | F^T | g]; pivots are broadcast
