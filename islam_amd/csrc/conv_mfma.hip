@@ -33,12 +33,13 @@ constexpr int TW = 32, TH = 8, KC = 16, PS = 24;     // PS: bf16 elements per LD
 constexpr int THREADS = 256;
 constexpr int MAX_IN_PER_THREAD = 48;                // halo-tile (pixel, channel-pair) items a thread prefetches per chunk (large dilations / stride 2)
 
+// two floats -> packed bf16 pair (a in the low half), round-to-nearest-even as torch's .to(bfloat16): one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    // round-to-nearest-even, as torch's .to(bfloat16)
-    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r);
 }
 
 template <int TN, int NPRE>
