@@ -29,7 +29,7 @@ def _is_canonical_chain(links, n_nodes):
 
 def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtrans, imu_dvels,
              device='cuda:0', radius=1e4, loss_weight=(1, 1, 1, 1), reproj=None, target='vo', seg_len=(0, 0),
-             return_info=False):
+             return_info=False, general_solver='auto'):
     dev = torch.device(device)
     if dev.type != 'cuda':
         raise RuntimeError("islam_amd.run_pvgo runs on the MI355X only (device=%r); there is no CPU fallback" % (device,))
@@ -58,10 +58,20 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
         prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
         res, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts64, prm, reproj=rp)
     else:                # loop closures / arbitrary links: dense formulation on the device (islam_amd/pvgo_dense.py)
-        from .pvgo_dense import run_lm_dense
-        if N > 12000:
-            raise UnsupportedGraphError('dense general-topology path is sized for N <= 12000 nodes, (9N)^2 doubles (got %d)' % N)
-        nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
+        from .pvgo_dense import off_band_edges, run_lm_band_pcg, run_lm_dense
+        k_off = len(off_band_edges(np.asarray(edges.cpu())))
+        how = general_solver
+        if how == 'auto':        # a long chain with a few loop closures: block-tridiagonal solver + low-rank correction (PCG)
+            how = 'band_pcg' if (N > 512 and k_off <= 64) else 'dense'
+        if how == 'band_pcg':
+            nodes, vels, res = run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
+        elif how == 'dense':
+            if N > 12000:
+                raise UnsupportedGraphError('dense general-topology path is sized for N <= 12000 nodes, (9N)^2 doubles (got %d '
+                                            'nodes, %d off-band edges; general_solver="band_pcg" has no such limit)' % (N, k_off))
+            nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
+        else:
+            raise ValueError("general_solver must be 'auto', 'dense' or 'band_pcg'")
 
     if target == 'vo':
         vo = vo_motions if isinstance(vo_motions, torch.Tensor) else torch.as_tensor(vo_motions)

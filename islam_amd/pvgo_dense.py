@@ -10,7 +10,14 @@ normal matrix PyPose factorises, but never forms the Jacobian PyPose multiplies 
     O(E) work instead of the 2*rows*cols^2 dense product;
   * fp64 POTRF / POTRS from rocSOLVER (the only O(N^3) piece; its trailing updates are fp64 MFMA GEMMs);
   * retraction, trial residuals and the trust-region term (J D)^T (2R + J D) from the per-factor blocks.
-Sized by the dense matrix: (9N)^2 doubles (N = 5001: 16 GB of the 288 GB)."""
+Sized by the dense matrix: (9N)^2 doubles (N = 5001: 16 GB of the 288 GB).
+
+Long trajectories with a few loop closures do not need the dense matrix at all (run_lm_band_pcg): the IMU factors always
+couple consecutive nodes and a VO edge (i, j) adds S = w J^T J to the diagonal blocks of i and j and -S to the block (i, j), so
+  A = B + R,  B = block-tridiagonal (all diagonal blocks, the couplings |i-j| = 1),  R = the off-band blocks of the k long edges,
+B is positive definite on its own, rank(R) <= 12 k, and conjugate gradients preconditioned with B^-1 -- the block-tridiagonal
+solver of the chain path, islam_pvgo_solve_chain, ~60 us per application at N = 5001 -- reaches the solution of the SAME
+normal equations in at most 12 k + 1 iterations.  Same LM control, same trial / trust-region evaluation; memory O(N + k)."""
 import numpy as np
 import torch
 
@@ -112,3 +119,138 @@ def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weig
                 break
         ctl.end_step()
     return nodes, vels, dict(steps=ctl.steps, trials=trials, loss=ctl.loss, trace=ctl.trace)
+
+
+# ------------------------------------------------------------------------------------------ band + low-rank (PCG)
+def _edge_blocks(vo, w0):
+    """Per VO edge: S = w0 J^T J (E,6,6) and g = w0 J^T r (E,6), J = [[G, C], [0, G]] (edge_normal in csrc/pvgo.hip)."""
+    E = vo.shape[1]
+    G = vo[6:15].t().reshape(E, 3, 3)
+    C = vo[15:24].t().reshape(E, 3, 3)
+    J = torch.zeros((E, 6, 6), dtype=vo.dtype, device=vo.device)
+    J[:, :3, :3], J[:, :3, 3:], J[:, 3:, 3:] = G, C, G
+    r = vo[0:6].t()
+    Jt = J.transpose(1, 2)
+    return w0 * (Jt @ J), w0 * (Jt @ r[:, :, None])[:, :, 0]
+
+
+def off_band_edges(edges_host):
+    """Indices of the edges that couple nodes more than one apart (the part of A outside the block-tridiagonal band)."""
+    d = np.abs(edges_host[:, 1] - edges_host[:, 0])
+    return np.nonzero(d > 1)[0]
+
+
+class _BandSystem:
+    """A = B + R of one linearisation: B as (Hd, Ho) of the chain solver, R as the list of off-band 6x6 blocks."""
+
+    def __init__(self, vo, lin, edges, dts, N, w, vmin, vmax, off_idx):
+        dev = vo.device
+        Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w[1], w[2], w[3]), -_NOCLAMP, _NOCLAMP)     # IMU factors
+        S, g = _edge_blocks(vo, w[0])
+        E = S.shape[0]
+        i, j = edges[:, 0], edges[:, 1]
+        Sp = torch.zeros((E, 9, 9), dtype=S.dtype, device=dev)
+        Sp[:, :6, :6] = S
+        gp = torch.zeros((E, 9), dtype=S.dtype, device=dev)
+        gp[:, :6] = g
+        Hd.index_add_(0, i, Sp)
+        Hd.index_add_(0, j, Sp)
+        rhs.index_add_(0, i, gp)                     # b = -J^T W r: +g at the edge's first node, -g at its second
+        rhs.index_add_(0, j, -gp)
+        adj = (j - i).abs() == 1
+        Ho.index_add_(0, torch.minimum(i, j)[adj], -Sp[adj])
+        self.Hd, self.Ho, self.b = Hd, Ho, rhs
+        self.io, self.jo, self.So = i[off_idx], j[off_idx], S[off_idx]
+        self.diag0 = Hd.diagonal(dim1=1, dim2=2).clamp(vmin, vmax).clone()                  # A.diagonal().clamp_(min, max)
+
+    def set_diagonal(self, d):
+        self.Hd.diagonal(dim1=1, dim2=2).copy_(d)
+
+    def matvec(self, p):
+        y = (self.Hd @ p[:, :, None])[:, :, 0]
+        y[:-1] += (self.Ho[:-1] @ p[1:, :, None])[:, :, 0]
+        y[1:] += (self.Ho[:-1].transpose(1, 2) @ p[:-1, :, None])[:, :, 0]
+        if self.io.numel():
+            y6 = torch.zeros((p.shape[0], 6), dtype=p.dtype, device=p.device)
+            y6.index_add_(0, self.io, (self.So @ p[self.jo, :6, None])[:, :, 0])
+            y6.index_add_(0, self.jo, (self.So @ p[self.io, :6, None])[:, :, 0])
+            y[:, :6] -= y6
+        return y
+
+
+def _pcg(sysm, ws, rtol=1e-13):
+    """Solve (B + R) x = b with conjugate gradients preconditioned by B^-1 (the block-tridiagonal solver).  Raises
+    IslamHipError (ISLAM_ENOTPD) from the solver if B is not positive definite."""
+    Minv = lambda r: ops.pvgo_solve_chain(sysm.Hd, sysm.Ho, r.contiguous(), 0.0, workspace=ws)
+    b = sysm.b
+    x = Minv(b)
+    k = int(sysm.io.numel())
+    if k == 0:
+        return x, 0
+    r = b - sysm.matvec(x)
+    bnorm = float(b.norm())
+    z = Minv(r)
+    p = z.clone()
+    rz = (r * z).sum()
+    its = 0
+    for its in range(1, 12 * k + 12):
+        Hp = sysm.matvec(p)
+        alpha = rz / (p * Hp).sum()
+        x = x + alpha * p
+        r = r - alpha * Hp
+        if float(r.norm()) <= rtol * bnorm:
+            break
+        z = Minv(r)
+        rz_new = (r * z).sum()
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x, its
+
+
+def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, max_steps=10, patience=3,
+                    decreasing=1e-3, vmin=1e-4, vmax=1e32):
+    """The LM of run_lm_dense on the band + low-rank form of the same normal equations.  In: float64 contiguous device
+    tensors.  Returns (nodes, vels, info dict)."""
+    from ._lib import IslamHipError
+    N, E, M = nodes.shape[0], edges.shape[0], nodes.shape[0] - 1
+    if E != M:
+        raise ValueError('PoseVelGraph needs as many VO edges as IMU intervals (dts broadcasts over both, pvgo.py:51): E=%d, N-1=%d' % (E, M))
+    dev = nodes.device
+    w = [float(x) ** 2 for x in loss_weight[:4]]
+    dummy = torch.zeros((M, 7), dtype=torch.float64, device=dev)
+    dummy[:, 6] = 1.0
+    off_idx = torch.from_numpy(off_band_edges(edges.cpu().numpy())).to(dev)
+    ws = ops.pvgo_workspace(N, dev)
+    ctl = LMControl(radius=radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
+    trials = pcg_its = 0
+    while ctl.continual:
+        vo, lin = _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
+        if not ctl.has_loss:
+            ctl.set_initial_loss(float(_loss(vo, lin)))
+        ctl.begin_step()
+        sysm = _BandSystem(vo, lin, edges, dts, N, w, vmin, vmax, off_idx)
+        d = sysm.diag0
+        while True:
+            d = d + d * ctl.damping                                   # cumulative, like A.diagonal().add_(...)
+            sysm.set_diagonal(d)
+            trials += 1
+            try:
+                D, its = _pcg(sysm, ws)
+            except IslamHipError:
+                print('Linear solver failed. Breaking optimization step...')
+                ctl.solver_failed()
+                break
+            pcg_its += its
+            if not bool(torch.isfinite(D).all()):
+                print('Linear solver failed. Breaking optimization step...')
+                ctl.solver_failed()
+                break
+            nt, vt = ops.pvgo_retract(nodes, vels, D.contiguous(), 1.0)
+            vo_t, lin_t = _linearize(nt, vt, edges, poses, drots, dtrans, dvels, dts, dummy)
+            s, q = torch.stack([_loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)]).tolist()
+            if ctl.after_trial(s, q):
+                nodes, vels = nt, vt
+                break
+        ctl.end_step()
+    return nodes, vels, dict(steps=ctl.steps, trials=trials, loss=ctl.loss, trace=ctl.trace, pcg_iterations=pcg_its,
+                             off_band_edges=int(off_idx.numel()))

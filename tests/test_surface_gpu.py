@@ -329,3 +329,60 @@ def test_graph_replay_of_the_frozen_forward(cuda):
     assert float((bn.running_mean - before).abs().max()) > 0
     vo.vonet.reset_graphs()
     assert len(vo.vonet._graphs) == 0
+
+
+def _loop_closure_problem(F, closures, seed=5):
+    """chain_problem(F) with some chain edges replaced by long-range ones (loop closures), measured with a little noise."""
+    prob, tr = chain_problem(F)
+    links = prob['links'].copy()
+    vo = prob['vo_motions'].copy()
+    gt = np.concatenate([tr['gt_pos'], tr['gt_quat']], 1)
+    rng = np.random.default_rng(seed)
+    for e, (i, j) in closures.items():
+        links[e] = (i, j)
+        rel = lie.se3_mul(lie.se3_inv(gt[i]), gt[j])
+        vo[e] = lie.se3_mul(rel, lie.se3_exp(rng.normal(0, 0.01, 6)))
+    return dict(prob, links=links, vo_motions=vo)
+
+
+def test_general_topology_band_pcg_equals_dense(cuda):
+    """run_lm_band_pcg (block-tridiagonal solver + conjugate gradients on the off-band blocks of the loop closures) solves
+    the SAME normal equations as the dense path: identical LM trajectory, and both match the oracle's dense LM."""
+    from islam_amd import lietensor as pp
+    from islam_amd.pvgo import run_pvgo
+    p2 = _loop_closure_problem(33, {3: (0, 9), 11: (4, 17), 19: (30, 2), 25: (25, 26), 28: (31, 8)})
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    out = {}
+    for how in ('dense', 'band_pcg'):
+        out[how] = run_pvgo(pp.SE3(t(p2['init_nodes'])), t(p2['init_vels']), pp.SE3(t(p2['vo_motions']).to(cuda)),
+                            torch.tensor(p2['links']), t(p2['dts']), pp.SO3(t(p2['imu_drots'])), t(p2['imu_dtrans']),
+                            t(p2['imu_dvels']), device='cuda', loss_weight=LW, general_solver=how, return_info=True)
+    info_d, info_p = out['dense'][5], out['band_pcg'][5]
+    assert info_p['off_band_edges'] == 4 and 0 < info_p['pcg_iterations'] <= info_p['trials'] * (12 * 4 + 11)
+    assert info_p['steps'] == info_d['steps'] and info_p['trials'] == info_d['trials']
+    np.testing.assert_allclose([x[0] for x in info_p['trace']], [x[0] for x in info_d['trace']], rtol=1e-9)
+    np.testing.assert_allclose(out['band_pcg'][2].tensor().numpy(), out['dense'][2].tensor().numpy(), atol=1e-9)
+    np.testing.assert_allclose(out['band_pcg'][3].numpy(), out['dense'][3].numpy(), atol=1e-9)
+    otl, orl, on, ov, _ = opvgo.run_pvgo(**p2, loss_weight=LW, mode='dense')
+    err = se3_log_err(out['band_pcg'][2].tensor().numpy(), on)
+    assert (err / np.maximum(np.linalg.norm(lie.se3_log(on), axis=-1), 1e-6)).max() < 1e-6
+
+
+def test_general_topology_long_chain_with_loop_closures(cuda):
+    """A 3000-node trajectory with six loop closures: the automatic choice is the band + PCG path (no (9N)^2 matrix); it
+    agrees with the dense path on the same problem."""
+    from islam_amd import lietensor as pp
+    from islam_amd.pvgo import run_pvgo
+    F = 3000
+    closures = {100: (0, 2900), 700: (350, 2100), 1300: (1299, 40), 1900: (2500, 600), 2400: (10, 1500), 2800: (2999, 1)}
+    p2 = _loop_closure_problem(F, closures, seed=9)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    args = (pp.SE3(t(p2['init_nodes'])), t(p2['init_vels']), pp.SE3(t(p2['vo_motions']).to(cuda)), torch.tensor(p2['links']),
+            t(p2['dts']), pp.SO3(t(p2['imu_drots'])), t(p2['imu_dtrans']), t(p2['imu_dvels']))
+    auto = run_pvgo(*args, device='cuda', loss_weight=LW, return_info=True)
+    assert auto[5]['off_band_edges'] == 6 and auto[5]['pcg_iterations'] > 0          # band + PCG was chosen
+    assert auto[5]["trace"][-1][0] <= auto[5]["trace"][0][0]                          # the loss went down
+    dense = run_pvgo(*args, device='cuda', loss_weight=LW, return_info=True, general_solver='dense')
+    assert dense[5]['trials'] == auto[5]['trials']
+    np.testing.assert_allclose(auto[2].tensor().numpy(), dense[2].tensor().numpy(), atol=1e-7)
+    np.testing.assert_allclose(auto[3].numpy(), dense[3].numpy(), atol=1e-7)
