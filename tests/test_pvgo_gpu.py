@@ -256,3 +256,33 @@ def test_lm_solver_failure_breaks_the_step_like_pypose(cuda):
     res2, _ = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, prm2)
     ref = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True)[5]
     assert res2.status == 0 and res2.trials == len(ref.trace)
+
+
+def test_eliminate_level0_hook_is_the_solvers_first_launch(cuda):
+    """islam_pvgo_eliminate_level0 (bench.py's roofline leg) launches exactly what a solve launches first: it damps the
+    stored diagonal like a solve does, writes nothing the caller owns, and rejects single-level problems."""
+    from islam_amd import ops
+    from islam_amd._lib import IslamHipError, c_double, c_int, c_size_t, check, lib, ptr, stream_ptr
+    N = 700
+    g = torch.Generator().manual_seed(1)
+    Hd = torch.eye(9, dtype=torch.float64).repeat(N, 1, 1) * 30 + 0.1 * torch.randn(N, 9, 9, generator=g, dtype=torch.float64)
+    Hd = (Hd + Hd.transpose(1, 2)).contiguous().to(cuda)
+    Ho = (0.2 * torch.randn(N, 9, 9, generator=g, dtype=torch.float64)).to(cuda)
+    rhs = torch.randn(N, 9, generator=g, dtype=torch.float64).to(cuda)
+    ws, nbytes = ops.pvgo_workspace(N, cuda)
+    sl = (c_int * 2)(0, 0)
+    Hd2, Ho2, rhs2 = Hd.clone(), Ho.clone(), rhs.clone()
+    check(lib().islam_pvgo_eliminate_level0(ptr(Hd2), ptr(Ho2), ptr(rhs2), c_double(0.25), N, sl, ptr(ws), c_size_t(nbytes),
+                                            stream_ptr(cuda)))
+    torch.cuda.synchronize()
+    dg = torch.diagonal(Hd, dim1=1, dim2=2)
+    torch.testing.assert_close(torch.diagonal(Hd2, dim1=1, dim2=2), dg * 1.25, rtol=1e-14, atol=0)
+    off = ~torch.eye(9, dtype=torch.bool, device=cuda)
+    assert torch.equal(Hd2[:, off], Hd[:, off]) and torch.equal(Ho2, Ho) and torch.equal(rhs2, rhs)
+    # the workspace it left behind is a valid start for a full solve (nothing persistent was corrupted)
+    dx = ops.pvgo_solve_chain(Hd.clone(), Ho, rhs, 0.25, workspace=(ws, nbytes))
+    dx_ref = ops.pvgo_solve_chain(Hd.clone(), Ho, rhs, 0.25)
+    assert torch.equal(dx, dx_ref)
+    with pytest.raises(IslamHipError):
+        check(lib().islam_pvgo_eliminate_level0(ptr(Hd2), ptr(Ho2), ptr(rhs2), c_double(0.0), 5, sl, ptr(ws), c_size_t(nbytes),
+                                                stream_ptr(cuda)))
