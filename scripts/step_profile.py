@@ -12,7 +12,7 @@ batch, steps, warmup = 8, 3, 3
 torch.manual_seed(0)
 vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16,
               flow_dtype=torch.bfloat16, host_glue=True, miopen_find=os.environ.get('FIND', '1') == '1',
-              pose_channels_last=os.environ.get('POSE_CL', '1') == '1')
+              pose_channels_last=os.environ.get('POSE_CL', '1') == '1', graph_frozen=os.environ.get('GRAPH', '1') == '1')
 with torch.no_grad():
     vo.vonet.stereoNet.conv_c13.weight.zero_(); vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
 n = (steps + warmup) * batch + 1
