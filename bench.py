@@ -126,7 +126,8 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     torch.manual_seed(0)
     vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True,
                   miopen_find=True, pose_channels_last=True,
-                  graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1')
+                  graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1',
+                  graph_pose=os.environ.get('ISLAM_NO_GRAPH') != '1')
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
         vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)

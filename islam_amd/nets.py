@@ -461,6 +461,8 @@ class VONet(nn.Module):
         self._graphs = {}
         self.graph_frozen = False
         self.pose_channels_last = False
+        self.graph_pose = False             # set before the first training forward; fixed input shape from then on
+        self._pose_graphed = None
 
     def set_pose_channels_last(self, on=True):
         """Run the trainable pose head on channels_last (NHWC) fp32 tensors: MIOpen's fp32 implicit-GEMM kernels are NHWC
@@ -534,7 +536,17 @@ class VONet(nn.Module):
         x = torch.cat([flow, intrinsic], 1)
         if self.pose_channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        pose = self.flowPoseNet(x)
+        if self.graph_pose and self.flowPoseNet.training and torch.is_grad_enabled():
+            # forward AND backward of the trainable pose head replay from two captured HIP graphs
+            # (torch.cuda.make_graphed_callables patches the module's forward; eval mode keeps the eager path, and so does a
+            # batch of another shape, e.g. the last one of an epoch)
+            if self._pose_graphed is None:
+                self._pose_eager = self.flowPoseNet.forward
+                torch.cuda.make_graphed_callables(self.flowPoseNet, (x.detach().clone(),))
+                self._pose_graphed = tuple(x.shape)
+            pose = self.flowPoseNet(x) if tuple(x.shape) == self._pose_graphed else self._pose_eager(x)
+        else:
+            pose = self.flowPoseNet(x)
         return flow, disp, pose
 
 

@@ -259,3 +259,41 @@ def test_pose_head_channels_last_is_the_same_function(cuda):
     vn.set_pose_channels_last(False)
     p2, _ = run()
     torch.testing.assert_close(p2, p0, rtol=1e-3, atol=1e-5)
+
+
+def test_pose_head_graph_replay_trains_like_eager(cuda):
+    """VONet.graph_pose: forward and backward of the trainable pose head replayed from HIP graphs give the eager pose and
+    parameter gradients, keep following the optimizer's in-place updates, and leave other batch shapes on the eager path."""
+    from islam_amd import nets
+    torch.manual_seed(7)
+    B = 2
+    mk = lambda: nets.VONet(fix_parts=('flow', 'stereo'))
+    va, vb = mk(), mk()
+    vb.load_state_dict(va.state_dict())
+    for v in (va, vb):
+        v.flowPoseNet.to(cuda).train()
+    vb.graph_pose = True
+    opt = [torch.optim.SGD(v.flowPoseNet.parameters(), lr=1e-3) for v in (va, vb)]
+    wts = torch.arange(1, 7, device=cuda, dtype=torch.float32)
+    for it in range(3):
+        flow = torch.randn(B, 2, 112, 160, device=cuda)
+        intr = torch.rand(B, 2, 112, 160, device=cuda)
+        frozen = (flow, torch.zeros(B, 1, 112, 160, device=cuda))
+        poses, grads = [], []
+        for v, o in zip((va, vb), opt):
+            o.zero_grad(set_to_none=True)
+            _, _, pose = v(None, None, None, None, intr, frozen=frozen)
+            (pose * wts).sum().backward()
+            poses.append(pose.detach().clone())
+            grads.append([p.grad.detach().clone() for p in v.flowPoseNet.parameters()])
+            o.step()
+        torch.testing.assert_close(poses[1], poses[0], rtol=1e-3, atol=1e-5)
+        for a, b in zip(grads[1], grads[0]):
+            torch.testing.assert_close(a, b, rtol=5e-3, atol=2e-3 * float(b.abs().max()) + 1e-8)
+    assert vb._pose_graphed == (B, 4, 112, 160)
+    # another batch size: eager path, same module, same parameters
+    flow = torch.randn(1, 2, 112, 160, device=cuda)
+    intr = torch.rand(1, 2, 112, 160, device=cuda)
+    out = [v(None, None, None, None, intr, frozen=(flow, None))[2] for v in (va, vb)]
+    torch.testing.assert_close(out[1], out[0], rtol=1e-3, atol=1e-5)
+    assert list(va.state_dict().keys()) == list(vb.state_dict().keys())
