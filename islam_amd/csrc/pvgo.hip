@@ -1413,8 +1413,11 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     else load_facrow(L.fac, L.inv, c0 + cnt - 1, lane < 9 ? lane : 8, cur);
     // address-translation warm-up: touch the pages this wave will read (separators) and write (its part of x) while it
     // has nothing else to do; with hundreds of waves starting at once the page walks otherwise land on the critical path
-    double warm0 = L.xsep[(size_t)(has_left ? p - 1 : p) * 9 + (lane & 7)];
-    double warm1 = L.x[(size_t)c0 * 9 + lane];
+    // (indices clamped to the arrays: x has n*9 entries, xsep (n/(m+1))*9; a read past the end of the caller's dx tensor
+    // can fall off the end of a mapped allocation)
+    const int nsep9 = (L.n / (L.m + 1)) * 9;
+    double warm0 = L.xsep[min((has_left ? p - 1 : p) * 9 + (lane & 7), max(nsep9 - 1, 0))];
+    double warm1 = L.x[min(c0 * 9 + lane, L.n * 9 - 1)];
     __builtin_amdgcn_sched_barrier(0);
     // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
     // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times)
