@@ -496,6 +496,8 @@ class VONet(nn.Module):
         self.reset_graphs()
 
     def reset_graphs(self):
+        if getattr(self, '_graphs', None):
+            torch.cuda.synchronize()            # no replay may still be in flight when the graphs and their memory pool go
         self._graphs = {}
 
     def _frozen_graphed(self, imgs):

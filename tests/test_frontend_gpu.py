@@ -297,3 +297,9 @@ def test_pose_head_graph_replay_trains_like_eager(cuda):
     out = [v(None, None, None, None, intr, frozen=(flow, None))[2] for v in (va, vb)]
     torch.testing.assert_close(out[1], out[0], rtol=1e-3, atol=1e-5)
     assert list(va.state_dict().keys()) == list(vb.state_dict().keys())
+    # destroy the captured graphs now, with the device idle (see test_graph_replay_of_the_frozen_forward)
+    torch.cuda.synchronize()
+    del va, vb, opt, out, poses, grads, pose
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()

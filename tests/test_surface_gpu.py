@@ -329,6 +329,13 @@ def test_graph_replay_of_the_frozen_forward(cuda):
     assert float((bn.running_mean - before).abs().max()) > 0
     vo.vonet.reset_graphs()
     assert len(vo.vonet._graphs) == 0
+    # destroy the captured graphs and their private memory pool HERE, with the device idle, not whenever the garbage
+    # collector gets to them in the middle of a later test's launches
+    torch.cuda.synchronize()
+    del vo, got_a, got_b, got_a2, ref
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def _loop_closure_problem(F, closures, seed=5):
