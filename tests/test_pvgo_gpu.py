@@ -286,3 +286,33 @@ def test_eliminate_level0_hook_is_the_solvers_first_launch(cuda):
     with pytest.raises(IslamHipError):
         check(lib().islam_pvgo_eliminate_level0(ptr(Hd2), ptr(Ho2), ptr(rhs2), c_double(0.0), 5, sl, ptr(ws), c_size_t(nbytes),
                                                 stream_ptr(cuda)))
+
+
+def test_block_tridiagonal_solver_random_sizes_and_segment_lengths(cuda):
+    """40 random chains (2..1500 nodes) with random pinned segment lengths: twisted and one-sided plans, every root size."""
+    from islam_amd import ops
+    import scipy.linalg as sla
+    rng0 = np.random.default_rng(777)
+    for case in range(40):
+        N = int(rng0.integers(2, 1500))
+        seg = (0, 0) if case % 3 == 0 else (int(rng0.integers(0, 9)), int(rng0.integers(0, 9)))
+        rng = np.random.default_rng(1000 + case)
+        Hd = np.zeros((N, 9, 9))
+        Ho = np.zeros((N, 9, 9))
+        Hd[:, np.arange(9), np.arange(9)] = rng.uniform(0.1, 2.0, (N, 9))
+        JJ = np.einsum('kri,krj->kij', *(2 * [rng.normal(size=(N - 1, 12, 18))]))
+        Hd[:-1] += JJ[:, :9, :9]
+        Hd[1:] += JJ[:, 9:, 9:]
+        Ho[:N - 1] = JJ[:, :9, 9:]
+        rhs = rng.normal(size=(N, 9))
+        damping = float(rng.uniform(0, 1))
+        t = lambda a: torch.tensor(a, dtype=torch.float64, device=cuda)
+        dx = ops.pvgo_solve_chain(t(Hd), t(Ho), t(rhs), damping, seg_len=seg).cpu().numpy()
+        ab = np.zeros((18, 9 * N))
+        for r in range(9):
+            for c in range(9):
+                if r >= c:
+                    ab[r - c, c::9] = Hd[:, r, c] * ((1 + damping) if r == c else 1.0)
+                ab[9 + c - r, r:9 * (N - 1):9] = Ho[:N - 1, r, c]
+        ref = sla.solveh_banded(ab, rhs.reshape(-1), lower=True).reshape(N, 9)
+        assert np.abs(dx - ref).max() <= 1e-9 * np.abs(ref).max(), (case, N, seg)
