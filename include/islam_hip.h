@@ -218,6 +218,13 @@ int islam_pvgo_build_normal(const double* lin, const double* dts, int N, const d
 /* Hd.diag += Hd.diag*damping (in place, cumulative), then solve -> dx (N,9).  status (device int[4]). */
 int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                            const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
+/* Stream-ordered variant for iterative methods (islam_amd/pvgo_dense.py: preconditioner of the loop-closure solver): enqueue
+ * only -- no read-back, no synchronisation.  islam_pvgo_solve_status synchronises the stream, returns ISLAM_ENOTPD if any solve
+ * enqueued on this workspace since the previous status call met a non-positive pivot, and re-initialises the workspace's
+ * status / hand-off words; call it once before the first enqueue on a fresh workspace. */
+int islam_pvgo_solve_chain_enqueue(double* Hd, const double* Ho, const double* rhs, double damping, int N,
+                                   const int seg_len[2], void* workspace, size_t workspace_bytes, double* dx, void* stream);
+int islam_pvgo_solve_status(int N, void* workspace, size_t workspace_bytes, void* stream);
 /* Profiling variant: HIP events around every launch of one solve (on `stream`).  ms[i] = duration of launch i
  * (eliminate level 0..L-1, then back-substitution L-2..0; at most 2*ISLAM_PVGO_MAX_LEVELS-1 entries),
  * plan[3*l..] = (nodes, segment length, segments) for l < ISLAM_PVGO_MAX_LEVELS, plan[3*ISLAM_PVGO_MAX_LEVELS] = first

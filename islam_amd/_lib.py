@@ -72,6 +72,9 @@ SIGNATURES = {
                                 [c_void_p] * 4),
     'islam_pvgo_solve_chain': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                         c_void_p, c_void_p]),
+    'islam_pvgo_solve_chain_enqueue': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
+                                                                c_void_p, c_void_p]),
+    'islam_pvgo_solve_status': (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
     'islam_pvgo_solve_chain_timed': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                               c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int),
                                                               ctypes.POINTER(c_int), c_void_p]),

@@ -2271,6 +2271,34 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
     return ISLAM_OK;
 }
 
+// Stream-ordered variant of islam_pvgo_solve_chain: enqueue only, no read-back and no synchronisation (an iterative method
+// calls it hundreds of times with the same matrix).  islam_pvgo_solve_status() reports, after a stream synchronisation,
+// whether ANY solve enqueued on this workspace since the last status call met a non-positive pivot.
+int islam_pvgo_solve_chain_enqueue(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
+                                   void* workspace, size_t workspace_bytes, double* dx, void* stream) {
+    if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_solve_chain_enqueue: N=%d < 1", N);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N))
+        return fail(ISLAM_EARG, "islam_pvgo_solve_chain_enqueue: workspace %zu < %zu bytes", workspace_bytes,
+                    islam_pvgo_workspace_bytes(N));
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    return enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, as_stream(stream));
+}
+
+// 0: every solve since the last call was positive definite; ISLAM_ENOTPD otherwise.  Also (re)initialises the workspace's
+// status and hand-off words: call it once BEFORE the first islam_pvgo_solve_chain_enqueue on a fresh workspace.
+int islam_pvgo_solve_status(int N, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 1 || workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_solve_status: bad workspace");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    int flag = 0;
+    ISLAM_HIP_CHECK(hipMemcpyAsync(&flag, w.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+    if (flag) return fail(ISLAM_ENOTPD, "islam_pvgo_solve_status: non-positive pivot (matrix not positive definite)");
+    return ISLAM_OK;
+}
+
 // Profiling variant of islam_pvgo_solve_chain: HIP events around every launch of one solve, on the stream the
 // kernels run on.  ms[i] = duration of launch i (eliminate level 0..L-1, then back-substitution L-2..0);
 // plan[3*l+0..2] = (nodes, segment length, segments) of level l.  Returns the number of launches in *nlaunch.

@@ -331,6 +331,24 @@ def pvgo_solve_chain(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
     return dx
 
 
+def pvgo_solve_chain_enqueue(Hd, Ho, rhs, workspace, seg_len=(0, 0)):
+    """Stream-ordered islam_pvgo_solve_chain (damping 0): no read-back, no synchronisation; pvgo_solve_status() tells later
+    whether any of the enqueued solves met a non-positive pivot."""
+    N = Hd.shape[0]
+    ws, nbytes = workspace
+    dx = torch.empty((N, 9), dtype=torch.float64, device=Hd.device)
+    sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+    check(lib().islam_pvgo_solve_chain_enqueue(ptr(Hd), ptr(Ho), ptr(rhs), c_double(0.0), N, sl, ptr(ws), c_size_t(nbytes),
+                                               ptr(dx), stream_ptr(Hd.device)))
+    return dx
+
+
+def pvgo_solve_status(N, workspace, device):
+    """Synchronises; raises IslamHipError (ISLAM_ENOTPD) if a solve enqueued since the last call was not positive definite."""
+    ws, nbytes = workspace
+    check(lib().islam_pvgo_solve_status(N, ptr(ws), c_size_t(nbytes), stream_ptr(device)))
+
+
 def pvgo_solve_chain_timed(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
     """One solve with HIP events around each launch.  Returns (dx, {launch name: ms}, [(n, m, P) per level])."""
     N = Hd.shape[0]

@@ -178,32 +178,38 @@ class _BandSystem:
         return y
 
 
-def _pcg(sysm, ws, rtol=1e-13):
-    """Solve (B + R) x = b with conjugate gradients preconditioned by B^-1 (the block-tridiagonal solver).  Raises
-    IslamHipError (ISLAM_ENOTPD) from the solver if B is not positive definite."""
-    Minv = lambda r: ops.pvgo_solve_chain(sysm.Hd, sysm.Ho, r.contiguous(), 0.0, workspace=ws)
+def _pcg(sysm, ws, rtol=1e-13, check_every=6):
+    """Solve (B + R) x = b with conjugate gradients preconditioned by B^-1 (the block-tridiagonal solver, enqueued without
+    host round trips; the residual is looked at every `check_every` iterations).  Raises IslamHipError (ISLAM_ENOTPD) if B
+    is not positive definite."""
+    N, dev = sysm.b.shape[0], sysm.b.device
+    Minv = lambda r: ops.pvgo_solve_chain_enqueue(sysm.Hd, sysm.Ho, r.contiguous(), ws)
     b = sysm.b
     x = Minv(b)
+    ops.pvgo_solve_status(N, ws, dev)                      # B = L D L^T went through: positive definite
     k = int(sysm.io.numel())
     if k == 0:
         return x, 0
+    zero = torch.zeros((), dtype=b.dtype, device=dev)
+    safe_div = lambda a, c: torch.where(c != 0, a / torch.where(c != 0, c, torch.ones_like(c)), zero)
     r = b - sysm.matvec(x)
-    bnorm = float(b.norm())
+    tol = rtol * float(b.norm())
     z = Minv(r)
     p = z.clone()
     rz = (r * z).sum()
     its = 0
     for its in range(1, 12 * k + 12):
         Hp = sysm.matvec(p)
-        alpha = rz / (p * Hp).sum()
+        alpha = safe_div(rz, (p * Hp).sum())               # (0/0 once the residual is exactly zero)
         x = x + alpha * p
         r = r - alpha * Hp
-        if float(r.norm()) <= rtol * bnorm:
+        if its % check_every == 0 and float(r.norm()) <= tol:
             break
         z = Minv(r)
         rz_new = (r * z).sum()
-        p = z + (rz_new / rz) * p
+        p = z + safe_div(rz_new, rz) * p
         rz = rz_new
+    ops.pvgo_solve_status(N, ws, dev)
     return x, its
 
 
@@ -221,6 +227,10 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
     dummy[:, 6] = 1.0
     off_idx = torch.from_numpy(off_band_edges(edges.cpu().numpy())).to(dev)
     ws = ops.pvgo_workspace(N, dev)
+    try:
+        ops.pvgo_solve_status(N, ws, dev)                  # initialises the fresh workspace's status / hand-off words
+    except IslamHipError:
+        pass
     ctl = LMControl(radius=radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
     trials = pcg_its = 0
     while ctl.continual:
