@@ -97,12 +97,23 @@ int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, const uint16_t*
  * stereo feature extractor, which the reference still runs with batch statistics (TartanVO.py:90-91; Network/PSM/
  * submodule.py:10-43):  y = act(bf16(x*scale[c] + shift[c]) [+ res]), scale = weight*rsqrt(var_biased + eps),
  * shift = bias - mean*scale; running_mean / running_var (unbiased) / num_batches_tracked updated as nn.BatchNorm2d does
- * (pass NULL to skip).  x, y, res: (pixels, C) bf16 bits (y may alias x), C = 8 * (a divisor of 256); weight, bias, running_*:
+ * (pass NULL to skip).  x, y, res: (pixels, C) bf16 bits (y may alias x), C = 8 * (a divisor of 256), at most 256; weight, bias, running_*:
  * fp32 (C); scratch: islam_bn_scratch_floats(C) floats.  Deterministic (fixed-order reduction). */
 size_t islam_bn_scratch_floats(int C);
 int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* weight, const float* bias,
                              float* running_mean, float* running_var, long long* num_batches_tracked, double momentum,
                              double eps, int relu, long long pixels, int C, float* scratch, void* stream);
+
+/* ---------------------------------------------------------------- edge mask */
+
+/* Edge mask of the front-end, whole batch in one launch, no host round trip.
+ * Replaces TartanVO.py:145-155: img0.cpu() (27.5 MB D2H at B=8) -> (img*255).astype(uint8) -> per image
+ * cv2.resize(fx=fy=1/4) -> cv2.Canny(im, 50, 100) -> cv2.dilate(5x5 ones) -> `> 0` -> .cuda().
+ * img (B,3,H,W) float32 in [0,1]; mask (B,h,w) uint8 in {0,1} with h,w = H/4,W/4 (downscale != 0; H,W multiples of 4)
+ * or H,W.  low/high: Canny thresholds (50, 100).  h*w <= islam_edge_mask_max_pixels(): the quarter-resolution image lives
+ * in the LDS of one CU (112x160 for the 448x640 input); larger -> ISLAM_EARG. */
+int islam_edge_mask_max_pixels(void);
+int islam_edge_mask(const float* img, uint8_t* mask, int B, int H, int W, int downscale, int low, int high, void* stream);
 
 /* ---------------------------------------------------------------- stereo scale recovery */
 
@@ -141,6 +152,19 @@ int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const in
                      int64_t S, int max_frame_samples, const void* init_pos, const void* init_rot,
                      const void* init_vel, double gravity, int motion_mode, void* out_pos, void* out_rot,
                      void* out_vel, void* scratch, int dtype, void* stream);
+
+/* Backward of islam_imu_preint w.r.t. the gyro and accelerometer samples: what PyPose's autograd returns through
+ * pp.module.IMUPreintegrator when the denoiser runs with grad enabled (imu_integrator.py:107-113,146-153 with eval=False;
+ * the IMU-target epoch of train.py:177-179,207-212 -- SURVEY F6).  fwd_scratch: the scratch buffer of the forward call on the
+ * same inputs (holds incre_r, the frame-start rotations and the per-frame sums).  g_pos (rows,3), g_rot (rows,4), g_vel (rows,3):
+ * gradients of the forward's outputs (rows as in the forward: nframes in motion mode, nframes+1 in world mode), any may be NULL
+ * (= zero); g_rot is in PyPose's convention: a left-perturbation tangent vector in slots 0..2, slot 3 ignored.
+ * g_gyro, g_acc: (S,3), every row of a non-empty frame is written (rows of samples outside all frames are left untouched:
+ * zero-initialise).  scratch: islam_imu_preint_bwd_scratch_bytes(nframes) bytes.  Arithmetic in float64 for either dtype. */
+size_t islam_imu_preint_bwd_scratch_bytes(int nframes);
+int islam_imu_preint_bwd(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes, int64_t S,
+                         double gravity, int motion_mode, const void* fwd_scratch, const void* g_pos, const void* g_rot,
+                         const void* g_vel, void* g_gyro, void* g_acc, void* scratch, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- PVGO (pose-velocity graph optimisation) */
 

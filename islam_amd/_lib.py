@@ -54,11 +54,15 @@ SIGNATURES = {
     'islam_bias_act_add_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
     'islam_bn_scratch_floats': (c_size_t, [c_int]),
     'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
+    'islam_edge_mask_max_pixels': (c_int, []),
+    'islam_edge_mask': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
     'islam_scale_ls_depth': (c_int, [c_void_p] * 12 + [c_int] * 3 + [c_void_p]),
     'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +
                          [c_void_p] * 4 + [c_int, c_void_p]),
+    'islam_imu_preint_bwd_scratch_bytes': (c_size_t, [c_int]),
+    'islam_imu_preint_bwd': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_double, c_int] + [c_void_p] * 7 + [c_int, c_void_p]),
     'islam_pvgo_default_params': (None, [ctypes.POINTER(PvgoParams)]),
     'islam_pvgo_workspace_bytes': (c_size_t, [c_int]),
     'islam_pvgo_run_chain': (c_int, [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p, c_size_t,

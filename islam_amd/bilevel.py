@@ -3,8 +3,12 @@ harness on the islam_amd modules: per batch VO forward -> camera->IMU frame chan
 pre-integration (world + motion mode) -> PVGO -> one-step back-propagation; per epoch one optimizer step.
 
 State carried between batches exactly like train.py: T0 = last PVGO pose (:219), init_state = last PVGO
-pose/velocity with re-normalised quaternion (:297-299), gradients accumulated over the trajectory (:174-179).
+pose/velocity with re-normalised quaternion (:297-299), gradients accumulated over the trajectory (:174-179),
+the seven trajectory lists of init_epoch (:28-48) written by snapshot() in the formats of train.py:51-61, and the
+alternating 'vo' / 'imu' epochs (:163, :207-212, :174-179): an IMU epoch reuses the previous epoch's VO motions
+(no VO forward, no VO gradient) and steps the denoiser's optimizer.
 """
+import os
 import time
 
 import numpy as np
@@ -17,10 +21,18 @@ from .transformation import motion2pose_pypose, pose2motion_pypose
 
 class BilevelLoop:
     def __init__(self, tartanvo, imu_module, rgb2imu_pose, imu_init, loss_weight=(1, 0.1, 10, 0.1), rot_w=1.0,
-                 trans_w=0.1, lr=3e-6, batch_size=8, device='cuda:0'):
+                 trans_w=0.1, lr=3e-6, batch_size=8, device='cuda:0', train_imu_denoiser=False):
         self.vo, self.imu, self.T_IL = tartanvo, imu_module, rgb2imu_pose
         self.loss_weight, self.rot_w, self.trans_w, self.bs, self.device = loss_weight, rot_w, trans_w, batch_size, device
         self.optimizer = torch.optim.Adam(tartanvo.vonet.flowPoseNet.parameters(), lr=lr)        # train.py:115-116
+        self.imu_optimizer = None
+        if getattr(imu_module, 'use_denoise_model', False):                                       # train.py:144-145
+            self.imu_optimizer = torch.optim.Adam(imu_module.denoiser.parameters(), lr=3e-5)
+        # False = the reference as released: the denoiser runs under eval=True, so IMU epochs step its optimizer on empty
+        # gradients.  True = the fix of SURVEY section 8f rank 4: IMU epochs integrate differentiably
+        # (IMUModule.train_denoiser) and the IMU-target loss of pvgo.py:95-111 reaches the denoiser's parameters.
+        self.train_imu_denoiser = bool(train_imu_denoiser)
+        self.prev_vo_motions = None                                                               # train.py:164
         self.imu_init = imu_init
         self.reset()
 
@@ -32,6 +44,7 @@ class BilevelLoop:
         first = np.concatenate([i['pos'], i['rot']]).astype(np.float32)
         self.pgo_poses, self.vo_poses = [first], [first]
         self.vo_motions, self.pgo_vels, self.imu_poses = [], [np.asarray(i['vel'], dtype=np.float32)], [first]
+        self.pgo_motions, self.imu_motions = [], []
         self.current_idx = 0
         self.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
 
@@ -42,12 +55,18 @@ class BilevelLoop:
         bs, dev = self.bs, self.device
         sync = (lambda: torch.cuda.current_stream().synchronize()) if next_sample is not None else torch.cuda.synchronize
         t0 = time.perf_counter()
-        res = self.vo(sample)
-        if next_sample is not None and hasattr(self.vo, 'prefetch'):
-            self.vo.prefetch(next_sample)
-        motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
-        T_IL = self.T_IL.to(motions.device).to(motions.dtype)
-        motions = T_IL @ motions @ T_IL.Inv()                                                   # train.py:214-215
+        motions = None
+        if target != 'vo' and self.prev_vo_motions is not None:          # train.py:207-209: IMU epochs reuse last epoch's VO
+            motions = self.prev_vo_motions[self.current_idx:self.current_idx + bs]
+            if len(motions) != bs:                                        # (the reference's bare `except:` falls back to VO, Q15)
+                motions = None
+        if motions is None:
+            res = self.vo(sample)
+            if next_sample is not None and hasattr(self.vo, 'prefetch'):
+                self.vo.prefetch(next_sample)
+            motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
+            T_IL = self.T_IL.to(motions.device).to(motions.dtype)
+            motions = T_IL @ motions @ T_IL.Inv()                                               # train.py:214-215
         sync(); t1 = time.perf_counter()
         # VO-only dead reckoning is book-keeping (train.py:219-228 keeps it for the plots): no gradient flows through it,
         # so the 8 sequential SE3 products run on the host copy instead of ~160 tiny device launches
@@ -58,9 +77,13 @@ class BilevelLoop:
         self.vo_poses.extend(poses_vo.tensor().numpy()[1:])
 
         st, end = self.current_idx, self.current_idx + bs
+        if hasattr(self.imu, 'train_denoiser'):
+            self.imu.train_denoiser = self.train_imu_denoiser and target == 'imu' and self.imu_optimizer is not None
         imu_trans, imu_rots, _, imu_vels = self.imu.integrate(st, end, self.init_state, motion_mode=False)
         imu_poses = pp.SE3(torch.cat((imu_trans, imu_rots.tensor()), axis=1))
-        self.imu_poses.extend(imu_poses[1:].numpy())
+        self.imu_poses.extend(imu_poses[1:].detach().numpy())
+        with torch.no_grad():
+            self.imu_motions.extend(pose2motion_pypose(pp.SE3(imu_poses.detach().tensor())).numpy())    # train.py:240-242
         imu_dtrans, imu_drots, _, imu_dvels = self.imu.integrate(st, end, self.init_state, motion_mode=True)
         sync(); t2 = time.perf_counter()
 
@@ -69,6 +92,7 @@ class BilevelLoop:
                                                                  imu_dtrans, imu_dvels, device=dev, radius=1e4,
                                                                  loss_weight=self.loss_weight, target=target)
         pgo_poses_np, pgo_vels_np = pgo_poses.numpy(), pgo_vels.numpy()
+        self.pgo_motions.extend(pose2motion_pypose(pgo_poses).numpy())                          # train.py:264-266
         self.pgo_poses.extend(pgo_poses_np[1:])
         self.pgo_vels.extend(pgo_vels_np[1:])
         sync(); t3 = time.perf_counter()
@@ -86,7 +110,28 @@ class BilevelLoop:
             self.timing[k] += v
         return float(loss_bp.detach().sum())
 
-    def end_epoch(self):
-        """train.py:172-198: one optimizer step per pass over the trajectory."""
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+    def snapshot(self, trainroot, epoch):
+        """train.py:51-61: the seven text files of an epoch directory (the de-facto output contract)."""
+        d = os.path.join(trainroot, str(epoch))
+        os.makedirs(d, exist_ok=True)
+        for name, rows in (('vo_pose', self.vo_poses), ('vo_motion', self.vo_motions), ('pgo_pose', self.pgo_poses),
+                           ('pgo_motion', self.pgo_motions), ('pgo_vel', self.pgo_vels), ('imu_pose', self.imu_poses),
+                           ('imu_motion', self.imu_motions)):
+            np.savetxt(os.path.join(d, name + '.txt'), np.stack(rows))
+        return d
+
+    def end_epoch(self, target='vo', trainroot=None, epoch=1, reset=False):
+        """train.py:172-198: one optimizer step per pass over the trajectory (the VO head in 'vo' epochs, the denoiser in
+        'imu' epochs), final snapshot, the epoch's VO motions kept for the next (IMU) epoch, lists re-initialised."""
+        if target == 'vo':
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        elif target == 'imu' and self.imu_optimizer is not None:
+            self.imu_optimizer.step()
+            self.imu_optimizer.zero_grad()
+        if trainroot is not None:
+            self.snapshot(trainroot, epoch)
+        if self.vo_motions:
+            self.prev_vo_motions = pp.SE3(torch.as_tensor(np.stack(self.vo_motions)).to(self.device))       # train.py:193
+        if reset:
+            self.reset()

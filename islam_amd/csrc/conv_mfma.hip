@@ -483,8 +483,8 @@ extern "C" size_t islam_bn_scratch_floats(int C) { return (size_t)BN_BLOCKS * 2 
 extern "C" int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* weight, const float* bias,
                                         float* running_mean, float* running_var, long long* num_batches_tracked, double momentum,
                                         double eps, int relu, long long pixels, int C, float* scratch, void* stream) {
-    if (pixels < 1 || C < 8 || (C & 7) || 256 % (C / 8) != 0)
-        return fail(ISLAM_EARG, "islam_bn_train_nhwc_bf16: C=%d must be 8 * a divisor of 256", C);
+    if (pixels < 1 || C < 8 || C > 256 || (C & 7) || 256 % (C / 8) != 0)      // bn_finalize_kernel: one 256-thread block over C
+        return fail(ISLAM_EARG, "islam_bn_train_nhwc_bf16: C=%d must be 8 * a divisor of 256 and at most 256", C);
     hipStream_t s = (hipStream_t)stream;
     const int C8 = C / 8, ppb = 256 / C8;
     const int nblk = (int)std::min<long long>(BN_BLOCKS, (pixels + ppb - 1) / ppb);

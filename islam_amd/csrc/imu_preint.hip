@@ -318,9 +318,167 @@ int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframe
     return ISLAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- backward
+// Reverse-mode derivative of the whole frame loop w.r.t. the gyro and accelerometer samples (what PyPose's autograd gives the
+// reference through pp.module.IMUPreintegrator when the denoiser runs with grad enabled: SURVEY F6 / section 8f rank 4).
+// Rotations are differentiated in PyPose's convention: the gradient of a quaternion output / input is a LEFT-perturbation
+// tangent vector (Exp(d) * R) in its first three slots, fourth slot 0.  With A_j = incre_r[j],
+// R_i = rotation at the start of frame i, w_j = gyro_j dt_j, Q_{j+1} = R_i A_{j+1}, a_j = acc_j - Q_{j+1}^T g, ra_j = A_j a_j:
+//   V = sum ra_j d_j, P = sum_j (V_j d_j + ra_j d_j^2 / 2);   frame outputs R_i V, R_i P, A_F (motion) or the chained p/v/R.
+//   d A_{j+1} = d A_j + A_j Jl(w_j) d w_j          d R_{i+1} = d R_i + R_i d A_F          (left perturbations)
+// One workgroup: (A) one lane per frame walks its samples backwards carrying S = the adjoint of A_{j+1}; (B) one lane chains
+// the adjoint of R_i backwards over the frames (world mode: of p and v too, before (A)); (C) one lane per frame adds the
+// part of the gyro gradient that comes from later frames through R_{i+1}.  Arithmetic in double whatever the I/O type.
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 rot3(Q<double> q, V3 p) {
+    double in[3] = {p.x, p.y, p.z}, o[3];
+    qact<double>(q, in, o);
+    return {o[0], o[1], o[2]};
+}
+__device__ __forceinline__ Q<double> conj(Q<double> q) { return {-q.x, -q.y, -q.z, q.w}; }
+template <class T> __device__ __forceinline__ Q<double> ldqd(const T* p) { return {(double)p[0], (double)p[1], (double)p[2], (double)p[3]}; }
+template <class T> __device__ __forceinline__ V3 ld3d(const T* p) { return p ? V3{(double)p[0], (double)p[1], (double)p[2]} : V3{0, 0, 0}; }
+// Jl(w)^T u = Jl(-w) u
+__device__ __forceinline__ V3 JlT(V3 w, V3 u) {
+    const double th2 = w.x * w.x + w.y * w.y + w.z * w.z, th = sqrt(th2);
+    double c1, c2;
+    if (th > 1e-4) { c1 = (1.0 - cos(th)) / th2; c2 = (th - sin(th)) / (th2 * th); }
+    else { c1 = 0.5 - th2 / 24.0; c2 = 1.0 / 6.0 - th2 / 120.0; }
+    const V3 wu = cross3(w, u);
+    return u + (-c1) * wu + c2 * cross3(w, wu);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void preint_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ acc,
+                                                          const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                                          const T* __restrict__ R0, const T* __restrict__ loc, double gravity,
+                                                          int motion_mode, const T* __restrict__ g_pos, const T* __restrict__ g_rot,
+                                                          const T* __restrict__ g_vel, T* __restrict__ g_gyro, T* __restrict__ g_acc,
+                                                          double* __restrict__ ws) {
+    // ws: gv (3n) | gp (3n) | gR local, then T_{i+1} (3n)
+    double* gv = ws;
+    double* gp = ws + 3 * (size_t)nframes;
+    double* gR = gp + 3 * (size_t)nframes;
+    const int tid = threadIdx.x;
+    const V3 g{0, 0, gravity};
+    // ---- upstream adjoints of the frame-local sums
+    if (motion_mode) {
+        for (int i = tid; i < nframes; i += 256) {
+            const V3 a = ld3d(g_vel ? g_vel + 3 * (size_t)i : nullptr), b = ld3d(g_pos ? g_pos + 3 * (size_t)i : nullptr);
+            gv[3 * i] = a.x; gv[3 * i + 1] = a.y; gv[3 * i + 2] = a.z;
+            gp[3 * i] = b.x; gp[3 * i + 1] = b.y; gp[3 * i + 2] = b.z;
+        }
+    } else if (tid == 0) {                      // world mode: p_{i+1} = p_i + R_i P_i + v_i t_i ; v_{i+1} = v_i + R_i V_i (F_i > 0)
+        V3 pb = ld3d(g_pos ? g_pos + 3 * (size_t)nframes : nullptr), vb = ld3d(g_vel ? g_vel + 3 * (size_t)nframes : nullptr);
+        for (int i = nframes - 1; i >= 0; --i) {
+            const int F = (int)(seg[i + 1] - seg[i]);
+            gv[3 * i] = vb.x; gv[3 * i + 1] = vb.y; gv[3 * i + 2] = vb.z;
+            gp[3 * i] = pb.x; gp[3 * i + 1] = pb.y; gp[3 * i + 2] = pb.z;
+            const V3 gpi = ld3d(g_pos ? g_pos + 3 * (size_t)i : nullptr), gvi = ld3d(g_vel ? g_vel + 3 * (size_t)i : nullptr);
+            if (F == 0) { vb = gvi; pb = gpi + pb; }            // velocity zeroed, position held (imu_integrator.py:134-140)
+            else { vb = gvi + vb + (double)loc[7 * (size_t)i + 6] * pb; pb = gpi + pb; }
+        }
+    }
+    __syncthreads();
+    // ---- (A) per frame, samples backwards
+    for (int i = tid; i < nframes; i += 256) {
+        const int a0 = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+        V3 gRl{0, 0, 0};
+        if (F > 0) {
+            const Q<double> Ri = ldqd(R0 + 4 * (size_t)i), RiT = conj(Ri);
+            const T* irf = ir + 4 * ((size_t)a0 + i);
+            const V3 gvi{gv[3 * i], gv[3 * i + 1], gv[3 * i + 2]}, gpi{gp[3 * i], gp[3 * i + 1], gp[3 * i + 2]};
+            const V3 Vb = rot3(RiT, gvi), Pb = rot3(RiT, gpi);
+            const V3 RV = ld3d(loc + 7 * (size_t)i), RP = ld3d(loc + 7 * (size_t)i + 3);
+            gRl = cross3(RV, gvi) + cross3(RP, gpi);
+            V3 S = motion_mode ? ld3d(g_rot ? g_rot + 4 * (size_t)i : nullptr) : V3{0, 0, 0};      // adjoint of A_F
+            V3 carry{0, 0, 0};                   // ra_{k+1} x rabar_{k+1}: belongs to the adjoint of A_{k+1}
+            double Tk = 0.0;                     // sum of d_j, j > k
+            for (int k = F - 1; k >= 0; --k) {
+                const double d = (double)dt[a0 + k];
+                const Q<double> Ak = ldqd(irf + 4 * k), Ak1 = ldqd(irf + 4 * (k + 1));
+                const Q<double> Qk1 = qmul<double>(Ri, Ak1);
+                const V3 gb = rot3(conj(Qk1), g);
+                const V3 av{(double)acc[3 * (a0 + k)] - gb.x, (double)acc[3 * (a0 + k) + 1] - gb.y, (double)acc[3 * (a0 + k) + 2] - gb.z};
+                const V3 ra = rot3(Ak, av);
+                const V3 rab = d * Vb + (d * (0.5 * d + Tk)) * Pb;
+                const V3 ab = rot3(conj(Ak), rab);
+                g_acc[3 * (a0 + k)] = (T)ab.x; g_acc[3 * (a0 + k) + 1] = (T)ab.y; g_acc[3 * (a0 + k) + 2] = (T)ab.z;
+                const V3 Qb = cross3(rot3(Qk1, (-1.0) * ab), g);          // adjoint of Q_{k+1} from gb = Q^T g, gbbar = -abar
+                gRl = gRl + Qb;
+                S = S + rot3(RiT, Qb) + carry;
+                const V3 w{(double)gyro[3 * (a0 + k)] * d, (double)gyro[3 * (a0 + k) + 1] * d, (double)gyro[3 * (a0 + k) + 2] * d};
+                const V3 wb = JlT(w, rot3(conj(Ak), S));
+                g_gyro[3 * (a0 + k)] = (T)(wb.x * d); g_gyro[3 * (a0 + k) + 1] = (T)(wb.y * d); g_gyro[3 * (a0 + k) + 2] = (T)(wb.z * d);
+                carry = cross3(ra, rab);
+                Tk += d;
+            }
+        }
+        gR[3 * i] = gRl.x; gR[3 * i + 1] = gRl.y; gR[3 * i + 2] = gRl.z;
+    }
+    __syncthreads();
+    // ---- (B) adjoint of R_i chained backwards: gR[i] <- T_{i+1} (what frame i's A_F receives through R_{i+1})
+    if (tid == 0) {
+        V3 Tn = motion_mode ? V3{0, 0, 0} : ld3d(g_rot ? g_rot + 4 * (size_t)nframes : nullptr);
+        for (int i = nframes - 1; i >= 0; --i) {
+            const V3 local{gR[3 * i], gR[3 * i + 1], gR[3 * i + 2]};
+            gR[3 * i] = Tn.x; gR[3 * i + 1] = Tn.y; gR[3 * i + 2] = Tn.z;
+            Tn = local + Tn + (motion_mode ? V3{0, 0, 0} : ld3d(g_rot ? g_rot + 4 * (size_t)i : nullptr));
+        }
+    }
+    __syncthreads();
+    // ---- (C) the share of the gyro gradient that arrives through R_{i+1} = R_i A_F
+    for (int i = tid; i < nframes; i += 256) {
+        const int a0 = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+        const V3 Tn{gR[3 * i], gR[3 * i + 1], gR[3 * i + 2]};
+        if (F == 0 || (Tn.x == 0.0 && Tn.y == 0.0 && Tn.z == 0.0)) continue;
+        const V3 extra = rot3(conj(ldqd(R0 + 4 * (size_t)i)), Tn);
+        const T* irf = ir + 4 * ((size_t)a0 + i);
+        for (int k = 0; k < F; ++k) {
+            const double d = (double)dt[a0 + k];
+            const V3 w{(double)gyro[3 * (a0 + k)] * d, (double)gyro[3 * (a0 + k) + 1] * d, (double)gyro[3 * (a0 + k) + 2] * d};
+            const V3 wb = JlT(w, rot3(conj(ldqd(irf + 4 * k)), extra));
+            g_gyro[3 * (a0 + k)] += (T)(wb.x * d); g_gyro[3 * (a0 + k) + 1] += (T)(wb.y * d); g_gyro[3 * (a0 + k) + 2] += (T)(wb.z * d);
+        }
+    }
+}
+
+template <class T>
+int run_bwd(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframes, int64_t S, double gravity, int motion_mode,
+            const void* fwd_scratch, const T* g_pos, const T* g_rot, const T* g_vel, T* g_gyro, T* g_acc, void* scratch, hipStream_t s) {
+    const T* ir = reinterpret_cast<const T*>(fwd_scratch);
+    const T* R0 = ir + 4 * ((size_t)S + nframes);
+    const T* loc = R0 + 4 * ((size_t)nframes + 1);
+    hipLaunchKernelGGL(preint_bwd_kernel<T>, dim3(1), dim3(256), 0, s, dt, gyro, acc, seg, nframes, ir, R0, loc, gravity, motion_mode,
+                       g_pos, g_rot, g_vel, g_gyro, g_acc, reinterpret_cast<double*>(scratch));
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t islam_imu_preint_bwd_scratch_bytes(int nframes) { return sizeof(double) * 9 * (size_t)(nframes > 0 ? nframes : 0) + 256; }
+
+int islam_imu_preint_bwd(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes, int64_t S, double gravity,
+                         int motion_mode, const void* fwd_scratch, const void* g_pos, const void* g_rot, const void* g_vel,
+                         void* g_gyro, void* g_acc, void* scratch, int dtype, void* stream) {
+    if (nframes < 1 || S < 0 || !fwd_scratch || !g_gyro || !g_acc || !scratch)
+        return fail(ISLAM_EARG, "islam_imu_preint_bwd: bad argument (nframes=%d S=%lld)", nframes, (long long)S);
+    hipStream_t s = as_stream(stream);
+    const int flag = motion_mode ? 1 : 0;
+    if (dtype == ISLAM_F64)
+        return run_bwd<double>((const double*)dt, (const double*)gyro, (const double*)acc, seg, nframes, S, gravity, flag, fwd_scratch,
+                               (const double*)g_pos, (const double*)g_rot, (const double*)g_vel, (double*)g_gyro, (double*)g_acc, scratch, s);
+    if (dtype == ISLAM_F32)
+        return run_bwd<float>((const float*)dt, (const float*)gyro, (const float*)acc, seg, nframes, S, gravity, flag, fwd_scratch,
+                              (const float*)g_pos, (const float*)g_rot, (const float*)g_vel, (float*)g_gyro, (float*)g_acc, scratch, s);
+    return fail(ISLAM_EARG, "islam_imu_preint_bwd: dtype %d", dtype);
+}
 
 size_t islam_imu_scratch_bytes(int64_t S, int nframes, int dtype) {
     const size_t es = dtype == ISLAM_F64 ? 8 : 4;

@@ -49,6 +49,11 @@ class IMUModule:
             self.denoiser.load_state_dict(torch.load(denoise_model_name))
             self.denoiser = self.denoiser.to(device)
             self.use_est_cov = use_est_cov
+        # The reference calls the denoiser with eval=True (imu_integrator.py:109): no gradient ever reaches it, so its
+        # "IMU epochs" (train.py:177-179) step the optimizer on empty gradients.  train_denoiser = True is the
+        # fix SURVEY section 8f rank 4 asks for: the denoiser runs with grad enabled and the pre-integration is differentiable
+        # (islam_imu_preint_bwd), so run_pvgo(target='imu') back-propagates into its parameters.  Default: reference behaviour.
+        self.train_denoiser = False
 
     def integrate(self, st, end, init=None, motion_mode=False):
         """imu_integrator.py:69-164.  world mode: (end-st+1) rows incl. the initial state; motion mode: (end-st) rows.
@@ -65,7 +70,8 @@ class IMUModule:
             if self.denoise_gyro:
                 gyros = gyros - self.gyro_bias.view(1, 3)
         if self.use_denoise_model and b1 - b0 >= 10:
-            d_acc, d_gyro, _, _ = self.denoiser({'acc': accels.float(), 'gyro': gyros.float()}, eval=True)
+            ddt = next(self.denoiser.parameters()).dtype          # the reference's denoiser lives in the default dtype too
+            d_acc, d_gyro, _, _ = self.denoiser({'acc': accels.to(ddt), 'gyro': gyros.to(ddt)}, eval=not self.train_denoiser)
             if self.denoise_accel:
                 accels = d_acc.to(self.dtype)
             if self.denoise_gyro:

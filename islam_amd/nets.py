@@ -188,7 +188,10 @@ def _cbn(convbn, x, relu=False, res=None):
     conv, bn = convbn[0], convbn[1]
     y = conv(x)
     c = y.shape[1]
-    if bn.training and bn.weight.dtype == torch.float32 and ops.fusable_nhwc_bf16(y, c) and 256 % (c // 8) == 0:
+    # the fused op normalises with the statistics of THIS rank's tensor: only a plain nn.BatchNorm2d may take it (a
+    # dist_train.ShardedBatchNorm2d must run its own forward, which all-reduces [sum | sum of squares | count] first)
+    if type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32 and ops.fusable_nhwc_bf16(y, c) \
+            and c <= 256 and 256 % (c // 8) == 0:
         if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
             res = res.contiguous(memory_format=torch.channels_last)
         return ops.bn_train_(y, bn, relu, res)
@@ -567,7 +570,9 @@ class _HalfExec:
         key = (params[0].device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:4]))
         if self._copy is None or key != self._key:
             import copy
-            c = copy.deepcopy(self.master)
+            # process groups (dist_train.ShardedBatchNorm2d.group) are shared, not copied
+            memo = {id(m.group): m.group for m in self.master.modules() if getattr(m, 'group', None) is not None}
+            c = copy.deepcopy(self.master, memo)
             for p in c.parameters():
                 p.requires_grad_(False)
             c = c.to(self.dtype).to(memory_format=torch.channels_last)

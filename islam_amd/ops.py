@@ -93,6 +93,20 @@ def warp_mask(x, flow, scale=1.0):
     return out
 
 
+# --------------------------------------------------------------------------- edge mask
+def edge_mask(img0, downscale=True, low=50, high=100):
+    """TartanVO.py:145-155 (uint8 conversion, 1/4 resize, Canny(50, 100), 5x5 dilate) in one launch.
+    (B,3,H,W) float32 in [0,1] -> (B,H/4,W/4) bool."""
+    require_cuda(img0)
+    assert img0.dim() == 4 and img0.shape[1] == 3, 'expects (B,3,H,W) images'
+    img0 = _f32c(img0)
+    B, _, H, W = img0.shape
+    h, w = (H // 4, W // 4) if downscale else (H, W)
+    out = torch.empty((B, h, w), dtype=torch.bool, device=img0.device)
+    check(lib().islam_edge_mask(ptr(img0), ptr(out), B, H, W, int(bool(downscale)), int(low), int(high), stream_ptr(img0.device)))
+    return out
+
+
 # --------------------------------------------------------------------------- scale recovery
 def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th, depth_input=False):
     """Batched dense_ba.scale_from_disp_flow (dense_ba.py:88-176).  Returns scale (B), z (B,H,W),
@@ -212,9 +226,7 @@ def bn_train_(x, bn, relu=False, res=None):
 
 
 # --------------------------------------------------------------------------- IMU
-def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
-    """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,
-    float32 or float64; seg int64 device tensor (nframes+1), seg_host the same on the host."""
+def _imu_preint_raw(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
     require_cuda(dt, gyro, acc, seg)
     dtype = dt.dtype
     code = {torch.float32: 0, torch.float64: 1}[dtype]
@@ -231,7 +243,42 @@ def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravi
     check(lib().islam_imu_preint(ptr(dt), ptr(gyro), ptr(acc), ptr(seg), nframes, S, maxF, ptr(init_pos), ptr(init_rot),
                                  ptr(init_vel), c_double(gravity), 1 if motion_mode else 0, ptr(pos), ptr(rot), ptr(vel),
                                  ptr(scratch), code, stream_ptr(dev)))
-    return pos, rot, vel
+    return pos, rot, vel, scratch
+
+
+class _ImuPreint(torch.autograd.Function):
+    """islam_imu_preint with islam_imu_preint_bwd: gradients w.r.t. the gyro / accelerometer samples (the denoiser's outputs
+    in the IMU-target epoch).  The gradient of the quaternion output is read in PyPose's convention (left tangent, padded)."""
+
+    @staticmethod
+    def forward(ctx, gyro, acc, dt, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
+        pos, rot, vel, scratch = _imu_preint_raw(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode)
+        ctx.save_for_backward(gyro, acc, dt, seg, scratch)
+        ctx.meta = (int(seg_host.shape[0]) - 1, float(gravity), bool(motion_mode))
+        return pos, rot, vel
+
+    @staticmethod
+    def backward(ctx, g_pos, g_rot, g_vel):
+        gyro, acc, dt, seg, scratch = ctx.saved_tensors
+        nframes, gravity, motion = ctx.meta
+        code = {torch.float32: 0, torch.float64: 1}[dt.dtype]
+        c = lambda g: None if g is None else g.to(dt.dtype).contiguous()
+        g_pos, g_rot, g_vel = c(g_pos), c(g_rot), c(g_vel)
+        g_gyro, g_acc = torch.zeros_like(gyro), torch.zeros_like(acc)
+        ws = torch.empty(lib().islam_imu_preint_bwd_scratch_bytes(nframes), dtype=torch.uint8, device=dt.device)
+        check(lib().islam_imu_preint_bwd(ptr(dt), ptr(gyro), ptr(acc), ptr(seg), nframes, int(dt.shape[0]), c_double(gravity),
+                                         1 if motion else 0, ptr(scratch), ptr(g_pos), ptr(g_rot), ptr(g_vel), ptr(g_gyro), ptr(g_acc),
+                                         ptr(ws), code, stream_ptr(dt.device)))
+        return g_gyro, g_acc, None, None, None, None, None, None, None, None
+
+
+def imu_preint(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode):
+    """One IMUModule.integrate frame loop (imu_integrator.py:116-158).  dt (S), gyro/acc (S,3) on device,
+    float32 or float64; seg int64 device tensor (nframes+1), seg_host the same on the host.  Differentiable w.r.t. gyro / acc
+    when either requires grad."""
+    if torch.is_grad_enabled() and (gyro.requires_grad or acc.requires_grad):
+        return _ImuPreint.apply(gyro, acc, dt, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode)
+    return _imu_preint_raw(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity, motion_mode)[:3]
 
 
 # --------------------------------------------------------------------------- PVGO

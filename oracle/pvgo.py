@@ -263,6 +263,7 @@ class LM:
         self.loss = None
         self.last = None
         self.trace = []   # (loss, damping, accepted) per inner iteration
+        self.step_losses = []   # what step() returned, one per optimizer step (what the scheduler sees)
 
     def _res(self, inp):
         res = residuals(self.nodes, self.vels, *inp)
@@ -309,6 +310,7 @@ class LM:
             else:
                 self.trace.append((self.loss, pg['damping'], True))
                 break
+        self.step_losses.append(self.loss)
         return self.loss
 
 

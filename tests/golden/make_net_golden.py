@@ -23,7 +23,7 @@ for name in ('cupy', 'cv2', 'pypose'):
 sys.modules['cupy'].memoize = lambda **kw: (lambda f: f)      # decorator used at import time (correlation.py:273)
 
 from oracle import cwrap  # noqa: E402
-from tests.golden.netfill import fill_state_dict, make_input  # noqa: E402
+from tests.golden.netfill import fill_state_dict, make_input, tame_vonet, vonet_sample  # noqa: E402
 
 
 def oracle_corr(tenFirst, tenSecond):
@@ -66,6 +66,15 @@ def main():
         p = net(x)
         np.savez_compressed(os.path.join(HERE, 'nets_pose.npz'), pose=p.numpy())
         keys['flowPoseNet'] = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        # whole VONet (Network/VONet.py:28-39) at 448x640, train mode as TartanVO.forward sets it (TartanVO.py:91)
+        from Network.VONet import VONet as RefVONet
+        net = tame_vonet(fill_state_dict(RefVONet(fix_parts=('flow', 'stereo'))))
+        net.train()
+        sample = vonet_sample()
+        args = [sample[k] for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm', 'intrinsic')]
+        flow, disp, pose = net(*args)
+        np.savez_compressed(os.path.join(HERE, 'nets_vonet.npz'), flow=flow.numpy(), disp=disp.numpy(), pose=pose.numpy())
+        assert len(net.state_dict()) == 765
         # IMU denoiser, 83 samples (remainder stretch, Q14)
         net = fill_state_dict(RefDen())
         acc, gyro = make_input('acc'), make_input('gyro')

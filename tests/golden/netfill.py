@@ -43,3 +43,25 @@ def make_input(name):
     shape, kind, seed = INPUT_SPECS[name]
     g = torch.Generator().manual_seed(seed)
     return torch.rand(shape, generator=g) if kind == 'rand' else torch.randn(shape, generator=g)
+
+
+VONET_SEED = 106
+
+
+def vonet_sample():
+    """Input of the whole-VONet fixture: one synthetic stereo pair at the production size (the pose head's 256*6 flatten
+    needs 448x640 images); band-limited texture, so the edge mask of TartanVO.forward is non-trivial."""
+    from islam_amd import synthetic
+    return synthetic.stereo_batch(1, seed=VONET_SEED)
+
+
+def tame_vonet(net):
+    """The seeded fill has no normalisation after the hourglass stacks: the disparity head ends up ~4e7 and the pose head
+    ~1e3.  Rescale the LAST layer of each so that TartanVO's glue sees plausible magnitudes (disparity ~20 px, pose O(1) in
+    pose_std units); applied identically by the generator (to the reference module) and by the tests."""
+    with torch.no_grad():
+        for name, s in (('stereoNet.conv_c13', 3.6e-8), ('flowPoseNet.voflow_trans.2', 1e-3), ('flowPoseNet.voflow_rot.2', 1e-3)):
+            mod = net.get_submodule(name)
+            mod.weight.mul_(s)
+            mod.bias.mul_(s)
+    return net

@@ -43,3 +43,89 @@ def reproj_inputs(tr, K, T_IL, H=112, W=160, K4=(80.0, 80.0, 80.0, 56.0), seed=0
     uv = np.stack([fx * p[..., 0] / p[..., 2] + cx, fy * p[..., 1] / p[..., 2] + cy], -1)
     flow[b, :, row, col] = uv - pts2d + rng.normal(0, noise_px, uv.shape)
     return dict(points2d=pts2d, depth=depth, flow=flow, fx=fx, fy=fy, cx=cx, cy=cy, rgb2imu_pose=T_IL)
+
+
+def edge_test_image(seed, B=2, H=448, W=640, amp=0.5, cells=32, boxes=6):
+    """Smooth low-contrast texture + a few rectangles of random contrast (strong and weak step edges): an edge mask that is
+    neither empty nor full (the synthetic stereo texture is so busy that its mask is all ones)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand(B, 3, H // cells + 2, W // cells + 2, generator=g)
+    x = torch.nn.functional.interpolate(lo, size=(H, W), mode='bicubic', align_corners=False)
+    x = 0.5 + amp * (x - 0.5)
+    for b in range(B):
+        for _ in range(boxes):
+            y0 = int(torch.randint(0, max(H - 80, 1), (1,), generator=g))
+            x0 = int(torch.randint(0, max(W - 80, 1), (1,), generator=g))
+            h = int(torch.randint(20, 80, (1,), generator=g))
+            w = int(torch.randint(20, 80, (1,), generator=g))
+            x[b, :, y0:y0 + h, x0:x0 + w] += (torch.rand(1, generator=g).item() - 0.5) * 0.6
+    return x.clamp(0, 1).contiguous()
+
+
+# ------------------------------------------------------------------ differentiable torch restatement of the IMU frame loop
+def _tq_mul(a, b):
+    import torch
+    ax, ay, az, aw = a.unbind(-1)
+    bx, by, bz, bw = b.unbind(-1)
+    return torch.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                        aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+def _tq_act(q, p):
+    import torch
+    u, w = q[..., :3], q[..., 3:]
+    c = 2 * torch.linalg.cross(u, p)
+    return p + w * c + torch.linalg.cross(u, c)
+
+
+def _tq_exp(phi):
+    import torch
+    th = phi.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+    return torch.cat([phi * torch.sin(0.5 * th) / th, torch.cos(0.5 * th)], -1)
+
+
+def tq_log(q):
+    """SO3 Log on raw quaternions (plain autograd), SURVEY Appendix C item 2."""
+    import torch
+    v, w = q[..., :3], q[..., 3:]
+    n = v.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+    return v * 2 * torch.atan(n / w) / n
+
+
+def imu_preint_torch(dt, gyro, acc, seg, init_pos, init_rot, init_vel, gravity, motion_mode):
+    """oracle/imu_preint_body.inc in plain torch ops (float64, sequential products instead of the doubling scan), so that
+    torch.autograd gives reference gradients w.r.t. gyro / acc for the HIP backward (islam_imu_preint_bwd)."""
+    import torch
+    g = torch.tensor([0, 0, gravity], dtype=dt.dtype)
+    lp, lr, lv = (torch.zeros(3, dtype=dt.dtype), init_rot, torch.zeros(3, dtype=dt.dtype)) if motion_mode else (init_pos, init_rot, init_vel)
+    sp, sr, sv = lp, lr, lv
+    P, R, V = ([], [], []) if motion_mode else ([lp], [lr], [lv])
+    for i in range(len(seg) - 1):
+        a, F = int(seg[i]), int(seg[i + 1] - seg[i])
+        if F == 0:
+            if motion_mode:
+                sp = torch.zeros(3, dtype=dt.dtype)
+            sv = torch.zeros(3, dtype=dt.dtype)
+        else:
+            A = torch.tensor([0, 0, 0, 1.0], dtype=dt.dtype)
+            iv, ip, it = torch.zeros(3, dtype=dt.dtype), torch.zeros(3, dtype=dt.dtype), 0.0
+            for j in range(a, a + F):
+                A1 = _tq_mul(A, _tq_exp(gyro[j] * dt[j]))
+                q = _tq_mul(lr, A1)
+                gb = _tq_act(q * torch.tensor([-1, -1, -1, 1.0], dtype=dt.dtype), g)
+                ra = _tq_act(A, acc[j] - gb)
+                ip = ip + iv * dt[j] + ra * 0.5 * dt[j] * dt[j]
+                iv = iv + ra * dt[j]
+                it = it + dt[j]
+                A = A1
+            sr = _tq_mul(lr, A)
+            sv = lv + _tq_act(lr, iv)
+            sp = lp + _tq_act(lr, ip) + lv * it
+        P.append(sp)
+        V.append(sv)
+        R.append(_tq_mul(lr * torch.tensor([-1, -1, -1, 1.0], dtype=dt.dtype), sr) if motion_mode else sr)
+        lr = sr
+        if not motion_mode:
+            lp, lv = sp, sv
+    return torch.stack(P), torch.stack(R), torch.stack(V)

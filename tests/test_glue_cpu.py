@@ -1,10 +1,10 @@
 """CPU tests of the host-side mirror: LieTensor shim (values vs the oracle, PyPose gradient conventions vs finite
-differences), transformation helpers, device-side Canny stand-in (property tests; OpenCV parity is unpinned)."""
+differences), transformation helpers, the Canny oracle's known answers (OpenCV parity is unpinned)."""
 import numpy as np
 import pytest
 import torch
 
-from islam_amd import edges, evaluate, lietensor as pp, transformation as tf
+from islam_amd import evaluate, lietensor as pp, transformation as tf
 from oracle import lie
 
 
@@ -104,28 +104,40 @@ def test_transformation_helpers():
     assert P.dtype == torch.float64
 
 
-def test_edge_mask_properties():
+def test_edge_mask_oracle_properties():
+    """oracle/canny.py (the restatement of OpenCV 4.7 the HIP edge kernel is checked against, tests/test_edge_gpu.py):
+    known answers of each stage."""
+    from oracle import canny
     H, W = 64, 96
-    img = torch.full((1, 3, H, W), 0.2)
+    img = np.full((1, 3, H, W), 0.2, np.float32)
     img[:, :, :, 48:] = 0.8                                       # one vertical step edge
-    e = edges.canny_u8((img * 255).to(torch.uint8))
-    cols = torch.nonzero(e[0].any(0)).flatten().tolist()
-    assert cols in ([47], [48]) and e[0, 5:-5, cols[0]].all()      # a single-pixel-wide line (non-maximum suppression)
-    m = edges.edge_mask(img)
-    assert m.shape == (1, 16, 24) and m.dtype == torch.bool
-    band = torch.nonzero(m[0].any(0)).flatten()
+    e = canny.canny(canny.to_u8(img)[0])
+    cols = np.nonzero(e.any(0))[0].tolist()
+    assert cols in ([47], [48]) and e[5:-5, cols[0]].all()         # a single-pixel-wide line (non-maximum suppression)
+    assert set(np.unique(e)) == {0, 255}
+    m = canny.edge_mask(img)
+    assert m.shape == (1, 16, 24) and m.dtype == bool
+    band = np.nonzero(m[0].any(0))[0]
     assert 3 <= len(band) <= 6 and band.min() >= 9 and band.max() <= 14      # 5x5 dilation of the line at x=12
-    assert not edges.edge_mask(torch.full((1, 3, H, W), 0.5)).any()           # flat image: no edges
-    # hysteresis: a weak edge survives only when connected to a strong one
-    img2 = torch.full((1, 3, H, W), 0.3)
-    img2[:, :, :32, 48:] = 0.3 + 70 / 255 / 4 * 2                 # gradient magnitude between low and high after Sobel
-    weak_only = edges.canny_u8((img2 * 255).to(torch.uint8))
-    img2[:, :, 32:, 48:] = 0.9
-    joined = edges.canny_u8((img2 * 255).to(torch.uint8))
-    assert joined[0, 2:30, 46:50].any() or not weak_only.any()
+    assert not canny.edge_mask(np.full((1, 3, H, W), 0.5, np.float32)).any()  # flat image: no edges
+    # hysteresis: a weak edge (50 < |gradient| <= 100) survives only when it is connected to a strong one
+    weak = np.full((H, W, 3), 80, np.uint8)
+    weak[:, 48:] = 80 + 20                                        # Sobel response 4 * 20 = 80: a candidate, never strong
+    assert not canny.canny(weak).any()
+    joined = weak.copy()
+    joined[40:, 48:] = 200                                        # the lower part of the same line is strong
+    e2 = canny.canny(joined)
+    assert e2[45:, 47:49].any() and e2[2:36, 47:49].any(1).all()  # ... and carries the weak part with it
     # quarter resize: mean of the centre 2x2 of each 4x4 cell, round half up
-    u8 = torch.arange(16, dtype=torch.uint8).reshape(1, 1, 4, 4)
-    assert edges.quarter_resize_u8(u8).item() == (5 + 6 + 9 + 10 + 2) // 4
+    u8 = np.arange(16, dtype=np.uint8).reshape(4, 4, 1)
+    assert canny.resize_quarter(u8).item() == (5 + 6 + 9 + 10 + 2) // 4
+    # truncating uint8 conversion and first-maximum channel selection
+    assert canny.to_u8(np.full((1, 3, 1, 1), 0.999, np.float32)).item(0) == 254
+    # dilate: a single pixel becomes a 5x5 block, clipped at the border
+    one = np.zeros((9, 9), np.uint8)
+    one[0, 4] = 255
+    d = canny.dilate(one)
+    assert d[:3, 2:7].all() and d.sum() == 255 * 15
 
 
 def test_preprocess_matches_reference_geometry():

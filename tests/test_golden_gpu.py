@@ -1,0 +1,232 @@
+"""GPU execution paths of the conv nets against the REFERENCE-generated golden vectors (tests/golden/nets_*.npz, made by
+importing /root/reference's own modules in the build container, tests/golden/make_net_golden.py).
+
+Every path the product can take is held against the same vectors the CPU definitions are (tests/test_nets_cpu.py):
+  * eager fp32 on MIOpen (+ HIP correlation / warp)                          <= 2e-4 of the output's max
+  * PWCDCNet.forward_mfma (HIP implicit-GEMM convolutions, bf16 operands)     <= 3e-2 of max
+  * the bf16 channels-last execution copy of the stereo net in TRAIN mode (HIP BatchNorm / resize / epilogue kernels)
+  * HIP-graph replay of the frozen forward
+  * the whole VONet / TartanVO forward.
+Tolerances (measured error statistics: scripts/calib/golden_errors.py -> profiles/r02/golden_errors.txt).
+  fp32: same conv stacks, other kernel selection (Winograd / implicit GEMM re-associate the sums): 2e-4 * max as on the CPU
+  (measured 1e-6 .. 3e-6).
+  bf16 operands (flow net on islam_conv3x3_mfma): unit round-off u = 2^-9 per operand, signs random, ~60 layers deep:
+  measured max 5.8e-2 / rms 1.7e-2 of the output's max / rms with a mean signed error of 4e-3 -- noise, no bias.  Bounds:
+  max 8e-2, rms 3e-2, |mean signed error| 1e-2 of the rms.
+  bf16 execution copy of the stereo net: measured max 7.4e-2, rms 6.5e-2 -- but a mean signed error of 5e-2 .. 6.5e-2: the
+  error is a SYSTEMATIC loss of magnitude, not noise.  scripts/calib/bf16_rounding_probe.py traces it to MIOpen: its bf16
+  kernels for several of the net's shapes (3->32 s2, 32->32, 134->64 3x3) convert the fp32 accumulator to bf16 by
+  TRUNCATION (50 % of the outputs differ from round-to-nearest-even, all of them towards zero: -0.28 % per layer, ~25 such
+  layers in the un-normalised hourglass path), the others round to nearest.  The repo's own kernels (BatchNorm, resize,
+  epilogue, islam_conv3x3_mfma) round to nearest even.  Until the stereo net's convolutions run on the repo's own kernel
+  the bound is max 1.2e-1 / rms 1e-1, and the test RECORDS the bias (printed) instead of hiding it.
+A systematic error common to both of the repo's own paths (what a self-comparison cannot see) shows up here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.netfill import fill_state_dict, make_input, tame_vonet, vonet_sample
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _g(name):
+    return np.load(os.path.join(G, 'nets_%s.npz' % name))
+
+
+def _relmax(got, ref):
+    ref = np.asarray(ref)
+    return float(np.abs(got.detach().float().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3))
+
+
+def _stats(got, ref):
+    """(max error / max |ref|, rms error / rms ref, mean signed error / rms ref)."""
+    ref = np.asarray(ref, np.float64)
+    d = got.detach().float().cpu().numpy().astype(np.float64) - ref
+    rms = max(float(np.sqrt((ref * ref).mean())), 1e-12)
+    return float(np.abs(d).max() / max(np.abs(ref).max(), 1e-3)), float(np.sqrt((d * d).mean()) / rms), float(d.mean() / rms)
+
+
+BF16_OPERANDS = (8e-2, 3e-2, 1e-2)        # islam_conv3x3_mfma path: max, rms, |bias|
+BF16_MIOPEN = (1.2e-1, 1e-1, 1e-1)        # MIOpen's bf16 kernels (some truncate): max, rms, |bias|
+
+
+def _within(got, ref, bounds, what=''):
+    mx, rms, bias = _stats(got, ref)
+    print('%s: max %.3e rms %.3e bias %+.3e' % (what, mx, rms, bias))
+    assert mx <= bounds[0] and rms <= bounds[1] and abs(bias) <= bounds[2], (what, mx, rms, bias)
+    return mx
+
+
+# ------------------------------------------------------------------------------------------ eager fp32 on the GPU
+def test_pose_net_fp32_on_gpu_matches_reference(cuda):
+    from islam_amd import nets
+    net = fill_state_dict(nets.VOFlowRes(fix_parts=('flow', 'stereo'))).to(cuda)
+    with torch.no_grad():
+        out = net(make_input('pose').to(cuda))
+        out_cl = net.to(memory_format=torch.channels_last)(make_input('pose').to(cuda).contiguous(memory_format=torch.channels_last))
+    assert _relmax(out, _g('pose')['pose']) <= 2e-4
+    assert _relmax(out_cl, _g('pose')['pose']) <= 2e-4               # VONet.set_pose_channels_last layout
+
+
+def test_stereo_net_fp32_train_mode_on_gpu_matches_reference(cuda):
+    from islam_amd import nets
+    ref = _g('stereo')
+    net = fill_state_dict(nets.StereoNet7()).to(cuda).train()        # TartanVO.py:91: batch statistics
+    with torch.no_grad():
+        out = net(make_input('stereo').to(cuda))[0]
+    assert _relmax(out, ref['disp']) <= 2e-4
+    rm = net.state_dict()['feature_extraction.firstconv.0.1.running_mean'].cpu().numpy()
+    np.testing.assert_allclose(rm, ref['running_mean_after'], rtol=1e-4, atol=1e-6)
+
+
+def test_flow_net_fp32_on_gpu_matches_reference(cuda):
+    """PWCDCNet.forward on MIOpen with the HIP correlation and warp kernels in the loop (the fixture was made with the
+    reference's conv stacks around oracle/corr81.c, which restates the reference's in-repo CUDA source)."""
+    from islam_amd import nets
+    ref = _g('pwc')
+    net = fill_state_dict(nets.PWCDCNet()).to(cuda).eval()
+    with torch.no_grad():
+        flows, _ = net(make_input('pwc').to(cuda))
+    for i, f in enumerate(flows):
+        assert _relmax(f, ref['flow%d' % i]) <= 2e-4, i
+
+
+def test_imu_denoiser_on_gpu_matches_reference(cuda):
+    from islam_amd import nets
+    ref = _g('denoise')
+    net = fill_state_dict(nets.IMUCorrector_CNN_GRU_WO_COV()).to(cuda)
+    ca, cg, _, _ = net({'acc': make_input('acc').to(cuda), 'gyro': make_input('gyro').to(cuda)}, eval=True)
+    np.testing.assert_allclose(ca.cpu().numpy(), ref['cacc'], rtol=1e-4, atol=1e-5)       # MIOpen GRU: other summation order
+    np.testing.assert_allclose(cg.cpu().numpy(), ref['cgyro'], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ the paths the bench runs
+def test_flow_net_matrix_core_path_matches_reference(cuda):
+    """PWCDCNet.forward_mfma: islam_conv3x3_mfma (bf16 operands, fp32 accumulate), slice-written DenseNet blocks, batched
+    pyramid -- against the reference's fp32 outputs."""
+    from islam_amd import nets
+    ref = _g('pwc')
+    net = fill_state_dict(nets.PWCDCNet()).to(cuda).eval()
+    with torch.no_grad():
+        flows, _ = net.forward_mfma(make_input('pwc').to(cuda))
+    errs = [_within(f, ref['flow%d' % i], BF16_OPERANDS, 'flow%d' % i) for i, f in enumerate(flows)]
+    assert max(errs) > 1e-5                  # it IS the reduced-precision path (the fp32 path sits at ~1e-6)
+
+
+def test_stereo_net_bf16_execution_copy_matches_reference(cuda):
+    """The frozen stereo net as the bench runs it: bf16 channels-last execution copy in train mode, BatchNorm on
+    islam_bn_train_nhwc_bf16 (batch statistics + running-stat update), islam_resize_bilinear_nhwc_bf16,
+    islam_bias_act_add_nhwc_bf16 -- against the reference's fp32 train-mode forward."""
+    from islam_amd import nets
+    ref = _g('stereo')
+    vn = nets.VONet(fix_parts=('flow', 'stereo'))
+    fill_state_dict(vn.stereoNet)
+    vn = vn.to(cuda).train()
+    vn.set_frozen_dtype(torch.bfloat16)
+    key = 'feature_extraction.firstconv.0.1.running_mean'
+    rm0 = vn.stereoNet.state_dict()[key].clone()
+    x = make_input('stereo').to(cuda)
+    with torch.no_grad():
+        out = vn._run_frozen('stereo', vn.stereoNet, vn.frozen_dtype, x)[0]
+    assert out.dtype == torch.bfloat16
+    ex = vn._exec['stereo'].module()
+    assert ex.feature_extraction.firstconv[0][0].weight.dtype == torch.bfloat16         # the reduced-precision copy ran
+    _within(out, ref['disp'], BF16_MIOPEN, 'disp (bf16 execution copy)')
+    rm = vn.stereoNet.state_dict()[key]
+    assert not torch.equal(rm, rm0)                                    # train-mode statistics landed in the fp32 master
+    # running_mean = 0.9 * old + 0.1 * batch mean of the first conv's bf16 output: |error| <= 0.1 * 2^-8 * mean |activation|
+    np.testing.assert_allclose(rm.cpu().numpy(), ref['running_mean_after'], rtol=0, atol=2e-3 * float(np.abs(ref['running_mean_after']).max()) + 1e-5)
+
+
+def _vonet(cuda, **kw):
+    from islam_amd import nets
+    vn = tame_vonet(fill_state_dict(nets.VONet(fix_parts=('flow', 'stereo')))).to(cuda).train()
+    return vn
+
+
+def _vo_args(cuda):
+    s = vonet_sample()
+    return [s[k].to(cuda) for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm', 'intrinsic')]
+
+
+def test_whole_vonet_fp32_matches_reference(cuda):
+    """Network/VONet.py:28-39 at 448x640, train mode: flow[0], the 1/4 nearest-downscaled disparity, the pose."""
+    ref = _g('vonet')
+    vn = _vonet(cuda)
+    with torch.no_grad():
+        flow, disp, pose = vn(*_vo_args(cuda))
+    assert _relmax(flow, ref['flow']) <= 2e-4
+    assert _relmax(disp, ref['disp']) <= 2e-4
+    assert _relmax(pose, ref['pose']) <= 1e-3            # the 40-layer pose head amplifies the 1e-4 flow difference
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph):
+    """What bench.py runs: flow net on the matrix-core convolution, stereo net through the bf16 execution copy, optionally
+    replayed from a captured HIP graph (two replays: the second one must still be right, and BatchNorm running statistics
+    keep moving)."""
+    ref = _g('vonet')
+    vn = _vonet(cuda)
+    vn.set_frozen_dtype(torch.bfloat16, torch.bfloat16)
+    vn.set_graph_frozen(graph)
+    args = _vo_args(cuda)
+    key = 'feature_extraction.firstconv.0.1.running_mean'
+    for rep in range(2 if graph else 1):
+        rm0 = vn.stereoNet.state_dict()[key].clone()
+        with torch.no_grad():
+            flow, disp, pose = vn(*args)
+        _within(flow, ref['flow'], BF16_OPERANDS, 'flow')
+        _within(disp, ref['disp'], BF16_MIOPEN, 'disp')
+        assert _relmax(pose, ref['pose']) <= 1e-2, rep     # pose head (fp32) fed with that flow (measured 7e-4)
+        assert not torch.equal(vn.stereoNet.state_dict()[key], rm0)
+    if graph:
+        assert len(vn._graphs) == 1
+        torch.cuda.synchronize()
+        vn.reset_graphs()
+
+
+def test_tartanvo_forward_matches_reference_nets_and_oracle_glue(cuda, tmp_path):
+    """TartanVO.forward end to end (TartanVO.py:90-198): checkpoint loading by suffix match (:49-87), the three nets (vs the
+    reference-generated vectors), unit rescale, edge mask, stereo scale, frame change (vs oracle/tartanvo.py fed with the
+    device's own network outputs, so the glue is held to a tight tolerance on its own)."""
+    from islam_amd import nets
+    from islam_amd.TartanVO import TartanVO
+    from oracle import tartanvo as otv
+    ref = _g('vonet')
+    sd = tame_vonet(fill_state_dict(nets.VONet(fix_parts=('flow', 'stereo')))).state_dict()
+    ckpt = str(tmp_path / 'vonet.pkl')
+    torch.save({'module.' + k: v for k, v in sd.items()}, ckpt)          # released checkpoints carry DataParallel prefixes
+    sample = vonet_sample()
+    for kw, tol_f, tol_d, tol_p in ((dict(), 2e-4, 2e-4, 1e-3),
+                                    (dict(frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True), BF16_OPERANDS[0],
+                                     BF16_MIOPEN[0], 1e-2)):
+        vo = TartanVO(vo_model_name=ckpt, correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, **kw)
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running_' not in k:
+                assert torch.equal(vo.vonet.state_dict()[k].cpu(), v), k
+        res = vo(sample)
+        flow, disp = res['flow'], res['disp']
+        assert _relmax(flow, ref['flow'] * 5) <= tol_f and _relmax(disp, ref['disp'] * 12.5) <= tol_d
+        # glue: recompute from the device's own raw network outputs
+        raw_pose = None
+        with torch.no_grad():
+            vo.vonet.eval()                                                # no second running-stat update
+            args = [sample[k].to(cuda) for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm', 'intrinsic')]
+            _, _, raw_pose = vo.vonet(*args, frozen=((flow / 5).contiguous(), (disp / 12.5).contiguous()))
+        assert _relmax(raw_pose, ref['pose']) <= tol_p
+        base = torch.linalg.norm(sample['extrinsic'][:, :3], dim=1).numpy()
+        o = otv.forward_glue((flow / 5).cpu().numpy(), (disp / 12.5).cpu().numpy(), raw_pose.cpu().numpy(), sample['img0'].numpy(),
+                             sample['intrinsic_calib'].numpy(), base, sample['datatype'], use_kitti_coord=True)
+        got_mask = res['mask'].cpu().numpy()
+        assert (got_mask != o['mask']).mean() <= 2e-3                      # pixels on a float32 threshold may flip
+        np.testing.assert_array_equal(res['depth_mask'].cpu().numpy(), o['depth_mask'])
+        np.testing.assert_allclose(res['depth'].cpu().numpy(), o['depth'], rtol=1e-5, atol=1e-5)
+        assert o['mask'].sum() > 500                                        # dense_ba.py:132: enough valid pixels
+        motion = res['motion'].tensor().detach().cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(motion, o['motion'], rtol=2e-3, atol=2e-5)
+        assert res['motion'].requires_grad
+        del vo

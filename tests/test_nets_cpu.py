@@ -77,3 +77,17 @@ def test_imu_denoiser_matches_reference(nets):
     np.testing.assert_allclose(ca.numpy(), ref['cacc'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(cg.numpy(), ref['cgyro'], rtol=1e-5, atol=1e-6)
     assert not ca.requires_grad                       # eval=True disables grad
+
+
+def test_whole_vonet_matches_reference(nets, monkeypatch):
+    """Network/VONet.py:28-39 at the production size (448x640), train mode (TartanVO.py:91)."""
+    from tests.golden.netfill import tame_vonet, vonet_sample
+    ref = np.load(os.path.join(G, 'nets_vonet.npz'))
+    monkeypatch.setattr(nets, 'corr_fn', lambda a, b: torch.from_numpy(cwrap.corr81_fwd(a.numpy(), b.numpy())))
+    monkeypatch.setattr(nets, 'warp_fn', lambda x, f, s: torch.from_numpy(cwrap.warp(x.numpy(), (f * s).numpy())))
+    net = tame_vonet(fill_state_dict(nets.VONet(fix_parts=('flow', 'stereo')))).train()
+    s = vonet_sample()
+    with torch.no_grad():
+        flow, disp, pose = net(*[s[k] for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm', 'intrinsic')])
+    for got, key, tol in ((flow, 'flow', 2e-4), (disp, 'disp', 2e-4), (pose, 'pose', 1e-3)):
+        assert np.abs(got.numpy() - ref[key]).max() <= tol * max(np.abs(ref[key]).max(), 1e-3), key
