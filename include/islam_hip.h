@@ -85,6 +85,11 @@ int islam_conv3x3_mfma(const float* x, const uint16_t* wpacked, const float* bia
  * x (B,Hi,Wi,C), y (B,Ho,Wo,C) bf16 bits, C a multiple of 8; align_corners as in torch. */
 int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                     int align_corners, void* stream);
+/* The same, written into channels [yoff, yoff+C) of a (B,Ho,Wo,ytot) tensor (ytot, yoff multiples of 8): bilinear resizing is
+ * per channel, so the up-sampled concatenation of submodule.py:140-152 is assembled in place, piece by piece, without the
+ * intermediate torch.cat and without copying the up-sampled tensor into the next concatenation. */
+int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                         int align_corners, int ytot, int yoff, void* stream);
 
 /* In-place epilogue of a bias-free convolution on a channels-last bf16 tensor: y <- act(bf16(y + bias[c]) [+ res]),
  * act = ReLU (relu != 0) or identity; res NULL or a tensor of y's shape.  One pass for the bias add, activation and residual
@@ -103,6 +108,31 @@ size_t islam_bn_scratch_floats(int C);
 int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* weight, const float* bias,
                              float* running_mean, float* running_var, long long* num_batches_tracked, double momentum,
                              double eps, int relu, long long pixels, int C, float* scratch, void* stream);
+
+/* Channels-last bf16 convolution of the frozen stereo feature extractor on the matrix cores (implicit GEMM, fp32 accumulate,
+ * round-to-nearest-even output), with the surrounding train-mode BatchNorm folded into its two ends.  Replaces cuDNN under
+ * Network/PSM/submodule.py:10-13 `convbn` (Conv2d k=3 p=1 / k=1 p=0, stride 1, bias=False, then BatchNorm2d), :66-155.
+ *   y[b,ho,wo,n] = epi( sum w[n,c,r,s] * pre(x[b, ho+r-P, wo+s-P, c]) ),  P = ksize/2, zero padding, output size = input size
+ *   pre(v) = v  (in_affine NULL)  or  relu(bf16(v*in_affine[c] + in_affine[Cin+c]))  -- the producer's BatchNorm + ReLU on load
+ *   epi(a) = bf16(a), and with `stats` the per-channel sums of bf16(a) and bf16(a)^2 over all pixels (stats NULL: skipped);
+ *            or  act( bf16( bf16(a + bias[n]) [+ res] ) ),  act = ReLU if `relu`.
+ * x (B,H,W,Cin), res / y (B,H,W,Cout) bf16 bits, Cin and Cout multiples of 8; wpacked: bf16 [ksize*ksize][CoutP][CinP], CoutP =
+ * Cout rounded up to 64, CinP = Cin rounded up to 32, zero padded (islam_conv_nhwc_packed_elems elements).
+ * stats: islam_conv_nhwc_stats_floats(B,H,W,Cout) floats; on return its LAST 256*2*Cout floats hold the folded partial sums
+ * ([256][2][Cout], fixed-order = deterministic) that islam_bn_finalize reads.  ksize 1 or 3. */
+size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize);
+int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout);
+size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout);
+int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
+                         uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
+/* The two halves of islam_bn_train_nhwc_bf16 for a producer that delivers the statistics itself: folded = [256][2][C] partial
+ * sums, count = pixels; scale_shift (2*C floats) = [weight*rsqrt(var+eps) | bias - mean*scale]; running statistics updated like
+ * nn.BatchNorm2d (NULL: skipped).  C <= 256.  Apply: y = act( bf16(x*scale[c] + shift[c]) [+ res] ), C a multiple of 8. */
+int islam_bn_finalize(const float* folded, double count, const float* weight, const float* bias, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, double momentum, double eps, int C, float* scale_shift,
+                      void* stream);
+int islam_bn_apply_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* scale_shift, int relu,
+                             long long pixels, int C, void* stream);
 
 /* ---------------------------------------------------------------- edge mask */
 

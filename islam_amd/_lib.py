@@ -51,9 +51,16 @@ SIGNATURES = {
     'islam_conv3x3_packed_elems': (c_size_t, [c_int, c_int]),
     'islam_conv3x3_mfma': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_float, c_void_p]),
     'islam_resize_bilinear_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'islam_resize_bilinear_nhwc_bf16_into': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'islam_bias_act_add_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
     'islam_bn_scratch_floats': (c_size_t, [c_int]),
     'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
+    'islam_conv_nhwc_packed_elems': (c_size_t, [c_int] * 3),
+    'islam_conv_nhwc_stat_blocks': (c_int, [c_int] * 4),
+    'islam_conv_nhwc_stats_floats': (c_size_t, [c_int] * 4),
+    'islam_conv_nhwc_bf16': (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    'islam_bn_finalize': (c_int, [c_void_p, c_double] + [c_void_p] * 5 + [c_double, c_double, c_int, c_void_p, c_void_p]),
+    'islam_bn_apply_nhwc_bf16': (c_int, [c_void_p] * 4 + [c_int, ctypes.c_longlong, c_int, c_void_p]),
     'islam_edge_mask_max_pixels': (c_int, []),
     'islam_edge_mask': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'islam_scale_ls': (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),

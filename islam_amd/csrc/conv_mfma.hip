@@ -257,11 +257,12 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v 
 
 __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8,
                                                                         int Hi, int Wi, int Ho, int Wo, float sh, float sw,
-                                                                        int align, long long total) {
+                                                                        int align, long long total, int yC8, int yoff8) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cg = (int)(i % C8);
     long long p = i / C8;
+    const long long opix = p;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
@@ -290,15 +291,17 @@ __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const ui
     o.y = mix(a.y, bq.y, c.y, d.y);
     o.z = mix(a.z, bq.z, c.z, d.z);
     o.w = mix(a.w, bq.w, c.w, d.w);
-    y[i] = o;
+    y[opix * yC8 + yoff8 + cg] = o;                     // channels [8*yoff8, 8*yoff8 + C) of a (B,Ho,Wo,8*yC8) tensor
 }
 
 }  // namespace
 
-extern "C" int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                                               int align_corners, void* stream) {
+extern "C" int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                                    int align_corners, int ytot, int yoff, void* stream) {
     if (B < 1 || C < 8 || (C & 7) || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1)
         return fail(ISLAM_EARG, "islam_resize_bilinear_nhwc_bf16: bad shape (C=%d must be a multiple of 8)", C);
+    if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + C > ytot)
+        return fail(ISLAM_EARG, "islam_resize_bilinear_nhwc_bf16: output slice %d+%d of %d channels (multiples of 8)", yoff, C, ytot);
     float sh, sw;
     if (align_corners) {
         sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
@@ -309,9 +312,15 @@ extern "C" int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, i
     }
     const long long total = (long long)B * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(resize_bilinear_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, Hi, Wi, Ho, Wo, sh, sw, align_corners, total);
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, Hi, Wi, Ho, Wo, sh, sw, align_corners, total,
+                       ytot / 8, yoff / 8);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+extern "C" int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                               int align_corners, void* stream) {
+    return islam_resize_bilinear_nhwc_bf16_into(x, y, B, C, Hi, Wi, Ho, Wo, align_corners, C, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,6 +505,30 @@ extern "C" int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const ui
     const long long total = pixels * C8;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4*>(x),
                        reinterpret_cast<uint4*>(y), reinterpret_cast<const uint4*>(res), scale_shift, C8, relu, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// The two halves of islam_bn_train_nhwc_bf16 on their own, for convolutions that deliver the batch statistics themselves
+// (islam_conv_nhwc_bf16 with `stats`): finalize = fixed-order sum of the folded partials -> scale / shift (+ running statistics);
+// apply = one pass  y = act( bf16(x * scale[c] + shift[c]) [+ res] ).
+extern "C" int islam_bn_finalize(const float* folded, double count, const float* weight, const float* bias, float* running_mean,
+                                 float* running_var, long long* num_batches_tracked, double momentum, double eps, int C,
+                                 float* scale_shift, void* stream) {
+    if (count < 1 || C < 1 || C > 256) return fail(ISLAM_EARG, "islam_bn_finalize: C=%d (1..256)", C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, folded, BN_BLOCKS, C, count, weight, bias,
+                       running_mean, running_var, num_batches_tracked, momentum, eps, scale_shift);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+extern "C" int islam_bn_apply_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res, const float* scale_shift, int relu,
+                                        long long pixels, int C, void* stream) {
+    if (pixels < 1 || C < 8 || (C & 7)) return fail(ISLAM_EARG, "islam_bn_apply_nhwc_bf16: C=%d must be a multiple of 8", C);
+    const long long total = pixels * (C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), reinterpret_cast<const uint4*>(res), scale_shift,
+                       C / 8, relu, total);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

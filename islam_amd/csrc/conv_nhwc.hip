@@ -1,0 +1,322 @@
+// conv_nhwc.hip -- 3x3 / 1x1 stride-1 convolution of the frozen stereo network on the CDNA4 matrix cores, channels-last bf16.
+//
+// Replaces, for the bf16 execution copy of the stereo feature extractor, what the reference runs through cuDNN
+// (Network/PSM/submodule.py:10-13 `convbn` = Conv2d(bias=False) + BatchNorm2d, :66-155 BasicBlock / feature_extraction) and
+// what round 1 ran through MIOpen:
+//   y[b,ho,wo,n] = epi( sum_{r,s,c} w[n,c,r,s] * pre( x[b, ho + r - P, wo + s - P, c] ) ),   P = K/2, zero padding
+//   pre(v)  = v                      or   relu(bf16(v * in_scale[c] + in_shift[c]))   -- the PREVIOUS layer's train-mode
+//             BatchNorm + ReLU applied while the tile is staged: that layer's normalised tensor is never written
+//   epi(a)  = bf16(a)  [+ per-workgroup partial sums of bf16(a), bf16(a)^2 per output channel: the batch statistics of THIS
+//             layer's BatchNorm come out of the convolution's epilogue instead of another pass over the tensor]
+//          or  act( bf16( bf16(a + bias[n]) [+ res] ) )
+// Why not MIOpen: (1) several of its bf16 kernels for these shapes convert the fp32 accumulator to bf16 by TRUNCATION
+// (scripts/calib/bf16_rounding_probe.py: half of the outputs differ from round-to-nearest-even, all towards zero), a
+// systematic -0.28 % per layer that the reference-generated golden vectors expose as a 5-6 % bias of the disparity; this
+// kernel rounds to nearest even; (2) the BatchNorm that follows every convolution of the feature extractor costs two more
+// passes over the activation (statistics, apply), the convolution itself being memory-bound at 32 channels.
+//
+// GEMM view per image: M = Cout (A operand: weights), N = pixels (B operand: im2col of x), K = K*K*Cin, on
+// v_mfma_f32_32x32x16_bf16.  Workgroup = 256 threads = 4 waves, tile 32 x 16 output pixels x TN output channels, wave w
+// owns pixel rows 4w .. 4w+3.  K is walked in chunks of 32 input channels: the chunk's halo tile ([y][x][32 ch], 80-byte
+// pixel stride) and the K*K weight taps are staged in LDS once and feed K*K*2*4*TN/32 MFMAs per wave; activations are
+// read from HBM as 16-byte vectors along C (a pixel's 32 channels = one 64-byte line) while the previous chunk is being
+// multiplied.  The output tile is transposed through LDS so that the stores are 16 bytes per lane along C.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "../../include/islam_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace islam;
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TW = 32, KC = 32, PS = 40;             // PS: bf16 elements per LDS pixel / weight row (32 + 8 pad = 80 bytes)
+constexpr int THREADS = 256;                         // 4 waves x ROWS pixel rows: tile 32 x 4*ROWS pixels
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {      // round-to-nearest-even, one v_cvt_pk_bf16_f32
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float lo16(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float hi16(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned relu2(unsigned t) {
+    if (t & 0x8000u) t &= 0xffff0000u;
+    if (t & 0x80000000u) t &= 0x0000ffffu;
+    return t;
+}
+
+// Register blocking: a wave owns ROWS pixel rows x TN channels; for a horizontal tap offset s it reads the ROWS + K - 1 halo rows
+// once and reuses each for up to K vertical taps, and a weight operand for all its rows.  ROWS = 4 with TN = 32 (0.75 LDS
+// operand reads per MFMA, two workgroups per CU), ROWS = 2 with TN = 64 (0.83; the 4-row variant needs 95 KB of LDS and
+// leaves one wave per SIMD with nothing to hide its latencies behind: measured slower).
+template <int TN, int KS, int ROWS>
+__global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
+                                                             const float* __restrict__ in_affine, const float* __restrict__ bias,
+                                                             const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
+                                                             float* __restrict__ partial, int Cin, int CinP, int H, int W, int Cout,
+                                                             int CoutP, int relu, int tiles_x, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    constexpr int TH = 4 * ROWS, P = KS / 2, IH = TH + 2 * P, IW = TW + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
+    constexpr int NIN = (NPIX * (KC / 8) + THREADS - 1) / THREADS;       // 16-byte items of the halo tile per thread
+    constexpr int NWT = (TAPS * TN * (KC / 8) + THREADS - 1) / THREADS;  // 16-byte items of the weight taps per thread
+    constexpr int NT = TN / 32, NR = ROWS + KS - 1;
+    unsigned short* lin = lds;                               // [IH][IW][PS]
+    unsigned short* lw = lds + (size_t)NPIX * PS;            // [TAPS][TN][PS]
+    constexpr int DUMMY = (NPIX + TAPS * TN) * PS;           // 16 bytes of scratch behind both tiles
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int wo0 = tx * TW, ho0 = ty * TH, n0 = blockIdx.y * TN;
+    const unsigned short* xb = x + (size_t)b * H * W * Cin;
+
+    f32x16 acc[NT][ROWS];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][p][i] = 0.0f;
+
+    // staging map, the same for every chunk: item -> (halo pixel, channel octet); outside the image or past Cin -> zero.
+    // THREADS is a multiple of 4, so a thread's items all carry the same channel octet.
+    const int coct = 8 * (tid & 3);
+    int goff[NIN], loff[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int it = tid + k * THREADS;
+        goff[k] = -1; loff[k] = DUMMY;
+        if (it < NPIX * (KC / 8)) {
+            const int pix = it >> 2;
+            const int yy = pix / IW, xx = pix - yy * IW;
+            const int gy = ho0 - P + yy, gx = wo0 - P + xx;
+            loff[k] = pix * PS + coct;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * W + gx) * Cin + coct;
+        }
+    }
+    int woff[NWT], wlds[NWT];
+#pragma unroll
+    for (int k = 0; k < NWT; ++k) {
+        const int it = tid + k * THREADS;                    // ((tap*TN + n)*4 + octet)
+        woff[k] = 0; wlds[k] = DUMMY;
+        if (it < TAPS * TN * (KC / 8)) {
+            const int row = it >> 2, tap = row / TN, n = row - tap * TN;
+            woff[k] = (tap * CoutP + n0 + n) * CinP + coct;
+            wlds[k] = row * PS + coct;
+        }
+    }
+    uint4 pre[NIN], prew[NWT];
+    auto fetch = [&](int c0) {
+        const bool cok = c0 + coct < Cin;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k)
+            pre[k] = *reinterpret_cast<const uint4*>(xb + ((cok && goff[k] >= 0) ? (size_t)goff[k] + c0 : (size_t)0));   // masked: any valid address
+#pragma unroll
+        for (int k = 0; k < NWT; ++k) prew[k] = *reinterpret_cast<const uint4*>(wp + (size_t)woff[k] + c0);
+    };
+    auto stage = [&](int c0) {
+        const bool cok = c0 + coct < Cin;
+        float4 s0 = {1, 1, 1, 1}, s1 = s0, h0 = {0, 0, 0, 0}, h1 = h0;
+        if (in_affine && cok) {                              // previous layer's BatchNorm (batch statistics) + ReLU on load
+            const float* sc = in_affine + c0 + coct;
+            s0 = *reinterpret_cast<const float4*>(sc); s1 = *reinterpret_cast<const float4*>(sc + 4);
+            h0 = *reinterpret_cast<const float4*>(sc + Cin); h1 = *reinterpret_cast<const float4*>(sc + Cin + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            uint4 v = pre[k];
+            if (in_affine) {
+                v.x = relu2(pack2(fmaf(lo16(v.x), s0.x, h0.x), fmaf(hi16(v.x), s0.y, h0.y)));
+                v.y = relu2(pack2(fmaf(lo16(v.y), s0.z, h0.z), fmaf(hi16(v.y), s0.w, h0.w)));
+                v.z = relu2(pack2(fmaf(lo16(v.z), s1.x, h1.x), fmaf(hi16(v.z), s1.y, h1.y)));
+                v.w = relu2(pack2(fmaf(lo16(v.w), s1.z, h1.z), fmaf(hi16(v.w), s1.w, h1.w)));
+            }
+            if (!(cok && goff[k] >= 0)) v = make_uint4(0, 0, 0, 0);      // zero padding of the NORMALISED activation
+            *reinterpret_cast<uint4*>(lin + loff[k]) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NWT; ++k) *reinterpret_cast<uint4*>(lw + wlds[k]) = prew[k];
+    };
+
+    const int kg = lane >> 5, li = lane & 31;
+    const unsigned short* bbase = lin + ((size_t)(ROWS * wave) * IW + li) * PS + 8 * kg;
+    const unsigned short* abase = lw + (size_t)li * PS + 8 * kg;
+    fetch(0);
+    for (int c0 = 0; c0 < CinP; c0 += KC) {
+        __syncthreads();                                     // the previous chunk's operand reads are done
+        stage(c0);
+        __syncthreads();
+        if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 bf[NR];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) bf[q] = *reinterpret_cast<const bf16x8*>(bbase + ((size_t)q * IW + s) * PS + 16 * ks);
+#pragma unroll
+                for (int r = 0; r < KS; ++r) {
+                    bf16x8 af[NT];
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+                        af[a] = *reinterpret_cast<const bf16x8*>(abase + ((size_t)(r * KS + s) * TN + a * 32) * PS + 16 * ks);
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+#pragma unroll
+                        for (int p = 0; p < ROWS; ++p)
+                            acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[p + r], acc[a][p], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- epilogue.  D row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel x) = lane&31.  The tile goes through LDS
+    // ([pixel][TN channels] bf16, rounded once) so that the stores are 16 bytes per lane along C -- consecutive lanes complete
+    // whole 64 / 128-byte pixel rows -- and the same read feeds the residual add, the ReLU and the BatchNorm partial sums.
+    constexpr int TS = TN + 8;                               // bf16 elements per pixel row of the staging tile (16-byte pad)
+    constexpr int OCT = TN / 8, PPT = TW * TH * OCT / THREADS;     // channel octets per pixel, (pixel, octet) items per thread
+    unsigned short* tl = lds;                                // [TW*TH][TS]
+    float* red = reinterpret_cast<float*>(lds + (size_t)TW * TH * TS);     // [THREADS][17]
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * kg;
+                float v0 = acc[a][p][4 * g], v1 = acc[a][p][4 * g + 1], v2 = acc[a][p][4 * g + 2], v3 = acc[a][p][4 * g + 3];
+                if (bias && n0 + nl < Cout) { const float* bp = bias + n0 + nl; v0 += bp[0]; v1 += bp[1]; v2 += bp[2]; v3 += bp[3]; }
+                *reinterpret_cast<uint2*>(tl + (size_t)((ROWS * wave + p) * TW + li) * TS + nl) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+            }
+    __syncthreads();
+    unsigned short* yb = y + (size_t)b * H * W * Cout;
+    const unsigned short* rb = res ? res + (size_t)b * H * W * Cout : nullptr;
+    const int oct = tid % OCT, n = n0 + 8 * oct;
+    float sm[8], sq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sm[i] = 0.0f; sq[i] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int px = (tid + k * THREADS) / OCT;            // THREADS is a multiple of OCT: the octet is the same for every k
+        const int ho = ho0 + px / TW, wo = wo0 + (px % TW);
+        if (ho >= H || wo >= W || n >= Cout) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(tl + (size_t)px * TS + 8 * oct);
+        if (partial) {
+            const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float lo = lo16(wv[i]), hi = hi16(wv[i]);
+                sm[2 * i] += lo; sq[2 * i] = fmaf(lo, lo, sq[2 * i]);
+                sm[2 * i + 1] += hi; sq[2 * i + 1] = fmaf(hi, hi, sq[2 * i + 1]);
+            }
+        }
+        const size_t o = ((size_t)ho * W + wo) * Cout + n;
+        if (rb) {
+            const uint4 r = *reinterpret_cast<const uint4*>(rb + o);
+            v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
+            v.y = pack2(lo16(v.y) + lo16(r.y), hi16(v.y) + hi16(r.y));
+            v.z = pack2(lo16(v.z) + lo16(r.z), hi16(v.z) + hi16(r.z));
+            v.w = pack2(lo16(v.w) + lo16(r.w), hi16(v.w) + hi16(r.w));
+        }
+        if (relu) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }
+        *reinterpret_cast<uint4*>(yb + o) = v;
+    }
+    if (partial) {
+        // per-workgroup sums of the (bf16-rounded, as nn.BatchNorm2d sees them) outputs over the tile's valid pixels, per
+        // channel, in a fixed order: every thread holds the sums of its octet over its pixels, one lane per (channel, moment)
+        // adds the THREADS / OCT threads of that octet in thread order
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[tid * 17 + i] = sm[i]; red[tid * 17 + 8 + i] = sq[i]; }
+        __syncthreads();
+        if (tid < 2 * TN) {
+            const int which = tid / TN, c = tid - which * TN, o2 = c >> 3, i = c & 7;
+            float t = 0.0f;
+            for (int m = 0; m < THREADS / OCT; ++m) t += red[(o2 + OCT * m) * 17 + 8 * which + i];
+            if (n0 + c < Cout) partial[((size_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
+        }
+    }
+}
+
+constexpr int RED_BLOCKS = 256;         // = BN_BLOCKS of conv_mfma.hip: the layout bn_finalize_kernel reads
+
+// partial[nblk][2][C] -> out[RED_BLOCKS][2][C], block j adds the slices j, j + RED_BLOCKS, ... in that order (deterministic)
+__global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restrict__ partial, int nblk, int C2, float* __restrict__ out) {
+    const int j = blockIdx.x;
+    for (int c = threadIdx.x; c < C2; c += 256) {
+        float s = 0.0f;
+        for (int bI = j; bI < nblk; bI += RED_BLOCKS) s += partial[(size_t)bI * C2 + c];
+        out[(size_t)j * C2 + c] = s;
+    }
+}
+
+template <int TN, int KS, int ROWS>
+int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
+           unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, hipStream_t s) {
+    constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS;
+    const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
+    const size_t epi_lds = (size_t)TW * TH * (TN + 8) * sizeof(unsigned short) + (size_t)THREADS * 17 * sizeof(float);
+    const size_t lds = std::max(conv_lds, epi_lds);
+    int dev = 0;
+    ISLAM_HIP_CHECK(hipGetDevice(&dev));
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set[dev] = true;
+    }
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    dim3 grid(tiles_x * tiles_y * B, (Cout + TN - 1) / TN);      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
+    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP, H, W,
+                       Cout, CoutP, relu, tiles_x, tiles_x * tiles_y);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    return (size_t)ksize * ksize * CoutP * CinP;
+}
+
+static int tile_h(int Cout) { return Cout > 32 ? 8 : 16; }
+int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout) { return ((W + TW - 1) / TW) * ((H + tile_h(Cout) - 1) / tile_h(Cout)) * B; }
+
+size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout) {
+    return (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout + (size_t)RED_BLOCKS * 2 * Cout;
+}
+
+int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
+                         uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+    if (ksize != 1 && ksize != 3) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: kernel size %d (1 or 3)", ksize);
+    if (stats && (bias || res || relu)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: statistics go with the raw output (no bias / residual / ReLU)");
+    if ((size_t)B * H * W * std::max(Cin, Cout) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = Cout > 32;
+    int rc;
+    if (ksize == 3)
+        rc = wide ? launch<64, 3, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s)
+                  : launch<32, 3, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s);
+    else
+        rc = wide ? launch<64, 1, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s)
+                  : launch<32, 1, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s);
+    if (rc != ISLAM_OK) return rc;
+    if (stats) {
+        const int nblk = islam_conv_nhwc_stat_blocks(B, H, W, Cout);
+        hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout, stats + (size_t)nblk * 2 * Cout);
+        ISLAM_LAUNCH_CHECK();
+    }
+    return ISLAM_OK;
+}
+
+}  // extern "C"

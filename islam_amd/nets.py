@@ -181,17 +181,82 @@ def _convbn(cin, cout, k, stride, pad, dilation):
                          nn.BatchNorm2d(cout))
 
 
-def _cbn(convbn, x, relu=False, res=None):
+# Which convolutions of the frozen stereo net's bf16 channels-last execution copy run on islam_conv_nhwc_bf16 (hand-written
+# implicit GEMM, round-to-nearest-even, BatchNorm statistics from the epilogue, the producer's BatchNorm + ReLU applied on load,
+# bias / residual / ReLU fused) instead of MIOpen.  MIOpen's kernels for the 32- and 64-channel 3x3 shapes TRUNCATE the fp32
+# accumulator to bf16 (scripts/calib/bf16_rounding_probe.py) and are memory-bound there, so the fusion wins; its 128-channel
+# kernels round to nearest and reach ~780 TF/s, where the hand-written kernel reaches ~500: those stay on MIOpen.
+# ISLAM_HIP_CONV: 0 = all MIOpen (round-1 path), 1 (default) = 3x3 up to HIP_CONV_MAX_C channels, 2 = also the 1x1 convolutions
+# that carry a fused epilogue (MIOpen's 1x1 kernels round to nearest and are ~25 % faster: measured 12.40 vs 12.48 ms per forward).
+import os as _os
+
+HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '1'))
+HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '96'))
+
+
+def _hip_conv_ok(conv, x, fused_1x1=False):
+    if HIP_CONV_LEVEL < 1 or not isinstance(conv, nn.Conv2d) or not isinstance(x, torch.Tensor):
+        return False
+    k = conv.kernel_size[0]
+    if conv.kernel_size != (k, k) or k not in (1, 3) or conv.stride != (1, 1) or conv.padding != (k // 2, k // 2) \
+            or conv.dilation != (1, 1) or conv.groups != 1 or conv.in_channels % 8 or conv.out_channels % 8:
+        return False
+    if not ops.fusable_nhwc_bf16(x, conv.in_channels) or conv.weight.dtype != torch.bfloat16:
+        return False
+    if k == 1:
+        return HIP_CONV_LEVEL >= 2 and fused_1x1
+    return max(conv.in_channels, conv.out_channels) <= HIP_CONV_MAX_C
+
+
+def _packed_nhwc(conv, cin=None):
+    """bf16 tap-major weights of a convolution for islam_conv_nhwc_bf16, re-packed when the execution copy is rebuilt.
+    ``cin`` > conv.in_channels: zero weights for the extra (zero-filled) input channels of a padded buffer."""
+    key = (conv.weight._version, conv.weight.data_ptr(), cin)
+    hit = conv.__dict__.get('_nhwc_packed')
+    if hit is None or hit[0] != key:
+        w = conv.weight
+        if cin is not None and cin > w.shape[1]:
+            w = F.pad(w, (0, 0, 0, 0, 0, cin - w.shape[1]))
+        hit = conv.__dict__['_nhwc_packed'] = (key, ops.pack_conv_nhwc_weight(w))
+    return hit[1]
+
+
+class _Pending:
+    """A convbn output whose BatchNorm (+ ReLU) has not been applied yet: the raw convolution output and the [scale | shift] of
+    its batch statistics.  The consumer applies it while staging its input tile (islam_conv_nhwc_bf16 `in_affine`), or
+    materialize() does (one in-place pass)."""
+
+    def __init__(self, raw, affine):
+        self.raw, self.affine = raw, affine
+
+    def materialize(self):
+        return ops.bn_apply_(self.raw, self.affine, relu=True)
+
+
+def _cbn(convbn, x, relu=False, res=None, defer=False):
     """A `convbn` block (Conv2d, BatchNorm2d; submodule.py:10-13) together with the residual add and / or ReLU that follows
-    it.  On the frozen bf16 channels-last execution copy in training mode the BatchNorm (batch statistics, running-stat
-    update), the add and the ReLU are ONE HIP op on the convolution's output (ops.bn_train_); everywhere else plain torch."""
+    it.  On the frozen bf16 channels-last execution copy in training mode: the convolution on islam_conv_nhwc_bf16 with the batch
+    statistics from its epilogue where _hip_conv_ok says so (``x`` may be a _Pending producer; ``defer`` returns one), MIOpen +
+    ONE fused BatchNorm op (ops.bn_train_) otherwise; everywhere else plain torch."""
     conv, bn = convbn[0], convbn[1]
+    plain_bn = type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32
+    xin = x.raw if isinstance(x, _Pending) else x
+    if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin):
+        y, folded = ops.conv_nhwc(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0],
+                                  in_affine=x.affine if isinstance(x, _Pending) else None, stats=True)
+        affine = ops.bn_finalize(folded, bn, y.shape[0] * y.shape[2] * y.shape[3])
+        if defer and relu and res is None:
+            return _Pending(y, affine)
+        if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
+            res = res.contiguous(memory_format=torch.channels_last)
+        return ops.bn_apply_(y, affine, relu, res)
+    if isinstance(x, _Pending):
+        x = x.materialize()
     y = conv(x)
     c = y.shape[1]
     # the fused op normalises with the statistics of THIS rank's tensor: only a plain nn.BatchNorm2d may take it (a
     # dist_train.ShardedBatchNorm2d must run its own forward, which all-reduces [sum | sum of squares | count] first)
-    if type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32 and ops.fusable_nhwc_bf16(y, c) \
-            and c <= 256 and 256 % (c // 8) == 0:
+    if plain_bn and ops.fusable_nhwc_bf16(y, c) and c <= 256 and 256 % (c // 8) == 0:
         if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
             res = res.contiguous(memory_format=torch.channels_last)
         return ops.bn_train_(y, bn, relu, res)
@@ -209,7 +274,7 @@ class _PSMBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = _cbn(self.conv1[0], x, relu=True)
+        y = _cbn(self.conv1[0], x, relu=True, defer=True)      # its BatchNorm + ReLU may ride on conv2's input staging
         res = x if self.downsample is None else _cbn(self.downsample, x)
         return _cbn(self.conv2, y, res=res)
 
@@ -259,8 +324,8 @@ class feature_extraction(nn.Module):
 
     def forward(self, x):
         f = x
-        for i in (0, 2, 4):                                  # firstconv = (convbn, ReLU) x 3
-            f = _cbn(self.firstconv[i], f, relu=True)
+        for i in (0, 2, 4):                                  # firstconv = (convbn, ReLU) x 3; the middle one's BatchNorm + ReLU
+            f = _cbn(self.firstconv[i], f, relu=True, defer=(i == 2))      # is applied by the third convolution's load
         o0 = self.layer1(f)
         raw = self.layer2(o0)
         skip = self.layer4(self.layer3(raw))
@@ -268,9 +333,23 @@ class feature_extraction(nn.Module):
         pools = _spp_pools(skip)
         br = [ops.resize_bilinear(_cbn(getattr(self, 'branch%d' % i)[1], pools[k], relu=True), hw, align_corners=True)
               for i, k in ((4, 8), (3, 16), (2, 32), (1, 64))]
-        feat = torch.cat([raw, skip] + br, 1)
-        if self.bigger:
-            feat = torch.cat((ops.resize_bilinear(feat, [hw[0] * 2, hw[1] * 2], align_corners=True), o0), 1)
+        pieces = [raw, skip] + br
+        if self.bigger and ops.fusable_nhwc_bf16(skip, skip.shape[1]) and all(ops.fusable_nhwc_bf16(t, t.shape[1]) for t in pieces + [o0]):
+            # bilinear resizing is per channel: up(cat(pieces)) = cat(up(piece)) -- every piece is up-sampled straight into its
+            # channel slice of the 352-channel input of lastconv (no torch.cat of the pieces, no copy of the up-sampled 320
+            # channels into the second torch.cat: ~2 GB of traffic per forward at B=8)
+            ctot = sum(t.shape[1] for t in pieces) + o0.shape[1]
+            feat = torch.empty((skip.shape[0], ctot, hw[0] * 2, hw[1] * 2), dtype=skip.dtype, device=skip.device,
+                               memory_format=torch.channels_last)
+            off = 0
+            for t in pieces:
+                ops.resize_bilinear_into(t, feat, off, align_corners=True)
+                off += t.shape[1]
+            feat[:, off:].copy_(o0)
+        else:
+            feat = torch.cat(pieces, 1)
+            if self.bigger:
+                feat = torch.cat((ops.resize_bilinear(feat, [hw[0] * 2, hw[1] * 2], align_corners=True), o0), 1)
         return self.lastconv[2](_cbn(self.lastconv[0], feat, relu=True))
 
 
@@ -285,13 +364,18 @@ class _HGConv(nn.Module):
         return self.conv(x)
 
     def run(self, x, relu=False, res=None):
-        """act(conv(x) + bias [+ res]) with the bias add, ReLU and residual add in ONE in-place pass over the bias-free
-        MIOpen convolution's output (frozen bf16 channels-last execution copy only; see _HGResidual.forward)."""
+        """act(conv(x) + bias [+ res]): on islam_conv_nhwc_bf16 with the bias add, residual add and ReLU in its epilogue, or --
+        for the shapes MIOpen is faster on -- a bias-free MIOpen convolution and ONE in-place pass over its output (frozen
+        bf16 channels-last execution copy only; see _HGResidual.forward)."""
         c = self.conv
         b = self.__dict__.get('_b32')
         key = (c.bias._version, c.bias.data_ptr())
         if b is None or b[0] != key:
             b = self.__dict__['_b32'] = (key, c.bias.detach().float().contiguous())
+        if _hip_conv_ok(c, x, fused_1x1=True):
+            if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
+                res = res.contiguous(memory_format=torch.channels_last)
+            return ops.conv_nhwc(x, _packed_nhwc(c), c.out_channels, c.kernel_size[0], bias=b[1], res=res, relu=relu)
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act_add_(y, b[1], res, relu)
 
@@ -379,9 +463,25 @@ class StereoNet7(nn.Module):
         B, C2, H, W = x.shape
         f = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))          # left/right stacked along the batch
         f = f.reshape(B, f.shape[1] * 2, f.shape[2], f.shape[3])
-        x = torch.cat((f, F.interpolate(x, scale_factor=0.5, mode='bilinear')), 1)
+        half = F.interpolate(x, scale_factor=0.5, mode='bilinear')
         act, pool = self.actfun, lambda t: F.max_pool2d(t, kernel_size=2)
-        cat0 = self.conv_c1(self.conv_c0(x))                                  # 1/2, 64
+        c0 = self.conv_c0
+        if HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f, f.shape[1]) and c0.weight.dtype == torch.bfloat16 and f.shape[1] % 8 == 0:
+            # 134 = 128 + 6 input channels: the concatenation is built with 136 channels (two zero ones) so that conv_c0 runs on
+            # islam_conv_nhwc_bf16 -- MIOpen's bf16 kernel for this shape truncates its output (scripts/calib/bf16_rounding_probe.py)
+            # and this is the first layer of the un-normalised hourglass path, where that loss of magnitude is never renormalised
+            cin = (c0.in_channels + 7) // 8 * 8
+            buf = torch.zeros((B, cin, f.shape[2], f.shape[3]), dtype=f.dtype, device=f.device, memory_format=torch.channels_last)
+            buf[:, :f.shape[1]].copy_(f)
+            buf[:, f.shape[1]:c0.in_channels].copy_(half)
+            bkey = (c0.bias._version, c0.bias.data_ptr())
+            b32 = self.__dict__.get('_c0_b32')
+            if b32 is None or b32[0] != bkey:
+                b32 = self.__dict__['_c0_b32'] = (bkey, c0.bias.detach().float().contiguous())
+            x0 = ops.conv_nhwc(buf, _packed_nhwc(c0, cin), c0.out_channels, 3, bias=b32[1])
+        else:
+            x0 = c0(torch.cat((f, half), 1))
+        cat0 = self.conv_c1(x0)                                               # 1/2, 64
         cat1 = self.conv_c2_SSP(pool(self.conv_c2(cat0)))                     # 1/4, 128
         cat2 = pool(self.conv_c3(cat1))                                       # 1/8, 192
         cat3 = pool(self.conv_c4(cat2))                                       # 1/16, 256

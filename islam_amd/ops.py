@@ -176,6 +176,63 @@ def conv3x3_mfma(x, packed, bias, cout, stride=1, dilation=1, slope=0.1, out=Non
     return out
 
 
+def pack_conv_nhwc_weight(w):
+    """(Cout, Cin, k, k) -> bf16 [k*k][CoutP][CinP] (tap-major, zero padded; CoutP = Cout up to 64s, CinP = Cin up to 32s), the
+    layout islam_conv_nhwc_bf16 stages."""
+    Cout, Cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    assert w.shape[2] == w.shape[3] and k in (1, 3)
+    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 63) // 64 * 64
+    p = torch.zeros((k * k, CoutP, CinP), dtype=torch.bfloat16, device=w.device)
+    p[:, :Cout, :Cin] = w.detach().permute(2, 3, 0, 1).reshape(k * k, Cout, Cin).to(torch.bfloat16)
+    assert p.numel() == lib().islam_conv_nhwc_packed_elems(Cin, Cout, k)
+    return p.contiguous()
+
+
+def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False):
+    """Channels-last bf16 convolution (k = 1 or 3, stride 1, "same" padding) on islam_conv_nhwc_bf16.  x: (B,Cin,H,W) bf16
+    channels_last.  in_affine (2*Cin fp32): the producer's BatchNorm scale | shift, applied with a ReLU while x is staged.
+    stats=True: returns (y, folded) with folded = the [256][2][cout] partial sums of the raw output for bn_finalize."""
+    require_cuda(x, packed)
+    B, Cin, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    st = None
+    if stats:
+        st = torch.empty(lib().islam_conv_nhwc_stats_floats(B, H, W, cout), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.shape == y.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
+    check(lib().islam_conv_nhwc_bf16(ptr(x), ptr(packed), ptr(in_affine), ptr(bias), ptr(res), ptr(y), ptr(st), B, Cin, H, W, int(cout),
+                                     int(ksize), int(bool(relu)), stream_ptr(x.device)))
+    if stats:
+        return y, st[st.numel() - 256 * 2 * cout:]
+    return y
+
+
+def bn_finalize(folded, bn, count):
+    """[256][2][C] partial sums -> (2*C) fp32 [scale | shift] of a train-mode nn.BatchNorm2d; its running statistics are
+    updated like nn.BatchNorm2d would (islam_bn_finalize)."""
+    C = bn.num_features
+    out = torch.empty(2 * C, dtype=torch.float32, device=folded.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    check(lib().islam_bn_finalize(ptr(folded), c_double(float(count)), ptr(bn.weight), ptr(bn.bias),
+                                  ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                  ptr(bn.num_batches_tracked) if track else None, c_double(mom), c_double(float(bn.eps)), C, ptr(out),
+                                  stream_ptr(folded.device)))
+    return out
+
+
+def bn_apply_(x, scale_shift, relu=False, res=None):
+    """In place on a channels-last bf16 tensor: x <- act(bf16(x*scale[c] + shift[c]) [+ res]) (islam_bn_apply_nhwc_bf16)."""
+    B, C, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
+    check(lib().islam_bn_apply_nhwc_bf16(ptr(x), ptr(x), ptr(res), ptr(scale_shift), int(bool(relu)), ctypes.c_longlong(B * H * W), C,
+                                         stream_ptr(x.device)))
+    return x
+
+
 def resize_bilinear(x, size, align_corners=False):
     """F.interpolate(x, size, mode='bilinear', align_corners=...) -- on the HIP kernel for channels-last bf16 inference
     tensors (the frozen stereo net's execution copy), through torch otherwise."""
@@ -188,6 +245,17 @@ def resize_bilinear(x, size, align_corners=False):
                                                     stream_ptr(x.device)))
         return y
     return torch.nn.functional.interpolate(x, [Ho, Wo], mode='bilinear', align_corners=align_corners)
+
+
+def resize_bilinear_into(x, out, coff, align_corners=False):
+    """Bilinear resize of a channels-last bf16 tensor to out's spatial size, written into out[:, coff:coff+C] (out: channels-last
+    bf16 with a multiple of 8 channels; coff a multiple of 8).  islam_resize_bilinear_nhwc_bf16_into."""
+    B, C, Hi, Wi = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == B
+    check(lib().islam_resize_bilinear_nhwc_bf16_into(ptr(x), ptr(out), B, C, Hi, Wi, int(out.shape[2]), int(out.shape[3]),
+                                                     int(bool(align_corners)), int(out.shape[1]), int(coff), stream_ptr(x.device)))
+    return out
 
 
 def fusable_nhwc_bf16(x, channels):

@@ -1,0 +1,110 @@
+"""GPU tests of islam_conv_nhwc_bf16 (channels-last bf16 implicit-GEMM convolution with BatchNorm folded into both ends) against
+plain torch fp32 on the same bf16 operands.  The output must be the round-to-nearest-even bf16 of the fp32 result (up to fp32
+summation order): no truncation bias (what MIOpen's kernels for these shapes have, scripts/calib/bf16_rounding_probe.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def _mk(B, Cin, H, W, Cout, k, seed=0, dev='cuda'):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=CL)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev).to(torch.bfloat16)
+    return x, w
+
+
+def _ulps(got, ref32):
+    """|got - ref| in units of the bf16 spacing at ref."""
+    r = ref32.float()
+    spacing = torch.pow(2.0, torch.floor(torch.log2(r.abs().clamp_min(1e-30))) - 7)
+    return ((got.float() - r).abs() / spacing)
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,k', [(2, 32, 64, 96, 32, 3), (1, 64, 40, 72, 64, 3), (2, 128, 24, 40, 128, 3), (1, 352, 24, 32, 128, 3),
+                                               (2, 128, 33, 47, 64, 1), (1, 64, 17, 50, 128, 1), (1, 48, 19, 35, 40, 3), (3, 32, 7, 5, 32, 3)])
+def test_plain_convolution_rounds_to_nearest(cuda, B, Cin, H, W, Cout, k):
+    from islam_amd import ops
+    x, w = _mk(B, Cin, H, W, Cout, k)
+    y = ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w), Cout, k)
+    assert y.shape == (B, Cout, H, W) and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=CL)
+    ref = F.conv2d(x.float(), w.float(), None, 1, k // 2)
+    # RNE of a sum that differs from torch's only by summation order: half a bf16 spacing + the fp32 noise of the sum, which is
+    # relative to the LARGEST partial sum, not to the (possibly cancelled) result -> bound it against the output's scale
+    err = (y.float() - ref).abs()
+    scale = float(ref.abs().max())
+    assert float((err - 0.5 * torch.pow(2.0, torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)).max()) <= 1e-5 * scale
+    want = ref.to(torch.bfloat16)
+    differs = (y != want)
+    assert float(differs.float().mean()) < 0.02          # a truncating kernel differs on ~50 % of the outputs
+    big = ref.abs() > 1e-2 * scale
+    signed = (((y.float().abs() - ref.abs()) / ref.abs().clamp_min(1e-20))[big]).mean() * 512
+    assert abs(float(signed)) < 0.05                      # ... with a mean signed error of -1.44 (in units of 2^-9)
+
+
+def test_epilogue_bias_residual_relu(cuda):
+    from islam_amd import ops
+    x, w = _mk(2, 64, 30, 44, 64, 3, seed=1)
+    g = torch.Generator().manual_seed(2)
+    bias = torch.randn(64, generator=g).to(cuda)
+    res = torch.randn(2, 64, 30, 44, generator=g).to(cuda).to(torch.bfloat16).contiguous(memory_format=CL)
+    y = ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w), 64, 3, bias=bias, res=res, relu=True)
+    a = F.conv2d(x.float(), w.float(), None, 1, 1)
+    want = F.relu(((a + bias.view(1, -1, 1, 1)).to(torch.bfloat16).float() + res.float()).to(torch.bfloat16))
+    assert float((y != want).float().mean()) < 0.02
+    assert float((y.float() - want.float()).abs().max()) <= 2 ** -6 * float(want.float().abs().max())
+
+
+def test_batchnorm_statistics_from_the_epilogue_and_apply_on_load(cuda):
+    """convbn + ReLU -> convbn (+ residual), the PSM BasicBlock (submodule.py:66-88), train mode: statistics of both BatchNorms
+    from the convolutions' epilogues, the first normalisation + ReLU applied while the second convolution stages its input."""
+    from islam_amd import ops
+    torch.manual_seed(3)
+    B, C, H, W = 4, 32, 48, 80
+    x, w1 = _mk(B, C, H, W, C, 3, seed=4)
+    _, w2 = _mk(B, C, H, W, C, 3, seed=5)
+    bn1, bn2 = torch.nn.BatchNorm2d(C).to(cuda).train(), torch.nn.BatchNorm2d(C).to(cuda).train()
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    import copy
+    r1, r2 = copy.deepcopy(bn1), copy.deepcopy(bn2)
+    # reference: fp32 everywhere on the bf16 operands, bf16 roundings at the same places
+    with torch.no_grad():
+        a1 = F.conv2d(x.float(), w1.float(), None, 1, 1)
+        n1 = F.relu(r1(a1.to(torch.bfloat16).float()).to(torch.bfloat16))
+        a2 = F.conv2d(n1.float(), w2.float(), None, 1, 1)
+        want = (r2(a2.to(torch.bfloat16).float()).to(torch.bfloat16).float() + x.float()).to(torch.bfloat16)
+    y1, f1 = ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w1), C, 3, stats=True)
+    # the folded partial sums are the sums over the stored (bf16) outputs: what nn.BatchNorm2d would reduce
+    s = f1.view(256, 2, C).double().sum(0)
+    a1r = y1.double()
+    np.testing.assert_allclose(s[0].cpu().numpy(), a1r.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(s[1].cpu().numpy(), (a1r ** 2).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
+    ss1 = ops.bn_finalize(f1, bn1, B * H * W)
+    y2, f2 = ops.conv_nhwc(y1, ops.pack_conv_nhwc_weight(w2), C, 3, in_affine=ss1, stats=True)
+    ss2 = ops.bn_finalize(f2, bn2, B * H * W)
+    out = ops.bn_apply_(y2, ss2, relu=False, res=x)
+    d = (out.float() - want.float()).abs()
+    assert float(d.max()) <= 2 ** -5 * float(want.float().abs().max()) and float((out != want).float().mean()) < 0.1
+    for mine, ref in ((bn1, r1), (bn2, r2)):
+        torch.testing.assert_close(mine.running_mean, ref.running_mean, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(mine.running_var, ref.running_var, rtol=2e-3, atol=1e-5)
+        assert int(mine.num_batches_tracked) == 1
+    # deterministic: fixed-order statistics
+    _, f1b = ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w1), C, 3, stats=True)
+    assert torch.equal(f1, f1b)
+
+
+def test_argument_checks(cuda):
+    from islam_amd import _lib, ops
+    x, w = _mk(1, 32, 16, 16, 32, 3)
+    with pytest.raises(_lib.IslamHipError):
+        ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w), 32, 3, bias=torch.zeros(32, device=cuda), stats=True)
+    x6 = torch.zeros(1, 6, 16, 16, device=cuda, dtype=torch.bfloat16).contiguous(memory_format=CL)
+    with pytest.raises(_lib.IslamHipError):
+        ops.conv_nhwc(x6, torch.zeros(9 * 64 * 32, device=cuda, dtype=torch.bfloat16), 32, 3)

@@ -13,13 +13,13 @@ Tolerances (measured error statistics: scripts/calib/golden_errors.py -> profile
   bf16 operands (flow net on islam_conv3x3_mfma): unit round-off u = 2^-9 per operand, signs random, ~60 layers deep:
   measured max 5.8e-2 / rms 1.7e-2 of the output's max / rms with a mean signed error of 4e-3 -- noise, no bias.  Bounds:
   max 8e-2, rms 3e-2, |mean signed error| 1e-2 of the rms.
-  bf16 execution copy of the stereo net: measured max 7.4e-2, rms 6.5e-2 -- but a mean signed error of 5e-2 .. 6.5e-2: the
-  error is a SYSTEMATIC loss of magnitude, not noise.  scripts/calib/bf16_rounding_probe.py traces it to MIOpen: its bf16
-  kernels for several of the net's shapes (3->32 s2, 32->32, 134->64 3x3) convert the fp32 accumulator to bf16 by
-  TRUNCATION (50 % of the outputs differ from round-to-nearest-even, all of them towards zero: -0.28 % per layer, ~25 such
-  layers in the un-normalised hourglass path), the others round to nearest.  The repo's own kernels (BatchNorm, resize,
-  epilogue, islam_conv3x3_mfma) round to nearest even.  Until the stereo net's convolutions run on the repo's own kernel
-  the bound is max 1.2e-1 / rms 1e-1, and the test RECORDS the bias (printed) instead of hiding it.
+  bf16 execution copy of the stereo net (activations stored in bf16, ~110 layers).  Round 2 first measured max 7.4e-2 / rms
+  6.5e-2 with a mean signed error of 5e-2 .. 6.5e-2: not noise but a SYSTEMATIC loss of magnitude, which
+  scripts/calib/bf16_rounding_probe.py traced to MIOpen -- its bf16 kernels for several of the net's shapes (3->32 s2, 32->32,
+  134->64 3x3) convert the fp32 accumulator to bf16 by TRUNCATION (half of the outputs differ from round-to-nearest-even, all
+  towards zero: -0.28 % per layer, never renormalised in the hourglass path).  With those layers on islam_conv_nhwc_bf16
+  (round-to-nearest-even): max 2.4e-2, rms 1.2e-2, bias 1.6e-3 at 256x256 and max 3.9e-2, rms 1.7e-2, bias -1.4e-2 at 448x640.
+  Bounds: max 6e-2, rms 3e-2, |bias| 2.5e-2 of the rms; ISLAM_HIP_CONV=0 (all MIOpen) fails them.
 A systematic error common to both of the repo's own paths (what a self-comparison cannot see) shows up here."""
 import os
 
@@ -51,7 +51,7 @@ def _stats(got, ref):
 
 
 BF16_OPERANDS = (8e-2, 3e-2, 1e-2)        # islam_conv3x3_mfma path: max, rms, |bias|
-BF16_MIOPEN = (1.2e-1, 1e-1, 1e-1)        # MIOpen's bf16 kernels (some truncate): max, rms, |bias|
+BF16_STEREO = (6e-2, 3e-2, 2.5e-2)        # bf16 execution copy of the stereo net: max, rms, |bias|
 
 
 def _within(got, ref, bounds, what=''):
@@ -135,7 +135,7 @@ def test_stereo_net_bf16_execution_copy_matches_reference(cuda):
     assert out.dtype == torch.bfloat16
     ex = vn._exec['stereo'].module()
     assert ex.feature_extraction.firstconv[0][0].weight.dtype == torch.bfloat16         # the reduced-precision copy ran
-    _within(out, ref['disp'], BF16_MIOPEN, 'disp (bf16 execution copy)')
+    _within(out, ref['disp'], BF16_STEREO, 'disp (bf16 execution copy)')
     rm = vn.stereoNet.state_dict()[key]
     assert not torch.equal(rm, rm0)                                    # train-mode statistics landed in the fp32 master
     # running_mean = 0.9 * old + 0.1 * batch mean of the first conv's bf16 output: |error| <= 0.1 * 2^-8 * mean |activation|
@@ -180,7 +180,7 @@ def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph):
         with torch.no_grad():
             flow, disp, pose = vn(*args)
         _within(flow, ref['flow'], BF16_OPERANDS, 'flow')
-        _within(disp, ref['disp'], BF16_MIOPEN, 'disp')
+        _within(disp, ref['disp'], BF16_STEREO, 'disp')
         assert _relmax(pose, ref['pose']) <= 1e-2, rep     # pose head (fp32) fed with that flow (measured 7e-4)
         assert not torch.equal(vn.stereoNet.state_dict()[key], rm0)
     if graph:
@@ -203,7 +203,7 @@ def test_tartanvo_forward_matches_reference_nets_and_oracle_glue(cuda, tmp_path)
     sample = vonet_sample()
     for kw, tol_f, tol_d, tol_p in ((dict(), 2e-4, 2e-4, 1e-3),
                                     (dict(frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True), BF16_OPERANDS[0],
-                                     BF16_MIOPEN[0], 1e-2)):
+                                     BF16_STEREO[0], 1e-2)):
         vo = TartanVO(vo_model_name=ckpt, correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True, **kw)
         for k, v in sd.items():
             if v.is_floating_point() and 'running_' not in k:
