@@ -294,6 +294,45 @@ int islam_pvgo_eliminate_level0(double* Hd, const double* Ho, const double* rhs,
  * plan9 (3*ISLAM_PVGO_MAX_LEVELS+1 ints) receives (nodes, segment length, segments) per level (unused = 0) and, last,
  * the first level that runs inside the single-workgroup top kernel; returns the level count. */
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9);
+/* Sharding with an interface-only exchange: a rank owns a contiguous range of the segments of the
+ * exchange level xl -- the highest level below the root with at least `world` segments -- and everything below it between the
+ * two outer separators of that range.  islam_pvgo_shard_ranges: out[0] = xl, out[1] = P_xl, out[2+2l], out[3+2l] = first
+ * segment / number of segments owned at level l (2 + 2*ISLAM_PVGO_MAX_LEVELS ints).  upsweep: levels 0..xl over the rank's own
+ * segments; Hd/Ho/rhs are LOCAL level-0 arrays (row 0 = global node `node0`), `exchange` (351*P_xl doubles, array-major like the
+ * level-0 products) is zeroed and the rank's rows written: summing it over the ranks is the ONLY data-path collective of a
+ * solve (P_xl = 23 at N=5001: 64.6 KB, against 2.34 MB for the level-0 products).  downsweep: the levels above xl from the
+ * summed buffer (redundantly), then the local back-substitution; dx is LOCAL like Hd.  Factors live in `workspace`
+ * (islam_pvgo_workspace_bytes(N), the same buffer for both calls, ZERO-INITIALISED once by the caller: the product rows of
+ * other ranks' segments are read as zero contributions). */
+int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, int* out);
+int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2], int world,
+                             int rank, int node0, void* workspace, size_t workspace_bytes, double* exchange, int* flags,
+                             void* stream);
+int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
+                               size_t workspace_bytes, double* dx, int* flags, void* stream);
+/* The whole sharded LM loop in the library, on RCCL (islam_amd/csrc/pvgo_dist.hip): every rank passes the SAME full-size
+ * inputs (device, float64: nodes (N,7), vels (N,3) in/out -- the full solution on every rank --, poses (N-1,7), drots (N-1,4),
+ * dtrans, dvels (N-1,3), dts (N-1)) and works on its stretch of the chain; per LM trial two all-reduces (the interface blocks:
+ * 351 doubles per segment of the exchange level; [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]) and one
+ * 24-byte device->host read; accept / reject, TrustRegion and StopOnPlateau replicated on the host.  comm: an ncclComm_t made
+ * with islam_dist_comm_init (rank 0 creates the 128-byte id with islam_dist_unique_id and broadcasts it -- e.g. with
+ * torch.distributed) or NULL for world == 1.  workspace: islam_pvgo_workspace_bytes(N); scratch:
+ * islam_pvgo_sharded_scratch_bytes(N, world).  exchanged_bytes (may be NULL): bytes handed to the collectives of the trials.
+ * The _cb variant takes the all-reduce as a callback (in-place sum of `count` doubles at `buf`, stream-ordered on `stream`;
+ * return 0): the tests drive several ranks as threads on one GPU through it. */
+typedef int (*islam_allreduce_fn)(void* user, double* buf, size_t count, void* stream);
+int islam_dist_unique_id(void* out128);
+int islam_dist_comm_init(const void* id128, int world, int rank, void** comm);
+int islam_dist_comm_destroy(void* comm);
+size_t islam_pvgo_sharded_scratch_bytes(int N, int world);
+int islam_pvgo_run_chain_sharded(void* comm, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
+                                 const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                                 void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
+                                 long long* exchanged_bytes, void* stream);
+int islam_pvgo_run_chain_sharded_cb(islam_allreduce_fn fn, void* user, int world, int rank, double* nodes, double* vels,
+                                    const double* poses, const double* drots, const double* dtrans, const double* dvels, const double* dts,
+                                    int N, const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes, void* scratch,
+                                    size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream);
 /* Eliminate level-0 segments [seg0, seg0+nseg) of an N-node chain.  Hd/Ho/rhs/fac/inv are LOCAL arrays whose row 0 is
  * global node `node0`.  products: 351*P0 doubles, array-major (Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P |
  * cgR 9P); only the local segments' rows are written, so a zero-initialised buffer can be summed over ranks. */

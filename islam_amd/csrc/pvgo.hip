@@ -2423,6 +2423,148 @@ int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double*
     return ISLAM_OK;
 }
 
+// ---- sharding at a HIGHER level of the tree: the interface-only exchange of SURVEY section 8e.
+// A rank owns a contiguous range of the segments of the EXCHANGE level xl (the highest level below the root that still has
+// one segment per rank) and, below it, everything between the two outer separators of that range: at level l-1 the segments
+// whose separators are its level-l nodes.  Levels 0 .. xl are eliminated locally (every block a node needs comes from the
+// rank's own segments), only the products of level xl -- 351 doubles per segment, P_xl segments -- are summed over the
+// ranks, the few levels above are solved redundantly, and the back-substitution of levels xl .. 0 is local again.
+struct ShardRanges { int xl; int seg0[MAXL], nseg[MAXL]; };
+
+static int shard_ranges(const SolvePlan& sp, int world, int rank, ShardRanges& R) {
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    int xl = -1;
+    for (int l = 0; l < sp.nl - 1; ++l)
+        if (sp.lv[l].P >= world) xl = l;
+    if (xl < 0) return -1;
+    R.xl = xl;
+    const int P = sp.lv[xl].P;
+    const int s0 = (int)((long long)rank * P / world), s1 = (int)((long long)(rank + 1) * P / world);
+    for (int l = 0; l < MAXL; ++l) { R.seg0[l] = 0; R.nseg[l] = 0; }
+    R.seg0[xl] = s0;
+    R.nseg[xl] = s1 - s0;
+    for (int l = xl; l > 0; --l) {
+        const int m = sp.lv[l].m, n = sp.lv[l].n;
+        const int a = R.seg0[l] * (m + 1);                                                   // first owned node of level l
+        const int b = std::min(n - 1, (R.seg0[l] + R.nseg[l] - 1) * (m + 1) + m - 1);       // last one
+        R.seg0[l - 1] = a;                                                                    // segment a: right separator = node a
+        R.nseg[l - 1] = std::min(b + 1, sp.lv[l - 1].P - 1) - a + 1;                          // ... segment b+1: left separator = node b
+        // the last rank owns the chain to its end: when level l closes with a trailing separator (a node of the level above)
+        // the level-(l-1) segment beyond it still feeds that separator's block, which the rank's last segment composes
+        if (R.seg0[l] + R.nseg[l] == sp.lv[l].P) R.nseg[l - 1] = sp.lv[l - 1].P - a;
+    }
+    return 0;
+}
+
+// The block of an outer separator that a rank hands up (Dsep / rsep of the last segment of each of its levels) is composed
+// level by level as  own block - (Schur contribution of the segment on its left) - (that of the segment on its RIGHT); the
+// segment on the right belongs to the next rank.  The composition is additive, so the next rank subtracts its share -- the
+// left-separator contributions cL / cgL of its first segment of every level below xl -- from the same rows of the exchange
+// buffer, and the sum over the ranks is the complete block.
+struct OuterFix { const double* cL[MAXL]; const double* cgL[MAXL]; double* Dsep; double* rsep; int n; };
+__global__ void outer_block_kernel(OuterFix f) {
+    const int t = threadIdx.x;
+    if (t >= 90) return;
+    double v = 0.0;
+    for (int i = 0; i < f.n; ++i) v += t < 81 ? f.cL[i][t] : f.cgL[i][t - 81];
+    if (t < 81) f.Dsep[t] -= v; else f.rsep[t - 81] -= v;
+}
+
+struct OuterCopy { double* dst[MAXL + 1]; const double* src; int n; };
+__global__ void outer_separator_kernel(OuterCopy c) {       // the left outer separator's solution, handed down level by level
+    const int q = threadIdx.x;
+    if (q < 9)
+        for (int i = 0; i < c.n; ++i) c.dst[i][q] = c.src[q];
+}
+
+int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, int* out) {
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
+    ShardRanges R;
+    if (nl < 2 || shard_ranges(sp, world, rank, R) != 0)
+        return fail(ISLAM_EARG, "islam_pvgo_shard_ranges: N=%d cannot be split over %d ranks (rank %d)", N, world, rank);
+    out[0] = R.xl;
+    out[1] = sp.lv[R.xl].P;
+    for (int l = 0; l < MAXL; ++l) { out[2 + 2 * l] = R.seg0[l]; out[3 + 2 * l] = R.nseg[l]; }
+    return ISLAM_OK;
+}
+
+// Up-sweep of levels 0 .. xl over the rank's own segments.  Hd/Ho/rhs: LOCAL level-0 arrays whose row 0 is global node
+// `node0`; exchange: 351*P_xl doubles (array-major like the level-0 products), zeroed here, own rows written.
+int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2], int world,
+                             int rank, int node0, void* workspace, size_t workspace_bytes, double* exchange, int* flags,
+                             void* stream) {
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
+    ShardRanges R;
+    if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: N=%d, world=%d, rank=%d", N, world, rank);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: workspace too small");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(exchange, 0, sizeof(double) * 351 * (size_t)sp.lv[R.xl].P, s));
+    LevelBufs xb{};
+    products_view(exchange, sp.lv[R.xl].P, xb);
+    for (int l = 0; l <= R.xl; ++l) {
+        LevelSrc src{};
+        if (l == 0) {
+            src.level0 = 1;
+            src.Hd = Hd - (ptrdiff_t)node0 * 81; src.Ho = Ho - (ptrdiff_t)node0 * 81; src.rhs0 = rhs - (ptrdiff_t)node0 * 9;
+            src.state = nullptr; src.damping_override = damping;
+        } else {
+            src = level_src_from(w.lv[l - 1], sp.lv[l - 1].P);
+        }
+        LevelBufs ob = w.lv[l];
+        if (l == R.xl) { ob.Dsep = xb.Dsep; ob.rsep = xb.rsep; ob.cL = xb.cL; ob.cR = xb.cR; ob.fill = xb.fill; ob.cgL = xb.cgL; ob.cgR = xb.cgR; }
+        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n, sp.lv[l].m,
+                           flags, R.seg0[l], R.nseg[l], Gate{nullptr, 0.0});
+    }
+    if (R.seg0[R.xl] > 0 && R.xl > 0) {                      // this rank's share of its LEFT outer separator's block (see OuterFix)
+        OuterFix f{};
+        f.n = R.xl;
+        for (int l = 0; l < R.xl; ++l) { f.cL[l] = w.lv[l].cL + (size_t)R.seg0[l] * 81; f.cgL[l] = w.lv[l].cgL + (size_t)R.seg0[l] * 9; }
+        f.Dsep = xb.Dsep + (size_t)(R.seg0[R.xl] - 1) * 81;
+        f.rsep = xb.rsep + (size_t)(R.seg0[R.xl] - 1) * 9;
+        hipLaunchKernelGGL(outer_block_kernel, dim3(1), dim3(128), 0, s, f);
+    }
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// Levels above xl from the SUMMED exchange buffer (redundantly on every rank), then the back-substitution of levels xl .. 0
+// over the rank's own segments.  dx: LOCAL array, row 0 = global node `node0`; rows node0 .. the rank's right outer separator
+// are written (the left outer separator's row too when the rank has one).
+int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
+                               size_t workspace_bytes, double* dx, int* flags, void* stream) {
+    SolvePlan sp;
+    const int nl = plan_levels(N, seg_len, sp);
+    ShardRanges R;
+    if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: N=%d, world=%d, rank=%d", N, world, rank);
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: workspace too small");
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+    LevelBufs pb{};
+    products_view(const_cast<double*>(exchange), sp.lv[R.xl].P, pb);
+    const int rc = enqueue_levels(w, sp, R.xl + 1, level_src_from(pb, sp.lv[R.xl].P), &pb, w.lv[R.xl + 1].x, flags, s, nullptr, nullptr);
+    if (rc != ISLAM_OK) return rc;
+    double* x0 = dx - (ptrdiff_t)node0 * 9;                                   // level-0 solution, global indexing
+    auto x_of = [&](int l) { return l == 0 ? x0 : w.lv[l].x; };
+    if (R.seg0[R.xl] > 0) {
+        // the left outer separator is node seg0[l]-1 of level l+1 for every l <= xl; its value is known at level xl+1 and
+        // is what the first local segment of every level reads as its left separator (and what the trial step needs at level 0)
+        OuterCopy c{};
+        c.src = w.lv[R.xl + 1].x + (size_t)(R.seg0[R.xl] - 1) * 9;
+        c.n = 0;
+        for (int l = R.xl; l >= 0; --l) c.dst[c.n++] = x_of(l) + (size_t)(R.seg0[l] * (sp.lv[l].m + 1) - 1) * 9;
+        hipLaunchKernelGGL(outer_separator_kernel, dim3(1), dim3(64), 0, s, c);
+    }
+    for (int l = R.xl; l >= 0; --l)
+        hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1), x_of(l),
+                           sp.lv[l].n, sp.lv[l].m, R.seg0[l], R.nseg[l], Gate{nullptr, 0.0});
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 // Trial step on M links (nodes/vels/dx hold M+1 rows): writes nodes_t/vels_t (M+1 rows) and part (2 per 64-link block:
 // sum r^2 at the trial point, sum JD.(2R+JD)).  Same kernel islam_pvgo_run_chain launches.
 int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,

@@ -1,16 +1,18 @@
 """PVGO of ONE chain graph sharded over the GPUs of a node (BASELINE configs[3]).
 
 The reference is single-GPU; this is new design.  One process per GPU (torch.distributed, backend "nccl" = RCCL
-over xGMI).  The level-0 segments of the partitioned block Cholesky are split into contiguous ranges, one per rank.
-Per LM trial a rank
-  1. eliminates its own segments                     (islam_pvgo_shard_eliminate, local)
-  2. ALL-REDUCE #1: the level-0 products -- separator blocks of J^T W J / J^T W r, Schur contributions, fill --
-     351 doubles per segment, summed into a zero-initialised buffer (each row is written by exactly one rank)
-  3. solves levels >= 1 redundantly                    (islam_pvgo_reduced_solve, ~N/20 nodes)
-  4. back-substitutes its own segments, applies the trial step to its own links    (local)
-  5. ALL-REDUCE #2: [sum r^2, sum JD.(2R+JD)] + the new state of each rank's first node (halo for the
+over xGMI).  The chain is cut at separators of the EXCHANGE level xl of the partitioned block Cholesky -- the highest level
+below the root that still has one segment per rank (N=5001, 8 ranks: level 2 with 23 segments; islam_pvgo_shard_ranges) -- and a rank
+owns everything between two such separators, on every level below.  Per LM trial a rank
+  1. eliminates levels 0 .. xl of its own sub-tree       (islam_pvgo_shard_upsweep, local)
+  2. ALL-REDUCE #1: the level-xl products -- the interface blocks of J^T W J / J^T W r: separator blocks, Schur
+     contributions, fill -- 351 doubles per level-xl segment, summed into a zero-initialised buffer (each row is written
+     by exactly one rank): 64.6 KB at N=5001 / 8 ranks (round 1 summed the level-0 products: 2.34 MB)
+  3. solves the few levels above xl redundantly, back-substitutes levels xl .. 0 of its own sub-tree
+                                                         (islam_pvgo_shard_downsweep), applies the trial step to its own links
+  4. ALL-REDUCE #2: [sum r^2, sum JD.(2R+JD)] + the new state of each rank's first node (halo for the
      neighbour's boundary link): 2 + 10*world doubles
-  6. takes the accept/reject decision (LMControl, replicated: every rank sees identical all-reduced scalars).
+  5. takes the accept/reject decision (LMControl, replicated: every rank sees identical all-reduced scalars).
 Ranks cut the chain only at separator nodes, so no 9x9 block is ever split between ranks.
 
 The compute backend is injected (``backend=``): HipBackend in production; tests/np_shard_backend.py (numpy on the
@@ -24,14 +26,16 @@ import torch
 from .lm_control import LMControl
 
 
-def shard_plan(N, plan0, world):
-    """Contiguous split of the level-0 segments.  plan0 = (n, m, P).  Returns per-rank dicts."""
+def shard_plan(N, plan0, world, bounds=None):
+    """Contiguous split of the level-0 segments.  plan0 = (n, m, P); bounds[r] = first segment of rank r (bounds[world] = P),
+    default: an even split.  Returns per-rank dicts."""
     n, m, P = plan0
     assert n == N
     stride = m + 1
     if world > P:
         raise ValueError('cannot shard %d segments over %d ranks' % (P, world))
-    bounds = [int(round(r * P / world)) for r in range(world + 1)]
+    if bounds is None:
+        bounds = [int(round(r * P / world)) for r in range(world + 1)]
     out = []
     for r in range(world):
         seg0, seg1 = bounds[r], bounds[r + 1]
@@ -42,7 +46,7 @@ def shard_plan(N, plan0, world):
         node1 = min(sR + 1, N - 1) if has_right else N - 1 # one node past the right separator (link sR builds Hd[sR])
         own1 = sR if has_right else N - 1                  # owned links: [node0, own1)
         out.append(dict(seg0=seg0, nseg=seg1 - seg0, node0=node0, node1=node1, n_own_links=own1 - node0,
-                        has_left=seg0 > 0, has_right=has_right, sep_left=seg0 - 1, first_node=first))
+                        has_left=seg0 > 0, has_right=has_right, sep_left=seg0 - 1, first_node=first, rank=r, world=world))
     return out
 
 
@@ -75,31 +79,38 @@ class HipBackend:
     def build(self, lin, data, nloc, w4):
         return self.ops.pvgo_build_normal(lin, data['dts'], nloc, w4)
 
-    def eliminate(self, H, damping, N, seg_len, sh, products, scratch):
-        from ._lib import c_double, c_int, check, lib, ptr, stream_ptr
+    def level0_bounds(self, N, seg_len, world):
+        """First level-0 segment of every rank (+ the total): ranks own whole sub-trees below the exchange level."""
+        from ._lib import MAX_LEVELS, c_int, check, lib
+        sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
+        out = (c_int * (2 + 2 * MAX_LEVELS))()
+        bounds, info = [], None
+        for r in range(world):
+            check(lib().islam_pvgo_shard_ranges(N, sl, world, r, out))
+            bounds.append(out[2])
+            info = (out[0], out[1])
+        bounds.append(bounds[-1] + out[3])
+        self.exchange_level, self.exchange_segments = info
+        return bounds
+
+    def upsweep(self, H, damping, N, seg_len, sh, scratch):
+        """Levels 0 .. xl of the rank's sub-tree; returns the exchange buffer (351 doubles per level-xl segment, own rows)."""
+        from ._lib import c_double, c_int, c_size_t, check, lib, ptr, stream_ptr
         Hd, Ho, rhs = H
         sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
-        check(lib().islam_pvgo_shard_eliminate(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, sh['node0'], sh['seg0'],
-                                               sh['nseg'], ptr(products), ptr(scratch['fac']), ptr(scratch['inv']),
-                                               ptr(self.flags), stream_ptr(self.dev)))
+        ws, nbytes = scratch['ws']
+        ex = scratch['exchange']
+        check(lib().islam_pvgo_shard_upsweep(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, sh['world'], sh['rank'], sh['node0'],
+                                             ptr(ws), c_size_t(nbytes), ptr(ex), ptr(self.flags), stream_ptr(self.dev)))
+        return ex
 
-    def reduced_solve(self, products, N, seg_len, n1, scratch):
+    def downsweep(self, ex, N, seg_len, sh, scratch):
         from ._lib import c_int, c_size_t, check, lib, ptr, stream_ptr
         sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
         ws, nbytes = scratch['ws']
-        x1 = scratch['x1']
-        check(lib().islam_pvgo_reduced_solve(ptr(products), N, sl, ptr(ws), c_size_t(nbytes), ptr(x1), ptr(self.flags),
-                                             stream_ptr(self.dev)))
-        return x1
-
-    def backsub(self, x1, N, seg_len, sh, scratch):
-        from ._lib import c_int, check, lib, ptr, stream_ptr
-        sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
         dx = scratch['dx']
-        check(lib().islam_pvgo_shard_backsub(ptr(scratch['fac']), ptr(scratch['inv']), ptr(x1), N, sl, sh['node0'], sh['seg0'],
-                                             sh['nseg'], ptr(dx), stream_ptr(self.dev)))
-        if sh['has_left']:
-            dx[0] = x1[sh['sep_left']]
+        check(lib().islam_pvgo_shard_downsweep(ptr(ex), N, sl, sh['world'], sh['rank'], sh['node0'], ptr(ws), c_size_t(nbytes), ptr(dx),
+                                               ptr(self.flags), stream_ptr(self.dev)))
         return dx
 
     def trial(self, nodes, vels, dx, data, lin, n_own, scratch):
@@ -122,9 +133,10 @@ class HipBackend:
         from . import ops
         d = self.dev
         z = lambda *s: torch.zeros(s, dtype=torch.float64, device=d)
-        return dict(fac=z(nloc, 252), inv=z(nloc, 9), dx=z(nloc, 9), nodes_t=z(nloc, 7), vels_t=z(nloc, 3),
-                    part=z(2 * ((nloc + 63) // 64) + 2), x1=z(max(n1, 1), 9), ws=ops.pvgo_workspace(N, d),
-                    products=z(351 * P0))
+        ws = ops.pvgo_workspace(N, d)
+        ws[0].zero_()       # product rows of OTHER ranks' segments are read (as zero contributions) when an outer separator's block is composed
+        return dict(dx=z(nloc, 9), nodes_t=z(nloc, 7), vels_t=z(nloc, 3), part=z(2 * ((nloc + 63) // 64) + 2),
+                    ws=ws, exchange=z(351 * self.exchange_segments))
 
 
 class ShardedChainPVGO:
@@ -144,8 +156,8 @@ class ShardedChainPVGO:
         if len(self.levels) < 2:
             raise ValueError('N=%d is solved by a single wavefront; nothing to shard' % self.N)
         self.P0, self.n1 = self.levels[0][2], self.levels[1][0]
-        self.sh = shard_plan(self.N, self.levels[0], self.world)[self.rank]
-        self.all_sh = shard_plan(self.N, self.levels[0], self.world)
+        bounds = self.be.level0_bounds(self.N, seg_len, self.world)       # None: an even split of the level-0 segments
+        self.sh = shard_plan(self.N, self.levels[0], self.world, bounds)[self.rank]
         self.w4 = [float(x) ** 2 for x in loss_weight[:4]]
         self.radius = radius
         a, b = self.sh['node0'], self.sh['node1']
@@ -162,8 +174,8 @@ class ShardedChainPVGO:
         nodes, vels = self.init_nodes[a:b + 1].clone(), self.init_vels[a:b + 1].clone()
         ctl = LMControl(radius=self.radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
         n_own = sh['n_own_links']
-        products = self.scratch['products']
         trials = 0
+        self.exchanged_doubles = []                                     # per collective of the last run (tests: exchange volume)
         while ctl.continual:
             lin = be.linearize(nodes, vels, self.data)
             if not ctl.has_loss:
@@ -173,11 +185,10 @@ class ShardedChainPVGO:
             H = be.build(lin, self.data, self.nloc, self.w4)
             ctl.begin_step()
             while True:
-                products.zero_()
-                be.eliminate(H, ctl.damping, N, self.seg_len, sh, products, self.scratch)
-                yield products                                          # all-reduce #1: J^T W J / J^T W r interface blocks
-                x1 = be.reduced_solve(products, N, self.seg_len, self.n1, self.scratch)
-                dx = be.backsub(x1, N, self.seg_len, sh, self.scratch)
+                ex = be.upsweep(H, ctl.damping, N, self.seg_len, sh, self.scratch)
+                self.exchanged_doubles.append(ex.numel())
+                yield ex                                                # all-reduce #1: J^T W J / J^T W r interface blocks
+                dx = be.downsweep(ex, N, self.seg_len, sh, self.scratch)
                 nt, vt, sums = be.trial(nodes, vels, dx, self.data, lin, n_own, self.scratch)
                 msg = torch.zeros(3 + 10 * self.world, dtype=torch.float64, device=sums.device)
                 msg[:2] = sums
@@ -186,6 +197,7 @@ class ShardedChainPVGO:
                 o = 3 + 10 * self.rank
                 msg[o:o + 7] = nt[first_local]
                 msg[o + 7:o + 10] = vt[first_local]
+                self.exchanged_doubles.append(msg.numel())
                 yield msg                                               # all-reduce #2: loss, trust-region sums, halo
                 trials += 1
                 host = msg[:3].tolist()                                 # the one device->host read of the trial
@@ -238,3 +250,61 @@ def run_lockstep(solvers, **kw):
         for b in bufs:
             b.copy_(tot.to(b.device))
     return [s.result for s in solvers]
+
+
+# ---------------------------------------------------------------------------------------------- the loop in the library, on RCCL
+class RcclComm:
+    """An RCCL communicator of the library's own (islam_dist_comm_init): rank 0 makes the 128-byte id, torch.distributed
+    broadcasts it (any backend; one-off), every rank joins.  world == 1: no communicator at all."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        from ._lib import check, lib
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.handle = ctypes.c_void_p(0)
+        if self.world > 1:
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (ctypes.c_ubyte * 128)()
+                check(lib().islam_dist_unique_id(buf))
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            if dist.get_backend(group) == 'nccl':
+                ident = ident.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            raw = (ctypes.c_ubyte * 128)(*ident.cpu().tolist())
+            check(lib().islam_dist_comm_init(raw, self.world, self.rank, ctypes.byref(self.handle)))
+
+    def close(self):
+        from ._lib import check, lib
+        if self.handle:
+            check(lib().islam_dist_comm_destroy(self.handle))
+            self.handle = ctypes.c_void_p(0)
+
+
+def run_chain_sharded(comm, init_nodes, init_vels, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, seg_len=(0, 0), rank=None,
+                      world=None, allreduce_cb=None):
+    """islam_pvgo_run_chain_sharded: the sharded LM loop inside the library.  ``comm``: an RcclComm (or None with world 1);
+    ``allreduce_cb``: a ctypes callback instead of RCCL (tests).  Returns (nodes, vels, result, bytes handed to the collectives)."""
+    from . import ops
+    from ._lib import PvgoResult, c_size_t, check, lib, ptr, stream_ptr
+    dev = init_nodes.device
+    world = (comm.world if comm is not None else 1) if world is None else world
+    rank = (comm.rank if comm is not None else 0) if rank is None else rank
+    N = init_nodes.shape[0]
+    t = lambda x: x.to(dev, torch.float64).contiguous()
+    nodes, vels = t(init_nodes).clone(), t(init_vels).clone()
+    args = [t(x) for x in (poses, drots, dtrans, dvels, dts)]
+    prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
+    ws, nbytes = ops.pvgo_workspace(N, dev)
+    sbytes = lib().islam_pvgo_sharded_scratch_bytes(N, world)
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    res, xb = PvgoResult(), ctypes.c_longlong(0)
+    common = [ptr(nodes), ptr(vels)] + [ptr(a) for a in args] + [N, ctypes.byref(prm), ptr(ws), c_size_t(nbytes), ptr(scratch), c_size_t(sbytes),
+                                                                 ctypes.byref(res), ctypes.byref(xb), stream_ptr(dev)]
+    if allreduce_cb is not None:
+        check(lib().islam_pvgo_run_chain_sharded_cb(allreduce_cb, None, world, rank, *common))
+    else:
+        check(lib().islam_pvgo_run_chain_sharded(comm.handle if comm is not None else None, world, rank, *common))
+    return nodes, vels, res, int(xb.value)
+

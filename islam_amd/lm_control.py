@@ -2,6 +2,7 @@
 ends in a collective: pp.optim.LM's accept/reject rule, ppost.TrustRegion.update and StopOnPlateau as the reference
 constructs them (pvgo.py:169-180; SURVEY.md section 8a box).  The single-GPU path runs the same logic on the device
 (control_*_kernel in islam_amd/csrc/pvgo.hip)."""
+import numpy as np
 
 
 class LMControl:
@@ -25,8 +26,10 @@ class LMControl:
 
     def after_trial(self, loss_trial, qsum):
         """qsum = sum JD.(2R + JD) (unweighted).  Returns True when the step is kept (loop breaks), False on reject."""
-        den = -qsum
-        quality = (self.last - loss_trial) / den if den != 0.0 else float('inf') * (1 if self.last >= loss_trial else -1)
+        # plain IEEE division like PyPose, the device code (lm_control in csrc/pvgo.hip) and the C loop (csrc/pvgo_dist.hip):
+        # x/0 = +-inf, 0/0 = NaN -- and NaN fails both comparisons below, i.e. takes the shrink-the-radius branch
+        with np.errstate(divide='ignore', invalid='ignore'):
+            quality = float(np.float64(self.last - loss_trial) / np.float64(-qsum))
         radius = 1.0 / self.damping
         if quality > self.high:
             radius, self.down = self.up * radius, self.down0

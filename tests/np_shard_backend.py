@@ -73,6 +73,20 @@ class NumpyBackend:
         np.fill_diagonal(A, d)
         return dict(A=A, b=bl.b.copy())
 
+    def level0_bounds(self, N, seg_len, world):
+        return None                                  # an even split of the level-0 segments (exchange level 0)
+
+    def upsweep(self, H, damping, N, seg_len, sh, scratch):
+        """Exchange level 0: the level-0 products are what is summed over the ranks."""
+        products = scratch['products']
+        products.zero_()
+        self.eliminate(H, damping, N, seg_len, sh, products, scratch)
+        return products
+
+    def downsweep(self, ex, N, seg_len, sh, scratch):
+        n1 = plan_levels(N, seg_len)[1][0]
+        return self.backsub(self.reduced_solve(ex, N, seg_len, n1, scratch), N, seg_len, sh, scratch)
+
     def eliminate(self, H, damping, N, seg_len, sh, products, scratch):
         (n, m, P) = plan_levels(N, seg_len)[0]
         stride = m + 1

@@ -1,0 +1,111 @@
+"""GPU tests of the sharded LM loop INSIDE the library (islam_pvgo_run_chain_sharded, islam_amd/csrc/pvgo_dist.hip): world 1
+with and without an RCCL communicator, and 2 / 3 / 8 ranks driven as threads on one GPU through the callback variant (the
+all-reduce is a host-side sum across the threads) -- all must reproduce the fused single-GPU loop of islam_pvgo_run_chain."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import chain_problem
+
+pytestmark = pytest.mark.gpu
+LW = (1, 0.1, 10, 0.1)
+
+
+def _problem(F, cuda):
+    prob, _ = chain_problem(F)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=cuda)
+    return [t(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions', 'imu_drots', 'imu_dtrans', 'imu_dvels', 'dts')]
+
+
+def _single(args, seg=(0, 0)):
+    from islam_amd import ops
+    nodes, vels = args[0].clone(), args[1].clone()
+    res, trace = ops.pvgo_run_chain(nodes, vels, *args[2:], ops.pvgo_default_params(LW, radius=1e4, seg_len=seg), trace_cap=256)
+    return nodes, vels, res
+
+
+@pytest.mark.parametrize('F', [300, 5001])
+def test_world_one_with_and_without_a_communicator(cuda, F):
+    from islam_amd import dist_pvgo
+    args = _problem(F, cuda)
+    nodes, vels, res = _single(args)
+    n1, v1, r1, xb = dist_pvgo.run_chain_sharded(None, *args, LW)
+    assert (r1.trials, r1.steps, r1.status) == (res.trials, res.steps, 0)
+    torch.testing.assert_close(n1, nodes, rtol=0, atol=1e-9)
+    torch.testing.assert_close(v1, vels, rtol=0, atol=1e-9)
+    assert r1.loss == pytest.approx(res.loss, rel=1e-9)
+    # a real RCCL communicator of one rank: ncclCommInitRank / ncclCommDestroy through the C ABI
+    comm = dist_pvgo.RcclComm()
+    assert comm.world == 1
+    from islam_amd._lib import check, lib
+    ident = (ctypes.c_ubyte * 128)()
+    check(lib().islam_dist_unique_id(ident))
+    h = ctypes.c_void_p(0)
+    check(lib().islam_dist_comm_init(ident, 1, 0, ctypes.byref(h)))
+    comm.handle, comm.world = h, 1
+    n2, v2, r2, _ = dist_pvgo.run_chain_sharded(comm, *args, LW, world=1, rank=0)
+    comm.close()
+    assert torch.equal(n2, n1) and torch.equal(v2, v1) and r2.trials == r1.trials
+
+
+@pytest.mark.parametrize('world,F', [(2, 300), (3, 257), (8, 5001), (5, 1000)])
+def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
+    """Every rank's C loop runs in its own thread and CUDA stream; the injected all-reduce copies each rank's buffer to the
+    host, sums in rank order, and writes the sum back.  Exercises what the stage-level virtual-rank test cannot: pack / halo /
+    accept / final assembly of the C loop with more than one rank."""
+    from islam_amd import dist_pvgo
+    from islam_amd._lib import lib
+    args = _problem(F, cuda)
+    nodes, vels, res = _single(args)
+    hip = ctypes.CDLL('libamdhip64.so')
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    barrier = threading.Barrier(world)
+    slots, total = [None] * world, [None]
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+    def make_cb(rank):
+        def cb(user, buf, count, stream):
+            hip.hipStreamSynchronize(stream)
+            host = np.empty(count, dtype=np.float64)
+            hip.hipMemcpy(host.ctypes.data, buf, count * 8, 2)            # device -> host
+            slots[rank] = host
+            barrier.wait()
+            if rank == 0:
+                acc = slots[0].copy()
+                for r in range(1, world):
+                    acc += slots[r]
+                total[0] = acc
+            barrier.wait()
+            hip.hipMemcpy(buf, total[0].ctypes.data, count * 8, 1)       # host -> device
+            barrier.wait()
+            return 0
+        return CB(cb)
+    outs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                outs[rank] = dist_pvgo.run_chain_sharded(None, *args, LW, rank=rank, world=world, allreduce_cb=cbs[rank])
+        except Exception as e:                       # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+    lib()
+    cbs = [make_cb(r) for r in range(world)]
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errs, errs
+    for r, (n, v, rr, xb) in enumerate(outs):
+        assert (rr.trials, rr.steps, rr.status) == (res.trials, res.steps, 0), r
+        torch.testing.assert_close(n, nodes, rtol=0, atol=1e-9)
+        torch.testing.assert_close(v, vels, rtol=0, atol=1e-9)
+    if F == 5001:
+        per_trial = outs[0][3] / outs[0][2].trials
+        assert per_trial == 351 * 23 * 8 + (3 + 10 * world) * 8          # 64.6 KB of interface blocks + 664 B of scalars and halos

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 LW = (1, 0.1, 10, 0.1)
 
 
-@pytest.mark.parametrize('world,F,seg', [(1, 300, (0, 0)), (2, 300, (0, 0)), (4, 1000, (0, 0)), (8, 5001, (0, 0)), (3, 257, (5, 4))])
+@pytest.mark.parametrize('world,F,seg', [(1, 300, (0, 0)), (2, 300, (0, 0)), (4, 1000, (0, 0)), (8, 5001, (0, 0)), (3, 257, (5, 4)), (5, 5001, (0, 0)),
+                                         (2, 5001, (0, 0)), (8, 1000, (0, 0))])
 def test_sharded_equals_single_gpu(cuda, world, F, seg):
     from islam_amd import dist_pvgo, ops
     prob, _ = chain_problem(F)
@@ -26,3 +27,11 @@ def test_sharded_equals_single_gpu(cuda, world, F, seg):
         np.testing.assert_allclose([x[0] for x in o['trace']], trace[:, 0], rtol=1e-9)
         torch.testing.assert_close(o['nodes'], nodes, rtol=0, atol=1e-9)
         torch.testing.assert_close(o['vels'], vels, rtol=0, atol=1e-9)
+    # exchange volume: the level-xl interface blocks only, not the level-0 products
+    be = solvers[0].be
+    per_trial = solvers[0].exchanged_doubles[-2:]
+    assert per_trial == [351 * be.exchange_segments, 3 + 10 * world]
+    assert be.exchange_segments >= world
+    if F == 5001 and world == 8:
+        assert (be.exchange_level, be.exchange_segments) == (2, 23) and per_trial[0] * 8 == 64584          # 64.6 KB (round 1: 2.34 MB)
+        assert per_trial[0] < 351 * solvers[0].P0 // 30
