@@ -161,8 +161,11 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     el_seq, tm = run(False)
     el, _ = run(True)      # the frozen flow / disparity forward of batch k+1 overlaps the IMU / PVGO / backward of batch k
     return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo',
-            'nets': 'stereo net: bf16 NHWC execution copy on MIOpen (77 % of the FLOPs); flow net: HIP implicit-GEMM 3x3 '
-                    'convolutions (bf16 operands, fp32 accumulate and activations); pose head fp32 (trainable)',
+            'nets': 'stereo net: bf16 NHWC execution copy -- 3x3 (<= 96 channels) and hourglass 1x1 convolutions on the HIP implicit-GEMM '
+                    'kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load), the 128-channel ones on MIOpen (77 % of the '
+                    'FLOPs); flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, fp32 accumulate and activations); pose head '
+                    'fp32 (trainable)',
+            'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
             'ms_per_batch': el / steps * 1e3,
             'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
             'sequential_frames_per_s': steps * batch / el_seq, 'sequential_ms_per_batch': el_seq / steps * 1e3,
@@ -223,13 +226,28 @@ def main():
                                         prm, workspace=ws)
             return res.trials, res.steps
     else:
+        # N > 1: ONE graph sharded over the ranks, the whole LM loop inside the library on RCCL (islam_pvgo_run_chain_sharded,
+        # csrc/pvgo_dist.hip): per LM trial one all-reduce of the interface blocks of the exchange level and one of the
+        # loss / trust-region scalars + halos.  ISLAM_SHARDED_PYTHON=1: the Python-driven stage loop (islam_amd/dist_pvgo.py).
         from islam_amd import dist_pvgo
-        solver = dist_pvgo.ShardedChainPVGO(prob['init_nodes'], prob['init_vels'], prob['vo'], prob['drots'], prob['dtrans'],
-                                            prob['dvels'], prob['dts'], LOSS_WEIGHT, radius=1e4, group=None)
+        sharded_info = {}
+        if os.environ.get('ISLAM_SHARDED_PYTHON') == '1':
+            solver = dist_pvgo.ShardedChainPVGO(prob['init_nodes'], prob['init_vels'], prob['vo'], prob['drots'], prob['dtrans'],
+                                                prob['dvels'], prob['dts'], LOSS_WEIGHT, radius=1e4, group=None)
 
-        def step():
-            r = solver.run()
-            return r['trials'], r['steps']
+            def step():
+                r = solver.run()
+                return r['trials'], r['steps']
+            sharded_info['loop'] = 'python stage calls + torch.distributed'
+        else:
+            comm = dist_pvgo.RcclComm(device=device)
+
+            def step():
+                _, _, res, xb = dist_pvgo.run_chain_sharded(comm, prob['init_nodes'], prob['init_vels'], prob['vo'], prob['drots'],
+                                                            prob['dtrans'], prob['dvels'], prob['dts'], LOSS_WEIGHT, radius=1e4)
+                sharded_info['exchange_bytes_per_lm_iter'] = xb / max(res.trials, 1)
+                return res.trials, res.steps
+            sharded_info['loop'] = 'islam_pvgo_run_chain_sharded (C, RCCL)'
 
     for _ in range(args.warmup):
         step()
@@ -309,10 +327,42 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic_eliminate_L0.json')
         if os.path.exists(tpath) and N == N_FRAMES:
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+        # a burst of whole solves (all launches back to back, one event pair): what the solve costs inside the LM loop
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        Hb = Hd.clone()
+        for _ in range(3):
+            ops.pvgo_solve_chain_enqueue(Hb, Ho, rhs, ws2, damping=1e-4)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(40):
+            ops.pvgo_solve_chain_enqueue(Hb, Ho, rhs, ws2, damping=1e-4)    # (the un-anchored graph is singular without damping)
+        e1.record()
+        torch.cuda.synchronize()
+        ops.pvgo_solve_status(N, ws2, device)
+        solve_us = e0.elapsed_time(e1) * 1e3 / 40
+        us_iter = elapsed / trials * 1e6
+        n_all = sum(l[0] for l in levels)                               # nodes of every level of the tree
+        # algorithmic bytes of the other two launch families of an LM iteration
+        sweep_bytes = (252 + 9 + 9) * 8 * n_all                         # factor rows + reciprocal pivots read, solution written
+        sweep_key = [k for k in kern if 'downsweep' in k or k.startswith('top')]
+        sweep_us = kern[sweep_key[0]] if sweep_key else None
+        trial_bytes = (28 + 135 + 29 + 28) * 8 * N                      # trial residual pass, H / g written, retraction, next linearisation
+        trial_us = max(us_iter - solve_us, 0.0) if world == 1 and not force_sharded else None
+        per_launch = {'bt_eliminate_tw_kernel_L0': {'bytes': alg_bytes, 'us': elim0_s * 1e6, 'frac': achieved / HBM_PEAK_GBS}}
+        if sweep_us:
+            per_launch['bt_downsweep_kernel'] = {'bytes': sweep_bytes, 'us': sweep_us, 'frac': sweep_bytes / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                 'timing': 'event pair around the single launch (adds ~2 us)'}
+        if trial_us:
+            per_launch['trial_lin_kernel'] = {'bytes': trial_bytes, 'us': trial_us, 'frac': trial_bytes / (trial_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              'timing': 'LM iteration minus a burst-timed whole solve (%.2f us)' % solve_us}
+        iter_bytes = 5000 * N                                           # ~5.0 KB per node per LM iteration
         roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_tw_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': elim0_s * 1e6,
-                    'solve_launch_us': kern, 'levels_n_m_P': levels,
+                    'solve_launch_us': kern, 'solve_burst_us': solve_us, 'levels_n_m_P': levels,
+                    'iteration': {'bytes': iter_bytes, 'us': us_iter, 'frac': iter_bytes / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  'what': 'whole LM iteration (solve + trial + control + next linearisation), SURVEY 8(d) traffic model'},
+                    'per_launch': per_launch,
                     'note': 'latency-bound: %d dependent 9x9 block pivots on the critical path' % sum(l[1] for l in levels)}
         value = trials / elapsed
         out = {
@@ -328,6 +378,8 @@ def main():
         }
         if replicas is not None:
             out['independent_graphs'] = replicas
+        if world > 1 or force_sharded:
+            out['sharded'] = sharded_info
         if not args.no_frontend and world == 1:
             try:
                 out['stereo_vio'] = vio_frames_per_sec(device)

@@ -446,14 +446,14 @@ def pvgo_solve_chain(Hd, Ho, rhs, damping, seg_len=(0, 0), workspace=None):
     return dx
 
 
-def pvgo_solve_chain_enqueue(Hd, Ho, rhs, workspace, seg_len=(0, 0)):
-    """Stream-ordered islam_pvgo_solve_chain (damping 0): no read-back, no synchronisation; pvgo_solve_status() tells later
+def pvgo_solve_chain_enqueue(Hd, Ho, rhs, workspace, seg_len=(0, 0), damping=0.0):
+    """Stream-ordered islam_pvgo_solve_chain (the diagonal of Hd is damped in place, cumulatively): no read-back, no synchronisation; pvgo_solve_status() tells later
     whether any of the enqueued solves met a non-positive pivot."""
     N = Hd.shape[0]
     ws, nbytes = workspace
     dx = torch.empty((N, 9), dtype=torch.float64, device=Hd.device)
     sl = (c_int * 2)(int(seg_len[0]), int(seg_len[1]))
-    check(lib().islam_pvgo_solve_chain_enqueue(ptr(Hd), ptr(Ho), ptr(rhs), c_double(0.0), N, sl, ptr(ws), c_size_t(nbytes),
+    check(lib().islam_pvgo_solve_chain_enqueue(ptr(Hd), ptr(Ho), ptr(rhs), c_double(damping), N, sl, ptr(ws), c_size_t(nbytes),
                                                ptr(dx), stream_ptr(Hd.device)))
     return dx
 
