@@ -126,6 +126,8 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     torch.manual_seed(0)
     vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True,
                   miopen_find=True, pose_channels_last=True,
+                  pose_dtype=torch.bfloat16 if os.environ.get('ISLAM_POSE_BF16') == '1' else None,   # measured: 330 vs 325 frames/s -- not worth the numerics
+
                   graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1',
                   graph_pose=os.environ.get('ISLAM_NO_GRAPH') != '1')
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty

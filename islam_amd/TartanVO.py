@@ -55,7 +55,7 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_inp
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
                  device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
-                 host_glue=False, miopen_find=False, pose_channels_last=False, graph_frozen=False, graph_pose=False):
+                 host_glue=False, miopen_find=False, pose_channels_last=False, graph_frozen=False, graph_pose=False, pose_dtype=None):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -85,6 +85,7 @@ class TartanVO(nn.Module):
         if graph_frozen:        # the frozen flow + disparity forward replays from a HIP graph (VONet.set_graph_frozen)
             self.vonet.set_graph_frozen(True)
         self.vonet.graph_pose = bool(graph_pose)     # forward + backward of the trainable pose head as HIP graphs
+        self.vonet.pose_dtype = pose_dtype           # bf16 autocast for the trainable pose head (fp32 master weights)
 
     def load_model(self, model, modelname):
         """TartanVO.py:49-87: suffix matching of state-dict keys with a size check."""

@@ -156,7 +156,14 @@ def check(rc):
 
 
 def stream_ptr(device=None):
-    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    """Raw hipStream_t of torch's current stream on ``device`` (0 = default stream).  Every wrapper in ops.py fetches the
+    stream right before its library call, so this is also where the HIP *current device* is aligned with the tensors' device:
+    kernel launches, hipMemsetAsync and hipFuncSetAttribute inside the library act on the current device, and a stream of
+    another device would be an invalid handle there (run_pvgo(device='cuda:1') without torch.cuda.set_device(1))."""
+    if device is not None:
+        idx = torch.device(device).index
+        if idx is not None and idx != torch.cuda.current_device():
+            torch.cuda.set_device(idx)
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

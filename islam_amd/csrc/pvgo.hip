@@ -2118,11 +2118,13 @@ static void launch_eliminate(const LevelPlan& L, bool tw, const LevelSrc& src, c
 // lbegin == 1), xout receives the solution of level lbegin.  Big levels: one launch each way; levels >= sp.top: one launch.
 int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const LevelSrc& first, const LevelBufs* first_prev,
                    double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev, Gate gate = Gate{nullptr, 0.0}) {
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
+    static bool lds_attr_set[64] = {};                       // per device: the attribute lives in the device's code object
+    int dev_i = 0;
+    ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+    if (dev_i >= 0 && dev_i < 64 && !lds_attr_set[dev_i]) {
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)bt_top_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             TOPW * LDS_PER_WAVE * (int)sizeof(double)));
-        lds_attr_set = true;
+        lds_attr_set[dev_i] = true;
     }
     const int nl = sp.nl, top = std::max(sp.top, lbegin);
     int ne = 0;
@@ -2719,11 +2721,13 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     double* RH[2] = {w.rhs, w.rhs2};
     double* RED[2] = {w.red, w.red2};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
-    static bool lb_attr_set = false;
-    if (!lb_attr_set) {
+    static bool lb_attr_set[64] = {};                        // per device
+    int dev_i = 0;
+    ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+    if (dev_i >= 0 && dev_i < 64 && !lb_attr_set[dev_i]) {
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)linbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
-        lb_attr_set = true;
+        lb_attr_set[dev_i] = true;
     }
     const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
     // red_ready: RED[b] already holds the reduction at (xn)

@@ -568,6 +568,9 @@ class VONet(nn.Module):
         self.pose_channels_last = False
         self.graph_pose = False             # set before the first training forward; fixed input shape from then on
         self._pose_graphed = None
+        # BASELINE config 2 ("bf16 nets / fp64 LM") for the TRAINABLE pose head as well: fp32 master weights and optimizer
+        # state, forward + backward under bf16 autocast (standard mixed precision; the reference ran TF32)
+        self.pose_dtype = None
 
     def set_pose_channels_last(self, on=True):
         """Run the trainable pose head on channels_last (NHWC) fp32 tensors: MIOpen's fp32 implicit-GEMM kernels are NHWC
@@ -647,14 +650,22 @@ class VONet(nn.Module):
             # forward AND backward of the trainable pose head replay from two captured HIP graphs
             # (torch.cuda.make_graphed_callables patches the module's forward; eval mode keeps the eager path, and so does a
             # batch of another shape, e.g. the last one of an epoch)
-            if self._pose_graphed is None:
-                self._pose_eager = self.flowPoseNet.forward
-                torch.cuda.make_graphed_callables(self.flowPoseNet, (x.detach().clone(),))
-                self._pose_graphed = tuple(x.shape)
-            pose = self.flowPoseNet(x) if tuple(x.shape) == self._pose_graphed else self._pose_eager(x)
+            with self._pose_autocast():
+                if self._pose_graphed is None:
+                    self._pose_eager = self.flowPoseNet.forward
+                    torch.cuda.make_graphed_callables(self.flowPoseNet, (x.detach().clone(),))
+                    self._pose_graphed = tuple(x.shape)
+                pose = self.flowPoseNet(x) if tuple(x.shape) == self._pose_graphed else self._pose_eager(x)
         else:
-            pose = self.flowPoseNet(x)
-        return flow, disp, pose
+            with self._pose_autocast():
+                pose = self.flowPoseNet(x)
+        return flow, disp, pose.float()
+
+    def _pose_autocast(self):
+        import contextlib
+        if self.pose_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast('cuda', dtype=self.pose_dtype, cache_enabled=False)   # (no weight-cast cache: graph capture)
 
 
 class _HalfExec:

@@ -178,6 +178,9 @@ class _BandSystem:
         return y
 
 
+PCG_FAIL_RTOL = 1e-8      # true relative residual above which a PCG solve counts as failed
+
+
 def _pcg(sysm, ws, rtol=1e-13, check_every=6):
     """Solve (B + R) x = b with conjugate gradients preconditioned by B^-1 (the block-tridiagonal solver, enqueued without
     host round trips; the residual is looked at every `check_every` iterations).  Raises IslamHipError (ISLAM_ENOTPD) if B
@@ -189,7 +192,7 @@ def _pcg(sysm, ws, rtol=1e-13, check_every=6):
     ops.pvgo_solve_status(N, ws, dev)                      # B = L D L^T went through: positive definite
     k = int(sysm.io.numel())
     if k == 0:
-        return x, 0
+        return x, 0, 0.0
     zero = torch.zeros((), dtype=b.dtype, device=dev)
     safe_div = lambda a, c: torch.where(c != 0, a / torch.where(c != 0, c, torch.ones_like(c)), zero)
     r = b - sysm.matvec(x)
@@ -210,7 +213,9 @@ def _pcg(sysm, ws, rtol=1e-13, check_every=6):
         p = z + safe_div(rz_new, rz) * p
         rz = rz_new
     ops.pvgo_solve_status(N, ws, dev)
-    return x, its
+    # the TRUE residual of what is returned (the recurrence above can drift, and the loop may have hit its iteration cap)
+    rel = float((b - sysm.matvec(x)).norm()) / max(float(b.norm()), 1e-300)
+    return x, its, rel
 
 
 def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, max_steps=10, patience=3,
@@ -233,6 +238,7 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
         pass
     ctl = LMControl(radius=radius, max_steps=max_steps, patience=patience, decreasing=decreasing)
     trials = pcg_its = 0
+    pcg_worst = 0.0
     while ctl.continual:
         vo, lin = _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
         if not ctl.has_loss:
@@ -245,13 +251,16 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
             sysm.set_diagonal(d)
             trials += 1
             try:
-                D, its = _pcg(sysm, ws)
+                D, its, rel = _pcg(sysm, ws)
             except IslamHipError:
                 print('Linear solver failed. Breaking optimization step...')
                 ctl.solver_failed()
                 break
             pcg_its += its
-            if not bool(torch.isfinite(D).all()):
+            pcg_worst = max(pcg_worst, rel)
+            # an unconverged step must not reach LM silently: treat it like a failed factorisation (PyPose's Cholesky would
+            # have returned the exact solution or raised)
+            if not bool(torch.isfinite(D).all()) or rel > PCG_FAIL_RTOL:
                 print('Linear solver failed. Breaking optimization step...')
                 ctl.solver_failed()
                 break
@@ -263,4 +272,4 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
                 break
         ctl.end_step()
     return nodes, vels, dict(steps=ctl.steps, trials=trials, loss=ctl.loss, trace=ctl.trace, pcg_iterations=pcg_its,
-                             off_band_edges=int(off_idx.numel()))
+                             pcg_worst_relative_residual=pcg_worst, off_band_edges=int(off_idx.numel()))

@@ -11,10 +11,10 @@ if not f:
 disp = {}
 for r in csv.DictReader(open(f[0])):
     name = r['Kernel_Name']
-    if 'conv3x3_mfma_kernel' not in name:
+    if 'conv3x3_mfma_kernel' not in name and 'conv_nhwc_kernel' not in name:
         continue
-    m = re.search(r'conv3x3_mfma_kernel<(\d+), (\d+)>', name)
-    d = disp.setdefault(r['Dispatch_Id'], {'k': 'conv3x3_mfma<%s,%s>' % (m.group(1), m.group(2)) if m else 'conv3x3_mfma',
+    m = re.search(r'(conv3x3_mfma|conv_nhwc)_kernel<([\d, ]+)>', name)
+    d = disp.setdefault(r['Dispatch_Id'], {'k': '%s<%s>' % (m.group(1), m.group(2).replace(' ', '')) if m else 'conv',
                                            'grid': int(r['Grid_Size']),
                                            'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
     d[r['Counter_Name']] = float(r['Counter_Value'])
@@ -28,4 +28,4 @@ for (k, g), ds in sorted(groups.items(), key=lambda kv: -sum(d.get('SQ_VALU_MFMA
     ns = sum(d['ns'] for d in ds) / len(ds)
     tb += busy * len(ds); tt += ns * len(ds)
     print('%-24s %9d %5d %10.1f %14.0f %12.0f %8.1f%%' % (k, g, len(ds), ns / 1e3, busy, busy / 32, 100 * busy / (ns * 2.4 * 1024)))
-print('all conv3x3_mfma dispatches: MfmaUtil %.1f%% (time-weighted)' % (100 * tb / (tt * 2.4 * 1024)))
+print('all dispatches of the hand-written convolution kernels: MfmaUtil %.1f%% (time-weighted)' % (100 * tb / (tt * 2.4 * 1024)))

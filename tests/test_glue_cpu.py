@@ -206,3 +206,20 @@ def test_dense_ba_helpers_known_answers():
     assert kp.shape == (2, 6, 2)
     assert mask[0][kp[0, :, 1].long(), kp[0, :, 0].long()].all() and len({tuple(r) for r in kp[0].tolist()}) == 6
     assert (kp[1] == 0).all()
+
+
+def test_host_lm_control_follows_ieee_division_at_an_exactly_converged_point():
+    """at D == 0 the trust-region quality is 0/0 = NaN, which fails both comparisons and takes the
+    shrink-the-radius branch in PyPose (and in the device code); the host LMControl of the sharded / dense paths must take
+    the same damping trajectory as the oracle's TrustRegion."""
+    from islam_amd.lm_control import LMControl
+    from oracle import pvgo as opvgo
+    ctl, tr = LMControl(radius=1e4), opvgo.TrustRegion(radius=1e4)
+    ctl.set_initial_loss(2.5)
+    for last, loss, q in ((2.5, 2.5, 0.0), (2.5, 2.5, -0.0), (2.5, 2.4, 0.0), (2.5, 2.6, 0.0), (2.5, 2.0, -0.8)):
+        ctl.loss = last
+        ctl.begin_step()
+        ctl.after_trial(loss, q)
+        # the oracle's update takes J.D and R; a one-row system with (JD)^T (2R + JD) = q:  JD = 1, R = (q - 1) / 2
+        tr.update(last, loss, np.array([1.0]), np.array([(q - 1.0) / 2.0]))
+        assert ctl.damping == tr.pg['damping'], (last, loss, q)
