@@ -114,13 +114,23 @@ def test_product_fails_loudly_without_gpu():
         IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')
 
 
-def test_committed_bench_line_follows_the_contract():
-    """profiles/bench_r01_final.json is the last `python bench.py` line measured on the MI355X: one JSON object with the
-    driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline."""
+@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json'])
+def test_committed_bench_line_follows_the_contract(name):
+    """profiles/bench_rNN_final.json is the last `python bench.py` line of a round measured on the MI355X: one JSON object with
+    the driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline; from round 2 on
+    also the whole-iteration and per-launch roofline entries."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = open(os.path.join(root, 'profiles', 'bench_r01_final.json')).read().strip().split('\n')[-1]
+    line = open(os.path.join(root, 'profiles', name)).read().strip().split('\n')[-1]
     d = json.loads(line)
+    if 'r02' in name:
+        it = d['roofline']['iteration']
+        assert abs(it['frac'] - it['bytes'] / (it['us'] * 1e-6) / 1e9 / d['roofline']['peak']) < 1e-9
+        assert abs(it['us'] - d['us_per_lm_iter']) < 1e-9 and it['bytes'] == 5000 * 5001
+        pl = d['roofline']['per_launch']
+        assert {'bt_eliminate_tw_kernel_L0', 'bt_downsweep_kernel', 'trial_lin_kernel'} <= set(pl)
+        assert sum(v['us'] for v in pl.values()) < it['us']               # the three biggest launches fit inside the iteration
+        assert 0 < d['stereo_vio']['mfma_frac'] < 1
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
