@@ -115,7 +115,7 @@ int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const uint16_t* res
  *   y[b,ho,wo,n] = epi( sum w[n,c,r,s] * pre(x[b, ho+r-P, wo+s-P, c]) ),  P = ksize/2, zero padding, output size = input size
  *   pre(v) = v  (in_affine NULL)  or  relu(bf16(v*in_affine[c] + in_affine[Cin+c]))  -- the producer's BatchNorm + ReLU on load
  *   epi(a) = bf16(a), and with `stats` the per-channel sums of bf16(a) and bf16(a)^2 over all pixels (stats NULL: skipped);
- *            or  act( bf16( bf16(a + bias[n]) [+ res] ) ),  act = ReLU if `relu`.
+ *            or  act( bf16( bf16(a + bias[n]) [+ res] ) ),  act = ReLU if `relu` & 1;  `relu` & 2: pre(v) = relu(v) (in_affine NULL).
  * x (B,H,W,Cin), res / y (B,H,W,Cout) bf16 bits, Cin and Cout multiples of 8; wpacked: bf16 [ksize*ksize][CoutP][CinP], CoutP =
  * Cout rounded up to 64, CinP = Cin rounded up to 32, zero padded (islam_conv_nhwc_packed_elems elements).
  * stats: islam_conv_nhwc_stats_floats(B,H,W,Cout) floats; on return its LAST 256*2*Cout floats hold the folded partial sums

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
                                                              float* __restrict__ partial, int Cin, int CinP, int H, int W, int Cout,
-                                                             int CoutP, int relu, int tiles_x, int tiles) {
+                                                             int CoutP, int relu, int tiles_x, int tiles, int in_relu) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     constexpr int TH = 4 * ROWS, P = KS / 2, IH = TH + 2 * P, IW = TW + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
     constexpr int NIN = (NPIX * (KC / 8) + THREADS - 1) / THREADS;       // 16-byte items of the halo tile per thread
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 v.z = relu2(pack2(fmaf(lo16(v.z), s1.x, h1.x), fmaf(hi16(v.z), s1.y, h1.y)));
                 v.w = relu2(pack2(fmaf(lo16(v.w), s1.z, h1.z), fmaf(hi16(v.w), s1.w, h1.w)));
             }
+            else if (in_relu) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }     // ReLU of the input on load
             if (!(cok && goff[k] >= 0)) v = make_uint4(0, 0, 0, 0);      // zero padding of the NORMALISED activation
             *reinterpret_cast<uint4*>(lin + loff[k]) = v;
         }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
 
 template <int TN, int KS, int ROWS>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
-           unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, hipStream_t s) {
+           unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s) {
     constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS;
     const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
     const size_t epi_lds = (size_t)TW * TH * (TN + 8) * sizeof(unsigned short) + (size_t)THREADS * 17 * sizeof(float);
@@ -272,7 +273,7 @@ int launch(const unsigned short* x, const unsigned short* wp, const float* in_af
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y * B, (Cout + TN - 1) / TN);      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
     hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP, H, W,
-                       Cout, CoutP, relu, tiles_x, tiles_x * tiles_y);
+                       Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -295,6 +296,8 @@ size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout) {
 
 int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
                          uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream) {
+    const int in_relu = (relu >> 1) & 1;       // bit 1: ReLU of the INPUT while it is staged (hourglass.py:25-33 `self.relu(x)` before conv1)
+    relu &= 1;
     if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7))
         return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
     if (ksize != 1 && ksize != 3) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16: kernel size %d (1 or 3)", ksize);
@@ -305,11 +308,11 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
     const bool wide = Cout > 32;
     int rc;
     if (ksize == 3)
-        rc = wide ? launch<64, 3, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s)
-                  : launch<32, 3, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s);
+        rc = wide ? launch<64, 3, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s)
+                  : launch<32, 3, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
     else
-        rc = wide ? launch<64, 1, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s)
-                  : launch<32, 1, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, s);
+        rc = wide ? launch<64, 1, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s)
+                  : launch<32, 1, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
     if (rc != ISLAM_OK) return rc;
     if (stats) {
         const int nblk = islam_conv_nhwc_stat_blocks(B, H, W, Cout);

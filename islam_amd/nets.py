@@ -365,8 +365,8 @@ class _HGConv(nn.Module):
         assert x.shape[1] == self.inp_dim, '{} {}'.format(x.shape[1], self.inp_dim)
         return self.conv(x)
 
-    def run(self, x, relu=False, res=None):
-        """act(conv(x) + bias [+ res]): on islam_conv_nhwc_bf16 with the bias add, residual add and ReLU in its epilogue, or --
+    def run(self, x, relu=False, res=None, in_relu=False):
+        """act(conv([relu] x) + bias [+ res]): on islam_conv_nhwc_bf16 with the bias add, residual add and ReLU in its epilogue, or --
         for the shapes MIOpen is faster on -- a bias-free MIOpen convolution and ONE in-place pass over its output (frozen
         bf16 channels-last execution copy only; see _HGResidual.forward)."""
         c = self.conv
@@ -377,7 +377,9 @@ class _HGConv(nn.Module):
         if _hip_conv_ok(c, x, fused_1x1=True):
             if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
                 res = res.contiguous(memory_format=torch.channels_last)
-            return ops.conv_nhwc(x, _packed_nhwc(c), c.out_channels, c.kernel_size[0], bias=b[1], res=res, relu=relu)
+            return ops.conv_nhwc(x, _packed_nhwc(c), c.out_channels, c.kernel_size[0], bias=b[1], res=res, relu=relu, in_relu=in_relu)
+        if in_relu:
+            x = F.relu(x)
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act_add_(y, b[1], res, relu)
 
@@ -394,7 +396,7 @@ class _HGResidual(nn.Module):
     def forward(self, x):
         if ops.fusable_nhwc_bf16(x, self.conv1.conv.out_channels) and self.conv3.conv.out_channels % 8 == 0:
             res = self.skip_layer.run(x) if self.need_skip else x
-            y = self.conv2.run(self.conv1.run(self.relu(x), relu=True), relu=True)
+            y = self.conv2.run(self.conv1.run(x, relu=True, in_relu=True), relu=True)      # relu(x) rides on conv1's input staging
             return self.conv3.run(y, relu=False, res=res)
         res = self.skip_layer(x) if self.need_skip else x
         y = self.conv3(self.relu(self.conv2(self.relu(self.conv1(self.relu(x))))))

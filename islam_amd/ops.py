@@ -188,10 +188,11 @@ def pack_conv_nhwc_weight(w):
     return p.contiguous()
 
 
-def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False):
+def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False, in_relu=False):
     """Channels-last bf16 convolution (k = 1 or 3, stride 1, "same" padding) on islam_conv_nhwc_bf16.  x: (B,Cin,H,W) bf16
     channels_last.  in_affine (2*Cin fp32): the producer's BatchNorm scale | shift, applied with a ReLU while x is staged.
-    stats=True: returns (y, folded) with folded = the [256][2][cout] partial sums of the raw output for bn_finalize."""
+    stats=True: returns (y, folded) with folded = the [256][2][cout] partial sums of the raw output for bn_finalize.
+    in_relu: ReLU of the input while it is staged (no separate pass over x)."""
     require_cuda(x, packed)
     B, Cin, H, W = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
@@ -202,7 +203,7 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
     if res is not None:
         assert res.shape == y.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
     check(lib().islam_conv_nhwc_bf16(ptr(x), ptr(packed), ptr(in_affine), ptr(bias), ptr(res), ptr(y), ptr(st), B, Cin, H, W, int(cout),
-                                     int(ksize), int(bool(relu)), stream_ptr(x.device)))
+                                     int(ksize), int(bool(relu)) | (2 if in_relu else 0), stream_ptr(x.device)))
     if stats:
         return y, st[st.numel() - 256 * 2 * cout:]
     return y

@@ -108,3 +108,14 @@ def test_argument_checks(cuda):
     x6 = torch.zeros(1, 6, 16, 16, device=cuda, dtype=torch.bfloat16).contiguous(memory_format=CL)
     with pytest.raises(_lib.IslamHipError):
         ops.conv_nhwc(x6, torch.zeros(9 * 64 * 32, device=cuda, dtype=torch.bfloat16), 32, 3)
+
+
+def test_relu_of_the_input_on_load(cuda):
+    from islam_amd import ops
+    x, w = _mk(2, 64, 21, 37, 32, 1, seed=7)
+    b = torch.linspace(-0.5, 0.5, 32, device=cuda)
+    y = ops.conv_nhwc(x, ops.pack_conv_nhwc_weight(w), 32, 1, bias=b, relu=True, in_relu=True)
+    want = ops.conv_nhwc(F.relu(x), ops.pack_conv_nhwc_weight(w), 32, 1, bias=b, relu=True)
+    assert torch.equal(y, want)
+    ref = F.relu((F.conv2d(F.relu(x).float(), w.float(), None) + b.view(1, -1, 1, 1)).to(torch.bfloat16))
+    assert float((y != ref).float().mean()) < 0.02

@@ -319,3 +319,27 @@ def test_reprojection_factor_oracle():
     assert [t[2] for t in d[5].trace] == [t[2] for t in b[5].trace]
     np.testing.assert_allclose(d[2], b[2], atol=1e-9)
     np.testing.assert_allclose(d[4]['reproj'], (lw[4] / K) ** 2)
+
+
+def test_preprocess_oracle_known_answers():
+    """oracle/preprocess.py (OpenCV 4.7 INTER_LINEAR restated): identity at equal size, exact values of a 2x up-scale of a ramp,
+    border rules, and agreement of the host-side mirror (islam_amd.preprocess on CPU tensors: host logic) with it."""
+    import torch
+    from islam_amd import preprocess
+    from oracle import preprocess as opre
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(opre.resize_linear_u8(im, 37, 53), im)
+    ramp = np.tile((np.arange(8, dtype=np.uint8) * 10)[None, :, None], (4, 1, 1))
+    up = opre.resize_linear_u8(ramp, 8, 16)[0, :, 0]
+    # destination x samples source 0.5 x - 0.25: borders clamp to the first / last pixel, interior taps weigh 3/4 : 1/4
+    assert up.tolist()[:4] == [0, 2, 7, 12] and up[-1] == 70        # exact values 0, 2.5, 7.5, 12.5: the >>16 of the vertical pass truncates
+    for (H, W, h, w) in ((375, 1242, 448, 1484), (100, 60, 131, 79), (64, 64, 64, 100)):
+        im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        a = opre.resize_linear_u8(im, h, w)
+        b = preprocess.resize_linear_u8(torch.from_numpy(im).permute(2, 0, 1)[None], h, w)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_array_equal(a, b)
+        f = np.abs(a.astype(np.float64) - torch.nn.functional.interpolate(torch.from_numpy(im).permute(2, 0, 1)[None].float(), (h, w), mode='bilinear',
+                                                                            align_corners=False)[0].permute(1, 2, 0).numpy())
+        assert f.max() <= 1.0 + 1e-3                   # the fixed-point result stays within one grey level of exact bilinear
+    assert opre.crop_center_geometry(375, 1242) == (448, 1484, 422, 0)
