@@ -37,8 +37,6 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
     chain = _is_canonical_chain(links, N)
     rp = None
     if reproj is not None:               # 5th residual (pvgo.py:53-61,130-143): SparseReprojectionLoss-like object
-        if not chain:
-            raise UnsupportedGraphError('the reprojection factor couples consecutive nodes (pvgo.py:54-56): chain links only')
         w5 = (loss_weight[4] / reproj.N) ** 2                                                  # pvgo.py:131
         K = reproj.K.detach().cpu().double()
         rp = ops.pvgo_reproj_struct(reproj.point3d.detach().to(dev, torch.float64).contiguous(),
@@ -64,12 +62,12 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
         if how == 'auto':        # a long chain with a few loop closures: block-tridiagonal solver + low-rank correction (PCG)
             how = 'band_pcg' if (N > 512 and k_off <= 64) else 'dense'
         if how == 'band_pcg':
-            nodes, vels, res = run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
+            nodes, vels, res = run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius, reproj=rp)
         elif how == 'dense':
             if N > 12000:
                 raise UnsupportedGraphError('dense general-topology path is sized for N <= 12000 nodes, (9N)^2 doubles (got %d '
                                             'nodes, %d off-band edges; general_solver="band_pcg" has no such limit)' % (N, k_off))
-            nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius)
+            nodes, vels, res = run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts64, loss_weight, radius=radius, reproj=rp)
         else:
             raise ValueError("general_solver must be 'auto', 'dense' or 'band_pcg'")
 

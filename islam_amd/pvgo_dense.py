@@ -75,9 +75,54 @@ def _quality_term(vo, lin, edges, dts, D):
     return q
 
 
+class _ReprojTerms:
+    """The sparse reprojection factor (pvgo.py:53-61; 5th residual) of one linearisation point, in NODE coordinates.  The factor
+    always couples consecutive nodes k, k+1 (motion = nodes[:-1].Inv() @ nodes[1:], whatever `links` holds), so its blocks land
+    in the chain arrays (Hd, Ho, rhs) of either general-topology solver.  islam_pvgo_reproj_reduce gives, per link, J^T J / J^T r
+    / r^T r in the coordinates eta of a left perturbation of T_k = C^-1 (X_k^-1 X_{k+1}) C; eta = M (delta_{k+1} - delta_k),
+    M = Ad(C^-1 X_k^-1) = [[R, [t]x R], [0, R]] (reproj_link in csrc/pvgo.hip)."""
+
+    def __init__(self, nodes, rp, dx=None):
+        red = ops.pvgo_reproj_reduce(nodes, rp, dx)
+        self.rr = red[:, 27].sum()                                        # unweighted r^T r over all links
+        if dx is not None:
+            return                                                        # trial point: only the loss is needed
+        Mn, dev = red.shape[0], nodes.device
+        iu = torch.triu_indices(6, 6, device=dev)
+        S = torch.zeros((Mn, 6, 6), dtype=torch.float64, device=dev)
+        S[:, iu[0], iu[1]] = red[:, :21]
+        S = S + S.transpose(1, 2) - torch.diag_embed(S.diagonal(dim1=1, dim2=2))
+        b = red[:, 21:27]
+        from . import lietensor as pp
+        C = pp.SE3(torch.tensor([float(v) for v in rp.rgb2imu], dtype=torch.float64, device=dev))
+        Y = C.Inv() @ pp.SE3(nodes[:-1]).Inv()
+        R = Y.rotation().matrix()
+        T = pp._skew(Y.translation()) @ R
+        Mm = torch.zeros((Mn, 6, 6), dtype=torch.float64, device=dev)
+        Mm[:, :3, :3], Mm[:, :3, 3:], Mm[:, 3:, 3:] = R, T, R
+        Mt = Mm.transpose(1, 2)
+        self.S = Mt @ S @ Mm                                               # (M,6,6) unweighted J^T J w.r.t. (delta_{k+1} - delta_k)
+        self.g = (Mt @ b[:, :, None])[:, :, 0]                             # (M,6)   unweighted J^T r
+        self.w = float(rp.weight)
+
+    def add_to_chain(self, Hd, Ho, rhs):
+        """+w S on the pose blocks of nodes k and k+1, -w S on their coupling, b = -J^T W r: +w g at k, -w g at k+1."""
+        wS, wg = self.w * self.S, self.w * self.g
+        Hd[:-1, :6, :6] += wS
+        Hd[1:, :6, :6] += wS
+        Ho[:-1, :6, :6] -= wS
+        rhs[:-1, :6] += wg
+        rhs[1:, :6] -= wg
+
+    def quality(self, D):
+        """(J D)^T (2 R + J D) of the reprojection rows (unweighted, like the other factors)."""
+        d = D[1:, :6] - D[:-1, :6]
+        return (d * (2 * self.g + (self.S @ d[:, :, None])[:, :, 0])).sum()
+
+
 def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, max_steps=10, patience=3,
-                 decreasing=1e-3, vmin=1e-4, vmax=1e32):
-    """In: float64 contiguous device tensors.  Returns (nodes, vels, info dict)."""
+                 decreasing=1e-3, vmin=1e-4, vmax=1e32, reproj=None):
+    """In: float64 contiguous device tensors; reproj: ops.pvgo_reproj_struct or None.  Returns (nodes, vels, info dict)."""
     N, E, M = nodes.shape[0], edges.shape[0], nodes.shape[0] - 1
     if E != M:
         raise ValueError('PoseVelGraph needs as many VO edges as IMU intervals (dts broadcasts over both, pvgo.py:51): E=%d, N-1=%d' % (E, M))
@@ -93,10 +138,13 @@ def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weig
     trials = 0
     while ctl.continual:
         vo, lin = _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
+        rpt = _ReprojTerms(nodes, reproj) if reproj is not None else None
         if not ctl.has_loss:
-            ctl.set_initial_loss(float(_loss(vo, lin)))
+            ctl.set_initial_loss(float(_loss(vo, lin) + (rpt.rr if rpt is not None else 0.0)))
         ctl.begin_step()
         Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w[1], w[2], w[3]), -_NOCLAMP, _NOCLAMP)     # IMU factors
+        if rpt is not None:
+            rpt.add_to_chain(Hd, Ho, rhs)
         check(lib().islam_pvgo_assemble_dense(ptr(Hd), ptr(Ho), ptr(rhs), ptr(vo), ptr(edges), ptr(nptr), ptr(nadj),
                                               c_double(w[0]), N, E, ptr(A), ptr(b), stream_ptr(dev)))
         d = A.diagonal().clamp(vmin, vmax).clone()                    # A.diagonal().clamp_(min, max)
@@ -113,7 +161,10 @@ def run_lm_dense(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weig
             del L
             nt, vt = ops.pvgo_retract(nodes, vels, D, 1.0)
             vo_t, lin_t = _linearize(nt, vt, edges, poses, drots, dtrans, dvels, dts, dummy)
-            s, q = torch.stack([_loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)]).tolist()
+            st, qt = _loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)
+            if rpt is not None:
+                st, qt = st + _ReprojTerms(nodes, reproj, D).rr, qt + rpt.quality(D)
+            s, q = torch.stack([st, qt]).tolist()
             if ctl.after_trial(s, q):
                 nodes, vels = nt, vt
                 break
@@ -143,9 +194,11 @@ def off_band_edges(edges_host):
 class _BandSystem:
     """A = B + R of one linearisation: B as (Hd, Ho) of the chain solver, R as the list of off-band 6x6 blocks."""
 
-    def __init__(self, vo, lin, edges, dts, N, w, vmin, vmax, off_idx):
+    def __init__(self, vo, lin, edges, dts, N, w, vmin, vmax, off_idx, rpt=None):
         dev = vo.device
         Hd, Ho, rhs = ops.pvgo_build_normal(lin, dts, N, (0.0, w[1], w[2], w[3]), -_NOCLAMP, _NOCLAMP)     # IMU factors
+        if rpt is not None:
+            rpt.add_to_chain(Hd, Ho, rhs)
         S, g = _edge_blocks(vo, w[0])
         E = S.shape[0]
         i, j = edges[:, 0], edges[:, 1]
@@ -219,7 +272,7 @@ def _pcg(sysm, ws, rtol=1e-13, check_every=6):
 
 
 def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, max_steps=10, patience=3,
-                    decreasing=1e-3, vmin=1e-4, vmax=1e32):
+                    decreasing=1e-3, vmin=1e-4, vmax=1e32, reproj=None):
     """The LM of run_lm_dense on the band + low-rank form of the same normal equations.  In: float64 contiguous device
     tensors.  Returns (nodes, vels, info dict)."""
     from ._lib import IslamHipError
@@ -241,10 +294,11 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
     pcg_worst = 0.0
     while ctl.continual:
         vo, lin = _linearize(nodes, vels, edges, poses, drots, dtrans, dvels, dts, dummy)
+        rpt = _ReprojTerms(nodes, reproj) if reproj is not None else None
         if not ctl.has_loss:
-            ctl.set_initial_loss(float(_loss(vo, lin)))
+            ctl.set_initial_loss(float(_loss(vo, lin) + (rpt.rr if rpt is not None else 0.0)))
         ctl.begin_step()
-        sysm = _BandSystem(vo, lin, edges, dts, N, w, vmin, vmax, off_idx)
+        sysm = _BandSystem(vo, lin, edges, dts, N, w, vmin, vmax, off_idx, rpt)
         d = sysm.diag0
         while True:
             d = d + d * ctl.damping                                   # cumulative, like A.diagonal().add_(...)
@@ -266,7 +320,10 @@ def run_lm_band_pcg(nodes, vels, edges, poses, drots, dtrans, dvels, dts, loss_w
                 break
             nt, vt = ops.pvgo_retract(nodes, vels, D.contiguous(), 1.0)
             vo_t, lin_t = _linearize(nt, vt, edges, poses, drots, dtrans, dvels, dts, dummy)
-            s, q = torch.stack([_loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)]).tolist()
+            st, qt = _loss(vo_t, lin_t), _quality_term(vo, lin, edges, dts, D)
+            if rpt is not None:
+                st, qt = st + _ReprojTerms(nodes, reproj, D.contiguous()).rr, qt + rpt.quality(D)
+            s, q = torch.stack([st, qt]).tolist()
             if ctl.after_trial(s, q):
                 nodes, vels = nt, vt
                 break

@@ -91,14 +91,35 @@ def test_run_pvgo_with_reprojection_factor(cuda, F, K, compat):
     assert se3_log_err(on0, on).max() > 1e-3
 
 
-def test_reprojection_needs_chain_links(cuda):
+@pytest.mark.parametrize('how', ['dense', 'band_pcg'])
+def test_reprojection_factor_on_a_graph_with_loop_closures(cuda, how):
+    """The 5th residual couples consecutive nodes whatever `links` holds (pvgo.py:54-56), so it also works on general topologies:
+    both general solvers against the oracle's dense LM with the reprojection rows (missing item 6)."""
     from islam_amd import lietensor as pp
-    from islam_amd.pvgo import UnsupportedGraphError, run_pvgo
-    prob, tr, ref, hip = _build(9, 16, cuda, True)
-    links = prob['links'].copy()
-    links[3] = (0, 5)
+    from islam_amd.pvgo import run_pvgo
+    F, K = 21, 48
+    prob, tr, ref, hip = _build(F, K, cuda, True)
+    links, vo = prob['links'].copy(), prob['vo_motions'].copy()
+    gt = np.concatenate([tr['gt_pos'], tr['gt_quat']], 1)
+    rng = np.random.default_rng(5)
+    for e, (i, j) in {3: (0, 9), 11: (4, 17), 19: (20, 2)}.items():      # replace three chain edges by long-range ones
+        links[e] = (i, j)
+        vo[e] = lie.se3_mul(lie.se3_mul(lie.se3_inv(gt[i]), gt[j]), lie.se3_exp(rng.normal(0, 0.01, 6)))
+    p2 = dict(prob, links=links, vo_motions=vo)
+    otl, orl, on, ov, ocov, opt = opvgo.run_pvgo(**p2, loss_weight=LW5, mode='dense', reproj=ref, compat_first_motion=True,
+                                                 return_optimizer=True)
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
-    with pytest.raises(UnsupportedGraphError):
-        run_pvgo(pp.SE3(t(prob['init_nodes'])), t(prob['init_vels']), pp.SE3(t(prob['vo_motions']).to(cuda)), torch.tensor(links),
-                 t(prob['dts']), pp.SO3(t(prob['imu_drots'])), t(prob['imu_dtrans']), t(prob['imu_dvels']), device='cuda',
-                 loss_weight=LW5, reproj=hip)
+    tl, rl, nodes, vels, covs, res = run_pvgo(pp.SE3(t(p2['init_nodes'])), t(p2['init_vels']), pp.SE3(t(vo).to(cuda)), torch.tensor(links),
+                                              t(p2['dts']), pp.SO3(t(p2['imu_drots'])), t(p2['imu_dtrans']), t(p2['imu_dvels']),
+                                              device='cuda', loss_weight=LW5, reproj=hip, return_info=True, general_solver=how)
+    assert res['trials'] == len(opt.trace)
+    np.testing.assert_array_equal([a for _, _, a in res['trace']], [a for _, _, a in opt.trace])
+    assert res['loss'] == pytest.approx(opt.loss, rel=1e-7)
+    err = se3_log_err(nodes.numpy(), on)
+    refn = np.maximum(np.linalg.norm(lie.se3_log(on), axis=-1), 1e-6)
+    assert (err / refn).max() < 1e-6
+    np.testing.assert_allclose(vels.numpy(), ov, atol=1e-7)
+    np.testing.assert_allclose(covs['reproj'], ocov['reproj'])
+    # the factor matters here too
+    _, _, on0, _, _ = opvgo.run_pvgo(**p2, loss_weight=LW5[:4], mode='dense')
+    assert se3_log_err(on0, on).max() > 1e-3
