@@ -462,7 +462,11 @@ class StereoNet7(nn.Module):
         self.conv_c6_2 = nn.Conv2d(512, 512, 3, padding=1)
         self.deconv_c7_2 = nn.ConvTranspose2d(512, 512, 4, 2, 1)
 
-    def forward(self, x):
+    def forward(self, x, quarter=False):
+        """quarter=True returns only the pixels VONet keeps (Network/VONet.py:33-34 `F.interpolate(disp, scale_factor=0.25,
+        mode='nearest')` = disp[..., ::4, ::4]): conv_c12 / conv_c13 are 1x1 and an output pixel (4y, 4x) of the 4x4 stride-2
+        deconv_c11 depends on a 2x2 input patch only, so the full-resolution tail (a 294 MB tensor at B=8, 16x the needed work)
+        collapses to a 2x2 stride-2 convolution at half resolution -- the same arithmetic for the pixels that are used."""
         assert x.shape[1] % 2 == 0
         B, C2, H, W = x.shape
         f = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))          # left/right stacked along the batch
@@ -496,8 +500,26 @@ class StereoNet7(nn.Module):
         x = torch.cat((self.conv_c8(act(self.deconv_c8(x))), cat2), 1)
         x = torch.cat((self.conv_c9(act(self.deconv_c9(x))), cat1), 1)
         x = torch.cat((self.conv_c10(act(self.deconv_c10(x))), cat0), 1)
-        x = act(self.deconv_c11(x))
+        if quarter:
+            x = act(self._deconv_c11_quarter(x))
+        else:
+            x = act(self.deconv_c11(x))
         return self.conv_c13(act(self.conv_c12(x))), None
+
+    def _deconv_c11_quarter(self, x):
+        """deconv_c11(x)[..., ::4, ::4].  ConvTranspose2d(k=4, s=2, p=1): out[o, oy, ox] = b[o] + sum_i sum_ky,kx x[i, (oy+1-ky)/2,
+        (ox+1-kx)/2] W[i, o, ky, kx] over the taps where the division is exact; for oy = 4y: ky = 1 -> row 2y, ky = 3 -> row 2y-1.
+        That is a 2x2 convolution with stride 2 and one row / column of zero padding in front: K[o, i, a, b] = W[i, o, 3-2a, 3-2b]."""
+        dc = self.deconv_c11
+        key = (dc.weight._version, dc.weight.data_ptr())
+        hit = self.__dict__.get('_c11q')
+        if hit is None or hit[0] != key:
+            K = dc.weight.detach()[:, :, [3, 1]][:, :, :, [3, 1]].permute(1, 0, 2, 3).contiguous()
+            if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+                K = K.contiguous(memory_format=torch.channels_last)
+            hit = self.__dict__['_c11q'] = (key, K)
+        h, w = x.shape[2] // 2, x.shape[3] // 2
+        return F.conv2d(x, hit[1], dc.bias, stride=2, padding=1)[:, :, :h, :w]
 
 
 # ------------------------------------------------------------------------------------------ VOFlowRes
@@ -586,16 +608,17 @@ class VONet(nn.Module):
         self._exec = {}
         self._graphs = {}
 
-    def _run_frozen(self, name, master, dtype, x):
+    def _run_frozen(self, name, master, dtype, x, quarter=False):
         if dtype is None or any(p.requires_grad for p in master.parameters()):
-            return master(x)                 # trainable parts keep their fp32 autograd path
+            return master(x, quarter=True) if quarter else master(x)      # trainable parts keep their fp32 autograd path
         if name == 'flow':                   # fp32 activations, bf16 operands inside the HIP matrix-core convolutions
             with torch.no_grad():
                 return master.forward_mfma(x)
         ex = self._exec.get(name)
         if ex is None or ex.dtype != dtype:
             ex = self._exec[name] = _HalfExec(master, dtype)
-        return ex.module()(x.to(dtype).contiguous(memory_format=torch.channels_last))
+        xin = x.to(dtype).contiguous(memory_format=torch.channels_last)
+        return ex.module()(xin, quarter=True) if quarter else ex.module()(xin)
 
     def set_graph_frozen(self, on=True):
         """Replay the frozen flow + disparity forward (~750 launches) from a captured HIP graph instead of enqueueing it
@@ -639,9 +662,9 @@ class VONet(nn.Module):
 
     def _frozen_eager(self, img0, img1, img0_norm, img0_r_norm):
         flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0]
-        disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1))[0]
-        flow, disp = flow.float().contiguous(), disp.float().contiguous()
-        return flow, F.interpolate(disp, scale_factor=0.25, mode='nearest')
+        # Network/VONet.py:33-34 keeps disp[..., ::4, ::4] (nearest, scale 1/4): only those pixels are computed (StereoNet7.forward)
+        disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1), quarter=True)[0]
+        return flow.float().contiguous(), disp.float().contiguous()
 
     def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic, frozen=None):
         flow, disp = frozen if frozen is not None else self.frozen_forward(img0, img1, img0_norm, img0_r_norm)

@@ -91,3 +91,24 @@ def test_whole_vonet_matches_reference(nets, monkeypatch):
         flow, disp, pose = net(*[s[k] for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm', 'intrinsic')])
     for got, key, tol in ((flow, 'flow', 2e-4), (disp, 'disp', 2e-4), (pose, 'pose', 1e-3)):
         assert np.abs(got.numpy() - ref[key]).max() <= tol * max(np.abs(ref[key]).max(), 1e-3), key
+
+
+def test_quarter_resolution_tail_computes_exactly_the_pixels_vonet_keeps(nets):
+    """StereoNet7.forward(quarter=True) == forward()[..., ::4, ::4] == what Network/VONet.py:33-34 keeps of the disparity
+    (F.interpolate(scale_factor=0.25, mode='nearest')): the 4x4 stride-2 deconvolution restricted to every 4th output pixel is a
+    2x2 stride-2 convolution, the two 1x1 convolutions after it are pointwise."""
+    torch.manual_seed(1)
+    net = fill_state_dict(nets.StereoNet7()).eval()
+    x = make_input('stereo')[:1]
+    with torch.no_grad():
+        full = net(x)[0]
+        q = net(x, quarter=True)[0]
+        dq = net._deconv_c11_quarter(torch.randn(2, 128, 18, 26))
+        dfull = net.deconv_c11(torch.randn(2, 128, 18, 26, generator=torch.Generator().manual_seed(9)))
+    kept = torch.nn.functional.interpolate(full, scale_factor=0.25, mode='nearest')
+    assert q.shape == kept.shape == (1, 1, 64, 64)
+    assert float((q - kept).abs().max()) <= 1e-5 * float(kept.abs().max())
+    assert dq.shape == (2, 64, 9, 13) and dfull.shape == (2, 64, 36, 52)
+    xin = torch.randn(2, 128, 18, 26, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        torch.testing.assert_close(net._deconv_c11_quarter(xin), net.deconv_c11(xin)[..., ::4, ::4], rtol=1e-4, atol=1e-4 * float(dfull.abs().max()))
