@@ -469,25 +469,28 @@ class StereoNet7(nn.Module):
         collapses to a 2x2 stride-2 convolution at half resolution -- the same arithmetic for the pixels that are used."""
         assert x.shape[1] % 2 == 0
         B, C2, H, W = x.shape
-        f = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))          # left/right stacked along the batch
-        f = f.reshape(B, f.shape[1] * 2, f.shape[2], f.shape[3])
+        f2 = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))         # left/right stacked along the batch
         half = F.interpolate(x, scale_factor=0.5, mode='bilinear')
         act, pool = self.actfun, lambda t: F.max_pool2d(t, kernel_size=2)
         c0 = self.conv_c0
-        if HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f, f.shape[1]) and c0.weight.dtype == torch.bfloat16 and f.shape[1] % 8 == 0:
+        cf = f2.shape[1]
+        if HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f2, cf) and c0.weight.dtype == torch.bfloat16 and cf % 8 == 0:
             # 134 = 128 + 6 input channels: the concatenation is built with 136 channels (two zero ones) so that conv_c0 runs on
             # islam_conv_nhwc_bf16 -- MIOpen's bf16 kernel for this shape truncates its output (scripts/calib/bf16_rounding_probe.py)
             # and this is the first layer of the un-normalised hourglass path, where that loss of magnitude is never renormalised
             cin = (c0.in_channels + 7) // 8 * 8
-            buf = torch.zeros((B, cin, f.shape[2], f.shape[3]), dtype=f.dtype, device=f.device, memory_format=torch.channels_last)
-            buf[:, :f.shape[1]].copy_(f)
-            buf[:, f.shape[1]:c0.in_channels].copy_(half)
+            buf = torch.empty((B, cin, f2.shape[2], f2.shape[3]), dtype=f2.dtype, device=f2.device, memory_format=torch.channels_last)
+            buf[:, :cf].copy_(f2[0::2])                      # f.reshape(B, 2*cf, h, w) of the reference: [left | right] features per
+            buf[:, cf:2 * cf].copy_(f2[1::2])                # image, written straight into the padded buffer (one copy, not two)
+            buf[:, 2 * cf:c0.in_channels].copy_(half)
+            buf[:, c0.in_channels:].zero_()
             bkey = (c0.bias._version, c0.bias.data_ptr())
             b32 = self.__dict__.get('_c0_b32')
             if b32 is None or b32[0] != bkey:
                 b32 = self.__dict__['_c0_b32'] = (bkey, c0.bias.detach().float().contiguous())
             x0 = ops.conv_nhwc(buf, _packed_nhwc(c0, cin), c0.out_channels, 3, bias=b32[1])
         else:
+            f = f2.reshape(B, cf * 2, f2.shape[2], f2.shape[3])
             x0 = c0(torch.cat((f, half), 1))
         cat0 = self.conv_c1(x0)                                               # 1/2, 64
         cat1 = self.conv_c2_SSP(pool(self.conv_c2(cat0)))                     # 1/4, 128
