@@ -333,18 +333,6 @@ int islam_pvgo_run_chain_sharded_cb(islam_allreduce_fn fn, void* user, int world
                                     const double* poses, const double* drots, const double* dtrans, const double* dvels, const double* dts,
                                     int N, const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes, void* scratch,
                                     size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream);
-/* Eliminate level-0 segments [seg0, seg0+nseg) of an N-node chain.  Hd/Ho/rhs/fac/inv are LOCAL arrays whose row 0 is
- * global node `node0`.  products: 351*P0 doubles, array-major (Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P |
- * cgR 9P); only the local segments' rows are written, so a zero-initialised buffer can be summed over ranks. */
-int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
-                               int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
-                               void* stream);
-/* Levels >= 1 from the summed products -> x1 (n1,9): the step at the level-0 separators (run redundantly per rank). */
-int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
-                             double* x1, int* flags, void* stream);
-/* Back-substitution of the local segments into the LOCAL dx (row 0 = global node `node0`). */
-int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
-                             int seg0, int nseg, double* dx, void* stream);
 /* Trial step on M links (M+1 node rows): retract on a copy, residuals, partial sums part[2*nblk] =
  * (sum r^2, sum JD.(2R+JD)) per 64-link block (ppost.TrustRegion.update's denominator is -sum). */
 int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,

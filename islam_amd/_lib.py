@@ -105,11 +105,6 @@ SIGNATURES = {
     'islam_pvgo_shard_upsweep': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_size_t,
                                          c_void_p, c_void_p, c_void_p]),
     'islam_pvgo_shard_downsweep': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_size_t] + [c_void_p] * 3),
-    'islam_pvgo_shard_eliminate': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int] +
-                                   [c_void_p] * 5),
-    'islam_pvgo_reduced_solve': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t] + [c_void_p] * 3),
-    'islam_pvgo_shard_backsub': (c_int, [c_void_p] * 3 + [c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p,
-                                                          c_void_p]),
     'islam_pvgo_trial': (c_int, [c_void_p] * 9 + [c_int] + [c_void_p] * 4),
     'islam_pvgo_retract': (c_int, [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 3),
     'islam_pvgo_linearize_edges': (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_void_p]),

@@ -17,7 +17,7 @@
 //   3. factor with a partitioned ("spike") block LDL^T: the chain is cut into segments, each
 //      segment's interior is eliminated onto its two separator nodes -- by two wavefronts that start
 //      at the two ends and meet at the middle node (bt_eliminate_tw_kernel, "twisted"; the one-sided
-//      bt_eliminate_kernel serves the sharded entry points) -- one launch per level; the separators
+//      bt_eliminate_kernel serves segment lengths the twisted path does not handle) -- one launch per level; the separators
 //      form a ~6x smaller chain that is reduced the same way;
 //      the root solve and the whole back-substitution run in ONE launch (bt_downsweep_kernel) with
 //      per-segment ready words and write-through hand-off between levels.  Inside a wavefront one
@@ -41,6 +41,7 @@
 
 #include "common.h"
 #include "lie_dev.h"
+#include "pvgo_internal.h"
 
 using namespace islam;
 
@@ -94,11 +95,7 @@ __device__ __forceinline__ double ld_coherent(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Run-ahead gate.  The host enqueues LM iteration t+1 before it knows the outcome of trial t, assuming "accepted,
-// continue".  Every kernel of an iteration carries the epoch it was enqueued under; the deciding lane bumps the device
-// epoch (state[14]) on any other outcome, which turns the already-queued kernels into no-ops.
-struct Gate { const double* ctl; double epoch; };
-__device__ __forceinline__ bool gate_closed(const Gate& g) { return g.ctl != nullptr && g.ctl[14] != g.epoch; }
+// (the run-ahead gate -- struct Gate, gate_closed -- lives in pvgo_internal.h)
 
 // ------------------------------------------------------------------------------------------
 // residuals of one link (pvgo.py:36-51); also returns what the Jacobian needs
@@ -486,13 +483,13 @@ __global__ __launch_bounds__(LB_THREADS) void linbuild_kernel(const double* __re
                                                                double* __restrict__ lin, double* __restrict__ loss_part,
                                                                double* __restrict__ Hd, double* __restrict__ Ho,
                                                                double* __restrict__ rhs, const double* __restrict__ red,
-                                                               ReprojDev rp) {
+                                                               ReprojDev rp, Gate gate) {
     __shared__ double sl[64][LB_REC];
     extern __shared__ __attribute__((aligned(16))) double lb_out[];   // staged Hd (63x81) | Ho (63x81) | rhs (63x9)
     const int M = N - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blk = xcd_index(blockIdx.x, (N + LB_NODES - 1) / LB_NODES);
-    if (blk < 0) return;
+    if (blk < 0 || gate_closed(gate)) return;
     const int L = blk * LB_NODES - 1 + lane;                  // link handled by this lane (wave 0)
     if (wave == 0) {
         double sq = 0.0;
@@ -957,7 +954,8 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
 #pragma unroll
             for (int r = 0; r < 9; ++r) spike[r] = O[jj * 9 + r];
         } else {            // coupling (first rows, right separator cols)
-            const int cl = has_spike ? first : 0;
+            const int cl = first;        // (no right separator: a valid address inside the segment, the value is dropped below --
+                                         // row 0 of the chain lies outside a rank's LOCAL level-0 arrays in the sharded solve)
             const double* O = src.level0 ? (src.Ho + (size_t)cl * 81) : (src.fill + (size_t)(cl + 1) * 81);
 #pragma unroll
             for (int r = 0; r < 9; ++r) spike[r] = O[r * 9 + jj];
@@ -1326,7 +1324,11 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 // number after an agent-scope release fence), back-substitutes, publishes.  The waits replace four kernel boundaries and
 // overlap the first factor loads with the dependency.  Workgroups are dispatched in index order, so a waiting workgroup
 // only ever waits for lower-indexed ones (already resident or finished); the spin is bounded all the same.
-struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride; };
+// seg0 / nseg: the window of segments this launch back-substitutes (all P of them on one GPU; a rank's own range in the sharded
+// solve).  outer: the window's first segment takes its LEFT separator -- the rank's left cut node, a node of every level up to
+// the replicated ones -- from SweepArgs::outer_x instead of the level above (whose segment holding it belongs to the
+// previous rank).  x_last: last valid index of x (the sharded solve hands in a local array).
+struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, x_last; };
 struct SweepArgs {
     LevelSrc root_src;
     LevelDst root_dst;
@@ -1336,8 +1338,9 @@ struct SweepArgs {
     int nl;
     int* ready;               // per-segment words; ready[flag0 + p] == serial once segment p of that level is solved
     int serial;
-    int twisted;              // levels below the root were factored by bt_eliminate_tw_kernel
     int root_twisted;         // the root is eliminated by both wavefronts of workgroup 0 (root_n <= BS_PAR_MAX)
+    const double* outer_x;    // sharded solve: the solution at the rank's left cut node (9 doubles, a replicated level's x) ...
+    int outer_flag;           // ... and the ready word of the segment that publishes it
 };
 
 constexpr int READY_STRIDE = 32;      // ints between two ready words: one 128-byte line each (polled words spread over L2 channels)
@@ -1396,8 +1399,10 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     int li = 0;
     while (li + 1 < a.nl && b >= a.first_block[li + 1]) ++li;
     const SweepLevel L = a.lv[li];
-    const int p = xcd_index(b - a.first_block[li], L.P);   // blocks of a level are padded to a multiple of 8
-    if (p < 0) return;
+    const int pw = xcd_index(b - a.first_block[li], L.nseg);   // blocks of a level are padded to a multiple of 8
+    if (pw < 0) return;
+    const int p = L.seg0 + pw;
+    const bool outer_left = L.outer && pw == 0;
     const int stride = L.m + 1;
     const int c0 = p * stride;
     const int cnt = min(L.m, L.n - c0);
@@ -1417,7 +1422,7 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     // can fall off the end of a mapped allocation)
     const int nsep9 = (L.n / (L.m + 1)) * 9;
     double warm0 = L.xsep[min((has_left ? p - 1 : p) * 9 + (lane & 7), max(nsep9 - 1, 0))];
-    double warm1 = L.x[min(c0 * 9 + lane, L.n * 9 - 1)];
+    double warm1 = L.x[min(c0 * 9 + lane, L.x_last)];
     __builtin_amdgcn_sched_barrier(0);
     // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
     // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times)
@@ -1425,14 +1430,17 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     asm volatile("" ::"v"(warm0), "v"(warm1));
     // separators p-1 and p are nodes of the level above; node q there is published by its segment q / up_stride
     PROBE_WALL(pr, po + 315 + 10 * li);
-    if (has_left) wait_ready(a.ready + (size_t)(L.up_flag0 + (p - 1) / L.up_stride) * READY_STRIDE, a.serial, flags, lane);
+    if (has_left)
+        wait_ready(a.ready + (size_t)(outer_left ? a.outer_flag : L.up_flag0 + (p - 1) / L.up_stride) * READY_STRIDE, a.serial, flags, lane);
     PROBE_WALL(pr, po + 316 + 10 * li);
-    if (has_right && (!has_left || p / L.up_stride != (p - 1) / L.up_stride))
+    if (has_right && (!has_left || outer_left || p / L.up_stride != (p - 1) / L.up_stride))
         wait_ready(a.ready + (size_t)(L.up_flag0 + p / L.up_stride) * READY_STRIDE, a.serial, flags, lane);
     PROBE_WALL(pr, po + 311 + 10 * li);
     // one load per lane (lanes 0-8: left separator, 9-17: right separator), then lane broadcasts
     double sv = 0.0;
-    if (lane < 9 ? has_left : (lane < 18 && has_right)) sv = ld_coherent(&L.xsep[(size_t)(p - 1) * 9 + lane]);
+    if (lane < 9 ? has_left : (lane < 18 && has_right))
+        sv = ld_coherent((outer_left && lane < 9) ? a.outer_x + lane : &L.xsep[(size_t)(p - 1) * 9 + lane]);
+    if (outer_left && lane < 9) st_coherent(&L.x[(size_t)(c0 - 1) * 9 + lane], sv);      // the cut node's row of this level's x
 #ifdef ISLAM_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PROBE_WALL(pr, po + 317 + 10 * li);
@@ -1445,7 +1453,7 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     }
     if (has_right && lane >= 9 && lane < 18) st_coherent(&L.x[(size_t)sR * 9 + lane - 9], sv);
     PROBE_WALL(pr, po + 312 + 10 * li);
-    if (a.twisted) backsub_par_run_tw(L.x, c0, cnt, lane, xn, xL, cur);      // (twisted levels always have m <= BS_PAR_MAX)
+    if (L.twisted) backsub_par_run_tw(L.x, c0, cnt, lane, xn, xL, cur);      // (twisted levels always have m <= BS_PAR_MAX)
     else if (par) backsub_par_run(L.x, c0, cnt, lane, xn, xL, cur);
     else backsub_run(L.fac, L.inv, L.x, c0, cnt, lane, xn, xL, cur);
     PROBE_WALL(pr, po + 313 + 10 * li);
@@ -1454,72 +1462,7 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
 }
 
 // ------------------------------------------------------------------------------------------
-// state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
-//        [8] reject_count [9] accepted [10] error [11] has_loss
-// report (host-visible copy written after every trial): same slots as seen by the step that just ran, [15] = sequence number
-//        [12] optimizer steps [13] plateau patience count [14] run-ahead epoch (Gate)
-// report[12] = verdict: 0 accepted & continue, 1 rejected (retry with more damping), 2 accepted & stop, 3 solver failed &
-// continue (same iterate, new linearisation), 4 solver failed & stop;  report[13] = optimizer steps so far
-struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; int max_steps, patience; double decreasing; };
-
-// StopOnPlateau.step(loss) after a finished optimizer.step() (pvgo.py:172,177-180): returns 1 when the loop must stop
-__device__ __forceinline__ int scheduler_step(double* __restrict__ st, const TRParams& tr, double last, double loss, double rejects) {
-    int stop = 0;
-    st[12] += 1.0;
-    if (st[12] >= (double)tr.max_steps) stop = 1;
-    if ((last - loss) < tr.decreasing) st[13] += 1.0; else st[13] = 0.0;
-    if (st[13] >= (double)tr.patience) stop = 1;
-    if (rejects >= (double)tr.reject) stop = 1;
-    return stop;
-}
-
-// pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
-__device__ void lm_control(double s, double q, double* __restrict__ st, int* flags, const TRParams& tr,
-                           double* __restrict__ report, double seq) {
-    double rep[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rep[i] = 0.0;
-    if (flags[0] != 0) {                 // solver failed: PyPose prints and breaks the step, nothing changes
-        flags[0] = 0;
-        rep[0] = st[0]; rep[1] = st[1]; rep[2] = st[2]; rep[8] = st[8]; rep[10] = 1.0;
-        rep[12] = scheduler_step(st, tr, st[1], st[0], st[8]) ? 4.0 : 3.0;
-        st[8] = 0.0;
-        st[14] += 1.0;
-    } else {
-        const double last = st[1];
-        const double quality = (last - s) / (-q);
-        double radius = 1.0 / st[2], down = st[4];
-        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
-        else if (quality > tr.low) { down = tr.down; }
-        else { radius = radius * down; down = down * tr.factor; }
-        down = fmax(tr.rmin, fmin(down, tr.rmax));
-        radius = fmax(tr.rmin, fmin(radius, tr.rmax));
-        st[3] = radius; st[4] = down; st[2] = 1.0 / radius; st[5] = quality; st[6] = s; st[7] = -q;
-        rep[1] = last; rep[2] = st[2]; rep[3] = radius; rep[4] = down; rep[5] = quality; rep[6] = s; rep[7] = -q;
-        if (last < s && st[8] < (double)tr.reject) {       // reject: the host keeps the old iterate, loss = last
-            st[0] = last;
-            st[8] += 1.0;
-            rep[0] = last; rep[8] = st[8]; rep[9] = 0.0;
-            rep[12] = 1.0;
-            st[14] += 1.0;
-        } else {                                           // step kept (also when the reject limit is exhausted)
-            rep[0] = s; rep[8] = st[8]; rep[9] = 1.0;
-            const int stop = scheduler_step(st, tr, last, s, st[8]);
-            rep[12] = stop ? 2.0 : 0.0;
-            if (stop) st[14] += 1.0;
-            st[0] = s;
-            st[1] = s;                                     // next optimizer.step(): self.last = self.loss
-            st[8] = 0.0;
-        }
-    }
-    rep[13] = st[12];
-    if (report) {
-#pragma unroll
-        for (int i = 0; i < 15; ++i) __hip_atomic_store(&report[i], rep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // payload written through before the sequence number
-        __hip_atomic_store(&report[15], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
+// (device state / report layout, TRParams, scheduler_step and lm_control: pvgo_internal.h)
 
 // trial step: retract on a copy, new residuals, loss and trust-region denominator partials; the last block to
 // finish sums the partials in index order (deterministic) and takes the LM decision (no separate control launch).
@@ -1531,7 +1474,8 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
                                                     double* __restrict__ vels_t, double* part, double* st, int* flags,
                                                     unsigned* ticket, TRParams tr, double* report, double seq,
                                                     const double* __restrict__ red_lin, const double* __restrict__ red_trial,
-                                                    ReprojDev rp) {
+                                                    ReprojDev rp, int lin_stride, Gate gate) {
+    if (gate_closed(gate)) return;
     const int nblk = (M + 63) / 64;
     const int blk = xcd_index(blockIdx.x, nblk);
     int k = blk * 64 + threadIdx.x;
@@ -1561,7 +1505,7 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
         // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
         double rec[LIN_C];
 #pragma unroll
-        for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + k];
+        for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * lin_stride + k];
         M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
         V3<double> ddr = drj - dri, ddp = dpj - dpi;
         V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dt * dvi;
@@ -1989,8 +1933,7 @@ static inline int segment_steps(int m, bool twisted) { return (twisted && m >= 3
 // (the inter-level latency is memory round trips, not launch overhead), hence TOPW = 1.
 // seg_len[0..1] > 0 pin the segment length of levels 0 / 1 (tests, tuning).
 // twisted: plan for the two-sided elimination (a segment of m nodes costs m/2+1 steps; odd lengths, at most BS_PAR_MAX,
-// waste nothing).  The plan is marked twisted only if every level below the root qualifies; the sharded entry points
-// always plan one-sided (their level-0 factor is consumed by bt_backsub_kernel).
+// waste nothing).  The plan is marked twisted only if every level below the root qualifies.
 int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = false) {
     const double t_node = 2.3, t_launch = 4.0;
     double best_cost = 1e300;
@@ -2105,6 +2048,14 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
     return s;
 }
 
+// every down-sweep launch of the process gets its own serial number: what its ready words must hold to count as published
+static int next_serial() {
+    static std::atomic<int> g_serial{0};
+    int serial = ++g_serial;
+    if (serial == 0) serial = ++g_serial;                     // 0 is the reset value of the ready words
+    return serial;
+}
+
 // the up-sweep launch of one level below the root: one workgroup per segment (two wavefronts when twisted)
 static void launch_eliminate(const LevelPlan& L, bool tw, const LevelSrc& src, const LevelDst& dst, int* flags, hipStream_t s,
                              Gate gate) {
@@ -2142,17 +2093,16 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
     if (sweep) {
-        static std::atomic<int> g_serial{0};
-        int serial = ++g_serial;
-        if (serial == 0) serial = ++g_serial;                 // 0 is the reset value of the ready words
+        const int serial = next_serial();
         SweepArgs a{};
         a.root_src = src_of(top);
         a.root_dst = level_dst(w.lv[top], x_of(top));
         a.root_n = sp.lv[top].n;
         a.ready = w.ready;
         a.serial = serial;
-        a.twisted = tw ? 1 : 0;
         a.root_twisted = (tw && sp.lv[top].n <= BS_PAR_MAX) ? 1 : 0;
+        a.outer_x = nullptr;
+        a.outer_flag = 0;
         a.nl = top - lbegin;
         int flag = 1, blk = 8;
         for (int i = 0; i < a.nl; ++i) {
@@ -2160,6 +2110,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             SweepLevel& L = a.lv[i];
             L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
             L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
+            L.seg0 = 0; L.nseg = L.P; L.twisted = tw ? 1 : 0; L.outer = 0; L.x_last = L.n * 9 - 1;
             L.flag0 = flag;
             L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
             L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
@@ -2349,13 +2300,14 @@ int islam_pvgo_eliminate_level0(double* Hd, const double* Ho, const double* rhs,
     return ISLAM_OK;
 }
 
-// ---- sharded (multi-GPU) building blocks: the level-0 segments are split over the ranks, the level-0 products
-// (separator blocks, Schur contributions, fill) are summed over the ranks (RCCL all-reduce of a zero-initialised
-// buffer), levels >= 1 are solved redundantly by every rank, the back-substitution is local again.
+// ---- sharded (multi-GPU) building blocks
+// The sharded entry points plan like the single-GPU solve (twisted elimination wherever every level qualifies).
+static int shard_plan(int N, const int seg_len[2], SolvePlan& sp) { return plan_levels(N, seg_len, sp, solve_twisted()); }
+
 int islam_pvgo_plan(int N, const int seg_len[2], int* plan9) {
     if (N < 1) return fail(ISLAM_EARG, "islam_pvgo_plan: N=%d < 1", N);
     SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
+    const int nl = shard_plan(N, seg_len, sp);
     for (int l = 0; l < MAXL; ++l) {
         plan9[3 * l] = l < nl ? sp.lv[l].n : 0;
         plan9[3 * l + 1] = l < nl ? sp.lv[l].m : 0;
@@ -2368,61 +2320,6 @@ int islam_pvgo_plan(int N, const int seg_len[2], int* plan9) {
 static void products_view(double* base, int P, LevelBufs& b) {
     b.Dsep = base; b.rsep = base + 81 * (size_t)P; b.cL = base + 90 * (size_t)P; b.cR = base + 171 * (size_t)P;
     b.fill = base + 252 * (size_t)P; b.cgL = base + 333 * (size_t)P; b.cgR = base + 342 * (size_t)P;
-}
-
-// Eliminate level-0 segments [seg0, seg0+nseg).  Hd/Ho/rhs/fac/inv are LOCAL arrays whose element 0 is global node
-// `node0`; products = 351*P0 doubles (array-major: Dsep 81P | rsep 9P | cL 81P | cR 81P | fill 81P | cgL 9P | cgR 9P),
-// only the rows of the local segments are written.  flags: device int[1], OR-ed with 1 on a non-positive pivot.
-int islam_pvgo_shard_eliminate(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2],
-                               int node0, int seg0, int nseg, double* products, double* fac, double* inv, int* flags,
-                               void* stream) {
-    SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
-    const LevelPlan* plan = sp.lv;
-    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: N=%d is a single-level problem, nothing to shard", N);
-    if (seg0 < 0 || nseg < 1 || seg0 + nseg > plan[0].P) return fail(ISLAM_EARG, "islam_pvgo_shard_eliminate: bad segment range");
-    LevelSrc src{};
-    LevelDst dst{};
-    src.level0 = 1;
-    src.Hd = Hd - (ptrdiff_t)node0 * 81; src.Ho = Ho - (ptrdiff_t)node0 * 81; src.rhs0 = rhs - (ptrdiff_t)node0 * 9;
-    src.state = nullptr; src.damping_override = damping;
-    LevelBufs b{};
-    products_view(products, plan[0].P, b);
-    dst.fac = fac - (ptrdiff_t)node0 * FAC; dst.inv = inv - (ptrdiff_t)node0 * 9;
-    dst.Dsep = b.Dsep; dst.rsep = b.rsep; dst.cL = b.cL; dst.cR = b.cR; dst.cgL = b.cgL; dst.cgR = b.cgR; dst.fill = b.fill;
-    dst.x = nullptr;
-    hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), src, dst, plan[0].n, plan[0].m,
-                       flags, seg0, nseg, Gate{nullptr, 0.0});
-    ISLAM_LAUNCH_CHECK();
-    return ISLAM_OK;
-}
-
-// Levels >= 1 from the (summed) level-0 products -> x1 (plan[1].n x 9), the solution at the level-0 separators.
-int islam_pvgo_reduced_solve(const double* products, int N, const int seg_len[2], void* workspace, size_t workspace_bytes,
-                             double* x1, int* flags, void* stream) {
-    SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
-    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: single-level problem");
-    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_reduced_solve: workspace too small");
-    Workspace w = carve((void*)align_up((size_t)workspace), N);
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, as_stream(stream)));
-    LevelBufs pb{};
-    products_view(const_cast<double*>(products), sp.lv[0].P, pb);
-    return enqueue_levels(w, sp, 1, level_src_from(pb, sp.lv[0].P), &pb, x1, flags, as_stream(stream), nullptr, nullptr);
-}
-
-// Back-substitution of the local level-0 segments; dx is a LOCAL array (element 0 = global node `node0`).
-int islam_pvgo_shard_backsub(const double* fac, const double* inv, const double* x1, int N, const int seg_len[2], int node0,
-                             int seg0, int nseg, double* dx, void* stream) {
-    SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
-    const LevelPlan* plan = sp.lv;
-    if (nl < 2) return fail(ISLAM_EARG, "islam_pvgo_shard_backsub: single-level problem");
-    hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(nseg)), dim3(64), 0, as_stream(stream), fac - (ptrdiff_t)node0 * FAC,
-                       inv - (ptrdiff_t)node0 * 9, x1, dx - (ptrdiff_t)node0 * 9, plan[0].n, plan[0].m, seg0, nseg,
-                       Gate{nullptr, 0.0});
-    ISLAM_LAUNCH_CHECK();
-    return ISLAM_OK;
 }
 
 // ---- sharding at a HIGHER level of the tree: the interface-only exchange of SURVEY section 8e.
@@ -2464,24 +2361,17 @@ static int shard_ranges(const SolvePlan& sp, int world, int rank, ShardRanges& R
 // left-separator contributions cL / cgL of its first segment of every level below xl -- from the same rows of the exchange
 // buffer, and the sum over the ranks is the complete block.
 struct OuterFix { const double* cL[MAXL]; const double* cgL[MAXL]; double* Dsep; double* rsep; int n; };
-__global__ void outer_block_kernel(OuterFix f) {
+__global__ void outer_block_kernel(OuterFix f, Gate gate) {
     const int t = threadIdx.x;
-    if (t >= 90) return;
+    if (t >= 90 || gate_closed(gate)) return;
     double v = 0.0;
     for (int i = 0; i < f.n; ++i) v += t < 81 ? f.cL[i][t] : f.cgL[i][t - 81];
     if (t < 81) f.Dsep[t] -= v; else f.rsep[t - 81] -= v;
 }
 
-struct OuterCopy { double* dst[MAXL + 1]; const double* src; int n; };
-__global__ void outer_separator_kernel(OuterCopy c) {       // the left outer separator's solution, handed down level by level
-    const int q = threadIdx.x;
-    if (q < 9)
-        for (int i = 0; i < c.n; ++i) c.dst[i][q] = c.src[q];
-}
-
 int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, int* out) {
     SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
+    const int nl = shard_plan(N, seg_len, sp);
     ShardRanges R;
     if (nl < 2 || shard_ranges(sp, world, rank, R) != 0)
         return fail(ISLAM_EARG, "islam_pvgo_shard_ranges: N=%d cannot be split over %d ranks (rank %d)", N, world, rank);
@@ -2491,18 +2381,34 @@ int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, in
     return ISLAM_OK;
 }
 
+// linbuild_kernel / trial_lin_kernel stage their node blocks in dynamic LDS above the default limit (once per device)
+static int ensure_linbuild_lds() {
+    static bool lb_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
+    int dev_i = 0;
+    ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+    if (dev_i >= 0 && dev_i < 64 && !lb_attr_set[dev_i]) {
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)linbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
+        lb_attr_set[dev_i] = true;
+    }
+    return ISLAM_OK;
+}
+
+}  // extern "C"
+
+namespace islam {
+
 // Up-sweep of levels 0 .. xl over the rank's own segments.  Hd/Ho/rhs: LOCAL level-0 arrays whose row 0 is global node
 // `node0`; exchange: 351*P_xl doubles (array-major like the level-0 products), zeroed here, own rows written.
-int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2], int world,
-                             int rank, int node0, void* workspace, size_t workspace_bytes, double* exchange, int* flags,
-                             void* stream) {
+int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double damping, const double* state, int N,
+                        const int seg_len[2], int world, int rank, int node0, void* workspace, size_t workspace_bytes,
+                        double* exchange, int* flags, Gate gate, hipStream_t s) {
     SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
+    const int nl = shard_plan(N, seg_len, sp);
     ShardRanges R;
     if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: N=%d, world=%d, rank=%d", N, world, rank);
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
-    hipStream_t s = as_stream(stream);
     ISLAM_HIP_CHECK(hipMemsetAsync(exchange, 0, sizeof(double) * 351 * (size_t)sp.lv[R.xl].P, s));
     LevelBufs xb{};
     products_view(exchange, sp.lv[R.xl].P, xb);
@@ -2511,14 +2417,18 @@ int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, do
         if (l == 0) {
             src.level0 = 1;
             src.Hd = Hd - (ptrdiff_t)node0 * 81; src.Ho = Ho - (ptrdiff_t)node0 * 81; src.rhs0 = rhs - (ptrdiff_t)node0 * 9;
-            src.state = nullptr; src.damping_override = damping;
+            src.state = state; src.damping_override = damping;
         } else {
             src = level_src_from(w.lv[l - 1], sp.lv[l - 1].P);
         }
         LevelBufs ob = w.lv[l];
         if (l == R.xl) { ob.Dsep = xb.Dsep; ob.rsep = xb.rsep; ob.cL = xb.cL; ob.cR = xb.cR; ob.fill = xb.fill; ob.cgL = xb.cgL; ob.cgR = xb.cgR; }
-        hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n, sp.lv[l].m,
-                           flags, R.seg0[l], R.nseg[l], Gate{nullptr, 0.0});
+        if (sp.twisted)
+            hipLaunchKernelGGL(bt_eliminate_tw_kernel, dim3(xcd_grid(R.nseg[l])), dim3(128), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n,
+                               sp.lv[l].m, flags, R.seg0[l], R.nseg[l], gate);
+        else
+            hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n,
+                               sp.lv[l].m, flags, R.seg0[l], R.nseg[l], gate);
     }
     if (R.seg0[R.xl] > 0 && R.xl > 0) {                      // this rank's share of its LEFT outer separator's block (see OuterFix)
         OuterFix f{};
@@ -2526,45 +2436,115 @@ int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, do
         for (int l = 0; l < R.xl; ++l) { f.cL[l] = w.lv[l].cL + (size_t)R.seg0[l] * 81; f.cgL[l] = w.lv[l].cgL + (size_t)R.seg0[l] * 9; }
         f.Dsep = xb.Dsep + (size_t)(R.seg0[R.xl] - 1) * 81;
         f.rsep = xb.rsep + (size_t)(R.seg0[R.xl] - 1) * 9;
-        hipLaunchKernelGGL(outer_block_kernel, dim3(1), dim3(128), 0, s, f);
+        hipLaunchKernelGGL(outer_block_kernel, dim3(1), dim3(128), 0, s, f, gate);
     }
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 
-// Levels above xl from the SUMMED exchange buffer (redundantly on every rank), then the back-substitution of levels xl .. 0
-// over the rank's own segments.  dx: LOCAL array, row 0 = global node `node0`; rows node0 .. the rank's right outer separator
-// are written (the left outer separator's row too when the rank has one).
-int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
-                               size_t workspace_bytes, double* dx, int* flags, void* stream) {
+// Levels above xl from the SUMMED exchange buffer (redundantly on every rank: one elimination launch each), then ONE launch
+// (bt_downsweep_kernel) for the root and the whole back-substitution: the replicated levels in full, levels xl .. 0 over the
+// rank's own segments.  dx: LOCAL array, row 0 = global node `node0`; rows node0 .. the rank's right outer separator are
+// written (the left outer separator's row too when the rank has one).
+int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
+                          size_t workspace_bytes, double* dx, int* flags, Gate gate, hipStream_t s) {
     SolvePlan sp;
-    const int nl = plan_levels(N, seg_len, sp);
+    const int nl = shard_plan(N, seg_len, sp);
     ShardRanges R;
     if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: N=%d, world=%d, rank=%d", N, world, rank);
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
-    hipStream_t s = as_stream(stream);
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+    const int top = nl - 1, xl = R.xl;
+    const bool tw = sp.twisted != 0;
     LevelBufs pb{};
-    products_view(const_cast<double*>(exchange), sp.lv[R.xl].P, pb);
-    const int rc = enqueue_levels(w, sp, R.xl + 1, level_src_from(pb, sp.lv[R.xl].P), &pb, w.lv[R.xl + 1].x, flags, s, nullptr, nullptr);
-    if (rc != ISLAM_OK) return rc;
+    products_view(const_cast<double*>(exchange), sp.lv[xl].P, pb);
+    auto src_of = [&](int l) { return level_src_from(l == xl + 1 ? pb : w.lv[l - 1], sp.lv[l - 1].P); };
     double* x0 = dx - (ptrdiff_t)node0 * 9;                                   // level-0 solution, global indexing
     auto x_of = [&](int l) { return l == 0 ? x0 : w.lv[l].x; };
-    if (R.seg0[R.xl] > 0) {
-        // the left outer separator is node seg0[l]-1 of level l+1 for every l <= xl; its value is known at level xl+1 and
-        // is what the first local segment of every level reads as its left separator (and what the trial step needs at level 0)
-        OuterCopy c{};
-        c.src = w.lv[R.xl + 1].x + (size_t)(R.seg0[R.xl] - 1) * 9;
-        c.n = 0;
-        for (int l = R.xl; l >= 0; --l) c.dst[c.n++] = x_of(l) + (size_t)(R.seg0[l] * (sp.lv[l].m + 1) - 1) * 9;
-        hipLaunchKernelGGL(outer_separator_kernel, dim3(1), dim3(64), 0, s, c);
+    for (int l = xl + 1; l < top; ++l)
+        launch_eliminate(sp.lv[l], tw, src_of(l), level_dst(w.lv[l], x_of(l)), flags, s, gate);
+    const int serial = next_serial();
+    SweepArgs a{};
+    a.root_src = src_of(top);
+    a.root_dst = level_dst(w.lv[top], x_of(top));
+    a.root_n = sp.lv[top].n;
+    a.ready = w.ready;
+    a.serial = serial;
+    a.root_twisted = (tw && sp.lv[top].n <= BS_PAR_MAX) ? 1 : 0;
+    a.nl = top;
+    a.outer_x = nullptr;
+    a.outer_flag = 0;
+    int flag = 1, blk = 8;
+    for (int i = 0; i < a.nl; ++i) {
+        const int l = top - 1 - i;
+        SweepLevel& L = a.lv[i];
+        L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
+        L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
+        const bool local = l <= xl;
+        L.seg0 = local ? R.seg0[l] : 0;
+        L.nseg = local ? R.nseg[l] : L.P;
+        L.twisted = tw ? 1 : 0;
+        L.outer = (l < xl && R.seg0[l] > 0) ? 1 : 0;
+        L.x_last = std::min(L.n, (L.seg0 + L.nseg) * (L.m + 1)) * 9 - 1;
+        L.flag0 = flag;
+        L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
+        L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
+        a.first_block[i] = blk;
+        flag += L.P;
+        blk += xcd_grid(L.nseg);
+        if (l == xl + 1 && R.seg0[xl] > 0) {                // the level that solves the rank's left cut node (node seg0[xl]-1 there)
+            a.outer_x = x_of(l) + (size_t)(R.seg0[xl] - 1) * 9;
+            a.outer_flag = L.flag0 + (R.seg0[xl] - 1) / (L.m + 1);
+        }
     }
-    for (int l = R.xl; l >= 0; --l)
-        hipLaunchKernelGGL(bt_backsub_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, w.lv[l].fac, w.lv[l].inv, x_of(l + 1), x_of(l),
-                           sp.lv[l].n, sp.lv[l].m, R.seg0[l], R.nseg[l], Gate{nullptr, 0.0});
+    if (xl + 1 == top && R.seg0[xl] > 0) { a.outer_x = x_of(top) + (size_t)(R.seg0[xl] - 1) * 9; a.outer_flag = 0; }
+    a.first_block[a.nl] = blk;
+    if ((size_t)flag * READY_STRIDE * sizeof(int) > w.ready_bytes) return fail(ISLAM_EARG, "pvgo: ready-flag buffer too small (%d words)", flag);
+    hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(128), 0, s, a, flags, gate);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+int trial_gated(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
+                const double* dtrans, const double* dvels, const double* dts, const double* lin, int lin_stride, int M,
+                double* nodes_t, double* vels_t, double* part, Gate gate, hipStream_t s) {
+    if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
+    hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, s, nodes, vels, dx, poses, drots, dtrans, dvels, dts, lin,
+                       M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{}, (double*)nullptr, 0.0,
+                       (const double*)nullptr, (const double*)nullptr, ReprojDev{}, lin_stride, gate);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int linbuild_gated(const double* nodes, const double* vels, const double* poses, const double* drots, const double* dtrans,
+                   const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, double* lin, double* loss_part,
+                   double* Hd, double* Ho, double* rhs, Gate gate, hipStream_t s) {
+    if (N < 2 || !prm) return fail(ISLAM_EARG, "pvgo linbuild: N=%d", N);
+    int rc = ensure_linbuild_lds();
+    if (rc != ISLAM_OK) return rc;
+    const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, nodes, vels, poses, drots, dtrans, dvels, dts,
+                       N, W, lin, loss_part, Hd, Ho, rhs, (const double*)nullptr, ReprojDev{}, gate);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+}  // namespace islam
+
+extern "C" {
+
+int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2], int world,
+                             int rank, int node0, void* workspace, size_t workspace_bytes, double* exchange, int* flags,
+                             void* stream) {
+    return shard_upsweep_gated(Hd, Ho, rhs, damping, nullptr, N, seg_len, world, rank, node0, workspace, workspace_bytes, exchange, flags,
+                               Gate{nullptr, 0.0}, as_stream(stream));
+}
+
+int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
+                               size_t workspace_bytes, double* dx, int* flags, void* stream) {
+    return shard_downsweep_gated(exchange, N, seg_len, world, rank, node0, workspace, workspace_bytes, dx, flags, Gate{nullptr, 0.0},
+                                 as_stream(stream));
 }
 
 // Trial step on M links (nodes/vels/dx hold M+1 rows): writes nodes_t/vels_t (M+1 rows) and part (2 per 64-link block:
@@ -2572,12 +2552,7 @@ int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[
 int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
                      const double* dtrans, const double* dvels, const double* dts, const double* lin, int M, double* nodes_t,
                      double* vels_t, double* part, void* stream) {
-    if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
-    hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, as_stream(stream), nodes, vels, dx, poses, drots, dtrans,
-                       dvels, dts, lin, M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{},
-                       (double*)nullptr, 0.0, (const double*)nullptr, (const double*)nullptr, ReprojDev{});
-    ISLAM_LAUNCH_CHECK();
-    return ISLAM_OK;
+    return trial_gated(nodes, vels, dx, poses, drots, dtrans, dvels, dts, lin, M, M, nodes_t, vels_t, part, Gate{nullptr, 0.0}, as_stream(stream));
 }
 
 int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N, double* nodes_out,
@@ -2721,20 +2696,17 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     double* RH[2] = {w.rhs, w.rhs2};
     double* RED[2] = {w.red, w.red2};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
-    static bool lb_attr_set[64] = {};                        // per device
-    int dev_i = 0;
-    ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
-    if (dev_i >= 0 && dev_i < 64 && !lb_attr_set[dev_i]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)linbuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_DYN_BYTES));
-        lb_attr_set[dev_i] = true;
+    {
+        const int rc_lds = ensure_linbuild_lds();
+        if (rc_lds != ISLAM_OK) return rc_lds;
     }
     const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
     // red_ready: RED[b] already holds the reduction at (xn)
     auto enqueue_linbuild = [&](const double* xn, const double* xv, int b, bool red_ready) {
         if (reproj && !red_ready) enqueue_reproj_reduce(xn, nullptr, M, rp, RED[b], s);
         hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, xn, xv, poses, drots, dtrans, dvels,
-                           dts, N, W, LIN[b], w.loss_part, HD[b], HO[b], RH[b], reproj ? RED[b] : (const double*)nullptr, rp);
+                           dts, N, W, LIN[b], w.loss_part, HD[b], HO[b], RH[b], reproj ? RED[b] : (const double*)nullptr, rp,
+                           Gate{nullptr, 0.0});
     };
     // one pass of PyPose's inner `while self.last <= self.loss`: damped solve on buffer pb, then trial + linearisation at
     // the trial point into buffer 1-pb; every kernel is gated on `epoch`

@@ -1,19 +1,25 @@
 // pvgo_dist.hip -- the LM loop of ONE chain graph sharded over the GPUs of a node, in the library, on RCCL.
 //
 // No reference counterpart (the reference is single-GPU).  One process per GPU; every rank calls
-// islam_pvgo_run_chain_sharded with the SAME full-size inputs (the problem is 0.9 MB) and works on its own stretch of the chain:
-//   per LM step     linearise + normal equations of the local links                        (islam_pvgo_linearize / build_normal)
-//   per LM trial    up-sweep of the local sub-tree                                          (islam_pvgo_shard_upsweep)
-//                   ncclAllReduce #1: the interface blocks, 351 doubles per segment of the exchange level (64.6 KB at
-//                                     N = 5001 on 8 ranks)
-//                   top levels redundantly + local back-substitution                        (islam_pvgo_shard_downsweep)
-//                   trial step on the local links                                           (islam_pvgo_trial)
-//                   ncclAllReduce #2: [sum r^2 | sum JD.(2R+JD) | failed pivots | one 10-double halo per rank]
-//                   one 24-byte device->host read, then pp.optim.LM's accept / reject rule, TrustRegion.update and
-//                   StopOnPlateau on the host -- replicated: every rank sees the same all-reduced scalars.
-//   once            ncclAllReduce of the assembled solution (N x 10 doubles, own rows, zero elsewhere).
-// The same protocol as islam_amd/dist_pvgo.py (which drives the stage entry points from Python and is what the gloo / virtual-
-// rank tests exercise); this file removes the interpreter and torch.distributed from the loop.  comm == NULL: world 1.
+// islam_pvgo_run_chain_sharded with the SAME full-size inputs (the problem is 0.9 MB) and works on its own stretch of the chain.
+// One LM trial = one gated chain of launches on the rank's stream:
+//   linbuild_kernel            linearise + normal equations of the local links (only after an accepted step)
+//   bt_eliminate_tw_kernel x   up-sweep of the local sub-tree, levels 0 .. xl                  (shard_upsweep_gated)
+//   ncclAllReduce #1           the interface blocks, 351 doubles per segment of the exchange level (64.6 KB at N = 5001 / 8 ranks)
+//   bt_downsweep_kernel        levels above xl redundantly + root + the local back-substitution, one launch (shard_downsweep_gated)
+//   trial_kernel               trial step on the local links
+//   msg_kernel                 [sum r^2 | sum JD.(2R+JD) | failed pivots | one 10-double halo per rank]
+//   ncclAllReduce #2
+//   decide_kernel              pp.optim.LM's accept / reject rule, TrustRegion.update and StopOnPlateau ON THE DEVICE, replicated:
+//                              every rank sees the same all-reduced scalars, takes the same decision and writes a 128-byte verdict
+//                              to pinned host memory.
+// As in the single-GPU loop (pvgo.hip) the host runs one trial AHEAD: it enqueues trial t+1 under the assumption "accepted,
+// continue" before it has seen the verdict of trial t; every kernel carries the epoch it was enqueued under and returns at once
+// if the deciding lane bumped the device epoch.  The collectives of a cancelled chain still run (on unchanged buffers) -- every
+// rank takes the same decisions, so the ranks enqueue the same sequence of collectives.  No stream synchronisation and no
+// device->host copy inside the loop.  Once, at the end: ncclAllReduce of the assembled solution (N x 10 doubles).
+// The same protocol as islam_amd/dist_pvgo.py (which drives the stage entry points from Python with host-side control and is
+// what the gloo / virtual-rank tests exercise).  comm == NULL: world 1.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -22,6 +28,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "pvgo_internal.h"
 
 using namespace islam;
 
@@ -50,8 +57,9 @@ __global__ __launch_bounds__(256) void own_loss_kernel(const double* __restrict_
 }
 
 // msg = [sum r^2 | sum JD.(2R+JD) | failed | halo of every rank (10 each)]: own part filled, the rest zero
-__global__ void pack_msg_kernel(const double* __restrict__ part, int nblk, int* __restrict__ flags, const double* __restrict__ nt,
-                                const double* __restrict__ vt, int first_local, int rank, int world, double* __restrict__ msg) {
+__global__ void msg_kernel(const double* __restrict__ part, int nblk, int* __restrict__ flags, const double* __restrict__ nt,
+                           const double* __restrict__ vt, int first_local, int rank, int world, double* __restrict__ msg, Gate gate) {
+    if (gate_closed(gate)) return;
     const int t = threadIdx.x;
     for (int i = t; i < 3 + 10 * world; i += blockDim.x) msg[i] = 0.0;
     __syncthreads();
@@ -65,14 +73,26 @@ __global__ void pack_msg_kernel(const double* __restrict__ part, int nblk, int* 
     if (t >= 10 && t < 13) msg[3 + 10 * rank + 7 + (t - 10)] = vt[(size_t)first_local * 3 + (t - 10)];
 }
 
-// accepted trial: own rows <- trial rows; the row past the right outer separator <- the next rank's first node (halo)
-__global__ __launch_bounds__(256) void accept_kernel(double* __restrict__ nodes, double* __restrict__ vels, const double* __restrict__ nt,
-                                                      const double* __restrict__ vt, int rows, const double* __restrict__ halo, int halo_row) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < rows * 7) nodes[i] = nt[i];
-    if (i < rows * 3) vels[i] = vt[i];
-    if (halo && i < 7) nodes[(size_t)halo_row * 7 + i] = halo[i];
-    if (halo && i >= 7 && i < 10) vels[(size_t)halo_row * 3 + (i - 7)] = halo[i];
+// after all-reduce #2: the halo row of the trial iterate (the next rank's first node) and the LM decision -- identical on every
+// rank, because the summed message is
+__global__ void decide_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags, TRParams tr,
+                              double* __restrict__ report, double seq, double* __restrict__ nt, double* __restrict__ vt,
+                              const double* __restrict__ halo, int halo_row, Gate gate) {
+    if (gate_closed(gate)) return;
+    const int t = threadIdx.x;
+    if (halo && t < 7) nt[(size_t)halo_row * 7 + t] = halo[t];
+    if (halo && t >= 7 && t < 10) vt[(size_t)halo_row * 3 + (t - 7)] = halo[t];
+    if (t == 0) {
+        flags[0] = msg[2] > 0.0 ? 1 : 0;                                // a failed pivot on ANY rank fails the step everywhere
+        lm_control(msg[0], msg[1], st, flags, tr, report, seq);
+    }
+}
+
+// the loss of the very first optimizer.step() (summed over the ranks in msg[0])
+__global__ void begin_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags) {
+    if (threadIdx.x != 0) return;
+    st[0] = msg[0]; st[1] = msg[0]; st[8] = 0.0; st[11] = 1.0; st[12] = 0.0; st[13] = 0.0;
+    flags[0] = 0;
 }
 
 __global__ __launch_bounds__(256) void scatter_full_kernel(const double* __restrict__ nodes, const double* __restrict__ vels, int r0, int r1,
@@ -125,37 +145,6 @@ int shard_of(int N, const int seg_len[2], int world, int rank, Shard& sh) {
     return ISLAM_OK;
 }
 
-// host-side LM control (islam_amd/lm_control.py; the fused single-GPU loop runs the same rules on the device)
-struct Control {
-    double radius, damping, high, low, up, down0, down, factor, rmin, rmax, decreasing, loss = 0, last = 0;
-    int reject, max_steps, patience, reject_count = 0, steps = 0, patience_count = 0;
-    bool continual = true;
-    explicit Control(const islam_pvgo_params& p)
-        : radius(p.radius), damping(1.0 / p.radius), high(p.high), low(p.low), up(p.up), down0(p.down), down(p.down), factor(p.factor),
-          rmin(p.rmin), rmax(p.rmax), decreasing(p.decreasing), reject(p.reject), max_steps(p.max_steps), patience(p.patience) {}
-    void begin_step() { last = loss; reject_count = 0; }
-    bool after_trial(double loss_trial, double qsum) {
-        const double quality = (last - loss_trial) / (-qsum);       // plain IEEE division like PyPose and the device code: 0/0 = NaN -> shrink
-        double r = 1.0 / damping;
-        if (quality > high) { r = up * r; down = down0; }
-        else if (quality > low) { down = down0; }
-        else { r = r * down; down = down * factor; }
-        down = std::max(rmin, std::min(down, rmax));
-        r = std::max(rmin, std::min(r, rmax));
-        radius = r; damping = 1.0 / r;
-        if (last < loss_trial && reject_count < reject) { loss = last; ++reject_count; return false; }
-        loss = loss_trial;
-        return true;
-    }
-    void end_step() {
-        ++steps;
-        if (steps >= max_steps) continual = false;
-        if ((last - loss) < decreasing) ++patience_count; else patience_count = 0;
-        if (patience_count >= patience) continual = false;
-        if (reject_count >= reject) continual = false;
-    }
-};
-
 inline size_t a256(size_t n) { return align_up(n * sizeof(double)) / sizeof(double); }
 
 }  // namespace
@@ -186,8 +175,8 @@ int islam_dist_comm_destroy(void* comm) {
 
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
-    size_t d = 2 * a256(LIN_C * n) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) + a256(2 * (n / 64 + 2)) +
-               a256(3 + 10 * (size_t)world) + a256(10 * n) + a256(351 * (n / 5 + 2)) + a256(64);
+    size_t d = a256(LIN_C * n) + a256(n / 32 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
+               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + a256(351 * (n / 5 + 2)) + a256(64) + a256(16);
     return d * sizeof(double) + 512;
 }
 
@@ -209,7 +198,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     auto take = [&](size_t n) { double* r = p; p += a256(n); return r; };
     const size_t nn = (size_t)N + 2;
     double* lin = take(LIN_C * nn);
-    double* lin2 = take(LIN_C * nn);
+    double* loss_part = take(nn / 32 + 4);
     double* Hd = take(81 * nn); double* Ho = take(81 * nn); double* rhs = take(9 * nn); double* dx = take(9 * nn);
     double* nl = take(7 * nn); double* nt = take(7 * nn); double* vl = take(3 * nn); double* vt = take(3 * nn);
     double* part = take(2 * (nn / 64 + 2));
@@ -217,73 +206,107 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     double* full = take(10 * nn);
     double* ex = take(351 * (nn / 5 + 2));
     int* flags = (int*)take(64);
-    double* lin_own = nullptr;                                     // trial reads the linearisation with the OWN link count as stride
+    double* state = take(16);
+    // verdicts in pinned, device-visible host memory (two slots, alternating with the trial number); the host polls the
+    // sequence number -- no stream synchronisation, no copy
+    static thread_local double* host_state = nullptr;
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped));
+    double* report = nullptr;
+    ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
+    volatile double* hs_all = host_state;
+    hs_all[15] = 0.0;
+    hs_all[31] = 0.0;
+    double init[16] = {0};
+    init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
+    init[3] = prm->radius;
+    init[4] = prm->down;
+    init[14] = 1.0;                // run-ahead epoch
+    ISLAM_HIP_CHECK(hipMemcpyAsync(state, init, sizeof(init), hipMemcpyHostToDevice, s));
     ISLAM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));     // product rows of other ranks' segments read as zero
     ISLAM_HIP_CHECK(hipMemcpyAsync(nl, nodes + (size_t)a * 7, sizeof(double) * 7 * nloc, hipMemcpyDeviceToDevice, s));
     ISLAM_HIP_CHECK(hipMemcpyAsync(vl, vels + (size_t)a * 3, sizeof(double) * 3 * nloc, hipMemcpyDeviceToDevice, s));
+    ISLAM_HIP_CHECK(hipMemcpyAsync(nt, nl, sizeof(double) * 7 * nloc, hipMemcpyDeviceToDevice, s));     // rows no trial writes (a last
+    ISLAM_HIP_CHECK(hipMemcpyAsync(vt, vl, sizeof(double) * 3 * nloc, hipMemcpyDeviceToDevice, s));     // rank's unused tail) stay defined
     const double *lp = poses + (size_t)a * 7, *lr = drots + (size_t)a * 4, *ltr = dtrans + (size_t)a * 3, *lv = dvels + (size_t)a * 3,
                  *ldt = dts + a;
-    Control ctl(*prm);
-    bool has_loss = false;
-    int trials = 0, status = ISLAM_OK;
+    const TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
+                      prm->max_steps, prm->patience, prm->decreasing};
+    const bool halo = sh.has_right && rank + 1 < world && b > a + n_own;
+    const long long iter_bytes = (world > 1) ? 8LL * (351LL * sh.Pxl + nmsg) : 0;
     long long xbytes = 0;
-    double host[3];
-    if (n_own != Mloc) lin_own = lin2;
-    while (ctl.continual) {
-        rc = islam_pvgo_linearize(nl, vl, lp, lr, ltr, lv, ldt, nloc, lin, part, s);
-        if (rc != ISLAM_OK) return rc;
-        if (!has_loss) {
-            hipLaunchKernelGGL(own_loss_kernel, dim3(1), dim3(256), 0, s, lin, Mloc, n_own, msg);
-            if (world > 1 && (rc = red.sum(msg, 1, s)) != ISLAM_OK) return rc;
-            ISLAM_HIP_CHECK(hipMemcpyAsync(host, msg, sizeof(double), hipMemcpyDeviceToHost, s));
-            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
-            ctl.loss = host[0];
-            has_loss = true;
-        }
-        ISLAM_HIP_CHECK(hipMemsetAsync(Hd, 0, sizeof(double) * 81 * nloc, s));
-        ISLAM_HIP_CHECK(hipMemsetAsync(Ho, 0, sizeof(double) * 81 * nloc, s));
-        ISLAM_HIP_CHECK(hipMemsetAsync(rhs, 0, sizeof(double) * 9 * nloc, s));
-        rc = islam_pvgo_build_normal(lin, ldt, nloc, prm->w, prm->vmin, prm->vmax, Hd, Ho, rhs, s);
-        if (rc != ISLAM_OK) return rc;
-        if (lin_own)                                                // component-major with stride n_own: 42 strided row copies
-            ISLAM_HIP_CHECK(hipMemcpy2DAsync(lin_own, sizeof(double) * n_own, lin, sizeof(double) * Mloc, sizeof(double) * n_own, LIN_C,
-                                             hipMemcpyDeviceToDevice, s));
-        ctl.begin_step();
-        while (true) {
-            rc = islam_pvgo_shard_upsweep(Hd, Ho, rhs, ctl.damping, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, ex, flags, s);
-            if (rc != ISLAM_OK) return rc;
-            if (world > 1 && (rc = red.sum(ex, 351 * (size_t)sh.Pxl, s)) != ISLAM_OK) return rc;
-            xbytes += 351LL * sh.Pxl * 8;
-            rc = islam_pvgo_shard_downsweep(ex, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, dx, flags, s);
-            if (rc != ISLAM_OK) return rc;
-            rc = islam_pvgo_trial(nl, vl, dx, lp, lr, ltr, lv, ldt, lin_own ? lin_own : lin, n_own, nt, vt, part, s);
-            if (rc != ISLAM_OK) return rc;
-            hipLaunchKernelGGL(pack_msg_kernel, dim3(1), dim3(64), 0, s, part, nblk, flags, nt, vt, first_local, rank, world, msg);
-            if (world > 1 && (rc = red.sum(msg, nmsg, s)) != ISLAM_OK) return rc;
-            xbytes += 8LL * nmsg;
-            ISLAM_HIP_CHECK(hipMemcpyAsync(host, msg, 3 * sizeof(double), hipMemcpyDeviceToHost, s));     // the one read of the trial
-            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
-            ++trials;
-            if (host[2] > 0.0) { status = ISLAM_ENOTPD; break; }    // PyPose: "Linear solver failed. Breaking optimization step..."
-            if (ctl.after_trial(host[0], host[1])) {
-                const bool halo = sh.has_right && rank + 1 < world && b > a + n_own;
-                hipLaunchKernelGGL(accept_kernel, dim3((7 * (n_own + 1) + 255) / 256), dim3(256), 0, s, nl, vl, nt, vt, n_own + 1,
-                                   halo ? msg + 3 + 10 * (rank + 1) : (const double*)nullptr, b - a);
-                break;
+
+    struct IterCfg { double *cur_n, *cur_v, *tri_n, *tri_v; };
+    // one pass of PyPose's inner `while self.last <= self.loss`; relin: the iterate changed, linearise first
+    auto enqueue_iter = [&](const IterCfg& c, double seq, double epoch, bool relin) -> int {
+        const Gate gate{state, epoch};
+        int r;
+        if (relin && (r = linbuild_gated(c.cur_n, c.cur_v, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, gate, s)) != ISLAM_OK) return r;
+        if ((r = shard_upsweep_gated(Hd, Ho, rhs, 0.0, state, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, ex, flags, gate, s)) != ISLAM_OK) return r;
+        if (world > 1 && (r = red.sum(ex, 351 * (size_t)sh.Pxl, s)) != ISLAM_OK) return r;
+        if ((r = shard_downsweep_gated(ex, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, dx, flags, gate, s)) != ISLAM_OK) return r;
+        if ((r = trial_gated(c.cur_n, c.cur_v, dx, lp, lr, ltr, lv, ldt, lin, Mloc, n_own, c.tri_n, c.tri_v, part, gate, s)) != ISLAM_OK) return r;
+        hipLaunchKernelGGL(msg_kernel, dim3(1), dim3(64), 0, s, part, nblk, flags, c.tri_n, c.tri_v, first_local, rank, world, msg, gate);
+        if (world > 1 && (r = red.sum(msg, nmsg, s)) != ISLAM_OK) return r;
+        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, s, msg, state, flags, tr, report + 16 * ((long long)seq & 1), seq, c.tri_n,
+                           c.tri_v, halo ? msg + 3 + 10 * (rank + 1) : (const double*)nullptr, b - a, gate);
+        ISLAM_LAUNCH_CHECK();
+        xbytes += iter_bytes;
+        return ISLAM_OK;
+    };
+
+    // first linearisation and the loss of the initial iterate
+    const Gate open{nullptr, 0.0};
+    if ((rc = linbuild_gated(nl, vl, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, open, s)) != ISLAM_OK) return rc;
+    hipLaunchKernelGGL(own_loss_kernel, dim3(1), dim3(256), 0, s, lin, Mloc, n_own, msg);
+    if (world > 1 && (rc = red.sum(msg, 1, s)) != ISLAM_OK) return rc;
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, s, msg, state, flags);
+
+    IterCfg A{nl, vl, nt, vt};            // the iteration whose verdict is awaited
+    int steps = 0, trials = 0, status = ISLAM_OK;
+    double loss = 0.0, damping = init[2], epoch = 1.0;
+    if ((rc = enqueue_iter(A, 1.0, epoch, false)) != ISLAM_OK) return rc;
+    for (;;) {
+        const double seq = (double)(trials + 1);
+        // run ahead: the next iteration under the assumption "trial accepted, loop continues"
+        const IterCfg B{A.tri_n, A.tri_v, A.cur_n, A.cur_v};
+        if (steps + 1 < prm->max_steps && (rc = enqueue_iter(B, seq + 1.0, epoch, true)) != ISLAM_OK) return rc;
+        volatile double* hs = hs_all + 16 * ((long long)seq & 1);
+        {
+            unsigned long spins = 0;
+            while (hs[15] != seq) {
+                if (++spins > 400000000ul) {
+                    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                    if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain_sharded: no status from the device (trial %d)", trials + 1);
+                }
             }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
-        ctl.end_step();
+        ++trials;
+        const int verdict = (int)hs[12];
+        damping = hs[2];
+        loss = hs[0];
+        steps = (int)hs[13];
+        if (verdict == 0) { A = B; continue; }          // accepted, continue: B is the iteration now in flight
+        epoch += 1.0;                                   // any other verdict bumped the device epoch: B's kernels are no-ops
+        if (verdict == 1) {                             // rejected: same iterate, same (cumulatively damped) linearisation
+            if ((rc = enqueue_iter(A, seq + 1.0, epoch, false)) != ISLAM_OK) return rc;
+            continue;
+        }
+        if (verdict == 2) { A = B; break; }             // accepted, StopOnPlateau says stop
+        status = ISLAM_ENOTPD;                          // "Linear solver failed. Breaking optimization step..."
+        if (verdict == 4) break;
+        if ((rc = enqueue_iter(A, seq + 1.0, epoch, true)) != ISLAM_OK) return rc;      // same iterate, new linearisation
     }
     // the full solution on every rank: own rows (the left outer separator belongs to the previous rank), summed
     ISLAM_HIP_CHECK(hipMemsetAsync(full, 0, sizeof(double) * 10 * (size_t)N, s));
     const int r0 = sh.has_left ? 1 : 0, r1 = n_own + 1;
-    hipLaunchKernelGGL(scatter_full_kernel, dim3(((r1 - r0) * 10 + 255) / 256), dim3(256), 0, s, nl, vl, r0, r1, a, full);
+    hipLaunchKernelGGL(scatter_full_kernel, dim3(((r1 - r0) * 10 + 255) / 256), dim3(256), 0, s, A.cur_n, A.cur_v, r0, r1, a, full);
     if (world > 1 && (rc = red.sum(full, 10 * (size_t)N, s)) != ISLAM_OK) return rc;
     hipLaunchKernelGGL(unpack_full_kernel, dim3((N * 10 + 255) / 256), dim3(256), 0, s, full, N, nodes, vels);
     ISLAM_LAUNCH_CHECK();
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
-    res->steps = ctl.steps; res->trials = trials; res->status = status; res->loss = ctl.loss; res->damping = ctl.damping;
+    res->steps = steps; res->trials = trials; res->status = status; res->loss = loss; res->damping = damping;
     if (exchanged_bytes) *exchanged_bytes = xbytes;
     return ISLAM_OK;
 }

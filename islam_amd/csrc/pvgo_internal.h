@@ -1,0 +1,103 @@
+// What pvgo.hip (the single-GPU LM loop and the stage kernels) shares with pvgo_dist.hip (the sharded LM loop): the run-ahead
+// gate, the LM control rules as they run on the device, and the stage entry points WITH a gate.  Internal to libislam_hip.so --
+// the public islam_pvgo_* stage functions of include/islam_hip.h call the same code ungated.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace islam {
+
+// Run-ahead gate.  The host enqueues LM iteration t+1 before it knows the outcome of trial t, assuming "accepted,
+// continue".  Every kernel of an iteration carries the epoch it was enqueued under; the deciding lane bumps the device
+// epoch (state[14]) on any other outcome, which turns the already-queued kernels into no-ops.
+struct Gate { const double* ctl; double epoch; };
+__device__ __forceinline__ bool gate_closed(const Gate& g) { return g.ctl != nullptr && g.ctl[14] != g.epoch; }
+
+// ------------------------------------------------------------------------------------------
+// state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
+//        [8] reject_count [9] accepted [10] error [11] has_loss
+// report (host-visible copy written after every trial): same slots as seen by the step that just ran, [15] = sequence number
+//        [12] optimizer steps [13] plateau patience count [14] run-ahead epoch (Gate)
+// report[12] = verdict: 0 accepted & continue, 1 rejected (retry with more damping), 2 accepted & stop, 3 solver failed &
+// continue (same iterate, new linearisation), 4 solver failed & stop;  report[13] = optimizer steps so far
+struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; int max_steps, patience; double decreasing; };
+
+// StopOnPlateau.step(loss) after a finished optimizer.step() (pvgo.py:172,177-180): returns 1 when the loop must stop
+__device__ __forceinline__ int scheduler_step(double* __restrict__ st, const TRParams& tr, double last, double loss, double rejects) {
+    int stop = 0;
+    st[12] += 1.0;
+    if (st[12] >= (double)tr.max_steps) stop = 1;
+    if ((last - loss) < tr.decreasing) st[13] += 1.0; else st[13] = 0.0;
+    if (st[13] >= (double)tr.patience) stop = 1;
+    if (rejects >= (double)tr.reject) stop = 1;
+    return stop;
+}
+
+// pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
+__device__ inline void lm_control(double s, double q, double* __restrict__ st, int* flags, const TRParams& tr,
+                                  double* __restrict__ report, double seq) {
+    double rep[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rep[i] = 0.0;
+    if (flags[0] != 0) {                 // solver failed: PyPose prints and breaks the step, nothing changes
+        flags[0] = 0;
+        rep[0] = st[0]; rep[1] = st[1]; rep[2] = st[2]; rep[8] = st[8]; rep[10] = 1.0;
+        rep[12] = scheduler_step(st, tr, st[1], st[0], st[8]) ? 4.0 : 3.0;
+        st[8] = 0.0;
+        st[14] += 1.0;
+    } else {
+        const double last = st[1];
+        const double quality = (last - s) / (-q);
+        double radius = 1.0 / st[2], down = st[4];
+        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
+        else if (quality > tr.low) { down = tr.down; }
+        else { radius = radius * down; down = down * tr.factor; }
+        down = fmax(tr.rmin, fmin(down, tr.rmax));
+        radius = fmax(tr.rmin, fmin(radius, tr.rmax));
+        st[3] = radius; st[4] = down; st[2] = 1.0 / radius; st[5] = quality; st[6] = s; st[7] = -q;
+        rep[1] = last; rep[2] = st[2]; rep[3] = radius; rep[4] = down; rep[5] = quality; rep[6] = s; rep[7] = -q;
+        if (last < s && st[8] < (double)tr.reject) {       // reject: the host keeps the old iterate, loss = last
+            st[0] = last;
+            st[8] += 1.0;
+            rep[0] = last; rep[8] = st[8]; rep[9] = 0.0;
+            rep[12] = 1.0;
+            st[14] += 1.0;
+        } else {                                           // step kept (also when the reject limit is exhausted)
+            rep[0] = s; rep[8] = st[8]; rep[9] = 1.0;
+            const int stop = scheduler_step(st, tr, last, s, st[8]);
+            rep[12] = stop ? 2.0 : 0.0;
+            if (stop) st[14] += 1.0;
+            st[0] = s;
+            st[1] = s;                                     // next optimizer.step(): self.last = self.loss
+            st[8] = 0.0;
+        }
+    }
+    rep[13] = st[12];
+    if (report) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) __hip_atomic_store(&report[i], rep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // payload written through before the sequence number
+        __hip_atomic_store(&report[15], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ---- gated stage entry points (defined in pvgo.hip) --------------------------------------------------------------------------
+// linearisation + normal equations of a chain of N nodes in one launch (linbuild_kernel): lin (42 x (N-1), component-major),
+// loss_part (one partial sum per 63-node block), Hd / Ho (N x 81), rhs (N x 9)
+int linbuild_gated(const double* nodes, const double* vels, const double* poses, const double* drots, const double* dtrans,
+                   const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, double* lin, double* loss_part,
+                   double* Hd, double* Ho, double* rhs, Gate gate, hipStream_t s);
+// islam_pvgo_shard_upsweep; state != nullptr: the damping is read from state[2] on the device
+int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double damping, const double* state, int N,
+                        const int seg_len[2], int world, int rank, int node0, void* workspace, size_t workspace_bytes,
+                        double* exchange, int* flags, Gate gate, hipStream_t s);
+// islam_pvgo_shard_downsweep
+int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
+                          size_t workspace_bytes, double* dx, int* flags, Gate gate, hipStream_t s);
+// islam_pvgo_trial on M links whose linearisation records are lin[c * lin_stride + k]
+int trial_gated(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
+                const double* dtrans, const double* dvels, const double* dts, const double* lin, int lin_stride, int M,
+                double* nodes_t, double* vels_t, double* part, Gate gate, hipStream_t s);
+
+}  // namespace islam

@@ -10,7 +10,7 @@ torch.manual_seed(0)
 vonet = nets.VONet(fix_parts=('flow', 'stereo')).to(dev).train()
 vonet.set_frozen_dtype(torch.bfloat16)
 x = torch.randn(8, 6, 448, 640, device=dev)
-run = lambda: vonet._run_frozen('stereo', vonet.stereoNet, torch.bfloat16, x)
+run = lambda: vonet._run_frozen('stereo', vonet.stereoNet, torch.bfloat16, x, quarter=True)
 with torch.no_grad():
     for _ in range(4):
         run()

@@ -11,29 +11,46 @@ from oracle import pvgo as opvgo
 MAXL, TOPW, MAXTOP = 6, 1, 4
 
 
-def plan_levels(N, seg_len=(0, 0), with_top=False):
-    """Mirror of plan_levels() in islam_amd/csrc/pvgo.hip (same arithmetic, same tie-breaking)."""
+BS_PAR_MAX = 7
+
+
+def plan_levels(N, seg_len=(0, 0), with_top=False, twisted=False):
+    """Mirror of plan_levels() in islam_amd/csrc/pvgo.hip (same arithmetic, same tie-breaking).  ``twisted``: the plan of the
+    two-sided elimination -- what islam_pvgo_plan returns; the numpy backend below keeps the one-sided tree (any tree is a
+    valid partition, it only has to be the same on every rank)."""
     import math
     t_node, t_launch = 2.3, 4.0
     best, best_cost, best_top = None, 1e300, 0
     for depth in range(1, MAXL + 1):
         m_auto = max(4, int(math.ceil(math.pow(float(N), 1.0 / depth))) - 1)
-        lv, n = [], N
+        if twisted:
+            if m_auto > BS_PAR_MAX and depth < MAXL:
+                continue
+            if m_auto % 2 == 0 and m_auto + 1 <= BS_PAR_MAX:
+                m_auto += 1
+        lv, n, tw = [], N, twisted
         for l in range(MAXL):
             m = m_auto
             if l < 2 and seg_len[l] > 0:
                 m = max(seg_len[l], 4)
-            if l == MAXL - 1 or l >= depth - 1 or m + 1 >= n or n <= 12:
+            if l == MAXL - 1 or l >= depth - 1 or m + 1 >= n or n <= (BS_PAR_MAX if twisted else 12):
                 lv.append((n, n, 1))
                 break
+            if m > BS_PAR_MAX:
+                tw = False
             lv.append((n, m, (n + m) // (m + 1)))
             n = n // (m + 1)
         top = len(lv) - 1
         while top > 0 and lv[top - 1][2] <= TOPW and (len(lv) - (top - 1)) <= MAXTOP:
             top -= 1
+        if len(lv) < 2 or top != len(lv) - 1:
+            tw = False
         cost = t_launch
-        for l, (_, m, _) in enumerate(lv):
-            cost += m * t_node + (2 * t_launch if l < top else 0.0)
+        for l, (nn, m, _) in enumerate(lv):
+            root = l == len(lv) - 1
+            ltw = tw and (not root or nn <= BS_PAR_MAX)
+            steps = m // 2 + 1 if (ltw and m >= 3) else m
+            cost += steps * t_node + (2 * t_launch if l < top else 0.0)
         if cost < best_cost - 1e-9:
             best, best_cost, best_top = lv, cost, top
     return (best, best_top) if with_top else best

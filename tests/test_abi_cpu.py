@@ -70,7 +70,7 @@ def test_level_plan_matches_python_mirror(lib):
             out = (ctypes.c_int * 19)()
             nl = lib.islam_pvgo_plan(N, sl, out)
             got = [(out[3 * l], out[3 * l + 1], out[3 * l + 2]) for l in range(nl)]
-            ref, top = plan_levels(N, seg, with_top=True)
+            ref, top = plan_levels(N, seg, with_top=True, twisted=True)
             assert got == ref and out[18] == top, (N, seg)
             n = N
             for (nn, m, P) in got[:-1]:
