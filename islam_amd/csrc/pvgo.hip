@@ -2366,7 +2366,7 @@ __global__ void outer_block_kernel(OuterFix f, Gate gate) {
     if (t >= 90 || gate_closed(gate)) return;
     double v = 0.0;
     for (int i = 0; i < f.n; ++i) v += t < 81 ? f.cL[i][t] : f.cgL[i][t - 81];
-    if (t < 81) f.Dsep[t] -= v; else f.rsep[t - 81] -= v;
+    if (t < 81) f.Dsep[t] = -v; else f.rsep[t - 81] = -v;       // a row of the PREVIOUS rank's segment: nothing else is written there locally
 }
 
 int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, int* out) {
@@ -2399,17 +2399,19 @@ static int ensure_linbuild_lds() {
 namespace islam {
 
 // Up-sweep of levels 0 .. xl over the rank's own segments.  Hd/Ho/rhs: LOCAL level-0 arrays whose row 0 is global node
-// `node0`; exchange: 351*P_xl doubles (array-major like the level-0 products), zeroed here, own rows written.
+// `node0`; exchange: 351*P_xl doubles (array-major like the level-0 products), own rows written -- and the rank's share of its
+// left outer separator's block, a row of the previous rank's segment; zero_exchange: every other row is zeroed first (a caller
+// that never lets anything else touch the buffer zeroes it once and passes false).
 int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double damping, const double* state, int N,
                         const int seg_len[2], int world, int rank, int node0, void* workspace, size_t workspace_bytes,
-                        double* exchange, int* flags, Gate gate, hipStream_t s) {
+                        double* exchange, bool zero_exchange, int* flags, Gate gate, hipStream_t s) {
     SolvePlan sp;
     const int nl = shard_plan(N, seg_len, sp);
     ShardRanges R;
     if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: N=%d, world=%d, rank=%d", N, world, rank);
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_upsweep: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
-    ISLAM_HIP_CHECK(hipMemsetAsync(exchange, 0, sizeof(double) * 351 * (size_t)sp.lv[R.xl].P, s));
+    if (zero_exchange) ISLAM_HIP_CHECK(hipMemsetAsync(exchange, 0, sizeof(double) * 351 * (size_t)sp.lv[R.xl].P, s));
     LevelBufs xb{};
     products_view(exchange, sp.lv[R.xl].P, xb);
     for (int l = 0; l <= R.xl; ++l) {
@@ -2537,7 +2539,7 @@ extern "C" {
 int islam_pvgo_shard_upsweep(double* Hd, const double* Ho, const double* rhs, double damping, int N, const int seg_len[2], int world,
                              int rank, int node0, void* workspace, size_t workspace_bytes, double* exchange, int* flags,
                              void* stream) {
-    return shard_upsweep_gated(Hd, Ho, rhs, damping, nullptr, N, seg_len, world, rank, node0, workspace, workspace_bytes, exchange, flags,
+    return shard_upsweep_gated(Hd, Ho, rhs, damping, nullptr, N, seg_len, world, rank, node0, workspace, workspace_bytes, exchange, true, flags,
                                Gate{nullptr, 0.0}, as_stream(stream));
 }
 

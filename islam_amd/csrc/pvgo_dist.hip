@@ -56,36 +56,51 @@ __global__ __launch_bounds__(256) void own_loss_kernel(const double* __restrict_
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-// msg = [sum r^2 | sum JD.(2R+JD) | failed | halo of every rank (10 each)]: own part filled, the rest zero
-__global__ void msg_kernel(const double* __restrict__ part, int nblk, int* __restrict__ flags, const double* __restrict__ nt,
-                           const double* __restrict__ vt, int first_local, int rank, int world, double* __restrict__ msg, Gate gate) {
-    if (gate_closed(gate)) return;
-    const int t = threadIdx.x;
-    for (int i = t; i < 3 + 10 * world; i += blockDim.x) msg[i] = 0.0;
-    __syncthreads();
-    if (t < 2) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[2 * b + t];            // fixed order: deterministic
-        msg[t] = s;
-    }
-    if (t == 2) { msg[2] = flags[0] ? 1.0 : 0.0; flags[0] = 0; }
-    if (t >= 3 && t < 10) msg[3 + 10 * rank + (t - 3)] = nt[(size_t)first_local * 7 + (t - 3)];
-    if (t >= 10 && t < 13) msg[3 + 10 * rank + 7 + (t - 10)] = vt[(size_t)first_local * 3 + (t - 10)];
-}
-
 // after all-reduce #2: the halo row of the trial iterate (the next rank's first node) and the LM decision -- identical on every
 // rank, because the summed message is
-__global__ void decide_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags, TRParams tr,
-                              double* __restrict__ report, double seq, double* __restrict__ nt, double* __restrict__ vt,
-                              const double* __restrict__ halo, int halo_row, Gate gate) {
-    if (gate_closed(gate)) return;
-    const int t = threadIdx.x;
+__device__ __forceinline__ void decide(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags, const TRParams& tr,
+                                       double* __restrict__ report, double seq, double* __restrict__ nt, double* __restrict__ vt,
+                                       const double* __restrict__ halo, int halo_row, int t) {
     if (halo && t < 7) nt[(size_t)halo_row * 7 + t] = halo[t];
     if (halo && t >= 7 && t < 10) vt[(size_t)halo_row * 3 + (t - 7)] = halo[t];
     if (t == 0) {
         flags[0] = msg[2] > 0.0 ? 1 : 0;                                // a failed pivot on ANY rank fails the step everywhere
         lm_control(msg[0], msg[1], st, flags, tr, report, seq);
     }
+}
+
+// msg = [sum r^2 | sum JD.(2R+JD) | failed | halo of every rank (10 each)]: own part filled, the rest zero.  One wavefront.
+// decide_now (world 1: nothing to sum over ranks): the decision is taken here.
+__global__ __launch_bounds__(64) void msg_kernel(const double* __restrict__ part, int nblk, int* __restrict__ flags,
+                                                 const double* __restrict__ nt_c, const double* __restrict__ vt_c, int first_local, int rank,
+                                                 int world, double* __restrict__ msg, int decide_now, double* __restrict__ st, TRParams tr,
+                                                 double* __restrict__ report, double seq, double* __restrict__ nt, double* __restrict__ vt,
+                                                 Gate gate) {
+    if (gate_closed(gate)) return;
+    const int t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = t; i < nblk; i += 64) { s += part[2 * i]; q += part[2 * i + 1]; }       // fixed pattern: deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); q += __shfl_down(q, o, 64); }
+    if (decide_now) {
+        if (t == 0) {
+            msg[0] = s; msg[1] = q; msg[2] = flags[0] ? 1.0 : 0.0;
+            decide(msg, st, flags, tr, report, seq, nt, vt, nullptr, 0, 0);
+        }
+        return;
+    }
+    for (int i = 3 + t; i < 3 + 10 * world; i += 64) msg[i] = 0.0;
+    if (t == 0) { msg[0] = s; msg[1] = q; msg[2] = flags[0] ? 1.0 : 0.0; flags[0] = 0; }
+    __syncthreads();
+    if (t >= 3 && t < 10) msg[3 + 10 * rank + (t - 3)] = nt_c[(size_t)first_local * 7 + (t - 3)];
+    if (t >= 10 && t < 13) msg[3 + 10 * rank + 7 + (t - 10)] = vt_c[(size_t)first_local * 3 + (t - 10)];
+}
+
+__global__ void decide_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags, TRParams tr,
+                              double* __restrict__ report, double seq, double* __restrict__ nt, double* __restrict__ vt,
+                              const double* __restrict__ halo, int halo_row, Gate gate) {
+    if (gate_closed(gate)) return;
+    decide(msg, st, flags, tr, report, seq, nt, vt, halo, halo_row, threadIdx.x);
 }
 
 // the loss of the very first optimizer.step() (summed over the ranks in msg[0])
@@ -116,6 +131,15 @@ struct Reducer {
     ncclComm_t comm = nullptr;
     islam_allreduce_fn fn = nullptr;
     void* user = nullptr;
+    // recv = sum over the ranks of send (send is left untouched)
+    int sum_to(const double* send, double* recv, size_t count, hipStream_t s) const {
+        if (fn) {
+            ISLAM_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+            return sum(recv, count, s);
+        }
+        ISLAM_NCCL_CHECK(ncclAllReduce(send, recv, count, ncclDouble, ncclSum, comm, s));
+        return ISLAM_OK;
+    }
     int sum(double* buf, size_t count, hipStream_t s) const {
         if (fn) {
             if (fn(user, buf, count, (void*)s) != 0) return fail(ISLAM_EHIP, "islam_pvgo_run_chain_sharded: all-reduce callback failed");
@@ -176,7 +200,7 @@ int islam_dist_comm_destroy(void* comm) {
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
     size_t d = a256(LIN_C * n) + a256(n / 32 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
-               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + a256(351 * (n / 5 + 2)) + a256(64) + a256(16);
+               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(16);
     return d * sizeof(double) + 512;
 }
 
@@ -204,7 +228,8 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     double* part = take(2 * (nn / 64 + 2));
     double* msg = take(nmsg);
     double* full = take(10 * nn);
-    double* ex = take(351 * (nn / 5 + 2));
+    double* ex_own = take(351 * (nn / 5 + 2));        // own rows of the exchange level, everything else stays zero (zeroed once)
+    double* ex = world > 1 ? take(351 * (nn / 5 + 2)) : ex_own;      // the sum over the ranks
     int* flags = (int*)take(64);
     double* state = take(16);
     // verdicts in pinned, device-visible host memory (two slots, alternating with the trial number); the host polls the
@@ -224,6 +249,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     ISLAM_HIP_CHECK(hipMemcpyAsync(state, init, sizeof(init), hipMemcpyHostToDevice, s));
     ISLAM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));     // product rows of other ranks' segments read as zero
+    ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * 351 * (size_t)sh.Pxl, s));
     ISLAM_HIP_CHECK(hipMemcpyAsync(nl, nodes + (size_t)a * 7, sizeof(double) * 7 * nloc, hipMemcpyDeviceToDevice, s));
     ISLAM_HIP_CHECK(hipMemcpyAsync(vl, vels + (size_t)a * 3, sizeof(double) * 3 * nloc, hipMemcpyDeviceToDevice, s));
     ISLAM_HIP_CHECK(hipMemcpyAsync(nt, nl, sizeof(double) * 7 * nloc, hipMemcpyDeviceToDevice, s));     // rows no trial writes (a last
@@ -242,14 +268,18 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
         const Gate gate{state, epoch};
         int r;
         if (relin && (r = linbuild_gated(c.cur_n, c.cur_v, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, gate, s)) != ISLAM_OK) return r;
-        if ((r = shard_upsweep_gated(Hd, Ho, rhs, 0.0, state, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, ex, flags, gate, s)) != ISLAM_OK) return r;
-        if (world > 1 && (r = red.sum(ex, 351 * (size_t)sh.Pxl, s)) != ISLAM_OK) return r;
+        if ((r = shard_upsweep_gated(Hd, Ho, rhs, 0.0, state, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, ex_own, false, flags, gate, s)) != ISLAM_OK) return r;
+        if (world > 1 && (r = red.sum_to(ex_own, ex, 351 * (size_t)sh.Pxl, s)) != ISLAM_OK) return r;
         if ((r = shard_downsweep_gated(ex, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, dx, flags, gate, s)) != ISLAM_OK) return r;
         if ((r = trial_gated(c.cur_n, c.cur_v, dx, lp, lr, ltr, lv, ldt, lin, Mloc, n_own, c.tri_n, c.tri_v, part, gate, s)) != ISLAM_OK) return r;
-        hipLaunchKernelGGL(msg_kernel, dim3(1), dim3(64), 0, s, part, nblk, flags, c.tri_n, c.tri_v, first_local, rank, world, msg, gate);
-        if (world > 1 && (r = red.sum(msg, nmsg, s)) != ISLAM_OK) return r;
-        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, s, msg, state, flags, tr, report + 16 * ((long long)seq & 1), seq, c.tri_n,
-                           c.tri_v, halo ? msg + 3 + 10 * (rank + 1) : (const double*)nullptr, b - a, gate);
+        double* rep = report + 16 * ((long long)seq & 1);
+        hipLaunchKernelGGL(msg_kernel, dim3(1), dim3(64), 0, s, part, nblk, flags, c.tri_n, c.tri_v, first_local, rank, world, msg,
+                           world == 1 ? 1 : 0, state, tr, rep, seq, c.tri_n, c.tri_v, gate);
+        if (world > 1) {
+            if ((r = red.sum(msg, nmsg, s)) != ISLAM_OK) return r;
+            hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, s, msg, state, flags, tr, rep, seq, c.tri_n, c.tri_v,
+                               halo ? msg + 3 + 10 * (rank + 1) : (const double*)nullptr, b - a, gate);
+        }
         ISLAM_LAUNCH_CHECK();
         xbytes += iter_bytes;
         return ISLAM_OK;

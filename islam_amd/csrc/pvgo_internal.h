@@ -91,7 +91,7 @@ int linbuild_gated(const double* nodes, const double* vels, const double* poses,
 // islam_pvgo_shard_upsweep; state != nullptr: the damping is read from state[2] on the device
 int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double damping, const double* state, int N,
                         const int seg_len[2], int world, int rank, int node0, void* workspace, size_t workspace_bytes,
-                        double* exchange, int* flags, Gate gate, hipStream_t s);
+                        double* exchange, bool zero_exchange, int* flags, Gate gate, hipStream_t s);
 // islam_pvgo_shard_downsweep
 int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
                           size_t workspace_bytes, double* dx, int* flags, Gate gate, hipStream_t s);
