@@ -313,8 +313,10 @@ int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[
 /* The whole sharded LM loop in the library, on RCCL (islam_amd/csrc/pvgo_dist.hip): every rank passes the SAME full-size
  * inputs (device, float64: nodes (N,7), vels (N,3) in/out -- the full solution on every rank --, poses (N-1,7), drots (N-1,4),
  * dtrans, dvels (N-1,3), dts (N-1)) and works on its stretch of the chain; per LM trial two all-reduces (the interface blocks:
- * 351 doubles per segment of the exchange level; [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]) and one
- * 24-byte device->host read; accept / reject, TrustRegion and StopOnPlateau replicated on the host.  comm: an ncclComm_t made
+ * 351 doubles per segment of the exchange level; [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]); accept /
+ * reject, TrustRegion and StopOnPlateau replicated on the DEVICE (every rank decides on the same summed scalars), the host
+ * runs one trial ahead and reads 128-byte verdicts from pinned memory -- no stream synchronisation inside the loop; the
+ * collectives of a cancelled run-ahead trial still execute, identically on every rank.  comm: an ncclComm_t made
  * with islam_dist_comm_init (rank 0 creates the 128-byte id with islam_dist_unique_id and broadcasts it -- e.g. with
  * torch.distributed) or NULL for world == 1.  workspace: islam_pvgo_workspace_bytes(N); scratch:
  * islam_pvgo_sharded_scratch_bytes(N, world).  exchanged_bytes (may be NULL): bytes handed to the collectives of the trials.
