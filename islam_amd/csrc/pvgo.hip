@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 // solve).  outer: the window's first segment takes its LEFT separator -- the rank's left cut node, a node of every level up to
 // the replicated ones -- from SweepArgs::outer_x instead of the level above (whose segment holding it belongs to the
 // previous rank).  x_last: last valid index of x (the sharded solve hands in a local array).
-struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, x_last; };
+struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, store_left, x_last; };
 struct SweepArgs {
     LevelSrc root_src;
     LevelDst root_dst;
@@ -1440,7 +1440,9 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     double sv = 0.0;
     if (lane < 9 ? has_left : (lane < 18 && has_right))
         sv = ld_coherent((outer_left && lane < 9) ? a.outer_x + lane : &L.xsep[(size_t)(p - 1) * 9 + lane]);
-    if (outer_left && lane < 9) st_coherent(&L.x[(size_t)(c0 - 1) * 9 + lane], sv);      // the cut node's row of this level's x
+    // the rank's left cut node has no segment of its own in the window: its row of this level's x (at level 0: the step the
+    // trial needs for the rank's first link) is written by the window's first segment
+    if (L.store_left && pw == 0 && lane < 9) st_coherent(&L.x[(size_t)(c0 - 1) * 9 + lane], sv);
 #ifdef ISLAM_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PROBE_WALL(pr, po + 317 + 10 * li);
@@ -2110,7 +2112,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             SweepLevel& L = a.lv[i];
             L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
             L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
-            L.seg0 = 0; L.nseg = L.P; L.twisted = tw ? 1 : 0; L.outer = 0; L.x_last = L.n * 9 - 1;
+            L.seg0 = 0; L.nseg = L.P; L.twisted = tw ? 1 : 0; L.outer = 0; L.store_left = 0; L.x_last = L.n * 9 - 1;
             L.flag0 = flag;
             L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
             L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
@@ -2487,6 +2489,7 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
         L.nseg = local ? R.nseg[l] : L.P;
         L.twisted = tw ? 1 : 0;
         L.outer = (l < xl && R.seg0[l] > 0) ? 1 : 0;
+        L.store_left = (local && R.seg0[l] > 0) ? 1 : 0;
         L.x_last = std::min(L.n, (L.seg0 + L.nseg) * (L.m + 1)) * 9 - 1;
         L.flag0 = flag;
         L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;

@@ -283,7 +283,7 @@ class RcclComm:
 
 
 def run_chain_sharded(comm, init_nodes, init_vels, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, seg_len=(0, 0), rank=None,
-                      world=None, allreduce_cb=None):
+                      world=None, allreduce_cb=None, params=None):
     """islam_pvgo_run_chain_sharded: the sharded LM loop inside the library.  ``comm``: an RcclComm (or None with world 1);
     ``allreduce_cb``: a ctypes callback instead of RCCL (tests).  Returns (nodes, vels, result, bytes handed to the collectives)."""
     from . import ops
@@ -295,7 +295,7 @@ def run_chain_sharded(comm, init_nodes, init_vels, poses, drots, dtrans, dvels, 
     t = lambda x: x.to(dev, torch.float64).contiguous()
     nodes, vels = t(init_nodes).clone(), t(init_vels).clone()
     args = [t(x) for x in (poses, drots, dtrans, dvels, dts)]
-    prm = ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)
+    prm = params if params is not None else ops.pvgo_default_params(loss_weight, radius=radius, seg_len=seg_len)      # params: a ready islam_pvgo_params
     ws, nbytes = ops.pvgo_workspace(N, dev)
     sbytes = lib().islam_pvgo_sharded_scratch_bytes(N, world)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)

@@ -51,15 +51,11 @@ def test_world_one_with_and_without_a_communicator(cuda, F):
     assert torch.equal(n2, n1) and torch.equal(v2, v1) and r2.trials == r1.trials
 
 
-@pytest.mark.parametrize('world,F', [(2, 300), (3, 257), (8, 5001), (5, 1000)])
-def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
-    """Every rank's C loop runs in its own thread and CUDA stream; the injected all-reduce copies each rank's buffer to the
-    host, sums in rank order, and writes the sum back.  Exercises what the stage-level virtual-rank test cannot: pack / halo /
-    accept / final assembly of the C loop with more than one rank."""
+def _run_ranks_as_threads(args, world, params=None):
+    """Every rank's C loop in its own thread and stream; the injected all-reduce copies each rank's buffer to the host, sums in
+    rank order and writes the sum back."""
     from islam_amd import dist_pvgo
     from islam_amd._lib import lib
-    args = _problem(F, cuda)
-    nodes, vels, res = _single(args)
     hip = ctypes.CDLL('libamdhip64.so')
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
@@ -89,7 +85,7 @@ def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
     def run(rank):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                outs[rank] = dist_pvgo.run_chain_sharded(None, *args, LW, rank=rank, world=world, allreduce_cb=cbs[rank])
+                outs[rank] = dist_pvgo.run_chain_sharded(None, *args, LW, rank=rank, world=world, allreduce_cb=cbs[rank], params=params)
         except Exception as e:                       # noqa: BLE001
             errs.append(e)
             barrier.abort()
@@ -102,6 +98,16 @@ def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
     for th in threads:
         th.join(timeout=300)
     assert not errs, errs
+    return outs
+
+
+@pytest.mark.parametrize('world,F', [(2, 300), (3, 257), (8, 5001), (5, 1000)])
+def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
+    """Exercises what the stage-level virtual-rank test cannot: message / halo / decision / final assembly of the C loop with
+    more than one rank."""
+    args = _problem(F, cuda)
+    nodes, vels, res = _single(args)
+    outs = _run_ranks_as_threads(args, world)
     for r, (n, v, rr, xb) in enumerate(outs):
         assert (rr.trials, rr.steps, rr.status) == (res.trials, res.steps, 0), r
         torch.testing.assert_close(n, nodes, rtol=0, atol=1e-9)
@@ -111,3 +117,61 @@ def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
         chains, rest = divmod(outs[0][3], per_chain)                     # per enqueued trial chain; the host runs one trial ahead,
         trials = outs[0][2].trials                                       # so every reject / the stop cancels one chain whose
         assert rest == 0 and trials <= chains <= 2 * trials              # collectives still ran
+
+
+def _noisy(F, seed, sig, cuda):
+    """Dead-reckoning init perturbed hard enough that LM has to reject trials (tests/test_pvgo_gpu.py::_noisy_problem)."""
+    from oracle import lie
+    prob, _ = chain_problem(F)
+    rng = np.random.default_rng(seed)
+    n = prob['init_nodes'].copy()
+    n[:, :3] += rng.normal(0, sig, (F, 3))
+    n = lie.se3_mul(lie.se3_exp(np.concatenate([np.zeros((F, 3)), rng.normal(0, sig * 0.2, (F, 3))], 1)), n)
+    prob = dict(prob, init_nodes=n)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=cuda)
+    return [t(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions', 'imu_drots', 'imu_dtrans', 'imu_dvels', 'dts')]
+
+
+@pytest.mark.parametrize('world,F,seed,sig', [(1, 65, 8, 1.5), (2, 65, 8, 1.5), (3, 65, 8, 1.5), (2, 65, 2, 1.0), (4, 65, 2, 1.0), (2, 33, 1, 1.5)])
+def test_rejected_trials_cancel_the_run_ahead_chain_on_every_rank(cuda, world, F, seed, sig):
+    """Rejects (more damping on the same linearisation; the pre-enqueued chain -- kernels AND collectives -- cancelled by the
+    epoch gate) and the reject limit: the decision is taken on the device of every rank from the same summed scalars, so every
+    rank must follow the accept / reject sequence of the fused single-GPU loop, and a second run must not see stale state."""
+    from islam_amd import dist_pvgo, ops
+    args = _noisy(F, seed, sig, cuda)
+    nodes, vels = args[0].clone(), args[1].clone()
+    res, trace = ops.pvgo_run_chain(nodes, vels, *args[2:], ops.pvgo_default_params(LW, radius=1e4), trace_cap=256)
+    assert res.trials > res.steps                                         # there were rejected trials
+    for _ in range(2):
+        outs = [dist_pvgo.run_chain_sharded(None, *args, LW)] if world == 1 else _run_ranks_as_threads(args, world)
+        for r, (n, v, rr, xb) in enumerate(outs):
+            assert (rr.trials, rr.steps, rr.status) == (res.trials, res.steps, 0), r
+            assert rr.loss == pytest.approx(res.loss, rel=1e-9) and rr.damping == pytest.approx(res.damping, rel=1e-12)
+            torch.testing.assert_close(n, nodes, rtol=0, atol=1e-8)
+            torch.testing.assert_close(v, vels, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_failed_solve_breaks_the_step_on_every_rank(cuda, world):
+    """A negative information scalar makes the factorisation fail on some rank: the failed-pivot flag travels in all-reduce #2,
+    every rank reports ISLAM_ENOTPD, re-linearises the same iterate (PyPose keeps looping through the scheduler) and stops on
+    the plateau counter without moving (tests/test_pvgo_gpu.py::test_lm_solver_failure_breaks_the_step_like_pypose)."""
+    from islam_amd import dist_pvgo, ops
+    args = _problem(33, cuda)
+
+    def prm():
+        p = ops.pvgo_default_params(LW, radius=1e4)
+        for i, w in enumerate((1.0, -0.5, 100.0, 0.01)):
+            p.w[i] = w
+        return p
+    n0, v0 = args[0].clone(), args[1].clone()
+    ref, _ = ops.pvgo_run_chain(n0, v0, *args[2:], prm())
+    assert (ref.status, ref.steps, ref.trials) == (-3, 3, 3)              # the fused loop: StopOnPlateau(patience=3) ends it
+    outs = [dist_pvgo.run_chain_sharded(None, *args, LW, params=prm())] if world == 1 else _run_ranks_as_threads(args, world, params=prm())
+    for n, v, rr, xb in outs:
+        assert rr.status == -3 and rr.steps == 3 and rr.trials == 3
+        assert rr.loss == pytest.approx(ref.loss, rel=1e-9)
+        torch.testing.assert_close(n, args[0], rtol=0, atol=0)
+        torch.testing.assert_close(v, args[1], rtol=0, atol=0)
+    good = [dist_pvgo.run_chain_sharded(None, *args, LW)] if world == 1 else _run_ranks_as_threads(args, world)      # reusable afterwards
+    assert all(o[2].status == 0 for o in good)
