@@ -316,7 +316,8 @@ int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[
  * 351 doubles per segment of the exchange level; [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]); accept /
  * reject, TrustRegion and StopOnPlateau replicated on the DEVICE (every rank decides on the same summed scalars), the host
  * runs one trial ahead and reads 128-byte verdicts from pinned memory -- no stream synchronisation inside the loop; the
- * collectives of a cancelled run-ahead trial still execute, identically on every rank.  comm: an ncclComm_t made
+ * collectives of a cancelled run-ahead trial still execute, identically on every rank.  reproj (may be NULL): the sparse
+ * reprojection factor of islam_pvgo_run_chain_reproj over the WHOLE graph; a rank reduces the keypoints of its own links.  comm: an ncclComm_t made
  * with islam_dist_comm_init (rank 0 creates the 128-byte id with islam_dist_unique_id and broadcasts it -- e.g. with
  * torch.distributed) or NULL for world == 1.  workspace: islam_pvgo_workspace_bytes(N); scratch:
  * islam_pvgo_sharded_scratch_bytes(N, world).  exchanged_bytes (may be NULL): bytes handed to the collectives of the trials.
@@ -329,12 +330,13 @@ int islam_dist_comm_destroy(void* comm);
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world);
 int islam_pvgo_run_chain_sharded(void* comm, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
                                  const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
-                                 void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
-                                 long long* exchanged_bytes, void* stream);
+                                 const islam_pvgo_reproj* reproj, void* workspace, size_t workspace_bytes, void* scratch,
+                                 size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream);
 int islam_pvgo_run_chain_sharded_cb(islam_allreduce_fn fn, void* user, int world, int rank, double* nodes, double* vels,
                                     const double* poses, const double* drots, const double* dtrans, const double* dvels, const double* dts,
-                                    int N, const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes, void* scratch,
-                                    size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream);
+                                    int N, const islam_pvgo_params* prm, const islam_pvgo_reproj* reproj, void* workspace,
+                                    size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
+                                    long long* exchanged_bytes, void* stream);
 /* Trial step on M links (M+1 node rows): retract on a copy, residuals, partial sums part[2*nblk] =
  * (sum r^2, sum JD.(2R+JD)) per 64-link block (ppost.TrustRegion.update's denominator is -sum). */
 int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,

@@ -96,11 +96,12 @@ SIGNATURES = {
     'islam_dist_comm_init': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     'islam_dist_comm_destroy': (c_int, [c_void_p]),
     'islam_pvgo_sharded_scratch_bytes': (c_size_t, [c_int, c_int]),
-    'islam_pvgo_run_chain_sharded': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p, c_size_t,
-                                             c_void_p, c_size_t, ctypes.POINTER(PvgoResult), ctypes.POINTER(ctypes.c_longlong), c_void_p]),
-    'islam_pvgo_run_chain_sharded_cb': (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p,
-                                                c_size_t, c_void_p, c_size_t, ctypes.POINTER(PvgoResult), ctypes.POINTER(ctypes.c_longlong),
-                                                c_void_p]),
+    'islam_pvgo_run_chain_sharded': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams),
+                                             ctypes.POINTER(PvgoReproj), c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(PvgoResult),
+                                             ctypes.POINTER(ctypes.c_longlong), c_void_p]),
+    'islam_pvgo_run_chain_sharded_cb': (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams),
+                                                ctypes.POINTER(PvgoReproj), c_void_p, c_size_t, c_void_p, c_size_t,
+                                                ctypes.POINTER(PvgoResult), ctypes.POINTER(ctypes.c_longlong), c_void_p]),
     'islam_pvgo_shard_ranges': (c_int, [c_int, ctypes.POINTER(c_int), c_int, c_int, ctypes.POINTER(c_int)]),
     'islam_pvgo_shard_upsweep': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_size_t,
                                          c_void_p, c_void_p, c_void_p]),

@@ -2383,6 +2383,34 @@ int islam_pvgo_shard_ranges(int N, const int seg_len[2], int world, int rank, in
     return ISLAM_OK;
 }
 
+static int reproj_dev(const islam_pvgo_reproj* r, ReprojDev& d) {
+    if (!r->points || !r->targets || r->K < 1) return fail(ISLAM_EARG, "islam_pvgo_reproj: null points/targets or K=%d < 1", r->K);
+    d.points = r->points; d.targets = r->targets; d.K = r->K;
+    d.fx = r->fx; d.fy = r->fy; d.cx = r->cx; d.cy = r->cy;
+    d.C = {{r->rgb2imu[0], r->rgb2imu[1], r->rgb2imu[2]}, {r->rgb2imu[3], r->rgb2imu[4], r->rgb2imu[5], r->rgb2imu[6]}};
+    d.weight = r->weight;
+    d.compat_first = r->compat_first_motion;
+    return ISLAM_OK;
+}
+
+static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s,
+                                  Gate gate = Gate{nullptr, 0.0}) {
+    const int waves = std::min(4, std::max(1, (rp.K + 127) / 128));
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 64 * waves * (RP_NSUM + 1) * sizeof(double), s, nodes,
+                       dx, M, rp, red, gate);
+}
+
+// the factor as a rank of the sharded loop sees it: keypoints / targets of its local link 0 = global link `link0`; the frozen
+// first motion (pvgo.py:57) belongs to global link 0
+static int reproj_dev_local(const islam_pvgo_reproj* r, int link0, ReprojDev& d) {
+    const int rc = reproj_dev(r, d);
+    if (rc != ISLAM_OK) return rc;
+    d.points += (size_t)link0 * d.K * 3;
+    d.targets += (size_t)link0 * d.K * 2;
+    if (link0 != 0) d.compat_first = 0;
+    return ISLAM_OK;
+}
+
 // linbuild_kernel / trial_lin_kernel stage their node blocks in dynamic LDS above the default limit (once per device)
 static int ensure_linbuild_lds() {
     static bool lb_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
@@ -2512,25 +2540,45 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
 
 int trial_gated(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
                 const double* dtrans, const double* dvels, const double* dts, const double* lin, int lin_stride, int M,
-                double* nodes_t, double* vels_t, double* part, Gate gate, hipStream_t s) {
+                double* nodes_t, double* vels_t, double* part, const double* red_lin, const double* red_trial,
+                const islam_pvgo_reproj* reproj, int link0, Gate gate, hipStream_t s) {
     if (M < 1) return fail(ISLAM_EARG, "islam_pvgo_trial: M=%d < 1", M);
+    ReprojDev rp{};
+    if (reproj) {
+        const int rc = reproj_dev_local(reproj, link0, rp);
+        if (rc != ISLAM_OK) return rc;
+    }
     hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, s, nodes, vels, dx, poses, drots, dtrans, dvels, dts, lin,
                        M, nodes_t, vels_t, part, (double*)nullptr, (int*)nullptr, (unsigned*)nullptr, TRParams{}, (double*)nullptr, 0.0,
-                       (const double*)nullptr, (const double*)nullptr, ReprojDev{}, lin_stride, gate);
+                       reproj ? red_lin : (const double*)nullptr, reproj ? red_trial : (const double*)nullptr, rp, lin_stride, gate);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int reproj_reduce_gated(const double* nodes, const double* dx, int M, const islam_pvgo_reproj* reproj, int link0, double* red,
+                        Gate gate, hipStream_t s) {
+    if (M < 1 || !reproj) return fail(ISLAM_EARG, "pvgo reproj reduce: M=%d or null reproj", M);
+    ReprojDev rp{};
+    const int rc = reproj_dev_local(reproj, link0, rp);
+    if (rc != ISLAM_OK) return rc;
+    enqueue_reproj_reduce(nodes, dx, M, rp, red, s, gate);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 
 int linbuild_gated(const double* nodes, const double* vels, const double* poses, const double* drots, const double* dtrans,
                    const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, double* lin, double* loss_part,
-                   double* Hd, double* Ho, double* rhs, Gate gate, hipStream_t s) {
+                   double* Hd, double* Ho, double* rhs, const double* red, const islam_pvgo_reproj* reproj, int link0, Gate gate,
+                   hipStream_t s) {
     if (N < 2 || !prm) return fail(ISLAM_EARG, "pvgo linbuild: N=%d", N);
     int rc = ensure_linbuild_lds();
     if (rc != ISLAM_OK) return rc;
+    ReprojDev rp{};
+    if (reproj && (rc = reproj_dev_local(reproj, link0, rp)) != ISLAM_OK) return rc;
     const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
     hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, nodes, vels, poses, drots, dtrans, dvels, dts,
-                       N, W, lin, loss_part, Hd, Ho, rhs, (const double*)nullptr, ReprojDev{}, gate);
+                       N, W, lin, loss_part, Hd, Ho, rhs, reproj ? red : (const double*)nullptr, rp, gate);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -2557,7 +2605,8 @@ int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[
 int islam_pvgo_trial(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
                      const double* dtrans, const double* dvels, const double* dts, const double* lin, int M, double* nodes_t,
                      double* vels_t, double* part, void* stream) {
-    return trial_gated(nodes, vels, dx, poses, drots, dtrans, dvels, dts, lin, M, M, nodes_t, vels_t, part, Gate{nullptr, 0.0}, as_stream(stream));
+    return trial_gated(nodes, vels, dx, poses, drots, dtrans, dvels, dts, lin, M, M, nodes_t, vels_t, part, nullptr, nullptr, nullptr, 0,
+                       Gate{nullptr, 0.0}, as_stream(stream));
 }
 
 int islam_pvgo_retract(const double* nodes, const double* vels, const double* dx, double sign, int N, double* nodes_out,
@@ -2615,23 +2664,6 @@ int islam_pvgo_align(const double* nodes, const double* vels, const double* targ
                        nodes_out, vels_out);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
-}
-
-static int reproj_dev(const islam_pvgo_reproj* r, ReprojDev& d) {
-    if (!r->points || !r->targets || r->K < 1) return fail(ISLAM_EARG, "islam_pvgo_reproj: null points/targets or K=%d < 1", r->K);
-    d.points = r->points; d.targets = r->targets; d.K = r->K;
-    d.fx = r->fx; d.fy = r->fy; d.cx = r->cx; d.cy = r->cy;
-    d.C = {{r->rgb2imu[0], r->rgb2imu[1], r->rgb2imu[2]}, {r->rgb2imu[3], r->rgb2imu[4], r->rgb2imu[5], r->rgb2imu[6]}};
-    d.weight = r->weight;
-    d.compat_first = r->compat_first_motion;
-    return ISLAM_OK;
-}
-
-static void enqueue_reproj_reduce(const double* nodes, const double* dx, int M, const ReprojDev& rp, double* red, hipStream_t s,
-                                  Gate gate = Gate{nullptr, 0.0}) {
-    const int waves = std::min(4, std::max(1, (rp.K + 127) / 128));
-    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(xcd_grid(M)), dim3(64 * waves), 64 * waves * (RP_NSUM + 1) * sizeof(double), s, nodes,
-                       dx, M, rp, red, gate);
 }
 
 int islam_pvgo_reproj_reduce(const double* nodes, const double* dx, int N, const islam_pvgo_reproj* reproj, double* red,

@@ -43,13 +43,16 @@ constexpr int LIN_C = 42;          // components per link of the linearisation b
     } while (0)
 
 // unweighted loss of the local links [0, n_own): rows of the residuals in the component-major linearisation buffer
-__global__ __launch_bounds__(256) void own_loss_kernel(const double* __restrict__ lin, int M, int n_own, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void own_loss_kernel(const double* __restrict__ lin, int M, int n_own, const double* __restrict__ rpred,
+                                                       double* __restrict__ out) {
     __shared__ double red[256];
     const int rows[15] = {0, 1, 2, 3, 4, 5, 24, 25, 26, 36, 37, 38, 39, 40, 41};
     double s = 0.0;
-    for (int k = threadIdx.x; k < n_own; k += 256)
+    for (int k = threadIdx.x; k < n_own; k += 256) {
 #pragma unroll
         for (int r = 0; r < 15; ++r) { const double v = lin[(size_t)rows[r] * M + k]; s = fma(v, v, s); }
+        if (rpred) s += rpred[(size_t)k * ISLAM_REPROJ_REC + 27];                  // r^T r of the link's reprojection rows
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -200,14 +203,14 @@ int islam_dist_comm_destroy(void* comm) {
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
     size_t d = a256(LIN_C * n) + a256(n / 32 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
-               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(16);
+               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(16) + 2 * a256(ISLAM_REPROJ_REC * n);
     return d * sizeof(double) + 512;
 }
 
 static int run_sharded(const Reducer& red, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
                        const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
-                       void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
-                       long long* exchanged_bytes, void* stream) {
+                       const islam_pvgo_reproj* reproj, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                       islam_pvgo_result* res, long long* exchanged_bytes, void* stream) {
     if (!prm || !res || N < 2 || world < 1 || rank < 0 || rank >= world) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: bad argument");
     if (world > 1 && !red.comm && !red.fn) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: world=%d needs a communicator", world);
     if (scratch_bytes < islam_pvgo_sharded_scratch_bytes(N, world)) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: scratch too small");
@@ -232,6 +235,8 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     double* ex = world > 1 ? take(351 * (nn / 5 + 2)) : ex_own;      // the sum over the ranks
     int* flags = (int*)take(64);
     double* state = take(16);
+    double* rp_lin = take(ISLAM_REPROJ_REC * nn);      // reprojection factor: per-link reductions at the linearisation point ...
+    double* rp_tri = take(ISLAM_REPROJ_REC * nn);      // ... and at the trial point
     // verdicts in pinned, device-visible host memory (two slots, alternating with the trial number); the host polls the
     // sequence number -- no stream synchronisation, no copy
     static thread_local double* host_state = nullptr;
@@ -267,11 +272,16 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     auto enqueue_iter = [&](const IterCfg& c, double seq, double epoch, bool relin) -> int {
         const Gate gate{state, epoch};
         int r;
-        if (relin && (r = linbuild_gated(c.cur_n, c.cur_v, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, gate, s)) != ISLAM_OK) return r;
+        if (relin) {
+            if (reproj && (r = reproj_reduce_gated(c.cur_n, nullptr, Mloc, reproj, a, rp_lin, gate, s)) != ISLAM_OK) return r;
+            if ((r = linbuild_gated(c.cur_n, c.cur_v, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, rp_lin, reproj, a, gate, s)) != ISLAM_OK) return r;
+        }
         if ((r = shard_upsweep_gated(Hd, Ho, rhs, 0.0, state, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, ex_own, false, flags, gate, s)) != ISLAM_OK) return r;
         if (world > 1 && (r = red.sum_to(ex_own, ex, 351 * (size_t)sh.Pxl, s)) != ISLAM_OK) return r;
         if ((r = shard_downsweep_gated(ex, N, prm->seg_len, world, rank, a, workspace, workspace_bytes, dx, flags, gate, s)) != ISLAM_OK) return r;
-        if ((r = trial_gated(c.cur_n, c.cur_v, dx, lp, lr, ltr, lv, ldt, lin, Mloc, n_own, c.tri_n, c.tri_v, part, gate, s)) != ISLAM_OK) return r;
+        // (the reduction at the trial point covers the rank's own links: the step of the halo node is not known here)
+        if (reproj && (r = reproj_reduce_gated(c.cur_n, dx, n_own, reproj, a, rp_tri, gate, s)) != ISLAM_OK) return r;
+        if ((r = trial_gated(c.cur_n, c.cur_v, dx, lp, lr, ltr, lv, ldt, lin, Mloc, n_own, c.tri_n, c.tri_v, part, rp_lin, rp_tri, reproj, a, gate, s)) != ISLAM_OK) return r;
         double* rep = report + 16 * ((long long)seq & 1);
         hipLaunchKernelGGL(msg_kernel, dim3(1), dim3(64), 0, s, part, nblk, flags, c.tri_n, c.tri_v, first_local, rank, world, msg,
                            world == 1 ? 1 : 0, state, tr, rep, seq, c.tri_n, c.tri_v, gate);
@@ -287,8 +297,9 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
 
     // first linearisation and the loss of the initial iterate
     const Gate open{nullptr, 0.0};
-    if ((rc = linbuild_gated(nl, vl, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, open, s)) != ISLAM_OK) return rc;
-    hipLaunchKernelGGL(own_loss_kernel, dim3(1), dim3(256), 0, s, lin, Mloc, n_own, msg);
+    if (reproj && (rc = reproj_reduce_gated(nl, nullptr, Mloc, reproj, a, rp_lin, open, s)) != ISLAM_OK) return rc;
+    if ((rc = linbuild_gated(nl, vl, lp, lr, ltr, lv, ldt, nloc, prm, lin, loss_part, Hd, Ho, rhs, rp_lin, reproj, a, open, s)) != ISLAM_OK) return rc;
+    hipLaunchKernelGGL(own_loss_kernel, dim3(1), dim3(256), 0, s, lin, Mloc, n_own, reproj ? rp_lin : (const double*)nullptr, msg);
     if (world > 1 && (rc = red.sum(msg, 1, s)) != ISLAM_OK) return rc;
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, s, msg, state, flags);
 
@@ -343,22 +354,23 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
 
 int islam_pvgo_run_chain_sharded(void* comm, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
                                  const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
-                                 void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
-                                 long long* exchanged_bytes, void* stream) {
+                                 const islam_pvgo_reproj* reproj, void* workspace, size_t workspace_bytes, void* scratch,
+                                 size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream) {
     Reducer red;
     red.comm = (ncclComm_t)comm;
-    return run_sharded(red, world, rank, nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, workspace, workspace_bytes, scratch,
+    return run_sharded(red, world, rank, nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, reproj, workspace, workspace_bytes, scratch,
                        scratch_bytes, res, exchanged_bytes, stream);
 }
 
 int islam_pvgo_run_chain_sharded_cb(islam_allreduce_fn fn, void* user, int world, int rank, double* nodes, double* vels,
                                     const double* poses, const double* drots, const double* dtrans, const double* dvels, const double* dts,
-                                    int N, const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes, void* scratch,
-                                    size_t scratch_bytes, islam_pvgo_result* res, long long* exchanged_bytes, void* stream) {
+                                    int N, const islam_pvgo_params* prm, const islam_pvgo_reproj* reproj, void* workspace,
+                                    size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
+                                    long long* exchanged_bytes, void* stream) {
     Reducer red;
     red.fn = fn;
     red.user = user;
-    return run_sharded(red, world, rank, nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, workspace, workspace_bytes, scratch,
+    return run_sharded(red, world, rank, nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, reproj, workspace, workspace_bytes, scratch,
                        scratch_bytes, res, exchanged_bytes, stream);
 }
 

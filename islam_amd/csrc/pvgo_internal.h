@@ -83,11 +83,17 @@ __device__ inline void lm_control(double s, double q, double* __restrict__ st, i
 }
 
 // ---- gated stage entry points (defined in pvgo.hip) --------------------------------------------------------------------------
+// The reprojection factor on a rank's LOCAL stretch of the chain: `reproj` describes the whole graph, link0 = global index of
+// the local link 0 (keypoints / targets are offset by it; pvgo.py:57's frozen first motion applies to GLOBAL link 0 only).
+// red: ISLAM_REPROJ_REC doubles per link (islam_pvgo_reproj_reduce), at nodes (dx == nullptr) or at Exp(dx) * nodes
+int reproj_reduce_gated(const double* nodes, const double* dx, int M, const islam_pvgo_reproj* reproj, int link0, double* red,
+                        Gate gate, hipStream_t s);
 // linearisation + normal equations of a chain of N nodes in one launch (linbuild_kernel): lin (42 x (N-1), component-major),
-// loss_part (one partial sum per 63-node block), Hd / Ho (N x 81), rhs (N x 9)
+// loss_part (one partial sum per 63-node block), Hd / Ho (N x 81), rhs (N x 9); reproj != nullptr: red = the reduction at nodes
 int linbuild_gated(const double* nodes, const double* vels, const double* poses, const double* drots, const double* dtrans,
                    const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, double* lin, double* loss_part,
-                   double* Hd, double* Ho, double* rhs, Gate gate, hipStream_t s);
+                   double* Hd, double* Ho, double* rhs, const double* red, const islam_pvgo_reproj* reproj, int link0, Gate gate,
+                   hipStream_t s);
 // islam_pvgo_shard_upsweep; state != nullptr: the damping is read from state[2] on the device
 int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double damping, const double* state, int N,
                         const int seg_len[2], int world, int rank, int node0, void* workspace, size_t workspace_bytes,
@@ -95,9 +101,11 @@ int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double 
 // islam_pvgo_shard_downsweep
 int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
                           size_t workspace_bytes, double* dx, int* flags, Gate gate, hipStream_t s);
-// islam_pvgo_trial on M links whose linearisation records are lin[c * lin_stride + k]
+// islam_pvgo_trial on M links whose linearisation records are lin[c * lin_stride + k]; reproj != nullptr: red_lin / red_trial =
+// the reductions at the linearisation point and at the trial point
 int trial_gated(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
                 const double* dtrans, const double* dvels, const double* dts, const double* lin, int lin_stride, int M,
-                double* nodes_t, double* vels_t, double* part, Gate gate, hipStream_t s);
+                double* nodes_t, double* vels_t, double* part, const double* red_lin, const double* red_trial,
+                const islam_pvgo_reproj* reproj, int link0, Gate gate, hipStream_t s);
 
 }  // namespace islam

@@ -283,9 +283,10 @@ class RcclComm:
 
 
 def run_chain_sharded(comm, init_nodes, init_vels, poses, drots, dtrans, dvels, dts, loss_weight, radius=1e4, seg_len=(0, 0), rank=None,
-                      world=None, allreduce_cb=None, params=None):
+                      world=None, allreduce_cb=None, params=None, reproj=None):
     """islam_pvgo_run_chain_sharded: the sharded LM loop inside the library.  ``comm``: an RcclComm (or None with world 1);
-    ``allreduce_cb``: a ctypes callback instead of RCCL (tests).  Returns (nodes, vels, result, bytes handed to the collectives)."""
+    ``allreduce_cb``: a ctypes callback instead of RCCL (tests); ``reproj``: the sparse
+    reprojection factor (ops.pvgo_reproj_struct), as in ops.pvgo_run_chain.  Returns (nodes, vels, result, bytes handed to the collectives)."""
     from . import ops
     from ._lib import PvgoResult, c_size_t, check, lib, ptr, stream_ptr
     dev = init_nodes.device
@@ -300,7 +301,10 @@ def run_chain_sharded(comm, init_nodes, init_vels, poses, drots, dtrans, dvels, 
     sbytes = lib().islam_pvgo_sharded_scratch_bytes(N, world)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     res, xb = PvgoResult(), ctypes.c_longlong(0)
-    common = [ptr(nodes), ptr(vels)] + [ptr(a) for a in args] + [N, ctypes.byref(prm), ptr(ws), c_size_t(nbytes), ptr(scratch), c_size_t(sbytes),
+    if reproj is not None:                      # ops.pvgo_reproj_struct over the WHOLE graph: one keypoint set per link
+        assert reproj._keep[0].shape[0] == N - 1
+    common = [ptr(nodes), ptr(vels)] + [ptr(a) for a in args] + [N, ctypes.byref(prm), ctypes.byref(reproj) if reproj is not None else None,
+                                                                 ptr(ws), c_size_t(nbytes), ptr(scratch), c_size_t(sbytes),
                                                                  ctypes.byref(res), ctypes.byref(xb), stream_ptr(dev)]
     if allreduce_cb is not None:
         check(lib().islam_pvgo_run_chain_sharded_cb(allreduce_cb, None, world, rank, *common))

@@ -51,7 +51,7 @@ def test_world_one_with_and_without_a_communicator(cuda, F):
     assert torch.equal(n2, n1) and torch.equal(v2, v1) and r2.trials == r1.trials
 
 
-def _run_ranks_as_threads(args, world, params=None):
+def _run_ranks_as_threads(args, world, params=None, reproj=None):
     """Every rank's C loop in its own thread and stream; the injected all-reduce copies each rank's buffer to the host, sums in
     rank order and writes the sum back."""
     from islam_amd import dist_pvgo
@@ -85,7 +85,8 @@ def _run_ranks_as_threads(args, world, params=None):
     def run(rank):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                outs[rank] = dist_pvgo.run_chain_sharded(None, *args, LW, rank=rank, world=world, allreduce_cb=cbs[rank], params=params)
+                outs[rank] = dist_pvgo.run_chain_sharded(None, *args, LW, rank=rank, world=world, allreduce_cb=cbs[rank], params=params,
+                                                            reproj=reproj)
         except Exception as e:                       # noqa: BLE001
             errs.append(e)
             barrier.abort()
@@ -175,3 +176,32 @@ def test_failed_solve_breaks_the_step_on_every_rank(cuda, world):
         torch.testing.assert_close(v, args[1], rtol=0, atol=0)
     good = [dist_pvgo.run_chain_sharded(None, *args, LW)] if world == 1 else _run_ranks_as_threads(args, world)      # reusable afterwards
     assert all(o[2].status == 0 for o in good)
+
+
+@pytest.mark.parametrize('world,F,K,compat', [(1, 65, 48, True), (2, 65, 48, True), (3, 129, 40, False), (4, 300, 64, True)])
+def test_reprojection_factor_in_the_sharded_loop(cuda, world, F, K, compat):
+    """The sparse reprojection factor (pvgo.py:53-61) couples consecutive nodes only, so it shards with the chain: every rank
+    reduces the keypoints of its own links (global link 0 keeps the reference's frozen first motion, on rank 0 only).  Same LM
+    trajectory as islam_pvgo_run_chain_reproj on one GPU ("absent from the sharded loop")."""
+    from islam_amd import dist_pvgo, ops
+    from tests.helpers import reproj_inputs
+    from oracle import reproj as orp
+    prob, tr = chain_problem(F)
+    T_IL = np.array([0.1, -0.05, 0.02, 0.5, -0.5, 0.5, -0.5])
+    inp = reproj_inputs(tr, K, T_IL)
+    ref = orp.SparseReprojection(**inp)
+    P3, tgt = ref.point3d, ref.target                                   # (M, K, 3) camera-frame keypoints, (M, K, 2) pixel targets
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=cuda)
+    st = ops.pvgo_reproj_struct(t(P3), t(tgt), [inp['fx'], inp['fy'], inp['cx'], inp['cy']], T_IL, (2.0 / K) ** 2, compat)
+    args = [t(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions', 'imu_drots', 'imu_dtrans', 'imu_dvels', 'dts')]
+    nodes, vels = args[0].clone(), args[1].clone()
+    res, _ = ops.pvgo_run_chain(nodes, vels, *args[2:], ops.pvgo_default_params(LW, radius=1e4), reproj=st)
+    n0, v0 = args[0].clone(), args[1].clone()
+    plain, _ = ops.pvgo_run_chain(n0, v0, *args[2:], ops.pvgo_default_params(LW, radius=1e4))
+    assert float((n0 - nodes).abs().max()) > 1e-4                        # the factor matters
+    outs = [dist_pvgo.run_chain_sharded(None, *args, LW, reproj=st)] if world == 1 else _run_ranks_as_threads(args, world, reproj=st)
+    for n, v, rr, xb in outs:
+        assert (rr.trials, rr.steps, rr.status) == (res.trials, res.steps, 0)
+        assert rr.loss == pytest.approx(res.loss, rel=1e-9)
+        torch.testing.assert_close(n, nodes, rtol=0, atol=1e-9)
+        torch.testing.assert_close(v, vels, rtol=0, atol=1e-9)

@@ -11,7 +11,7 @@ LW = (1, 0.1, 10, 0.1)
 
 
 @pytest.mark.parametrize('world,F,seg', [(1, 300, (0, 0)), (2, 300, (0, 0)), (4, 1000, (0, 0)), (8, 5001, (0, 0)), (3, 257, (5, 4)), (5, 5001, (0, 0)),
-                                         (2, 5001, (0, 0)), (8, 1000, (0, 0))])
+                                         (2, 5001, (0, 0)), (8, 1000, (0, 0)), (3, 65, (0, 0)), (4, 33, (0, 0))])      # the last two: exchange level 0
 def test_sharded_equals_single_gpu(cuda, world, F, seg):
     from islam_amd import dist_pvgo, ops
     prob, _ = chain_problem(F)
