@@ -90,6 +90,16 @@ int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C
  * intermediate torch.cat and without copying the up-sampled tensor into the next concatenation. */
 int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                          int align_corners, int ytot, int yoff, void* stream);
+/* y = add + resize(x) in one pass (hourglass.py:60-69 `up1 + up2(low3)`): the up-sampled value is rounded to bf16 before the add,
+ * like the two separate ops.  add, y: (B,Ho,Wo,C). */
+int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                        int align_corners, void* stream);
+/* MaxPool2d(2, 2) / F.max_pool2d(kernel_size=2) of a channels-last bf16 tensor (hourglass.py:52, StereoNet7.py:117-125), relu != 0:
+ * of relu(x) (the two commute); (B,H,W,C) -> (B,H/2,W/2,C), C a multiple of 8. */
+int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int relu, void* stream);
+/* AvgPool2d((k,k), stride=(k,k)) of a channels-last bf16 tensor (the SPP branches, submodule.py:103-122): fp32 accumulation, one
+ * rounding; (B,H,W,C) -> (B,H/k,W/k,C). */
+int islam_avgpool_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int k, void* stream);
 
 /* In-place epilogue of a bias-free convolution on a channels-last bf16 tensor: y <- act(bf16(y + bias[c]) [+ res]),
  * act = ReLU (relu != 0) or identity; res NULL or a tensor of y's shape.  One pass for the bias add, activation and residual

@@ -257,7 +257,8 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v 
 
 __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8,
                                                                         int Hi, int Wi, int Ho, int Wo, float sh, float sw,
-                                                                        int align, long long total, int yC8, int yoff8) {
+                                                                        int align, long long total, int yC8, int yoff8,
+                                                                        const uint4* __restrict__ add) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cg = (int)(i % C8);
@@ -291,13 +292,75 @@ __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const ui
     o.y = mix(a.y, bq.y, c.y, d.y);
     o.z = mix(a.z, bq.z, c.z, d.z);
     o.w = mix(a.w, bq.w, c.w, d.w);
+    if (add) {                                          // u + up(low): the up-sampled value is rounded to bf16 first, like the two ops
+        const uint4 u = add[opix * C8 + cg];
+        auto sum = [&](unsigned va, unsigned vb) { return pack_bf16(bf16_lo(va) + bf16_lo(vb), bf16_hi(va) + bf16_hi(vb)); };
+        o.x = sum(o.x, u.x); o.y = sum(o.y, u.y); o.z = sum(o.z, u.z); o.w = sum(o.w, u.w);
+    }
     y[opix * yC8 + yoff8 + cg] = o;                     // channels [8*yoff8, 8*yoff8 + C) of a (B,Ho,Wo,8*yC8) tensor
+}
+
+// 2x2 / stride-2 max pooling (floor mode), optionally of relu(x): relu and max commute
+__global__ __launch_bounds__(256) void maxpool2_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8, int Hi, int Wi,
+                                                                 int Ho, int Wo, int relu, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % C8);
+    long long p = i / C8;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const uint4* base = x + (((size_t)b * Hi + 2 * oy) * Wi + 2 * ox) * C8 + cg;
+    const uint4 a = base[0], bq = base[C8], c = base[(size_t)Wi * C8], d = base[(size_t)Wi * C8 + C8];
+    auto mx = [&](unsigned va, unsigned vb, unsigned vc, unsigned vd) {
+        float lo = fmaxf(fmaxf(bf16_lo(va), bf16_lo(vb)), fmaxf(bf16_lo(vc), bf16_lo(vd)));
+        float hi = fmaxf(fmaxf(bf16_hi(va), bf16_hi(vb)), fmaxf(bf16_hi(vc), bf16_hi(vd)));
+        if (relu) { lo = fmaxf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }
+        return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);      // exact: the maximum IS one of the bf16 inputs
+    };
+    uint4 o;
+    o.x = mx(a.x, bq.x, c.x, d.x);
+    o.y = mx(a.y, bq.y, c.y, d.y);
+    o.z = mx(a.z, bq.z, c.z, d.z);
+    o.w = mx(a.w, bq.w, c.w, d.w);
+    y[i] = o;
+}
+
+// k x k / stride-k average pooling (floor mode): fp32 accumulation in row-major order, one rounding at the end (as ATen's mean)
+__global__ __launch_bounds__(256) void block_mean_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8, int Hi, int Wi,
+                                                                   int Ho, int Wo, int k, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i % C8);
+    long long p = i / C8;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const uint4* base = x + (((size_t)b * Hi + (size_t)k * oy) * Wi + (size_t)k * ox) * C8 + cg;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int r = 0; r < k; ++r)
+        for (int q = 0; q < k; ++q) {
+            const uint4 v = base[((size_t)r * Wi + q) * C8];
+            acc[0] += bf16_lo(v.x); acc[1] += bf16_hi(v.x); acc[2] += bf16_lo(v.y); acc[3] += bf16_hi(v.y);
+            acc[4] += bf16_lo(v.z); acc[5] += bf16_hi(v.z); acc[6] += bf16_lo(v.w); acc[7] += bf16_hi(v.w);
+        }
+    const float inv = 1.0f / (float)(k * k);
+    uint4 o;
+    o.x = pack_bf16(acc[0] * inv, acc[1] * inv);
+    o.y = pack_bf16(acc[2] * inv, acc[3] * inv);
+    o.z = pack_bf16(acc[4] * inv, acc[5] * inv);
+    o.w = pack_bf16(acc[6] * inv, acc[7] * inv);
+    y[i] = o;
 }
 
 }  // namespace
 
-extern "C" int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                                                    int align_corners, int ytot, int yoff, void* stream) {
+static int resize_bilinear_launch(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                  int align_corners, int ytot, int yoff, void* stream) {
     if (B < 1 || C < 8 || (C & 7) || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1)
         return fail(ISLAM_EARG, "islam_resize_bilinear_nhwc_bf16: bad shape (C=%d must be a multiple of 8)", C);
     if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + C > ytot)
@@ -313,7 +376,42 @@ extern "C" int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t*
     const long long total = (long long)B * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(resize_bilinear_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, Hi, Wi, Ho, Wo, sh, sw, align_corners, total,
-                       ytot / 8, yoff / 8);
+                       ytot / 8, yoff / 8, reinterpret_cast<const uint4*>(add));
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+extern "C" int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                                    int align_corners, int ytot, int yoff, void* stream) {
+    return resize_bilinear_launch(x, nullptr, y, B, C, Hi, Wi, Ho, Wo, align_corners, ytot, yoff, stream);
+}
+
+// y = add + resize(x): the hourglass's `up1 + up2(low3)` (Network/PSM/hourglass.py:60-69) in one pass; add, y: (B,Ho,Wo,C)
+extern "C" int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi,
+                                                   int Ho, int Wo, int align_corners, void* stream) {
+    if (!add) return fail(ISLAM_EARG, "islam_resize_bilinear_add_nhwc_bf16: null addend");
+    return resize_bilinear_launch(x, add, y, B, C, Hi, Wi, Ho, Wo, align_corners, C, 0, stream);
+}
+
+// MaxPool2d(2, 2) / F.max_pool2d(kernel_size=2) of a channels-last bf16 tensor, optionally of relu(x) (StereoNet7.py:117-125
+// `pool(act(conv(x)))`, hourglass.py:52 pool1); (B,H,W,C) -> (B,H/2,W/2,C)
+extern "C" int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int relu, void* stream) {
+    if (B < 1 || C < 8 || (C & 7) || H < 2 || W < 2) return fail(ISLAM_EARG, "islam_maxpool2_nhwc_bf16: bad shape (C=%d, %dx%d)", C, H, W);
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool2_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, H, W, Ho, Wo, relu, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// AvgPool2d((k,k), stride=(k,k)) of a channels-last bf16 tensor (the SPP branches, submodule.py:103-122); (B,H,W,C) -> (B,H/k,W/k,C)
+extern "C" int islam_avgpool_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int k, void* stream) {
+    if (B < 1 || C < 8 || (C & 7) || k < 1 || H < k || W < k) return fail(ISLAM_EARG, "islam_avgpool_nhwc_bf16: bad shape (C=%d, %dx%d, k=%d)", C, H, W, k);
+    const int Ho = H / k, Wo = W / k;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(block_mean_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(y), C / 8, H, W, Ho, Wo, k, total);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

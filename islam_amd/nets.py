@@ -285,6 +285,8 @@ def _block_mean(x, k):
     """AvgPool2d((k, k), stride=(k, k)) (floor mode, no padding) as a reshape + mean: one pass over x."""
     B, C, H, W = x.shape
     h, w = H // k, W // k
+    if ops.fusable_nhwc_bf16(x, C) and h >= 1 and w >= 1:
+        return ops.avgpool(x, k)
     return x[:, :, :h * k, :w * k].reshape(B, C, h, k, w, k).mean((3, 5))
 
 
@@ -416,8 +418,12 @@ class Hourglass(nn.Module):
 
     def forward(self, x):
         u = self.up1(x)
-        low = self.low3(self.low2(self.pool1(u)))
-        # self.up2 = nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False); HIP kernel for bf16 channels-last
+        fused = ops.fusable_nhwc_bf16(u, u.shape[1])
+        low = self.low3(self.low2(ops.maxpool2(u) if fused else self.pool1(u)))
+        # self.up2 = nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False); HIP kernels for bf16 channels-last:
+        # pooling, and the up-sampling with the addition of u in the same pass
+        if fused and ops.fusable_nhwc_bf16(low, low.shape[1]) and (low.shape[2] * 2, low.shape[3] * 2) == tuple(u.shape[2:]):
+            return ops.resize_bilinear_add(low, u)
         return u + ops.resize_bilinear(low, (low.shape[2] * 2, low.shape[3] * 2), align_corners=False)
 
 
@@ -471,7 +477,9 @@ class StereoNet7(nn.Module):
         B, C2, H, W = x.shape
         f2 = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))         # left/right stacked along the batch
         half = F.interpolate(x, scale_factor=0.5, mode='bilinear')
-        act, pool = self.actfun, lambda t: F.max_pool2d(t, kernel_size=2)
+        act = self.actfun
+        pool = ops.maxpool2                                                   # F.max_pool2d(t, kernel_size=2); HIP kernel for bf16 channels-last
+        relu_pool = (lambda t: ops.maxpool2(t, relu=True)) if act is F.relu else (lambda t: pool(act(t)))      # pool(relu(t)) in one pass
         c0 = self.conv_c0
         cf = f2.shape[1]
         if HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f2, cf) and c0.weight.dtype == torch.bfloat16 and cf % 8 == 0:
@@ -496,8 +504,8 @@ class StereoNet7(nn.Module):
         cat1 = self.conv_c2_SSP(pool(self.conv_c2(cat0)))                     # 1/4, 128
         cat2 = pool(self.conv_c3(cat1))                                       # 1/8, 192
         cat3 = pool(self.conv_c4(cat2))                                       # 1/16, 256
-        cat4 = pool(act(self.conv_c5(cat3)))                                  # 1/32, 384
-        x = act(self.conv_c6_2(pool(act(self.conv_c6(cat4)))))                # 1/64, 512
+        cat4 = relu_pool(self.conv_c5(cat3))                                  # 1/32, 384
+        x = act(self.conv_c6_2(relu_pool(self.conv_c6(cat4))))                # 1/64, 512
         x = torch.cat((act(self.deconv_c7_2(x)), cat4), 1)
         x = torch.cat((act(self.deconv_c7(x)), cat3), 1)
         x = torch.cat((self.conv_c8(act(self.deconv_c8(x))), cat2), 1)

@@ -259,6 +259,36 @@ def resize_bilinear_into(x, out, coff, align_corners=False):
     return out
 
 
+def resize_bilinear_add(x, add, align_corners=False):
+    """add + F.interpolate(x, add's size, mode='bilinear') in one pass over channels-last bf16 tensors
+    (islam_resize_bilinear_add_nhwc_bf16: the hourglass's `up1 + up2(low)`)."""
+    B, C, Hi, Wi = x.shape
+    assert fusable_nhwc_bf16(x, C) and fusable_nhwc_bf16(add, C) and add.shape[:2] == x.shape[:2]
+    y = torch.empty_like(add)
+    check(lib().islam_resize_bilinear_add_nhwc_bf16(ptr(x), ptr(add), ptr(y), B, C, Hi, Wi, int(add.shape[2]), int(add.shape[3]),
+                                                    int(bool(align_corners)), stream_ptr(x.device)))
+    return y
+
+
+def maxpool2(x, relu=False):
+    """F.max_pool2d([relu](x), 2): islam_maxpool2_nhwc_bf16 for channels-last bf16 inference tensors, torch otherwise."""
+    if fusable_nhwc_bf16(x, x.shape[1]) and x.shape[2] >= 2 and x.shape[3] >= 2:
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        check(lib().islam_maxpool2_nhwc_bf16(ptr(x), ptr(y), B, C, H, W, int(bool(relu)), stream_ptr(x.device)))
+        return y
+    return torch.nn.functional.max_pool2d(torch.relu(x) if relu else x, kernel_size=2)
+
+
+def avgpool(x, k):
+    """AvgPool2d((k, k), stride=(k, k)) of a channels-last bf16 inference tensor (islam_avgpool_nhwc_bf16)."""
+    B, C, H, W = x.shape
+    assert fusable_nhwc_bf16(x, C) and H >= k and W >= k
+    y = torch.empty((B, C, H // k, W // k), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib().islam_avgpool_nhwc_bf16(ptr(x), ptr(y), B, C, H, W, int(k), stream_ptr(x.device)))
+    return y
+
+
 def fusable_nhwc_bf16(x, channels):
     """True for the tensors the channels-last bf16 epilogue / resize kernels take (frozen execution copies, no autograd)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and channels % 8 == 0 and not x.requires_grad

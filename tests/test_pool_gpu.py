@@ -1,0 +1,48 @@
+"""GPU tests of the small channels-last bf16 kernels around the stereo net's convolutions: 2x2 max pooling (optionally of
+relu(x)), k x k average pooling (the SPP branches) and the hourglass's up-sample + add -- against the torch ops they replace
+(Network/PSM/hourglass.py:52-69, submodule.py:103-122, StereoNet7.py:117-125)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(shape, cuda, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(cuda, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 56, 80), (3, 192, 14, 20), (1, 8, 7, 9), (2, 384, 2, 2)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_maxpool2_is_exact(cuda, shape, relu):
+    from islam_amd import ops
+    x = _cl(shape, cuda, 1)
+    y = ops.maxpool2(x, relu=relu)
+    ref = F.max_pool2d(F.relu(x) if relu else x, kernel_size=2)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, ref)                                   # a maximum of bf16 values is one of them: bit-exact
+
+
+@pytest.mark.parametrize('shape,k', [((2, 128, 112, 160), 8), ((2, 128, 14, 20), 2), ((1, 64, 17, 19), 2), ((2, 64, 64, 72), 64)])
+def test_avgpool_matches_fp32_pooling(cuda, shape, k):
+    from islam_amd import ops
+    x = _cl(shape, cuda, 2)
+    y = ops.avgpool(x, k)
+    ref = F.avg_pool2d(x.float(), k, k)
+    assert y.shape == ref.shape
+    # fp32 accumulation, one rounding to bf16: within half a bf16 ulp (2^-9 relative) of the fp32 mean + summation-order noise
+    err = (y.float() - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) <= 1e-6
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 28, 40), (1, 192, 7, 10), (3, 128, 1, 3)])
+def test_upsample_add_equals_the_two_ops(cuda, shape):
+    from islam_amd import ops
+    B, C, h, w = shape
+    low, u = _cl(shape, cuda, 3), _cl((B, C, 2 * h, 2 * w), cuda, 4)
+    y = ops.resize_bilinear_add(low, u)
+    two = u + ops.resize_bilinear(low, (2 * h, 2 * w), align_corners=False)
+    assert torch.equal(y, two)                                   # same roundings: bf16 after the interpolation, bf16 after the add
+    ref = u.float() + F.interpolate(low.float(), scale_factor=2, mode='bilinear', align_corners=False)
+    assert float((y.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
