@@ -24,9 +24,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "../../include/islam_hip.h"
 #include "common.h"
+
+// scripts/conv_probe.sh builds two experiment variants of this file (never the product library): ISLAM_CONV_PROBE=1 skips the
+// multiply phase (what the staging pipeline costs on its own), =2 skips fetch + staging (what the multiply phase costs on its own)
+#ifndef ISLAM_CONV_PROBE
+#define ISLAM_CONV_PROBE 0
+#endif
 
 namespace {
 
@@ -36,9 +44,26 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // a REAL vector value: copies of HIP's uint4 struct become memcpy
+                                                                 // intrinsics that keep a register array in scratch
 
-constexpr int TW = 32, KC = 32, PS = 40;             // PS: bf16 elements per LDS pixel / weight row (32 + 8 pad = 80 bytes)
+constexpr int TW = 32;                               // (KC: input channels per staged chunk, template parameter; PS = KC + 8: bf16
+                                                     // elements per LDS pixel / weight row -- 80- or 48-byte stride, conflict-free 16-byte reads)
 constexpr int THREADS = 256;                         // 4 waves x ROWS pixel rows: tile 32 x 4*ROWS pixels
+
+// Compile-time loop: the index is an integral_constant, so the register arrays it indexes are split into scalars as soon as the
+// lambda is inlined.  With `#pragma unroll` the indices only become constant after the (late) unroll pass; an array that is
+// still indexed dynamically when SROA runs is left to AMDGPUPromoteAlloca, which keeps anything above 128 bytes in SCRATCH -- the
+// prefetched weights (nine uint4) then go through scratch_store right after their global loads, which forces a vmcnt wait
+// in front of the multiply phase and serialises the two (found in the ISA; 194 -> see DESIGN.md).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {      // round-to-nearest-even, one v_cvt_pk_bf16_f32
     const f32x2_t v = {a, b};
@@ -56,7 +81,7 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // once and reuses each for up to K vertical taps, and a weight operand for all its rows.  ROWS = 4 with TN = 32 (0.75 LDS
 // operand reads per MFMA, two workgroups per CU), ROWS = 2 with TN = 64 (0.83; the 4-row variant needs 95 KB of LDS and
 // leaves one wave per SIMD with nothing to hide its latencies behind: measured slower).
-template <int TN, int KS, int ROWS>
+template <int TN, int KS, int ROWS, int KC>
 __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
@@ -64,6 +89,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                                                              int CoutP, int relu, int tiles_x, int tiles, int in_relu) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     constexpr int TH = 4 * ROWS, P = KS / 2, IH = TH + 2 * P, IW = TW + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
+    constexpr int PS = KC + 8, OPP = KC / 8;                 // LDS row stride (elements), 16-byte octets per pixel / weight row
     constexpr int NIN = (NPIX * (KC / 8) + THREADS - 1) / THREADS;       // 16-byte items of the halo tile per thread
     constexpr int NWT = (TAPS * TN * (KC / 8) + THREADS - 1) / THREADS;  // 16-byte items of the weight taps per thread
     constexpr int NT = TN / 32, NR = ROWS + KS - 1;
@@ -85,51 +111,56 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             for (int i = 0; i < 16; ++i) acc[a][p][i] = 0.0f;
 
     // staging map, the same for every chunk: item -> (halo pixel, channel octet); outside the image or past Cin -> zero.
-    // THREADS is a multiple of 4, so a thread's items all carry the same channel octet.
-    const int coct = 8 * (tid & 3);
+    // THREADS is a multiple of OPP, so a thread's items all carry the same channel octet.
+    const int coct = 8 * (tid & (OPP - 1));
     int goff[NIN], loff[NIN];
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) {
+    static_for<0, NIN>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
         const int it = tid + k * THREADS;
         goff[k] = -1; loff[k] = DUMMY;
         if (it < NPIX * (KC / 8)) {
-            const int pix = it >> 2;
+            const int pix = it / OPP;
             const int yy = pix / IW, xx = pix - yy * IW;
             const int gy = ho0 - P + yy, gx = wo0 - P + xx;
             loff[k] = pix * PS + coct;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * W + gx) * Cin + coct;
         }
-    }
+    });
     int woff[NWT], wlds[NWT];
-#pragma unroll
-    for (int k = 0; k < NWT; ++k) {
-        const int it = tid + k * THREADS;                    // ((tap*TN + n)*4 + octet)
+    static_for<0, NWT>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const int it = tid + k * THREADS;                    // ((tap*TN + n)*OPP + octet)
         woff[k] = 0; wlds[k] = DUMMY;
         if (it < TAPS * TN * (KC / 8)) {
-            const int row = it >> 2, tap = row / TN, n = row - tap * TN;
+            const int row = it / OPP, tap = row / TN, n = row - tap * TN;
             woff[k] = (tap * CoutP + n0 + n) * CinP + coct;
             wlds[k] = row * PS + coct;
         }
-    }
-    uint4 pre[NIN], prew[NWT];
+    });
+    uint4 pre[NIN];
+    u32x4 prew[NWT];
+    float4 as0 = {1, 1, 1, 1}, as1 = as0, ah0 = {0, 0, 0, 0}, ah1 = ah0;     // the chunk's BatchNorm scale / shift, fetched with it
     auto fetch = [&](int c0) {
         const bool cok = c0 + coct < Cin;
-#pragma unroll
-        for (int k = 0; k < NIN; ++k)
+        if (in_affine && cok) {                              // previous layer's BatchNorm (batch statistics) + ReLU on load
+            const float* sc = in_affine + c0 + coct;
+            as0 = *reinterpret_cast<const float4*>(sc); as1 = *reinterpret_cast<const float4*>(sc + 4);
+            ah0 = *reinterpret_cast<const float4*>(sc + Cin); ah1 = *reinterpret_cast<const float4*>(sc + Cin + 4);
+        }
+        static_for<0, NIN>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
             pre[k] = *reinterpret_cast<const uint4*>(xb + ((cok && goff[k] >= 0) ? (size_t)goff[k] + c0 : (size_t)0));   // masked: any valid address
-#pragma unroll
-        for (int k = 0; k < NWT; ++k) prew[k] = *reinterpret_cast<const uint4*>(wp + (size_t)woff[k] + c0);
+        });
+        static_for<0, NWT>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            prew[k] = *reinterpret_cast<const u32x4*>(wp + (size_t)woff[k] + c0);
+        });
     };
     auto stage = [&](int c0) {
         const bool cok = c0 + coct < Cin;
-        float4 s0 = {1, 1, 1, 1}, s1 = s0, h0 = {0, 0, 0, 0}, h1 = h0;
-        if (in_affine && cok) {                              // previous layer's BatchNorm (batch statistics) + ReLU on load
-            const float* sc = in_affine + c0 + coct;
-            s0 = *reinterpret_cast<const float4*>(sc); s1 = *reinterpret_cast<const float4*>(sc + 4);
-            h0 = *reinterpret_cast<const float4*>(sc + Cin); h1 = *reinterpret_cast<const float4*>(sc + Cin + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) {
+        const float4 s0 = as0, s1 = as1, h0 = ah0, h1 = ah1;
+        static_for<0, NIN>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
             uint4 v = pre[k];
             if (in_affine) {
                 v.x = relu2(pack2(fmaf(lo16(v.x), s0.x, h0.x), fmaf(hi16(v.x), s0.y, h0.y)));
@@ -140,9 +171,11 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             else if (in_relu) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }     // ReLU of the input on load
             if (!(cok && goff[k] >= 0)) v = make_uint4(0, 0, 0, 0);      // zero padding of the NORMALISED activation
             *reinterpret_cast<uint4*>(lin + loff[k]) = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NWT; ++k) *reinterpret_cast<uint4*>(lw + wlds[k]) = prew[k];
+        });
+        static_for<0, NWT>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            *reinterpret_cast<u32x4*>(lw + wlds[k]) = prew[k];
+        });
     };
 
     const int kg = lane >> 5, li = lane & 31;
@@ -151,11 +184,18 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     fetch(0);
     for (int c0 = 0; c0 < CinP; c0 += KC) {
         __syncthreads();                                     // the previous chunk's operand reads are done
+#if ISLAM_CONV_PROBE != 2
         stage(c0);
+#endif
         __syncthreads();
+#if ISLAM_CONV_PROBE != 2
         if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
+#endif
+#if ISLAM_CONV_PROBE == 1
+        continue;
+#endif
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KC / 16; ++ks)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 bf[NR];
@@ -182,7 +222,13 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     constexpr int TS = TN + 8;                               // bf16 elements per pixel row of the staging tile (16-byte pad)
     constexpr int OCT = TN / 8, PPT = TW * TH * OCT / THREADS;     // channel octets per pixel, (pixel, octet) items per thread
     unsigned short* tl = lds;                                // [TW*TH][TS]
-    float* red = reinterpret_cast<float*>(lds + (size_t)TW * TH * TS);     // [THREADS][17]
+    float* red = reinterpret_cast<float*>(lds);              // [THREADS][17], over the staging tile once every thread has read its items
+    f32x4 bv[NT * 4];                                        // the lane's bias values, all requested before the first one is used
+    static_for<0, NT * 4>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const int nl = (i / 4) * 32 + 8 * (i % 4) + 4 * kg;
+        bv[i] = (bias && n0 + nl < Cout) ? *reinterpret_cast<const f32x4*>(bias + n0 + nl) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    });
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             for (int g = 0; g < 4; ++g) {
                 const int nl = a * 32 + 8 * g + 4 * kg;
                 float v0 = acc[a][p][4 * g], v1 = acc[a][p][4 * g + 1], v2 = acc[a][p][4 * g + 2], v3 = acc[a][p][4 * g + 3];
-                if (bias && n0 + nl < Cout) { const float* bp = bias + n0 + nl; v0 += bp[0]; v1 += bp[1]; v2 += bp[2]; v3 += bp[3]; }
+                if (bias) { const f32x4 bq = bv[a * 4 + g]; v0 += bq.x; v1 += bq.y; v2 += bq.z; v3 += bq.w; }
                 *reinterpret_cast<uint2*>(tl + (size_t)((ROWS * wave + p) * TW + li) * TS + nl) = make_uint2(pack2(v0, v1), pack2(v2, v3));
             }
     __syncthreads();
@@ -202,6 +248,15 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     float sm[8], sq[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sm[i] = 0.0f; sq[i] = 0.0f; }
+    u32x4 rv[PPT];                                           // the residual values of all the thread's items, requested at once
+    if (rb)                                                  // (one load -> wait -> store per item is PPT dependent round trips)
+        static_for<0, PPT>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const int px = (tid + k * THREADS) / OCT;
+            const int ho = ho0 + px / TW, wo = wo0 + (px % TW);
+            const bool ok = ho < H && wo < W && n < Cout;
+            rv[k] = *reinterpret_cast<const u32x4*>(rb + (ok ? ((size_t)ho * W + wo) * Cout + n : (size_t)0));
+        });
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int px = (tid + k * THREADS) / OCT;            // THREADS is a multiple of OCT: the octet is the same for every k
@@ -219,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
         }
         const size_t o = ((size_t)ho * W + wo) * Cout + n;
         if (rb) {
-            const uint4 r = *reinterpret_cast<const uint4*>(rb + o);
+            const u32x4 r = rv[k];
             v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
             v.y = pack2(lo16(v.y) + lo16(r.y), hi16(v.y) + hi16(r.y));
             v.z = pack2(lo16(v.z) + lo16(r.z), hi16(v.z) + hi16(r.z));
@@ -232,6 +287,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
         // per-workgroup sums of the (bf16-rounded, as nn.BatchNorm2d sees them) outputs over the tile's valid pixels, per
         // channel, in a fixed order: every thread holds the sums of its octet over its pixels, one lane per (channel, moment)
         // adds the THREADS / OCT threads of that octet in thread order
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) { red[tid * 17 + i] = sm[i]; red[tid * 17 + 8 + i] = sq[i]; }
         __syncthreads();
@@ -256,23 +312,23 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
     }
 }
 
-template <int TN, int KS, int ROWS>
+template <int TN, int KS, int ROWS, int KC>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s) {
-    constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS;
+    constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS, PS = KC + 8;
     const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
-    const size_t epi_lds = (size_t)TW * TH * (TN + 8) * sizeof(unsigned short) + (size_t)THREADS * 17 * sizeof(float);
+    const size_t epi_lds = std::max((size_t)TW * TH * (TN + 8) * sizeof(unsigned short), (size_t)THREADS * 17 * sizeof(float));
     const size_t lds = std::max(conv_lds, epi_lds);
     int dev = 0;
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[dev] = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y * B, (Cout + TN - 1) / TN);      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
-    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP, H, W,
+    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP, H, W,
                        Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
@@ -306,13 +362,16 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = Cout > 32;
+    // input channels per staged chunk: 32.  ISLAM_CONV_KC=16 selects 16-channel chunks (44 KB of LDS: three workgroups per CU
+    // instead of two, but twice the barriers) -- measured 10-20 % slower on every shape of the stereo net, kept for A/B runs
+    static const bool kc16 = [] { const char* e = std::getenv("ISLAM_CONV_KC"); return e && e[0] == '1'; }();
     int rc;
-    if (ksize == 3)
-        rc = wide ? launch<64, 3, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s)
-                  : launch<32, 3, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
-    else
-        rc = wide ? launch<64, 1, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s)
-                  : launch<32, 1, 4>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
+#define ISLAM_CONV_LAUNCH(TN_, KS_, ROWS_)                                                                                              \
+    (kc16 ? launch<TN_, KS_, ROWS_, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s) \
+          : launch<TN_, KS_, ROWS_, 32>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s))
+    if (ksize == 3) rc = wide ? ISLAM_CONV_LAUNCH(64, 3, 2) : ISLAM_CONV_LAUNCH(32, 3, 4);
+    else rc = wide ? ISLAM_CONV_LAUNCH(64, 1, 2) : ISLAM_CONV_LAUNCH(32, 1, 4);
+#undef ISLAM_CONV_LAUNCH
     if (rc != ISLAM_OK) return rc;
     if (stats) {
         const int nblk = islam_conv_nhwc_stat_blocks(B, H, W, Cout);
