@@ -176,6 +176,16 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
     // epilogue: D row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel x) = lane&31
     float* yb = y + ((size_t)b * ytot + coff) * Ho * Wo;
     const int wo = wo0 + li;
+    // the lane's bias values, all requested before the first one is used (index clamped: branch-free, so the loads are not
+    // serialised behind the stores -- one load -> wait -> store per register was 16 * NT dependent round trips)
+    float bb[NT][16];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int n = n0 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            bb[a][reg] = bias ? bias[min(n, Cout - 1)] : 0.0f;
+        }
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
             for (int reg = 0; reg < 16; ++reg) {
                 const int n = n0 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
                 if (n < Cout) {
-                    float v = acc[a][p][reg] + (bias ? bias[n] : 0.0f);
+                    float v = acc[a][p][reg] + bb[a][reg];
                     v = v >= 0.0f ? v : v * slope;
                     yb[((size_t)n * Ho + ho) * Wo + wo] = v;
                 }

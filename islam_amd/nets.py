@@ -193,7 +193,7 @@ def _convbn(cin, cout, k, stride, pad, dilation):
 import os as _os
 
 HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '2'))
-HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '96'))
+HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 
 
 def _hip_conv_ok(conv, x, fused_1x1=False):
