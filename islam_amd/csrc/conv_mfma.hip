@@ -22,6 +22,12 @@
 #include "../../include/islam_hip.h"
 #include "common.h"
 
+// scripts/conv_probe.sh builds experiment variants of this file (never the product library): ISLAM_CONV_PROBE=1 skips the multiply
+// phase of conv3x3_mfma_kernel, =2 skips fetch + staging
+#ifndef ISLAM_CONV_PROBE
+#define ISLAM_CONV_PROBE 0
+#endif
+
 namespace {
 
 using namespace islam;
@@ -156,9 +162,16 @@ __global__ __launch_bounds__(THREADS) void conv3x3_mfma_kernel(const float* __re
     fetch(0);
     for (int c0 = 0; c0 < CinP; c0 += KC) {
         __syncthreads();                                     // the previous chunk's operand reads are done
+#if ISLAM_CONV_PROBE != 2
         stage();
+#endif
         __syncthreads();
+#if ISLAM_CONV_PROBE != 2
         if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
+#endif
+#if ISLAM_CONV_PROBE == 1
+        continue;
+#endif
         // software pipeline over the nine taps: the operands of tap t+1 are requested before the MFMAs of tap t issue
         bf16x8 bq[2][2], aq[2][NT];
         load_tap(0, bq[0], aq[0]);
