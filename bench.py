@@ -163,10 +163,10 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
     el_seq, tm = run(False)
     el, _ = run(True)      # the frozen flow / disparity forward of batch k+1 overlaps the IMU / PVGO / backward of batch k
     return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo',
-            'nets': 'stereo net: bf16 NHWC execution copy -- 3x3 (<= 96 channels) and hourglass 1x1 convolutions on the HIP implicit-GEMM '
-                    'kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load), the 128-channel ones on MIOpen (77 % of the '
-                    'FLOPs); flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, fp32 accumulate and activations); pose head '
-                    'fp32 (trainable)',
+            'nets': 'stereo net: bf16 NHWC execution copy -- every stride-1 3x3 convolution and the hourglass 1x1 convolutions on the HIP '
+                    'implicit-GEMM kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load; pooling / up-sample+add / SPP '
+                    'kernels), strided and transposed convolutions on MIOpen; flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, '
+                    'fp32 accumulate and activations); pose head fp32 (trainable)',
             'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
             'ms_per_batch': el / steps * 1e3,
             'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',

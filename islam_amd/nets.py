@@ -184,8 +184,9 @@ def _convbn(cin, cout, k, stride, pad, dilation):
 # Which convolutions of the frozen stereo net's bf16 channels-last execution copy run on islam_conv_nhwc_bf16 (hand-written
 # implicit GEMM, round-to-nearest-even, BatchNorm statistics from the epilogue, the producer's BatchNorm + ReLU applied on load,
 # bias / residual / ReLU fused) instead of MIOpen.  MIOpen's kernels for the 32- and 64-channel 3x3 shapes TRUNCATE the fp32
-# accumulator to bf16 (scripts/calib/bf16_rounding_probe.py) and are memory-bound there, so the fusion wins; its 128-channel
-# kernels round to nearest and reach ~780 TF/s, where the hand-written kernel reaches ~500: those stay on MIOpen.
+# accumulator to bf16 (scripts/calib/bf16_rounding_probe.py); the hand-written kernel rounds to nearest even, delivers the
+# BatchNorm statistics from its epilogue and is faster than MIOpen's pick on every 3x3 shape of the net but one (64->128: 69 vs
+# 65 us; 128->128: 108 vs 123 us, 352->128: 1.00 vs 1.20 ms), so every stride-1 3x3 convolution runs on it (HIP_CONV_MAX_C).
 # ISLAM_HIP_CONV: 0 = all MIOpen (round-1 path), 1 = 3x3 up to HIP_CONV_MAX_C channels, 2 (default) = also the 1x1 convolutions of
 # the hourglass modules with their fused epilogue.  MIOpen's 1x1 kernels are ~25 % faster (12.40 vs 12.48 ms per forward), but some
 # of them truncate as well: against the reference-generated vectors level 1 leaves rms 3.6e-2 / bias 2.6e-2, level 2 rms 1.2e-2 /
