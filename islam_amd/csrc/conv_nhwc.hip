@@ -344,7 +344,9 @@ size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
 }
 
 static int tile_h(int Cout) { return Cout > 32 ? 8 : 16; }
-int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout) { return ((W + TW - 1) / TW) * ((H + tile_h(Cout) - 1) / tile_h(Cout)) * B; }
+static int tiles_of(int B, int H, int W, int th) { return ((W + TW - 1) / TW) * ((H + th - 1) / th) * B; }
+// rows of the per-workgroup partial sums a caller must provide room for (the smallest tile any kernel variant uses for this Cout)
+int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout) { return tiles_of(B, H, W, Cout > 32 ? 8 : 16); }
 
 size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout) {
     return (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout + (size_t)RED_BLOCKS * 2 * Cout;
@@ -374,8 +376,9 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 #undef ISLAM_CONV_LAUNCH
     if (rc != ISLAM_OK) return rc;
     if (stats) {
-        const int nblk = islam_conv_nhwc_stat_blocks(B, H, W, Cout);
-        hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout, stats + (size_t)nblk * 2 * Cout);
+        const int nblk = tiles_of(B, H, W, tile_h(Cout));                   // workgroups along x of the launch above
+        hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout,
+                           stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
     }
     return ISLAM_OK;
