@@ -135,6 +135,19 @@ int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout);
 size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout);
 int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
                          uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
+/* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d + LeakyReLU(0.1),
+ * :237-292 the blocks) on the channels-last kernel.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) MIRROR of the block's
+ * concatenation buffer; the result goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what correlation /
+ * warp / transposed convolutions / flow heads read -- and, when ymir != NULL, as bf16 into channels [moff, moff + Cout) of the
+ * (B,H,W,mtot) mirror for the next convolution.  Same arithmetic as islam_conv3x3_mfma (operands rounded to bf16 nearest-even,
+ * fp32 accumulation, bias, LeakyReLU(slope); slope 1: none).  wpacked: islam_conv_nhwc_packed_elems(Cin, Cout, 3) elements with
+ * zero rows for padded input channels.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8. */
+int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
+                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, float slope, void* stream);
+/* fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W) -> bf16 (nearest-even) channels [doff, doff + C) of dst (B,H,W,dtot);
+ * channels up to the next multiple of 8 are zeroed.  Fills the mirror with what the non-convolution producers wrote. */
+int islam_nchw_f32_to_nhwc_bf16(const float* src, int stot, int soff, uint16_t* dst, int dtot, int doff, int B, int C, int H, int W,
+                                void* stream);
 /* The two halves of islam_bn_train_nhwc_bf16 for a producer that delivers the statistics itself: folded = [256][2][C] partial
  * sums, count = pixels; scale_shift (2*C floats) = [weight*rsqrt(var+eps) | bias - mean*scale]; running statistics updated like
  * nn.BatchNorm2d (NULL: skipped).  C <= 256.  Apply: y = act( bf16(x*scale[c] + shift[c]) [+ res] ), C a multiple of 8. */

@@ -81,12 +81,19 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // once and reuses each for up to K vertical taps, and a weight operand for all its rows.  ROWS = 4 with TN = 32 (0.75 LDS
 // operand reads per MFMA, two workgroups per CU), ROWS = 2 with TN = 64 (0.83; the 4-row variant needs 95 KB of LDS and
 // leaves one wave per SIMD with nothing to hide its latencies behind: measured slower).
-template <int TN, int KS, int ROWS, int KC>
+// Channel slices and the flow net's second output.  x: channels [xoff, xoff + Cin) of a (B,H,W,xs) tensor; y: channels
+// [yoff, yoff + Cout) of a (B,H,W,ys) tensor (or nullptr: no channels-last output).  FLOW (template): the epilogue applies
+// LeakyReLU(slope) to the fp32 accumulator + bias and ALSO stores it as fp32 NCHW into channels [coff, coff + Cout) of y32
+// (B, ytot, H, W) -- PWC-Net's DenseNet buffer, whose non-convolution consumers (correlation, warp, transposed convolutions,
+// flow heads) read fp32 NCHW, while the next convolution reads the bf16 channels-last mirror this kernel writes beside it.
+struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; };
+
+template <int TN, int KS, int ROWS, int KC, bool FLOW>
 __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
                                                              float* __restrict__ partial, int Cin, int CinP, int H, int W, int Cout,
-                                                             int CoutP, int relu, int tiles_x, int tiles, int in_relu) {
+                                                             int CoutP, int relu, int tiles_x, int tiles, int in_relu, Slices sl) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     constexpr int TH = 4 * ROWS, P = KS / 2, IH = TH + 2 * P, IW = TW + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
     constexpr int PS = KC + 8, OPP = KC / 8;                 // LDS row stride (elements), 16-byte octets per pixel / weight row
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wo0 = tx * TW, ho0 = ty * TH, n0 = blockIdx.y * TN;
-    const unsigned short* xb = x + (size_t)b * H * W * Cin;
+    const unsigned short* xb = x + (size_t)b * H * W * sl.xs + sl.xoff;
 
     f32x16 acc[NT][ROWS];
 #pragma unroll
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             const int yy = pix / IW, xx = pix - yy * IW;
             const int gy = ho0 - P + yy, gx = wo0 - P + xx;
             loff[k] = pix * PS + coct;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * W + gx) * Cin + coct;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * W + gx) * sl.xs + coct;
         }
     });
     int woff[NWT], wlds[NWT];
@@ -239,10 +246,21 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 const int nl = a * 32 + 8 * g + 4 * kg;
                 float v0 = acc[a][p][4 * g], v1 = acc[a][p][4 * g + 1], v2 = acc[a][p][4 * g + 2], v3 = acc[a][p][4 * g + 3];
                 if (bias) { const f32x4 bq = bv[a * 4 + g]; v0 += bq.x; v1 += bq.y; v2 += bq.z; v3 += bq.w; }
+                if constexpr (FLOW) {
+                    v0 = v0 >= 0.0f ? v0 : v0 * sl.slope; v1 = v1 >= 0.0f ? v1 : v1 * sl.slope;
+                    v2 = v2 >= 0.0f ? v2 : v2 * sl.slope; v3 = v3 >= 0.0f ? v3 : v3 * sl.slope;
+                    const int ho = ho0 + ROWS * wave + p, wo = wo0 + li, nn = n0 + nl;      // lanes = 32 consecutive pixels of a row:
+                    if (ho < H && wo < W && nn < Cout) {                                    // 128-byte segments of a channel plane
+                        float* yp = sl.y32 + (((size_t)b * sl.ytot + sl.coff + nn) * H + ho) * W + wo;
+                        const size_t plane = (size_t)H * W;
+                        yp[0] = v0; yp[plane] = v1; yp[2 * plane] = v2; yp[3 * plane] = v3;
+                    }
+                }
                 *reinterpret_cast<uint2*>(tl + (size_t)((ROWS * wave + p) * TW + li) * TS + nl) = make_uint2(pack2(v0, v1), pack2(v2, v3));
             }
+    if (FLOW && !y) return;                                  // (uniform) no channels-last mirror asked for
     __syncthreads();
-    unsigned short* yb = y + (size_t)b * H * W * Cout;
+    unsigned short* yb = y + (size_t)b * H * W * sl.ys + sl.yoff;
     const unsigned short* rb = res ? res + (size_t)b * H * W * Cout : nullptr;
     const int oct = tid % OCT, n = n0 + 8 * oct;
     float sm[8], sq[8];
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 sm[2 * i + 1] += hi; sq[2 * i + 1] = fmaf(hi, hi, sq[2 * i + 1]);
             }
         }
-        const size_t o = ((size_t)ho * W + wo) * Cout + n;
+        const size_t o = ((size_t)ho * W + wo) * sl.ys + n;
         if (rb) {
             const u32x4 r = rv[k];
             v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
@@ -300,6 +318,26 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     }
 }
 
+// tile of 64 pixels x 32 channels: reads are 256-byte rows of a channel plane, writes 64 bytes per pixel (16 bytes per lane)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int stot, int soff, unsigned short* __restrict__ dst,
+                                                           int dtot, int doff, int C, int Cpad, long long pixels) {
+    __shared__ unsigned short t[64][40];                     // [pixel][32 channels + pad]: 80-byte rows
+    const int b = blockIdx.z, c0 = blockIdx.y * 32;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;  // 4 channel groups of 8
+    const float* sp = src + ((size_t)b * stot + soff + c0) * pixels + p0 + px;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cq * 8 + j;
+        const float v = (c0 + c < C && p0 + px < pixels) ? sp[(size_t)c * pixels] : 0.0f;
+        t[px][c] = (unsigned short)(pack2(v, 0.0f) & 0xffffu);
+    }
+    __syncthreads();
+    const int q = threadIdx.x >> 2, oct = threadIdx.x & 3;   // pixel, channel octet
+    if (p0 + q < pixels && c0 + 8 * oct < Cpad)
+        *reinterpret_cast<uint4*>(dst + ((size_t)b * pixels + p0 + q) * dtot + doff + c0 + 8 * oct) = *reinterpret_cast<const uint4*>(&t[q][8 * oct]);
+}
+
 constexpr int RED_BLOCKS = 256;         // = BN_BLOCKS of conv_mfma.hip: the layout bn_finalize_kernel reads
 
 // partial[nblk][2][C] -> out[RED_BLOCKS][2][C], block j adds the slices j, j + RED_BLOCKS, ... in that order (deterministic)
@@ -312,9 +350,11 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
     }
 }
 
-template <int TN, int KS, int ROWS, int KC>
+template <int TN, int KS, int ROWS, int KC, bool FLOW = false>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
-           unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s) {
+           unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
+           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f}) {
+    if (sl.xs == 0) { sl.xs = Cin; sl.ys = Cout; }           // dense tensors
     constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS, PS = KC + 8;
     const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
     const size_t epi_lds = std::max((size_t)TW * TH * (TN + 8) * sizeof(unsigned short), (size_t)THREADS * 17 * sizeof(float));
@@ -323,13 +363,13 @@ int launch(const unsigned short* x, const unsigned short* wp, const float* in_af
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[dev] = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y * B, (Cout + TN - 1) / TN);      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
-    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP, H, W,
-                       Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu);
+    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP,
+                       H, W, Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu, sl);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -381,6 +421,44 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
                            stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
     }
+    return ISLAM_OK;
+}
+
+
+// 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d + LeakyReLU(0.1),
+// :237-292) on the channels-last kernel above.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) mirror of the block's
+// concatenation buffer; the output goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what the
+// correlation / warp / transposed-convolution / flow-head consumers read -- and, when ymir is given, as bf16 into channels
+// [moff, moff + Cout) of the (B,H,W,mtot) mirror for the next convolution.  Same arithmetic as islam_conv3x3_mfma (bf16
+// operands rounded to nearest even, fp32 accumulation, bias, LeakyReLU(slope); slope 1: no activation), at 16-byte loads and
+// 32-channel chunks instead of fp32 loads converted on the fly.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8.
+int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
+                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, float slope, void* stream) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7) || !y32)
+        return fail(ISLAM_EARG, "islam_conv_nhwc_flow: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+    if ((xtot & 7) || (xoff & 7) || xoff < 0 || xoff + Cin > xtot) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: input slice %d+%d of %d", xoff, Cin, xtot);
+    if (coff < 0 || coff + Cout > ytot) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: output slice %d+%d of %d", coff, Cout, ytot);
+    if (ymir && ((mtot & 7) || (moff & 7) || moff < 0 || moff + Cout > mtot)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: mirror slice %d+%d of %d", moff, Cout, mtot);
+    if ((size_t)B * H * W * std::max(std::max(xtot, mtot), ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope};
+    hipStream_t s = (hipStream_t)stream;
+    return Cout > 32 ? launch<64, 3, 2, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B, Cin, CinP, H, W, Cout, CoutP, 0, 0, s, sl)
+                     : launch<32, 3, 4, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B, Cin, CinP, H, W, Cout, CoutP, 0, 0, s, sl);
+}
+
+// fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W)  ->  bf16 channels [doff, doff + C) of dst (B,H,W,dtot), rounded to
+// nearest even; channels [doff + C, doff + Cpad) are zeroed (Cpad = C rounded up to 8).  Fills the mirror's slice of what the
+// correlation / warp / transposed convolutions produced.  doff, dtot: multiples of 8.
+int islam_nchw_f32_to_nhwc_bf16(const float* src, int stot, int soff, uint16_t* dst, int dtot, int doff, int B, int C, int H, int W,
+                                void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1 || soff < 0 || soff + C > stot) return fail(ISLAM_EARG, "islam_nchw_f32_to_nhwc_bf16: source slice %d+%d of %d", soff, C, stot);
+    const int Cpad = (C + 7) / 8 * 8;
+    if ((dtot & 7) || (doff & 7) || doff < 0 || doff + Cpad > dtot) return fail(ISLAM_EARG, "islam_nchw_f32_to_nhwc_bf16: destination slice %d+%d of %d", doff, Cpad, dtot);
+    const long long pixels = (long long)H * W;
+    dim3 grid((unsigned)((pixels + 63) / 64), (Cpad + 31) / 32, B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, stot, soff, dst, dtot, doff, C, Cpad, pixels);
+    ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 

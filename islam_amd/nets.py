@@ -131,9 +131,27 @@ class PWCDCNet(nn.Module):
         out[:, coff:coff + y.shape[1]].copy_(y)
         return out
 
+    def _packed_flow(self, name, cin_eff):
+        """bf16 tap-major weights of a 3x3 conv for islam_conv_nhwc_flow, with zero rows for the mirror's padding channels."""
+        mod = getattr(self, name)
+        conv = mod[0] if isinstance(mod, nn.Sequential) else mod
+        cache = self.__dict__.setdefault('_flow_cache', {})
+        key = (conv.weight._version, conv.weight.data_ptr(), cin_eff)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            w = conv.weight.detach()
+            if cin_eff > w.shape[1]:
+                w = F.pad(w, (0, 0, 0, 0, 0, cin_eff - w.shape[1]))
+            hit = cache[name] = (key, ops.pack_conv_nhwc_weight(w.to(torch.bfloat16)), conv.bias.detach().float().contiguous(), conv)
+        return hit[1], hit[2], hit[3]
+
     def _dense_mfma(self, l, pieces):
         """The DenseNet block of one level without torch.cat: the buffer holds [conv4 | conv3 | conv2 | conv1 | conv0 |
-        input] (PWCNet.py:237-292 prepend the newest features); every layer reads a suffix and writes the slice before it."""
+        input] (PWCNet.py:237-292 prepend the newest features); every layer reads a suffix and writes the slice before it.
+        FLOW_NHWC: the convolutions read a bf16 channels-last MIRROR of the buffer (islam_conv_nhwc_flow: 16-byte loads, 32-channel
+        chunks) and write both the fp32 NCHW slice -- for the correlation / warp / transposed-convolution / flow-head consumers --
+        and the mirror's slice for the next convolution.  The values a convolution multiplies are the same either way: the fp32
+        path rounds its operands to bf16 when it stages them.  Returns (buffer, mirror or None)."""
         od = sum(p.shape[1] for p in pieces)
         B, _, H, W = pieces[0].shape
         tot = od + sum(self.DENSE)
@@ -143,10 +161,19 @@ class PWCDCNet(nn.Module):
             buf[:, o:o + p.shape[1]].copy_(p)
             o += p.shape[1]
         off = tot - od
+        if FLOW_NHWC and off % 8 == 0 and all(w % 8 == 0 for w in self.DENSE):
+            totp = off + (od + 7) // 8 * 8
+            mir = torch.empty((B, totp, H, W), dtype=torch.bfloat16, device=buf.device, memory_format=torch.channels_last)
+            ops.nchw_to_nhwc_mirror(buf, off, od, mir, off)            # the block's input (correlation, features, flow, up-features)
+            for i, w in enumerate(self.DENSE):
+                packed, bias, conv = self._packed_flow('conv%d_%d' % (l, i), totp - off)
+                ops.conv_nhwc_flow(mir, off, totp - off, packed, bias, buf, off - w, w, 0.1, ymir=mir, moff=off - w)
+                off -= w
+            return buf, mir
         for i, w in enumerate(self.DENSE):
             self._c('conv%d_%d' % (l, i), buf, out=buf, coff=off - w, xoff=off)
             off -= w
-        return buf
+        return buf, None
 
     def forward_mfma(self, x):
         """Same network as forward(), no autograd: both images go through the pyramid as one batch, convolutions through
@@ -160,7 +187,7 @@ class PWCDCNet(nn.Module):
             feats.append(f)
         p1, p2 = [t[:B] for t in feats], [t[B:] for t in feats]
         lrelu = lambda t: F.leaky_relu(t, 0.1)
-        x = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
+        x, mir = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
         flows = {}
         for l in range(5, 1, -1):
             flows[l + 1] = self._c('predict_flow%d' % (l + 1), x)
@@ -168,9 +195,15 @@ class PWCDCNet(nn.Module):
             up_feat = getattr(self, 'upfeat%d' % (l + 1))(x)
             a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
-            x = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
+            x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
         flow2 = self._c('predict_flow2', x)
-        x = self._c('dc_conv4', self._c('dc_conv3', self._c('dc_conv2', self._c('dc_conv1', x))))
+        if mir is not None:                               # dc_conv1 (565 -> 128, the largest convolution of the net) reads the mirror
+            packed, bias, conv = self._packed_flow('dc_conv1', mir.shape[1])
+            d1 = torch.empty((x.shape[0], conv.out_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+            d1 = ops.conv_nhwc_flow(mir, 0, mir.shape[1], packed, bias, d1, 0, conv.out_channels, 0.1)
+        else:
+            d1 = self._c('dc_conv1', x)
+        x = self._c('dc_conv4', self._c('dc_conv3', self._c('dc_conv2', d1)))
         flow2 = flow2 + self._c('dc_conv7', self._c('dc_conv6', self._c('dc_conv5', x)))
         return (flow2, flows[3], flows[4], flows[5], flows[6]), (None, None, None, None, None)
 
@@ -194,6 +227,8 @@ def _convbn(cin, cout, k, stride, pad, dilation):
 import os as _os
 
 HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '2'))
+# the flow net's DenseNet convolutions on the channels-last kernel through a bf16 mirror of the concatenation buffer (0: fp32 NCHW kernel)
+FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 
 

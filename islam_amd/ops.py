@@ -259,6 +259,32 @@ def resize_bilinear_into(x, out, coff, align_corners=False):
     return out
 
 
+def nchw_to_nhwc_mirror(src, soff, C, dst, doff):
+    """fp32 NCHW channels [soff, soff+C) of ``src`` -> bf16 channels [doff, doff+C) of the channels-last tensor ``dst`` (a
+    (B, Ctot, H, W) bf16 tensor in torch.channels_last memory format); the channels up to the next multiple of 8 are zeroed."""
+    B, stot, H, W = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.dtype == torch.bfloat16
+    assert dst.is_contiguous(memory_format=torch.channels_last) and dst.shape[0] == B and tuple(dst.shape[2:]) == (H, W)
+    check(lib().islam_nchw_f32_to_nhwc_bf16(ptr(src), stot, int(soff), ptr(dst), int(dst.shape[1]), int(doff), B, int(C), H, W,
+                                            stream_ptr(src.device)))
+    return dst
+
+
+def conv_nhwc_flow(xm, xoff, cin, packed, bias, y32, coff, cout, slope, ymir=None, moff=0):
+    """islam_conv_nhwc_flow: act(conv3x3(xm[:, xoff:xoff+cin]) + bias) -> y32[:, coff:coff+cout] (fp32 NCHW) and, if given,
+    ymir[:, moff:moff+cout] (bf16 channels-last mirror).  xm / ymir: bf16 tensors in torch.channels_last memory format."""
+    B, xtot, H, W = xm.shape
+    assert xm.dtype == torch.bfloat16 and xm.is_contiguous(memory_format=torch.channels_last)
+    assert y32.dtype == torch.float32 and y32.is_contiguous() and tuple(y32.shape[2:]) == (H, W) and y32.shape[0] == B
+    assert packed.dtype == torch.bfloat16 and packed.numel() == lib().islam_conv_nhwc_packed_elems(int(cin), int(cout), 3)
+    if ymir is not None:
+        assert ymir.dtype == torch.bfloat16 and ymir.is_contiguous(memory_format=torch.channels_last) and ymir.shape[0] == B
+    check(lib().islam_conv_nhwc_flow(ptr(xm), int(xtot), int(xoff), int(cin), ptr(packed), ptr(bias), ptr(y32), int(y32.shape[1]), int(coff),
+                                     ptr(ymir), int(ymir.shape[1]) if ymir is not None else 0, int(moff), B, H, W, int(cout),
+                                     c_float(slope), stream_ptr(xm.device)))
+    return y32
+
+
 def resize_bilinear_add(x, add, align_corners=False):
     """add + F.interpolate(x, add's size, mode='bilinear') in one pass over channels-last bf16 tensors
     (islam_resize_bilinear_add_nhwc_bf16: the hourglass's `up1 + up2(low)`)."""

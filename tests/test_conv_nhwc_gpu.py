@@ -119,3 +119,61 @@ def test_relu_of_the_input_on_load(cuda):
     assert torch.equal(y, want)
     ref = F.relu((F.conv2d(F.relu(x).float(), w.float(), None) + b.view(1, -1, 1, 1)).to(torch.bfloat16))
     assert float((y != ref).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('B,H,W,pieces,dense', [(2, 28, 40, (81, 64, 2, 2), (128, 128, 96, 64, 32)), (1, 7, 10, (81,), (128, 96, 32)),
+                                               (2, 33, 45, (81, 32, 2, 2), (64, 32))])
+def test_flow_block_on_the_channels_last_mirror(cuda, B, H, W, pieces, dense):
+    """islam_conv_nhwc_flow + islam_nchw_f32_to_nhwc_bf16: a DenseNet block of the flow net ([newest | ... | input] buffer, every
+    layer reads a suffix and writes the slice before it) through the bf16 mirror equals the same block on the fp32 NCHW kernel
+    (islam_conv3x3_mfma: identical bf16 operands, different summation order) and a torch reference on bf16-rounded operands."""
+    import torch.nn.functional as F
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(5)
+    od, nd = sum(pieces), sum(dense)
+    tot = od + nd
+    base = torch.randn(B, od, H, W, generator=g).to(cuda)
+    ws = []
+    cin = od
+    for c in dense:
+        ws.append(((torch.randn(c, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda), (torch.randn(c, generator=g) * 0.1).to(cuda)))
+        cin += c
+    # fp32 NCHW kernel
+    buf0 = torch.zeros(B, tot, H, W, device=cuda)
+    buf0[:, nd:] = base
+    off = nd
+    for (w, b), c in zip(ws, dense):
+        ops.conv3x3_mfma(buf0, ops.pack_conv3x3_weight(w), b, c, 1, 1, 0.1, buf0, off - c, off)
+        off -= c
+    # mirror path
+    buf1 = torch.zeros(B, tot, H, W, device=cuda)
+    buf1[:, nd:] = base
+    totp = nd + (od + 7) // 8 * 8
+    mir = torch.full((B, totp, H, W), float('nan'), dtype=torch.bfloat16, device=cuda).contiguous(memory_format=torch.channels_last)
+    ops.nchw_to_nhwc_mirror(buf1, nd, od, mir, nd)
+    assert torch.equal(mir[:, nd:nd + od].float(), base.to(torch.bfloat16).float())               # rounded to nearest even
+    assert float(mir[:, nd + od:].float().abs().max()) == 0.0 if totp > tot else True             # padding channels zeroed
+    off = nd
+    for (w, b), c in zip(ws, dense):
+        wp = ops.pack_conv_nhwc_weight(F.pad(w, (0, 0, 0, 0, 0, totp - off - w.shape[1])).to(torch.bfloat16))
+        ops.conv_nhwc_flow(mir, off, totp - off, wp, b, buf1, off - c, c, 0.1, ymir=mir, moff=off - c)
+        off -= c
+    scale = float(buf0.abs().max())
+    assert float((buf1 - buf0).abs().max()) <= 2e-3 * scale              # bf16 re-rounding of slightly different fp32 sums downstream
+    assert torch.equal(mir[:, :tot].float(), buf1.to(torch.bfloat16).float())                     # the mirror IS the rounded buffer
+    # torch reference on the operands the kernels see: bf16-rounded activations and weights, fp32 accumulation
+    ref = torch.zeros(B, tot, H, W, device=cuda)
+    ref[:, nd:] = base
+    off = nd
+    for (w, b), c in zip(ws, dense):
+        y = F.conv2d(ref[:, off:].to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), b.double(), padding=1)
+        ref[:, off - c:off] = F.leaky_relu(y, 0.1).float()
+        off -= c
+    assert float((buf1 - ref).abs().max()) <= 2e-3 * scale
+    # without a mirror output (dc_conv1): fp32 only, slope 1 = no activation
+    w, b = ws[0]
+    out = torch.empty(B, dense[0], H, W, device=cuda)
+    wp = ops.pack_conv_nhwc_weight(F.pad(w, (0, 0, 0, 0, 0, totp - nd - w.shape[1])).to(torch.bfloat16))
+    ops.conv_nhwc_flow(mir, nd, totp - nd, wp, b, out, 0, dense[0], 1.0)
+    y = F.conv2d(base.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), b.double(), padding=1).float()
+    assert float((out - y).abs().max()) <= 1e-4 * float(y.abs().max())
