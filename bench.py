@@ -166,7 +166,8 @@ def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
             'nets': 'stereo net: bf16 NHWC execution copy -- every stride-1 3x3 convolution and the hourglass 1x1 convolutions on the HIP '
                     'implicit-GEMM kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load; pooling / up-sample+add / SPP '
                     'kernels), strided and transposed convolutions on MIOpen; flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, '
-                    'fp32 accumulate and activations); pose head fp32 (trainable)',
+                    'fp32 accumulate; DenseNet blocks on the channels-last kernel through a bf16 mirror of the fp32 buffer); pose head '
+                    'fp32 (trainable)',
             'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
             'ms_per_batch': el / steps * 1e3,
             'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
