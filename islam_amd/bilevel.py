@@ -99,7 +99,7 @@ class BilevelLoop:
 
         loss_bp = torch.cat((self.rot_w * rot_loss, self.trans_w * trans_loss))                # train.py:280
         if loss_bp.requires_grad:
-            loss_bp.backward(torch.ones_like(loss_bp))
+            self._accumulate_gradients(loss_bp)
         sync(); t4 = time.perf_counter()
 
         self.current_idx += bs
@@ -109,6 +109,26 @@ class BilevelLoop:
         for k, v in zip(('vo', 'imu', 'pgo', 'opt'), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             self.timing[k] += v
         return float(loss_bp.detach().sum())
+
+    def _accumulate_gradients(self, loss_bp):
+        """loss_bp.backward(ones) (train.py:282-283) for the parameters the two optimizers own: the gradients of this batch are
+        taken with torch.autograd.grad and added to .grad with ONE multi-tensor add instead of one AccumulateGrad launch per
+        parameter (the optimizer steps once per epoch, so every batch but the first accumulates: ~110 tiny launches per batch).
+        Same arithmetic: grad <- grad + g in fp32."""
+        params = [p for opt in (self.optimizer, self.imu_optimizer) if opt is not None
+                  for grp in opt.param_groups for p in grp['params'] if p.requires_grad]
+        grads = torch.autograd.grad(loss_bp, params, torch.ones_like(loss_bp), allow_unused=True)
+        acc, new = [], []
+        for p, g in zip(params, grads):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g.detach().clone()          # (a graphed backward hands out static buffers: never keep them)
+            else:
+                acc.append(p.grad)
+                new.append(g.detach())
+        if acc:
+            torch._foreach_add_(acc, new)
 
     def snapshot(self, trainroot, epoch):
         """train.py:51-61: the seven text files of an epoch directory (the de-facto output contract)."""
