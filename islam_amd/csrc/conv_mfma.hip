@@ -533,14 +533,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const uint4* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+constexpr int FIN_THREADS = 1024;     // bn_finalize_kernel: one workgroup; 1024 / C slices of the partial blocks, each a short chain of loads
+
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                                           const float* __restrict__ weight, const float* __restrict__ bias,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ num_batches, double momentum, double eps,
                                                           float* __restrict__ scale_shift) {
-    // 256 threads = (256 / C) slices of the partial blocks x C channels (C <= 256); slices are combined in slice order
-    __shared__ double ls[256], lq[256];
-    const int nsl = 256 / C, c = threadIdx.x % C, sl = threadIdx.x / C;
+    // FIN_THREADS threads = (FIN_THREADS / C) slices of the partial blocks x C channels (C <= 256); slices are combined in slice
+    // order (deterministic).  With 256 threads a 32-channel layer walked 32 blocks per slice: 9 us for a 16 KB reduction.
+    __shared__ double ls[FIN_THREADS], lq[FIN_THREADS];
+    const int nsl = FIN_THREADS / C, c = threadIdx.x % C, sl = threadIdx.x / C;
     double s = 0.0, q = 0.0;
     if (sl < nsl) {
         const int per = (nblk + nsl - 1) / nsl, b0 = sl * per, b1 = min(nblk, b0 + per);
@@ -621,7 +624,7 @@ extern "C" int islam_bn_train_nhwc_bf16(const uint16_t* x, uint16_t* y, const ui
     float* partial = scratch;
     float* scale_shift = scratch + (size_t)BN_BLOCKS * 2 * C;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const uint4*>(x), C8, pixels, partial);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, C, (double)pixels, weight, bias, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, partial, nblk, C, (double)pixels, weight, bias, running_mean,
                        running_var, num_batches_tracked, momentum, eps, scale_shift);
     const long long total = pixels * C8;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4*>(x),
@@ -637,7 +640,7 @@ extern "C" int islam_bn_finalize(const float* folded, double count, const float*
                                  float* running_var, long long* num_batches_tracked, double momentum, double eps, int C,
                                  float* scale_shift, void* stream) {
     if (count < 1 || C < 1 || C > 256) return fail(ISLAM_EARG, "islam_bn_finalize: C=%d (1..256)", C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, folded, BN_BLOCKS, C, count, weight, bias,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, (hipStream_t)stream, folded, BN_BLOCKS, C, count, weight, bias,
                        running_mean, running_var, num_batches_tracked, momentum, eps, scale_shift);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
