@@ -1714,6 +1714,13 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     PROBE_WALL(pr, 410);
 }
 
+// state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
+__global__ __launch_bounds__(64) void control_init_kernel(double* __restrict__ st, int* __restrict__ flags, double radius, double down) {
+    const int t = threadIdx.x;
+    if (t < 16) st[t] = t == 2 ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
+    if (t < 4) flags[t] = 0;
+}
+
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
                                                             double* __restrict__ st, int* flags) {
     double s = 0.0;
@@ -2713,13 +2720,10 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     hs_all[15] = 0.0;
     hs_all[31] = 0.0;
 
-    double init[16] = {0};
-    init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
-    init[3] = prm->radius;
-    init[4] = prm->down;
-    init[14] = 1.0;                // run-ahead epoch
-    ISLAM_HIP_CHECK(hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, s));
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));       // flags[0] solver error, flags[2] ticket
+    const double damping0 = 1.0 / prm->radius;               // TrustRegion: damping = 1/radius
+    // device state and flags (flags[0] solver error, flags[2] ticket) initialised by a one-wave kernel: a host->device copy of a
+    // stack array stalls the host for a staging round trip at the start of every run_pvgo
+    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
     unsigned* ticket = reinterpret_cast<unsigned*>(w.flags + 2);
     TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
                 prm->max_steps, prm->patience, prm->decreasing};
@@ -2766,7 +2770,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
 
     IterCfg A{0, nodes, vels, w.nodes_t, w.vels_t};       // the iteration whose verdict is awaited
     int steps = 0, trials = 0, status = ISLAM_OK;
-    double loss = 0.0, damping = init[2];
+    double loss = 0.0, damping = damping0;
     double epoch = 1.0;
     enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);

@@ -106,6 +106,12 @@ __global__ void decide_kernel(const double* __restrict__ msg, double* __restrict
     decide(msg, st, flags, tr, report, seq, nt, vt, halo, halo_row, threadIdx.x);
 }
 
+// state <- [damping = 1 / radius (TrustRegion), radius, down, run-ahead epoch 1], everything else zero
+__global__ void state_init_kernel(double* __restrict__ st, double radius, double down) {
+    const int t = threadIdx.x;
+    if (t < 16) st[t] = t == 2 ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
+}
+
 // the loss of the very first optimizer.step() (summed over the ranks in msg[0])
 __global__ void begin_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags) {
     if (threadIdx.x != 0) return;
@@ -246,12 +252,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     volatile double* hs_all = host_state;
     hs_all[15] = 0.0;
     hs_all[31] = 0.0;
-    double init[16] = {0};
-    init[2] = 1.0 / prm->radius;   // TrustRegion: damping = 1/radius
-    init[3] = prm->radius;
-    init[4] = prm->down;
-    init[14] = 1.0;                // run-ahead epoch
-    ISLAM_HIP_CHECK(hipMemcpyAsync(state, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, s, state, prm->radius, prm->down);     // (no host->device copy: see pvgo.hip)
     ISLAM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));     // product rows of other ranks' segments read as zero
     ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * 351 * (size_t)sh.Pxl, s));
@@ -305,7 +306,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
 
     IterCfg A{nl, vl, nt, vt};            // the iteration whose verdict is awaited
     int steps = 0, trials = 0, status = ISLAM_OK;
-    double loss = 0.0, damping = init[2], epoch = 1.0;
+    double loss = 0.0, damping = 1.0 / prm->radius, epoch = 1.0;
     if ((rc = enqueue_iter(A, 1.0, epoch, false)) != ISLAM_OK) return rc;
     for (;;) {
         const double seq = (double)(trials + 1);
