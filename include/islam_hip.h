@@ -141,9 +141,11 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
  * warp / transposed convolutions / flow heads read -- and, when ymir != NULL, as bf16 into channels [moff, moff + Cout) of the
  * (B,H,W,mtot) mirror for the next convolution.  Same arithmetic as islam_conv3x3_mfma (operands rounded to bf16 nearest-even,
  * fp32 accumulation, bias, LeakyReLU(slope); slope 1: none).  wpacked: islam_conv_nhwc_packed_elems(Cin, Cout, 3) elements with
- * zero rows for padded input channels.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8. */
+ * zero rows for padded input channels.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8.  y32 or ymir may be NULL (not both).
+ * dilation d > 1 (the context layers dc_conv2-5): evaluated as d*d dense convolutions on the sub-grids (a::d, c::d) of the image;
+ * H and W must be multiples of d. */
 int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
-                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, float slope, void* stream);
+                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, int dilation, float slope, void* stream);
 /* fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W) -> bf16 (nearest-even) channels [doff, doff + C) of dst (B,H,W,dtot);
  * channels up to the next multiple of 8 are zeroed.  Fills the mirror with what the non-convolution producers wrote. */
 int islam_nchw_f32_to_nhwc_bf16(const float* src, int stot, int soff, uint16_t* dst, int dtot, int doff, int B, int C, int H, int W,

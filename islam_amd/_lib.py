@@ -52,7 +52,7 @@ SIGNATURES = {
     'islam_conv3x3_mfma': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_float, c_void_p]),
     'islam_resize_bilinear_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'islam_conv_nhwc_flow': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
-                                     c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                     c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'islam_nchw_f32_to_nhwc_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'islam_resize_bilinear_add_nhwc_bf16': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     'islam_maxpool2_nhwc_bf16': (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),

@@ -86,7 +86,10 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // LeakyReLU(slope) to the fp32 accumulator + bias and ALSO stores it as fp32 NCHW into channels [coff, coff + Cout) of y32
 // (B, ytot, H, W) -- PWC-Net's DenseNet buffer, whose non-convolution consumers (correlation, warp, transposed convolutions,
 // flow heads) read fp32 NCHW, while the next convolution reads the bf16 channels-last mirror this kernel writes beside it.
-struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; };
+// Dilation d > 1 (the flow net's context layers): a 3x3 convolution with dilation d is d*d independent dense 3x3 convolutions on the
+// sub-grids (a::d, c::d) of the image, so the kernel runs on B*d*d "images" of (H, W) = (Hf/d, Wf/d) pixels whose neighbours are
+// d pixels apart in memory (Hf, Wf must be multiples of d); Wf = full row length in pixels.
+struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; };
 
 template <int TN, int KS, int ROWS, int KC, bool FLOW>
 __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
@@ -107,7 +110,10 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wo0 = tx * TW, ho0 = ty * TH, n0 = blockIdx.y * TN;
-    const unsigned short* xb = x + (size_t)b * H * W * sl.xs + sl.xoff;
+    // image b = (batch index, sub-grid row a, sub-grid column c); pixel (gy, gx) of it is full-resolution pixel (gy*d + a, gx*d + c)
+    const int dd = sl.d * sl.d, bb = b / dd, sga = (b - bb * dd) / sl.d, sgc = b - bb * dd - sga * sl.d;
+    const size_t img0 = ((size_t)(bb * H * sl.d + sga)) * sl.Wf + sgc;          // first pixel of the image, in full-resolution pixels
+    const unsigned short* xb = x + img0 * sl.xs + sl.xoff;
 
     f32x16 acc[NT][ROWS];
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             const int yy = pix / IW, xx = pix - yy * IW;
             const int gy = ho0 - P + yy, gx = wo0 - P + xx;
             loff[k] = pix * PS + coct;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * W + gx) * sl.xs + coct;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * sl.Wf + gx) * sl.d * sl.xs + coct;
         }
     });
     int woff[NWT], wlds[NWT];
@@ -250,9 +256,9 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                     v0 = v0 >= 0.0f ? v0 : v0 * sl.slope; v1 = v1 >= 0.0f ? v1 : v1 * sl.slope;
                     v2 = v2 >= 0.0f ? v2 : v2 * sl.slope; v3 = v3 >= 0.0f ? v3 : v3 * sl.slope;
                     const int ho = ho0 + ROWS * wave + p, wo = wo0 + li, nn = n0 + nl;      // lanes = 32 consecutive pixels of a row:
-                    if (ho < H && wo < W && nn < Cout) {                                    // 128-byte segments of a channel plane
-                        float* yp = sl.y32 + (((size_t)b * sl.ytot + sl.coff + nn) * H + ho) * W + wo;
-                        const size_t plane = (size_t)H * W;
+                    if (sl.y32 && ho < H && wo < W && nn < Cout) {                          // 128-byte segments of a channel plane (d = 1)
+                        const size_t plane = (size_t)H * sl.d * sl.Wf;
+                        float* yp = sl.y32 + ((size_t)bb * sl.ytot + sl.coff + nn) * plane + ((size_t)(ho * sl.d + sga)) * sl.Wf + wo * sl.d + sgc;
                         yp[0] = v0; yp[plane] = v1; yp[2 * plane] = v2; yp[3 * plane] = v3;
                     }
                 }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             }
     if (FLOW && !y) return;                                  // (uniform) no channels-last mirror asked for
     __syncthreads();
-    unsigned short* yb = y + (size_t)b * H * W * sl.ys + sl.yoff;
+    unsigned short* yb = y + img0 * sl.ys + sl.yoff;
     const unsigned short* rb = res ? res + (size_t)b * H * W * Cout : nullptr;
     const int oct = tid % OCT, n = n0 + 8 * oct;
     float sm[8], sq[8];
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 sm[2 * i + 1] += hi; sq[2 * i + 1] = fmaf(hi, hi, sq[2 * i + 1]);
             }
         }
-        const size_t o = ((size_t)ho * W + wo) * sl.ys + n;
+        const size_t o = ((size_t)ho * sl.Wf + wo) * sl.d * sl.ys + n;
         if (rb) {
             const u32x4 r = rv[k];
             v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
@@ -353,8 +359,9 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
 template <int TN, int KS, int ROWS, int KC, bool FLOW = false>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
-           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f}) {
+           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0}) {
     if (sl.xs == 0) { sl.xs = Cin; sl.ys = Cout; }           // dense tensors
+    if (sl.Wf == 0) sl.Wf = W;
     constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS, PS = KC + 8;
     const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
     const size_t epi_lds = std::max((size_t)TW * TH * (TN + 8) * sizeof(unsigned short), (size_t)THREADS * 17 * sizeof(float));
@@ -431,20 +438,25 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 // correlation / warp / transposed-convolution / flow-head consumers read -- and, when ymir is given, as bf16 into channels
 // [moff, moff + Cout) of the (B,H,W,mtot) mirror for the next convolution.  Same arithmetic as islam_conv3x3_mfma (bf16
 // operands rounded to nearest even, fp32 accumulation, bias, LeakyReLU(slope); slope 1: no activation), at 16-byte loads and
-// 32-channel chunks instead of fp32 loads converted on the fly.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8.
+// 32-channel chunks instead of fp32 loads converted on the fly.  Cin, Cout, xtot, xoff, mtot, moff: multiples of 8.  y32 or ymir may
+// be NULL (not both).  dilation d > 1: d*d dense convolutions on the sub-grids of the image (H, W multiples of d).
 int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
-                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, float slope, void* stream) {
-    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7) || !y32)
-        return fail(ISLAM_EARG, "islam_conv_nhwc_flow: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+                         int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, int dilation, float slope,
+                         void* stream) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7) || (!y32 && !ymir))
+        return fail(ISLAM_EARG, "islam_conv_nhwc_flow: bad shape (Cin=%d, Cout=%d must be multiples of 8; one output at least)", Cin, Cout);
+    if (dilation < 1 || H % dilation || W % dilation)
+        return fail(ISLAM_EARG, "islam_conv_nhwc_flow: dilation %d must divide the image size %dx%d", dilation, H, W);
     if ((xtot & 7) || (xoff & 7) || xoff < 0 || xoff + Cin > xtot) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: input slice %d+%d of %d", xoff, Cin, xtot);
-    if (coff < 0 || coff + Cout > ytot) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: output slice %d+%d of %d", coff, Cout, ytot);
+    if (y32 && (coff < 0 || coff + Cout > ytot)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: output slice %d+%d of %d", coff, Cout, ytot);
     if (ymir && ((mtot & 7) || (moff & 7) || moff < 0 || moff + Cout > mtot)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: mirror slice %d+%d of %d", moff, Cout, mtot);
     if ((size_t)B * H * W * std::max(std::max(xtot, mtot), ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: tensor too large for 32-bit offsets");
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
-    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope};
+    const int d = dilation;
+    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W};
     hipStream_t s = (hipStream_t)stream;
-    return Cout > 32 ? launch<64, 3, 2, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B, Cin, CinP, H, W, Cout, CoutP, 0, 0, s, sl)
-                     : launch<32, 3, 4, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B, Cin, CinP, H, W, Cout, CoutP, 0, 0, s, sl);
+    return Cout > 32 ? launch<64, 3, 2, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl)
+                     : launch<32, 3, 4, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl);
 }
 
 // fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W)  ->  bf16 channels [doff, doff + C) of dst (B,H,W,dtot), rounded to

@@ -197,6 +197,23 @@ class PWCDCNet(nn.Module):
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
             x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
         flow2 = self._c('predict_flow2', x)
+        Hc, Wc = x.shape[2], x.shape[3]
+        if mir is not None and all(Hc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0 and Wc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0
+                                   for i in range(1, 7)):
+            # the context network on the channels-last kernel, bf16 between its layers (what the next layer's operands are rounded
+            # to anyway); a dilated layer runs as d*d dense convolutions on the sub-grids of the map (islam_conv_nhwc_flow)
+            cur, cin = mir, mir.shape[1]
+            for i in range(1, 7):
+                packed, bias, conv = self._packed_flow('dc_conv%d' % i, cin)
+                co = conv.out_channels
+                if i < 6:
+                    out = torch.empty((x.shape[0], co, Hc, Wc), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+                    ops.conv_nhwc_flow(cur, 0, cin, packed, bias, None, 0, co, 0.1, ymir=out, moff=0, dilation=conv.dilation[0])
+                else:
+                    out = torch.empty((x.shape[0], co, Hc, Wc), dtype=torch.float32, device=x.device)
+                    ops.conv_nhwc_flow(cur, 0, cin, packed, bias, out, 0, co, 0.1, dilation=conv.dilation[0])
+                cur, cin = out, co
+            return (flow2 + self._c('dc_conv7', cur), flows[3], flows[4], flows[5], flows[6]), (None, None, None, None, None)
         if mir is not None:                               # dc_conv1 (565 -> 128, the largest convolution of the net) reads the mirror
             packed, bias, conv = self._packed_flow('dc_conv1', mir.shape[1])
             d1 = torch.empty((x.shape[0], conv.out_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)

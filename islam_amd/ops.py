@@ -270,19 +270,23 @@ def nchw_to_nhwc_mirror(src, soff, C, dst, doff):
     return dst
 
 
-def conv_nhwc_flow(xm, xoff, cin, packed, bias, y32, coff, cout, slope, ymir=None, moff=0):
-    """islam_conv_nhwc_flow: act(conv3x3(xm[:, xoff:xoff+cin]) + bias) -> y32[:, coff:coff+cout] (fp32 NCHW) and, if given,
-    ymir[:, moff:moff+cout] (bf16 channels-last mirror).  xm / ymir: bf16 tensors in torch.channels_last memory format."""
+def conv_nhwc_flow(xm, xoff, cin, packed, bias, y32, coff, cout, slope, ymir=None, moff=0, dilation=1):
+    """islam_conv_nhwc_flow: act(conv3x3(xm[:, xoff:xoff+cin], dilation) + bias) -> y32[:, coff:coff+cout] (fp32 NCHW, may be None)
+    and / or ymir[:, moff:moff+cout] (bf16 channels-last mirror).  xm / ymir: bf16 tensors in torch.channels_last memory format."""
     B, xtot, H, W = xm.shape
     assert xm.dtype == torch.bfloat16 and xm.is_contiguous(memory_format=torch.channels_last)
-    assert y32.dtype == torch.float32 and y32.is_contiguous() and tuple(y32.shape[2:]) == (H, W) and y32.shape[0] == B
+    assert y32 is not None or ymir is not None
+    if y32 is not None:
+        assert y32.dtype == torch.float32 and y32.is_contiguous() and tuple(y32.shape[2:]) == (H, W) and y32.shape[0] == B
     assert packed.dtype == torch.bfloat16 and packed.numel() == lib().islam_conv_nhwc_packed_elems(int(cin), int(cout), 3)
     if ymir is not None:
         assert ymir.dtype == torch.bfloat16 and ymir.is_contiguous(memory_format=torch.channels_last) and ymir.shape[0] == B
-    check(lib().islam_conv_nhwc_flow(ptr(xm), int(xtot), int(xoff), int(cin), ptr(packed), ptr(bias), ptr(y32), int(y32.shape[1]), int(coff),
-                                     ptr(ymir), int(ymir.shape[1]) if ymir is not None else 0, int(moff), B, H, W, int(cout),
+        assert tuple(ymir.shape[2:]) == (H, W)
+    check(lib().islam_conv_nhwc_flow(ptr(xm), int(xtot), int(xoff), int(cin), ptr(packed), ptr(bias), ptr(y32),
+                                     int(y32.shape[1]) if y32 is not None else 0, int(coff), ptr(ymir),
+                                     int(ymir.shape[1]) if ymir is not None else 0, int(moff), B, H, W, int(cout), int(dilation),
                                      c_float(slope), stream_ptr(xm.device)))
-    return y32
+    return y32 if y32 is not None else ymir
 
 
 def resize_bilinear_add(x, add, align_corners=False):

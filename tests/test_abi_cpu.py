@@ -61,7 +61,7 @@ def test_host_only_entry_points(lib):
     rc = lib.islam_pvgo_linearize(None, None, None, None, None, None, None, 1, None, None, None)
     assert rc == -1
     # round-2 entry points: shapes and channel slices are checked on the host too
-    assert lib.islam_conv_nhwc_flow(None, 568, 4, 120, None, None, None, 565, 0, None, 0, 0, 1, 8, 8, 128, 0.1, None) == -1      # y32 missing / xoff % 8
+    assert lib.islam_conv_nhwc_flow(None, 568, 4, 120, None, None, None, 565, 0, None, 0, 0, 1, 8, 8, 128, 1, 0.1, None) == -1   # no output / xoff % 8
     assert b'islam_conv_nhwc_flow' in lib.islam_last_error()
     assert lib.islam_nchw_f32_to_nhwc_bf16(None, 10, 8, None, 16, 0, 1, 4, 2, 2, None) == -1                                     # 8 + 4 > 10 channels
     assert b'source slice' in lib.islam_last_error()

@@ -177,3 +177,31 @@ def test_flow_block_on_the_channels_last_mirror(cuda, B, H, W, pieces, dense):
     ops.conv_nhwc_flow(mir, nd, totp - nd, wp, b, out, 0, dense[0], 1.0)
     y = F.conv2d(base.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), b.double(), padding=1).float()
     assert float((out - y).abs().max()) <= 1e-4 * float(y.abs().max())
+
+
+@pytest.mark.parametrize('d,H,W,Cin,Cout', [(2, 28, 40, 128, 128), (4, 28, 40, 128, 96), (8, 16, 24, 96, 64), (16, 32, 48, 64, 32), (2, 6, 10, 40, 8)])
+def test_dilated_flow_convolution_on_sub_grids(cuda, d, H, W, Cin, Cout):
+    """islam_conv_nhwc_flow(dilation=d) = d*d dense convolutions on the sub-grids of the map: equals the dilated convolution of the
+    fp32 NCHW kernel (same bf16 operands) and of torch on bf16-rounded operands, through both outputs (fp32 NCHW, bf16 mirror)."""
+    import torch.nn.functional as F
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(d)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(cuda)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(cuda)
+    xm = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref = F.leaky_relu(F.conv2d(xm.double(), w.to(torch.bfloat16).double(), b.double(), padding=d, dilation=d), 0.1).float()
+    wp = ops.pack_conv_nhwc_weight(w.to(torch.bfloat16))
+    y32 = torch.full((B, Cout, H, W), float('nan'), device=cuda)
+    ym = torch.full((B, Cout, H, W), float('nan'), dtype=torch.bfloat16, device=cuda).contiguous(memory_format=torch.channels_last)
+    ops.conv_nhwc_flow(xm, 0, Cin, wp, b, y32, 0, Cout, 0.1, ymir=ym, moff=0, dilation=d)
+    scale = float(ref.abs().max())
+    assert float((y32 - ref).abs().max()) <= 1e-4 * scale
+    assert torch.equal(ym.float(), y32.to(torch.bfloat16).float())
+    only = torch.full_like(ym, float('nan'))
+    ops.conv_nhwc_flow(xm, 0, Cin, wp, b, None, 0, Cout, 0.1, ymir=only, moff=0, dilation=d)              # mirror-only output
+    assert torch.equal(only, ym)
+    if Cin >= 16 and d <= 8:                                                                               # the fp32 NCHW kernel's range
+        old = ops.conv3x3_mfma(xm.float().contiguous(), ops.pack_conv3x3_weight(w), b, Cout, 1, d, 0.1)
+        assert float((y32 - old).abs().max()) <= 1e-4 * scale
