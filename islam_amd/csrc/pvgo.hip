@@ -348,7 +348,10 @@ __device__ __forceinline__ ReprojLink reproj_link(const double* __restrict__ rec
 // Fused linearise + build (what the LM loop launches): a workgroup of 64 lanes linearises 64 consecutive links (the
 // first one is a halo shared with the previous workgroup), hands the weighted per-link pieces over through LDS and builds
 // the blocks of its 63 nodes.  Same arithmetic as linearize_kernel + build_normal_kernel, one launch, no re-read of `lin`.
-constexpr int LB_NODES = 63;
+#ifndef ISLAM_LB_NODES
+#define ISLAM_LB_NODES 63
+#endif
+constexpr int LB_NODES = ISLAM_LB_NODES;   // nodes per workgroup of linbuild / trial_lin (<= 63: lane 0 = the link shared with the previous block)
 constexpr int LB_THREADS = 256;       // wave 0 linearises the links; waves 0-2 build Hd / Ho / rhs; all four copy out
 constexpr int LB_DYN_BYTES = (2 * LB_NODES * 81 + LB_NODES * 9) * (int)sizeof(double);
 constexpr int LB_REC = 41;          // Srr 9 | Srp 9 | Spp 9 | gr 3 | gp 3 | rv 3 | rt 3 | dt 1, +1 pad
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(LB_THREADS) void linbuild_kernel(const double* __re
     const int L = blk * LB_NODES - 1 + lane;                  // link handled by this lane (wave 0)
     if (wave == 0) {
         double sq = 0.0;
-        if (L >= 0 && L < M) {
+        if (L >= 0 && L < M && lane <= LB_NODES) {
             const SE3<double> Xi = se3_load(nodes + 7 * L), Xj = se3_load(nodes + 7 * (L + 1));
             const double dt = dts[L];
             const LinkRes r = link_residuals(Xi, Xj, ld3(vels + 3 * L), ld3(vels + 3 * (L + 1)), se3_load(poses + 7 * L),
@@ -1614,7 +1617,7 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     const int blk = xcd_index(blockIdx.x, nlb);
     if (blk < 0 || gate_closed(gate)) return;
     const int L = blk * LB_NODES - 1 + lane;
-    const bool valid = L >= 0 && L < M;
+    const bool valid = L >= 0 && L < M && lane <= LB_NODES;      // lanes past the block's last link idle when LB_NODES < 63
     const bool owns = valid && (lane > 0 || blk == 0);
 #ifdef ISLAM_PROBE
     const bool pr = threadIdx.x == 0 && blk == nlb / 2;

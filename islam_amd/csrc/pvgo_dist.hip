@@ -208,7 +208,7 @@ int islam_dist_comm_destroy(void* comm) {
 
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
-    size_t d = a256(LIN_C * n) + a256(n / 32 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
+    size_t d = a256(LIN_C * n) + a256(n / 8 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
                a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(16) + 2 * a256(ISLAM_REPROJ_REC * n);
     return d * sizeof(double) + 512;
 }
@@ -231,7 +231,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     auto take = [&](size_t n) { double* r = p; p += a256(n); return r; };
     const size_t nn = (size_t)N + 2;
     double* lin = take(LIN_C * nn);
-    double* loss_part = take(nn / 32 + 4);
+    double* loss_part = take(nn / 8 + 4);
     double* Hd = take(81 * nn); double* Ho = take(81 * nn); double* rhs = take(9 * nn); double* dx = take(9 * nn);
     double* nl = take(7 * nn); double* nt = take(7 * nn); double* vl = take(3 * nn); double* vt = take(3 * nn);
     double* part = take(2 * (nn / 64 + 2));
