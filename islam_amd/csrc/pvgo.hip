@@ -1254,6 +1254,91 @@ __device__ __forceinline__ void backsub_par_run_tw(double* __restrict__ x, int c
     }
 }
 
+// The back-substitution of a twisted segment is LINEAR in the two separator solutions:  x_t = G_t [1; -xL; -xR]  with a 9 x 19
+// matrix G_t per interior node that depends on the factor only.  influence_tw computes the G_t BEFORE the separators are known
+// (the down-sweep's workgroups wait 7-14 us for them anyway, their factor rows already loaded): the same recurrences as
+// backsub_par_run_tw with 19 right-hand sides -- [y | F~ | U~] for the middle node, [y | F~ | 0] - U~ G_{t+1} left of it,
+// [y | 0 | F~] - U~ G_{t-1} right of it -- one lane per column, the two halves of the segment on the two halves of the wave, the
+// factor rows broadcast from LDS.  What is left on the critical path once the separators arrive is one 18-term dot product per
+// lane instead of h+1 dependent 9-step triangular solves (1.45 -> ~0.2 us per level of the tree).
+// In: lane 9t+r holds FacRow `row` of node t (t < cnt <= BS_PAR_MAX).  Out: g = row r of G_t on lane 9t+r.
+constexpr int INF_FR = 30;                                  // doubles per (node, row) record in LDS: lt 9 | u 9 | f 9 | y | iv | pad
+constexpr int INF_GS = 20;                                  // row stride of G in LDS (19 + pad)
+constexpr int LDS_INFLUENCE = 9 * BS_PAR_MAX * (INF_FR + INF_GS);
+__device__ __forceinline__ void influence_tw(const FacRow& row, int cnt, int lane, double* __restrict__ lds, double (&g)[19]) {
+    double* rec = lds;                                      // [9 * cnt][INF_FR]
+    double* G = lds + 9 * BS_PAR_MAX * INF_FR;              // [9 * cnt][INF_GS]
+    if (lane < 9 * cnt) {
+        double* p = rec + lane * INF_FR;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { p[q] = row.lt[q]; p[9 + q] = row.u[q]; p[18 + q] = row.f[q]; }
+        p[27] = row.y;
+        p[28] = row.iv;
+    }
+    lds_sync();
+    const int h = twisted_mid(cnt);
+    const int grp = lane >> 5, c = lane & 31;               // group 0: middle, h-1, ..., 0; group 1: (middle,) h+1, ..., cnt-1
+    const bool col = c < 19;
+    const int cc = col ? c : 0;
+    // right-hand side column c of node tn: kind 0 = middle, 1 = left of it (side A), 2 = right of it (side B)
+    auto solve = [&](int tn, int kind, double (&X)[9]) {
+        const double* R = rec + (size_t)tn * 9 * INF_FR;
+        double b[9];
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const double* p = R + rr * INF_FR;
+            double v = 0.0;
+            if (cc == 0) v = p[27];
+            else if (cc < 10) v = kind != 2 ? p[18 + cc - 1] : 0.0;                      // F~ multiplies xL for the middle and side A
+            else v = kind == 0 ? p[9 + cc - 10] : (kind == 2 ? p[18 + cc - 10] : 0.0);   // middle: U~ multiplies xR; side B: F~ does
+            if (kind != 0) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v = fma(-p[9 + q], X[q], v);                 // - U~ G_neighbour
+            }
+            b[rr] = v;
+        }
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            const double xi = b[i] * R[i * INF_FR + 28];
+            X[i] = xi;
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr)
+                if (rr < i) b[rr] = fma(-R[rr * INF_FR + i], xi, b[rr]);
+        }
+    };
+    double X[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) X[q] = 0.0;
+    solve(h, 0, X);                                         // both groups: each chain starts from the middle node's G
+    if (grp == 0 && col) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) G[(h * 9 + q) * INF_GS + cc] = X[q];
+    }
+    const int steps = max(h, cnt - 1 - h);
+    for (int j = 1; j <= steps; ++j) {
+        const int tn = grp == 0 ? h - j : h + j;
+        const bool on = grp == 0 ? tn >= 0 : tn < cnt;
+        const int tc = min(max(tn, 0), cnt - 1);            // inactive lanes recompute a valid node and drop the result
+        double Y[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Y[q] = X[q];
+        solve(tc, grp == 0 ? 1 : 2, Y);
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) X[q] = Y[q];
+            if (col) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) G[(tc * 9 + q) * INF_GS + cc] = Y[q];
+            }
+        }
+    }
+    lds_sync();
+    const int lr = min(lane, 9 * cnt - 1);
+#pragma unroll
+    for (int k = 0; k < 19; ++k) g[k] = G[lr * INF_GS + k];
+    lds_sync();
+}
+
 __device__ __forceinline__ void backsub_level_segment(const double* __restrict__ fac, const double* __restrict__ inv,
                                                       const double* __restrict__ xsep, double* __restrict__ x, int n, int m,
                                                       int p, int lane) {
@@ -1366,7 +1451,7 @@ __device__ __forceinline__ void publish_ready(int* f, int serial, int lane) {
 
 // 128 threads: the second wavefront only helps workgroup 0 with a twisted root elimination and exits everywhere else.
 __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
-    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
+    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED > LDS_INFLUENCE ? LDS_TWISTED : LDS_INFLUENCE];
     if (gate_closed(gate)) return;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
@@ -1427,6 +1512,11 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     double warm0 = L.xsep[min((has_left ? p - 1 : p) * 9 + (lane & 7), max(nsep9 - 1, 0))];
     double warm1 = L.x[min(c0 * 9 + lane, L.x_last)];
     __builtin_amdgcn_sched_barrier(0);
+    // twisted segments: everything of the back-substitution that does not need the separators, now (influence_tw)
+    const bool infl = L.twisted && par && cnt >= 1;
+    double g[19];
+    if (infl) influence_tw(cur, cnt, lane, lds, g);
+    PROBE_WALL(pr, po + 318 + 10 * li);
     // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
     // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times)
     for (int i = 0; i <= li; ++i) __builtin_amdgcn_s_sleep(48);
@@ -1458,7 +1548,15 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     }
     if (has_right && lane >= 9 && lane < 18) st_coherent(&L.x[(size_t)sR * 9 + lane - 9], sv);
     PROBE_WALL(pr, po + 312 + 10 * li);
-    if (L.twisted) backsub_par_run_tw(L.x, c0, cnt, lane, xn, xL, cur);      // (twisted levels always have m <= BS_PAR_MAX)
+    if (infl) {                                      // x = G [1; -xL; -xR]: one dot product per lane (xn holds the right separator)
+        double v = g[0];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v = fma(-g[1 + q], xL[q], v);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v = fma(-g[10 + q], xn[q], v);
+        if (lane < 9 * cnt) st_coherent(&L.x[(size_t)c0 * 9 + lane], v);
+    }
+    else if (L.twisted) backsub_par_run_tw(L.x, c0, cnt, lane, xn, xL, cur);      // (twisted levels always have m <= BS_PAR_MAX)
     else if (par) backsub_par_run(L.x, c0, cnt, lane, xn, xL, cur);
     else backsub_run(L.fac, L.inv, L.x, c0, cnt, lane, xn, xL, cur);
     PROBE_WALL(pr, po + 313 + 10 * li);
