@@ -1518,8 +1518,10 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     if (infl) influence_tw(cur, cnt, lane, lds, g);
     PROBE_WALL(pr, po + 318 + 10 * li);
     // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
-    // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times)
-    for (int i = 0; i <= li; ++i) __builtin_amdgcn_s_sleep(48);
+    // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times; the
+    // influence matrices take ~5.5 us, about as long as the root: only the levels further down sleep on top of that)
+    if (infl) { for (int i = 1; i <= li; ++i) __builtin_amdgcn_s_sleep(24); }
+    else { for (int i = 0; i <= li; ++i) __builtin_amdgcn_s_sleep(48); }
     asm volatile("" ::"v"(warm0), "v"(warm1));
     // separators p-1 and p are nodes of the level above; node q there is published by its segment q / up_stride
     PROBE_WALL(pr, po + 315 + 10 * li);

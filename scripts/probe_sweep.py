@@ -24,5 +24,5 @@ print('root: start 0, eliminated %.2f, solved %.2f, published %.2f us' % (us(b[3
 for po, name in ((0, 'seg 1'), (50, 'seg P/2'), (100, 'seg P-1')):
     for li in range(4):
         o = po + 310 + 10 * li
-        print('level idx %d %-8s: start %.2f presleep-done %.2f wait1 %.2f ready-seen %.2f sv-arrived %.2f xsep-loaded %.2f  solved %.2f  published %.2f' % (
-            li, name, us(b[o]), us(b[o + 5]), us(b[o + 6]), us(b[o + 1]), us(b[o + 7]), us(b[o + 2]), us(b[o + 3]), us(b[o + 4])))
+        print('level idx %d %-8s: start %.2f influence-done %.2f presleep-done %.2f wait1 %.2f ready-seen %.2f sv-arrived %.2f xsep-loaded %.2f  solved %.2f  published %.2f' % (
+            li, name, us(b[o]), us(b[o + 8]), us(b[o + 5]), us(b[o + 6]), us(b[o + 1]), us(b[o + 7]), us(b[o + 2]), us(b[o + 3]), us(b[o + 4])))
