@@ -1513,7 +1513,9 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     double warm1 = L.x[min(c0 * 9 + lane, L.x_last)];
     __builtin_amdgcn_sched_barrier(0);
     // twisted segments: everything of the back-substitution that does not need the separators, now (influence_tw)
-    const bool infl = L.twisted && par && cnt >= 1;
+    // (only when the whole grid is resident, ~8 workgroups per CU: on longer chains the later workgroups do not wait, so the
+    // extra 5 us would sit on their critical path -- N = 50 001: 254 vs 248 us per LM iteration)
+    const bool infl = L.twisted && par && cnt >= 1 && gridDim.x <= 2048;
     double g[19];
     if (infl) influence_tw(cur, cnt, lane, lds, g);
     PROBE_WALL(pr, po + 318 + 10 * li);
