@@ -1416,7 +1416,11 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 // solve).  outer: the window's first segment takes its LEFT separator -- the rank's left cut node, a node of every level up to
 // the replicated ones -- from SweepArgs::outer_x instead of the level above (whose segment holding it belongs to the
 // previous rank).  x_last: last valid index of x (the sharded solve hands in a local array).
-struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, store_left, x_last; };
+// merge: this level does not wait for the level above it (the PRODUCER, lv[i-1]) but composes its influence matrices with the
+// producer's -- published through gx / the G-ready words gflag0 + segment -- and takes its solution straight from the level
+// above the producer.  publish_g: this level is such a producer.
+struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, store_left, x_last;
+                    int merge, publish_g, gflag0; double* gx; };
 struct SweepArgs {
     LevelSrc root_src;
     LevelDst root_dst;
@@ -1519,6 +1523,112 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     double g[19];
     if (infl) influence_tw(cur, cnt, lane, lds, g);
     PROBE_WALL(pr, po + 318 + 10 * li);
+    if (infl && L.publish_g) {                      // hand the influence matrices to the level below (row r of node t: 19 doubles)
+        if (lane < 9 * cnt) {
+            double* gp = L.gx + ((size_t)c0 * 9 + lane) * 19;
+#pragma unroll
+            for (int k = 0; k < 19; ++k) st_coherent(gp + k, g[k]);
+        }
+        publish_ready(a.ready + (size_t)(L.gflag0 + p) * READY_STRIDE, a.serial, lane);
+    }
+    if (infl && L.merge) {
+        // Two levels in one hand-off.  This segment's separators q0 = p-1, q1 = p are nodes of the producer level; each is either
+        // an interior node of a producer segment -- x_q = G_q [1; -U(s-1); -U(s)] with U the solution one level further up -- or
+        // a separator of the producer level, i.e. itself a node U(s).  Substituting gives x = c^ + M0 U(base-1) + M1 U(base) +
+        // M2 U(base+1): composed while everybody waits, evaluated as soon as the level above the producer has published.
+        const SweepLevel P = a.lv[li - 1];
+        const int ps = P.m + 1, nup = P.n / ps;
+        const int q0 = p - 1, q1 = p;
+        const int base = has_left ? q0 / ps : 0;
+        const int s1 = has_right ? q1 / ps : base;
+        const bool int0 = has_left && (q0 - base * ps) < P.m;
+        const bool int1 = has_right && (q1 - s1 * ps) < P.m;
+        const int rx = lane - 9 * cnt;                       // nine extra lanes: the right separator's own solution, x_{q1} = -(-e_r) x_{q1}
+        if (rx >= 0) {
+#pragma unroll
+            for (int k = 0; k < 19; ++k) g[k] = 0.0;
+            if (has_right && rx < 9) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (k == rx) g[10 + k] = -1.0;
+            }
+        }
+        if (int0) wait_ready(a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE, a.serial, flags, lane);
+        if (int1 && (!int0 || s1 != base)) wait_ready(a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE, a.serial, flags, lane);
+        double* G0 = lds;
+        double* G1 = lds + 172;
+        for (int e = lane; e < 171; e += 64) {
+            G0[e] = int0 ? ld_coherent(P.gx + (size_t)q0 * 171 + e) : 0.0;
+            G1[e] = int1 ? ld_coherent(P.gx + (size_t)q1 * 171 + e) : 0.0;
+        }
+        lds_sync();
+        double chat = g[0], M0[9], M1[9], M2[9], tL[9], tR[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { M0[k] = 0.0; M1[k] = 0.0; M2[k] = 0.0; tL[k] = 0.0; tR[k] = 0.0; }
+        if (int0) {                                          // - A x_{q0},  x_{q0} = c0 - A0 U(base-1) - B0 U(base)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double aj = g[1 + j];
+                chat = fma(-aj, G0[j * 19], chat);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { M0[k] = fma(aj, G0[j * 19 + 1 + k], M0[k]); M1[k] = fma(aj, G0[j * 19 + 10 + k], M1[k]); }
+            }
+        } else if (has_left) {                               // q0 is the producer level's separator `base` = node U(base)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) M1[k] -= g[1 + k];
+        }
+        if (int1) {                                          // - B x_{q1},  x_{q1} = c1 - A1 U(s1-1) - B1 U(s1)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double bj = g[10 + j];
+                chat = fma(-bj, G1[j * 19], chat);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { tL[k] = fma(bj, G1[j * 19 + 1 + k], tL[k]); tR[k] = fma(bj, G1[j * 19 + 10 + k], tR[k]); }
+            }
+        } else if (has_right) {                              // q1 is node U(s1)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) tR[k] = -g[10 + k];
+        }
+        const bool sh = s1 != base;                          // the right separator's segment is the next one: its U's are base, base+1
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            M0[k] += sh ? 0.0 : tL[k];
+            M1[k] += sh ? tL[k] : tR[k];
+            M2[k] += sh ? tR[k] : 0.0;
+        }
+        lds_sync();
+        // wait for the (up to three) nodes of the level above the producer, then one load, 27 broadcasts, 27 FMAs
+        int lastf = -1;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int j = base - 1 + sl;
+            if (j >= 0 && j < nup) {
+                const int f = P.up_flag0 + j / P.up_stride;
+                if (f != lastf) wait_ready(a.ready + (size_t)f * READY_STRIDE, a.serial, flags, lane);
+                lastf = f;
+            }
+        }
+        PROBE_WALL(pr, po + 311 + 10 * li);
+        double uv = 0.0;
+        {
+            const int j = base - 1 + lane / 9;
+            if (lane < 27 && j >= 0 && j < nup) uv = ld_coherent(&P.xsep[(size_t)(base - 1) * 9 + lane]);
+        }
+        double v = chat;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v = fma(M0[k], bcast(uv, k), v);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v = fma(M1[k], bcast(uv, 9 + k), v);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v = fma(M2[k], bcast(uv, 18 + k), v);
+        PROBE_WALL(pr, po + 312 + 10 * li);
+        if (lane < 9 * cnt) st_coherent(&L.x[(size_t)c0 * 9 + lane], v);
+        else if (has_right && rx < 9) st_coherent(&L.x[(size_t)sR * 9 + rx], v);
+        PROBE_WALL(pr, po + 313 + 10 * li);
+        if (li + 1 < a.nl) publish_ready(a.ready + (size_t)(L.flag0 + p) * READY_STRIDE, a.serial, lane);
+        PROBE_WALL(pr, po + 314 + 10 * li);
+        return;
+    }
     // the solution cannot arrive before the root is solved and li levels above are expanded: stay off the memory system
     // until then (s_sleep 48 = 3072 clocks per level of distance -- deliberately short of the measured arrival times; the
     // influence matrices take ~5.5 us, about as long as the root: only the levels further down sleep on top of that)
@@ -2089,7 +2199,7 @@ int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = fal
     return best.nl;
 }
 
-struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x; };
+struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x, *gx; };     // gx: influence matrices handed down (levels >= 1)
 
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
@@ -2143,6 +2253,7 @@ Workspace carve(void* base, int N) {
         b.fill = take((size_t)segs * 81);
         b.cgL = take((size_t)segs * 9);
         b.cgR = take((size_t)segs * 9);
+        b.gx = l >= 1 ? take((size_t)n * 171) : nullptr;
         n = segs;
     }
     w.bytes = (size_t)(p - (char*)base);
@@ -2160,6 +2271,14 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
     s.level0 = 0; s.Dsep = pb.Dsep; s.rsep = pb.rsep; s.cL = pb.cL; s.cR = pb.cR; s.cgL = pb.cgL; s.cgR = pb.cgR;
     s.fill = pb.fill; s.Pprev = Pprev;
     return s;
+}
+
+// ISLAM_PVGO_MERGE=1: pairs of down-sweep levels share one hand-off (SweepLevel::merge).  Correct (all solver tests pass with it)
+// but OFF by default: measured 73.0 vs 71.4 us per LM iteration -- exchanging the influence matrices and composing them (342 LDS
+// reads + FMAs per lane) finishes ~4 us after the root has published, later than the hand-off it saves (scripts/probe_sweep.py).
+static bool merge_levels() {
+    static const bool v = [] { const char* e = std::getenv("ISLAM_PVGO_MERGE"); return e && e[0] == '1'; }();
+    return v;
 }
 
 // every down-sweep launch of the process gets its own serial number: what its ready words must hold to count as published
@@ -2225,6 +2344,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
             L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
             L.seg0 = 0; L.nseg = L.P; L.twisted = tw ? 1 : 0; L.outer = 0; L.store_left = 0; L.x_last = L.n * 9 - 1;
+            L.merge = 0; L.publish_g = 0; L.gflag0 = 0; L.gx = nullptr;
             L.flag0 = flag;
             L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
             L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
@@ -2233,6 +2353,20 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             blk += xcd_grid(L.P);
         }
         a.first_block[a.nl] = blk;
+        // pairs of levels share ONE hand-off, from the bottom of the tree up: (L0, L1), (L2, L3), ... (twisted levels with
+        // influence matrices only, i.e. a fully resident grid; the consumer needs 9 spare lanes: segments of at most 6 nodes)
+        if (tw && blk <= 2048 && merge_levels()) {
+            for (int i = a.nl - 1; i >= 1; i -= 2) {
+                SweepLevel &C = a.lv[i], &Pp = a.lv[i - 1];
+                const int lp = top - 1 - (i - 1);            // tree level of the producer
+                if (C.m > 6 || Pp.m > BS_PAR_MAX || w.lv[lp].gx == nullptr) continue;
+                C.merge = 1;
+                Pp.publish_g = 1;
+                Pp.gx = w.lv[lp].gx;
+                Pp.gflag0 = flag;
+                flag += Pp.P;
+            }
+        }
         if ((size_t)flag * READY_STRIDE * sizeof(int) > w.ready_bytes) return fail(ISLAM_EARG, "pvgo: ready-flag buffer too small (%d words)", flag);
         hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(128), 0, s, a, flags, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
