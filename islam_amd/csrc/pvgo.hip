@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(64) void bt_backsub_kernel(const double* __restrict
 // producer's -- published through gx / the G-ready words gflag0 + segment -- and takes its solution straight from the level
 // above the producer.  publish_g: this level is such a producer.
 struct SweepLevel { const double *fac, *inv; const double* xsep; double* x; int n, m, P, flag0, up_flag0, up_stride, seg0, nseg, twisted, outer, store_left, x_last;
-                    int merge, publish_g, gflag0; double* gx; };
+                    int merge, publish_g, skip_x, gflag0; double* gx; };
 struct SweepArgs {
     LevelSrc root_src;
     LevelDst root_dst;
@@ -1531,11 +1531,13 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
         }
         publish_ready(a.ready + (size_t)(L.gflag0 + p) * READY_STRIDE, a.serial, lane);
     }
+    if (infl && L.publish_g && L.skip_x) return;     // nobody reads this level's own solution: its nodes are separators of the level below
     if (infl && L.merge) {
         // Two levels in one hand-off.  This segment's separators q0 = p-1, q1 = p are nodes of the producer level; each is either
-        // an interior node of a producer segment -- x_q = G_q [1; -U(s-1); -U(s)] with U the solution one level further up -- or
-        // a separator of the producer level, i.e. itself a node U(s).  Substituting gives x = c^ + M0 U(base-1) + M1 U(base) +
-        // M2 U(base+1): composed while everybody waits, evaluated as soon as the level above the producer has published.
+        // an interior node of a producer segment s -- x_q = G_q [1; -U(s-1); -U(s)], U = the solution one level further up -- or
+        // a separator of the producer level, i.e. itself the node U(s).  Lanes 0-8 / 9-17 fetch row r of G_q0 / G_q1 while
+        // everybody waits; when U arrives they evaluate x_q0, x_q1 (27 broadcasts, 18 FMAs), the wave broadcasts those (18 more)
+        // and every lane takes its own dot product as usual.
         const SweepLevel P = a.lv[li - 1];
         const int ps = P.m + 1, nup = P.n / ps;
         const int q0 = p - 1, q1 = p;
@@ -1543,61 +1545,24 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
         const int s1 = has_right ? q1 / ps : base;
         const bool int0 = has_left && (q0 - base * ps) < P.m;
         const bool int1 = has_right && (q1 - s1 * ps) < P.m;
-        const int rx = lane - 9 * cnt;                       // nine extra lanes: the right separator's own solution, x_{q1} = -(-e_r) x_{q1}
-        if (rx >= 0) {
+        const bool sh = s1 != base;                          // q1's producer segment is the next one: its U's are base, base+1
+        if (int0) wait_ready(a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE, a.serial, flags, lane);
+        if (int1 && (!int0 || sh)) wait_ready(a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE, a.serial, flags, lane);
+        const int rq = lane < 9 ? lane : lane - 9;           // row of G_q0 (lanes 0-8) / G_q1 (lanes 9-17)
+        const bool mineint = lane < 9 ? int0 : (lane < 18 && int1);
+        const bool minesep = lane < 9 ? (has_left && !int0) : (lane < 18 && has_right && !int1);
+        double gq[19];
+        {
+            const double* gp = P.gx + ((size_t)(lane < 9 ? q0 : q1) * 9 + rq) * 19;
 #pragma unroll
-            for (int k = 0; k < 19; ++k) g[k] = 0.0;
-            if (has_right && rx < 9) {
+            for (int k = 0; k < 19; ++k) gq[k] = mineint ? ld_coherent(gp + k) : 0.0;      // (plain / non-temporal loads: measured slower)
+            if (minesep) {                                   // the separator IS the node U(s): x_q[r] = -(-1) U(s)[r]
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
-                    if (k == rx) g[10 + k] = -1.0;
+                    if (k == rq) gq[10 + k] = -1.0;
             }
         }
-        if (int0) wait_ready(a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE, a.serial, flags, lane);
-        if (int1 && (!int0 || s1 != base)) wait_ready(a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE, a.serial, flags, lane);
-        double* G0 = lds;
-        double* G1 = lds + 172;
-        for (int e = lane; e < 171; e += 64) {
-            G0[e] = int0 ? ld_coherent(P.gx + (size_t)q0 * 171 + e) : 0.0;
-            G1[e] = int1 ? ld_coherent(P.gx + (size_t)q1 * 171 + e) : 0.0;
-        }
-        lds_sync();
-        double chat = g[0], M0[9], M1[9], M2[9], tL[9], tR[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { M0[k] = 0.0; M1[k] = 0.0; M2[k] = 0.0; tL[k] = 0.0; tR[k] = 0.0; }
-        if (int0) {                                          // - A x_{q0},  x_{q0} = c0 - A0 U(base-1) - B0 U(base)
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const double aj = g[1 + j];
-                chat = fma(-aj, G0[j * 19], chat);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { M0[k] = fma(aj, G0[j * 19 + 1 + k], M0[k]); M1[k] = fma(aj, G0[j * 19 + 10 + k], M1[k]); }
-            }
-        } else if (has_left) {                               // q0 is the producer level's separator `base` = node U(base)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) M1[k] -= g[1 + k];
-        }
-        if (int1) {                                          // - B x_{q1},  x_{q1} = c1 - A1 U(s1-1) - B1 U(s1)
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const double bj = g[10 + j];
-                chat = fma(-bj, G1[j * 19], chat);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { tL[k] = fma(bj, G1[j * 19 + 1 + k], tL[k]); tR[k] = fma(bj, G1[j * 19 + 10 + k], tR[k]); }
-            }
-        } else if (has_right) {                              // q1 is node U(s1)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) tR[k] = -g[10 + k];
-        }
-        const bool sh = s1 != base;                          // the right separator's segment is the next one: its U's are base, base+1
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            M0[k] += sh ? 0.0 : tL[k];
-            M1[k] += sh ? tL[k] : tR[k];
-            M2[k] += sh ? tR[k] : 0.0;
-        }
-        lds_sync();
-        // wait for the (up to three) nodes of the level above the producer, then one load, 27 broadcasts, 27 FMAs
+        // wait for the (up to three) nodes of the level above the producer
         int lastf = -1;
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl) {
@@ -1614,16 +1579,23 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
             const int j = base - 1 + lane / 9;
             if (lane < 27 && j >= 0 && j < nup) uv = ld_coherent(&P.xsep[(size_t)(base - 1) * 9 + lane]);
         }
-        double v = chat;
+        const bool second = lane >= 9 && sh;                 // lanes of q1 when its segment is base+1: (UL, UR) = slots (1, 2)
+        double xq = gq[0];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v = fma(M0[k], bcast(uv, k), v);
+        for (int k = 0; k < 9; ++k) {
+            const double u0 = bcast(uv, k), u1 = bcast(uv, 9 + k), u2 = bcast(uv, 18 + k);
+            xq = fma(-gq[1 + k], second ? u1 : u0, xq);
+            xq = fma(-gq[10 + k], second ? u2 : u1, xq);
+        }
+        double v = g[0];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v = fma(M1[k], bcast(uv, 9 + k), v);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v = fma(M2[k], bcast(uv, 18 + k), v);
+        for (int k = 0; k < 9; ++k) {
+            v = fma(-g[1 + k], bcast(xq, k), v);
+            v = fma(-g[10 + k], bcast(xq, 9 + k), v);
+        }
         PROBE_WALL(pr, po + 312 + 10 * li);
         if (lane < 9 * cnt) st_coherent(&L.x[(size_t)c0 * 9 + lane], v);
-        else if (has_right && rx < 9) st_coherent(&L.x[(size_t)sR * 9 + rx], v);
+        if (has_right && lane >= 9 && lane < 18) st_coherent(&L.x[(size_t)sR * 9 + lane - 9], xq);
         PROBE_WALL(pr, po + 313 + 10 * li);
         if (li + 1 < a.nl) publish_ready(a.ready + (size_t)(L.flag0 + p) * READY_STRIDE, a.serial, lane);
         PROBE_WALL(pr, po + 314 + 10 * li);
@@ -2274,8 +2246,11 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
 }
 
 // ISLAM_PVGO_MERGE=1: pairs of down-sweep levels share one hand-off (SweepLevel::merge).  Correct (all solver tests pass with it)
-// but OFF by default: measured 73.0 vs 71.4 us per LM iteration -- exchanging the influence matrices and composing them (342 LDS
-// reads + FMAs per lane) finishes ~4 us after the root has published, later than the hand-off it saves (scripts/probe_sweep.py).
+// but OFF by default: no gain.  First version (composed 9 x 28 matrices per lane: 342 LDS reads + FMAs): 73.0 vs 71.4 us per LM
+// iteration; present version (the consumer fetches rows of the producer's G and evaluates the two levels back to back): 71.1-71.4
+// vs 71.4-71.8 us -- the consumers see the upstream words 2-3 us after they are published (scripts/probe_sweep.py), i.e. the
+// G exchange (19 write-through stores per producer lane, flag, 19 coherent loads per consumer lane) ends later than the hand-off
+// it replaces.
 static bool merge_levels() {
     static const bool v = [] { const char* e = std::getenv("ISLAM_PVGO_MERGE"); return e && e[0] == '1'; }();
     return v;
@@ -2344,7 +2319,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
             L.fac = w.lv[l].fac; L.inv = w.lv[l].inv; L.xsep = x_of(l + 1); L.x = x_of(l);
             L.n = sp.lv[l].n; L.m = sp.lv[l].m; L.P = sp.lv[l].P;
             L.seg0 = 0; L.nseg = L.P; L.twisted = tw ? 1 : 0; L.outer = 0; L.store_left = 0; L.x_last = L.n * 9 - 1;
-            L.merge = 0; L.publish_g = 0; L.gflag0 = 0; L.gx = nullptr;
+            L.merge = 0; L.publish_g = 0; L.skip_x = 0; L.gflag0 = 0; L.gx = nullptr;
             L.flag0 = flag;
             L.up_flag0 = i == 0 ? 0 : a.lv[i - 1].flag0;
             L.up_stride = i == 0 ? (1 << 30) : sp.lv[l + 1].m + 1;
@@ -2354,14 +2329,15 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
         }
         a.first_block[a.nl] = blk;
         // pairs of levels share ONE hand-off, from the bottom of the tree up: (L0, L1), (L2, L3), ... (twisted levels with
-        // influence matrices only, i.e. a fully resident grid; the consumer needs 9 spare lanes: segments of at most 6 nodes)
+        // influence matrices only, i.e. a fully resident grid)
         if (tw && blk <= 2048 && merge_levels()) {
             for (int i = a.nl - 1; i >= 1; i -= 2) {
                 SweepLevel &C = a.lv[i], &Pp = a.lv[i - 1];
                 const int lp = top - 1 - (i - 1);            // tree level of the producer
-                if (C.m > 6 || Pp.m > BS_PAR_MAX || w.lv[lp].gx == nullptr) continue;
+                if (C.m > BS_PAR_MAX || Pp.m > BS_PAR_MAX || w.lv[lp].gx == nullptr) continue;
                 C.merge = 1;
                 Pp.publish_g = 1;
+                Pp.skip_x = 1;                               // (its x array is only ever read as the consumer's separators)
                 Pp.gx = w.lv[lp].gx;
                 Pp.gflag0 = flag;
                 flag += Pp.P;
