@@ -1454,7 +1454,9 @@ __device__ __forceinline__ void publish_ready(int* f, int serial, int lane) {
 }
 
 // 128 threads: the second wavefront only helps workgroup 0 with a twisted root elimination and exits everywhere else.
-__global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
+// (two waves per SIMD, i.e. at most 256 VGPRs: the ~1000 workgroups of the N = 5001 tree must all be resident -- at 268 VGPRs the second
+// half of the level-0 segments started only when the first had finished: 17 -> 25 us)
+__global__ __launch_bounds__(128, 2) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
     __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED > LDS_INFLUENCE ? LDS_TWISTED : LDS_INFLUENCE];
     if (gate_closed(gate)) return;
     const int lane = threadIdx.x & 63;
@@ -1524,12 +1526,15 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
     if (infl) influence_tw(cur, cnt, lane, lds, g);
     PROBE_WALL(pr, po + 318 + 10 * li);
     if (infl && L.publish_g) {                      // hand the influence matrices to the level below (row r of node t: 19 doubles)
-        if (lane < 9 * cnt) {
-            double* gp = L.gx + ((size_t)c0 * 9 + lane) * 19;
-#pragma unroll
-            for (int k = 0; k < 19; ++k) st_coherent(gp + k, g[k]);
+        // straight from influence_tw's LDS copy, 512 contiguous bytes per store instruction (a lane storing its own row -- 19
+        // stores, 152 bytes apart between lanes -- took 2.2 us: 855 separate write-through transactions)
+        {
+            const double* Gl = lds + 9 * BS_PAR_MAX * INF_FR;
+            double* gp = L.gx + (size_t)c0 * 171;
+            for (int e = lane; e < 171 * cnt; e += 64) st_coherent(gp + e, Gl[(e / 19) * INF_GS + (e % 19)]);
         }
         publish_ready(a.ready + (size_t)(L.gflag0 + p) * READY_STRIDE, a.serial, lane);
+        PROBE_WALL(pr, po + 317 + 10 * li);                  // (probe build: G published)
     }
     if (infl && L.publish_g && L.skip_x) return;     // nobody reads this level's own solution: its nodes are separators of the level below
     if (infl && L.merge) {
@@ -1548,20 +1553,39 @@ __global__ __launch_bounds__(128) void bt_downsweep_kernel(SweepArgs a, int* fla
         const bool sh = s1 != base;                          // q1's producer segment is the next one: its U's are base, base+1
         if (int0) wait_ready(a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE, a.serial, flags, lane);
         if (int1 && (!int0 || sh)) wait_ready(a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE, a.serial, flags, lane);
+        PROBE_WALL(pr, po + 315 + 10 * li);                  // (probe build: G-ready words seen)
         const int rq = lane < 9 ? lane : lane - 9;           // row of G_q0 (lanes 0-8) / G_q1 (lanes 9-17)
         const bool mineint = lane < 9 ? int0 : (lane < 18 && int1);
         const bool minesep = lane < 9 ? (has_left && !int0) : (lane < 18 && has_right && !int1);
         double gq[19];
         {
-            const double* gp = P.gx + ((size_t)(lane < 9 ? q0 : q1) * 9 + rq) * 19;
+            // both matrices through LDS with contiguous loads (six per lane), then every lane picks its row
+            double* Gq = lds;                                // [2][171]
+            double tq[6];
 #pragma unroll
-            for (int k = 0; k < 19; ++k) gq[k] = mineint ? ld_coherent(gp + k) : 0.0;      // (plain / non-temporal loads: measured slower)
+            for (int i = 0; i < 6; ++i) {                    // all six loads in flight, then the LDS writes
+                const int e = min(lane + 64 * i, 341);
+                const bool first = e < 171;
+                const double* gsrc = P.gx + (size_t)(first ? q0 : q1) * 171 + (first ? e : e - 171);
+                tq[i] = (first ? int0 : int1) ? ld_coherent(gsrc) : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (lane + 64 * i < 342) Gq[lane + 64 * i] = tq[i];
+            lds_sync();
+            const double* gp = Gq + (lane < 9 ? 0 : 171) + rq * 19;
+#pragma unroll
+            for (int k = 0; k < 19; ++k) gq[k] = mineint ? gp[k] : 0.0;
             if (minesep) {                                   // the separator IS the node U(s): x_q[r] = -(-1) U(s)[r]
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
                     if (k == rq) gq[10 + k] = -1.0;
             }
         }
+#ifdef ISLAM_PROBE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROBE_WALL(pr, po + 316 + 10 * li);                  // (probe build: rows of G arrived)
+#endif
         // wait for the (up to three) nodes of the level above the producer
         int lastf = -1;
 #pragma unroll
@@ -2245,14 +2269,13 @@ static LevelSrc level_src_from(const LevelBufs& pb, int Pprev) {
     return s;
 }
 
-// ISLAM_PVGO_MERGE=1: pairs of down-sweep levels share one hand-off (SweepLevel::merge).  Correct (all solver tests pass with it)
-// but OFF by default: no gain.  First version (composed 9 x 28 matrices per lane: 342 LDS reads + FMAs): 73.0 vs 71.4 us per LM
-// iteration; present version (the consumer fetches rows of the producer's G and evaluates the two levels back to back): 71.1-71.4
-// vs 71.4-71.8 us -- the consumers see the upstream words 2-3 us after they are published (scripts/probe_sweep.py), i.e. the
-// G exchange (19 write-through stores per producer lane, flag, 19 coherent loads per consumer lane) ends later than the hand-off
-// it replaces.
+// Pairs of down-sweep levels share one hand-off (SweepLevel::merge) unless ISLAM_PVGO_NO_MERGE=1 (A/B runs): 70.4 vs 71.5-71.8 us
+// per LM iteration at N = 5001.  History: composing the two levels' influence matrices into one 9 x 28 map per lane (342 LDS
+// reads + FMAs) was slower (73.0 us); fetching rows of the producer's G lane by lane (19 stores / 19 loads, 152 bytes apart
+// between lanes) made the exchange end 2-3 us after the upstream words were published (no gain); with the matrices copied through
+// LDS in contiguous 512-byte stores / loads the exchange is done ~1 us after the influence matrices are.
 static bool merge_levels() {
-    static const bool v = [] { const char* e = std::getenv("ISLAM_PVGO_MERGE"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char* e = std::getenv("ISLAM_PVGO_NO_MERGE"); return !(e && e[0] == '1'); }();
     return v;
 }
 
