@@ -1435,13 +1435,16 @@ struct SweepArgs {
     int outer_flag;           // ... and the ready word of the segment that publishes it
 };
 
+#ifndef ISLAM_POLL_SLEEP
+#define ISLAM_POLL_SLEEP 8          // s_sleep between two polls of a ready word (x 64 clocks); scripts/poll_sweep.sh
+#endif
 constexpr int READY_STRIDE = 32;      // ints between two ready words: one 128-byte line each (polled words spread over L2 channels)
 
 __device__ __forceinline__ void wait_ready(const int* f, int serial, int* flags, int lane) {
     if (lane == 0) {
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) {
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(ISLAM_POLL_SLEEP);
             if (++spins > (1 << 22)) { atomicOr(flags, 2); break; }     // never observed; keeps a logic error from hanging the GPU
         }
     }
