@@ -136,6 +136,40 @@ def build(verbose=False):
     subprocess.check_call(cmd)
 
 
+class _StreamArg(c_void_p):
+    """hipStream_t argument that remembers which device its stream lives on (see stream_ptr)."""
+    device_index = None
+
+
+def _scoped(fn):
+    """Library calls launch on the HIP *current device*.  When the stream handed over (always the last argument) belongs to
+    another device, the call runs under ``torch.cuda.device(...)`` and the caller's current device is restored afterwards."""
+    def call(*args):
+        s = args[-1] if args else None
+        idx = getattr(s, 'device_index', None)
+        if idx is not None and idx != torch.cuda.current_device():
+            with torch.cuda.device(idx):
+                return fn(*args)
+        return fn(*args)
+    call.__name__ = getattr(fn, '__name__', 'islam_fn')
+    call.raw = fn
+    return call
+
+
+class _Lib:
+    """The loaded shared object: one attribute per symbol of include/islam_hip.h (device-scoped wrappers of the ctypes functions)."""
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, _scoped(fn))
+
+    def __getattr__(self, name):                  # symbols outside SIGNATURES (probe builds)
+        return getattr(self._cdll, name)
+
+
 def lib():
     """Load libislam_hip.so; raises if it has not been built."""
     global _lib
@@ -143,12 +177,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(islam_amd has no CPU fallback)' % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _Lib(ctypes.CDLL(LIB_PATH))
     return _lib
 
 
@@ -158,15 +187,15 @@ def check(rc):
 
 
 def stream_ptr(device=None):
-    """Raw hipStream_t of torch's current stream on ``device`` (0 = default stream).  Every wrapper in ops.py fetches the
-    stream right before its library call, so this is also where the HIP *current device* is aligned with the tensors' device:
-    kernel launches, hipMemsetAsync and hipFuncSetAttribute inside the library act on the current device, and a stream of
-    another device would be an invalid handle there (run_pvgo(device='cuda:1') without torch.cuda.set_device(1))."""
+    """Raw hipStream_t of torch's current stream on ``device`` (0 = default stream).  Kernel launches, hipMemsetAsync and
+    hipFuncSetAttribute inside the library act on the HIP *current device*, and a stream of another device would be an invalid
+    handle there (run_pvgo(device='cuda:1') without torch.cuda.set_device(1)): the returned handle carries its device index
+    and the library call it is passed to runs under a scoped ``torch.cuda.device`` (``_scoped``) -- the caller's current device
+    is never changed."""
+    s = _StreamArg(torch.cuda.current_stream(device).cuda_stream)
     if device is not None:
-        idx = torch.device(device).index
-        if idx is not None and idx != torch.cuda.current_device():
-            torch.cuda.set_device(idx)
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        s.device_index = torch.device(device).index
+    return s
 
 
 def ptr(t):

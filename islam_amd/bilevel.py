@@ -61,12 +61,17 @@ class BilevelLoop:
             if len(motions) != bs:                                        # (the reference's bare `except:` falls back to VO, Q15)
                 motions = None
         if motions is None:
-            res = self.vo(sample)
+            # a VO forward inside an IMU epoch (first epoch, or a short slice of last epoch's motions) must not leave gradients
+            # on the pose head: the next 'vo' epoch's optimizer.step() would apply them (the IMU epoch never zeroes them)
+            with torch.set_grad_enabled(target == 'vo'):
+                res = self.vo(sample)
             if next_sample is not None and hasattr(self.vo, 'prefetch'):
                 self.vo.prefetch(next_sample)
             motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
             T_IL = self.T_IL.to(motions.device).to(motions.dtype)
             motions = T_IL @ motions @ T_IL.Inv()                                               # train.py:214-215
+            if target != 'vo':
+                motions = motions.detach()
         sync(); t1 = time.perf_counter()
         # VO-only dead reckoning is book-keeping (train.py:219-228 keeps it for the plots): no gradient flows through it,
         # so the 8 sequential SE3 products run on the host copy instead of ~160 tiny device launches
@@ -117,6 +122,8 @@ class BilevelLoop:
         Same arithmetic: grad <- grad + g in fp32."""
         params = [p for opt in (self.optimizer, self.imu_optimizer) if opt is not None
                   for grp in opt.param_groups for p in grp['params'] if p.requires_grad]
+        if not params:                               # everything frozen: nothing to accumulate (autograd.grad rejects an empty list)
+            return
         grads = torch.autograd.grad(loss_bp, params, torch.ones_like(loss_bp), allow_unused=True)
         acc, new = [], []
         for p, g in zip(params, grads):

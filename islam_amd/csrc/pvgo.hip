@@ -2954,7 +2954,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     // (two slots, alternating with the trial number), the host polls its sequence number (no stream synchronisation,
     // no copy on the critical path)
     static thread_local double* host_state = nullptr;
-    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped));
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));   // portable: one buffer per thread serves calls on any device
     double* report = nullptr;
     ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
     volatile double* hs_all = host_state;

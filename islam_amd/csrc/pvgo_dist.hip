@@ -112,6 +112,11 @@ __global__ void state_init_kernel(double* __restrict__ st, double radius, double
     if (t < 16) st[t] = t == 2 ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
 }
 
+// error path: an epoch no enqueued chain carries turns everything still queued into no-ops
+__global__ void close_gate_kernel(double* __restrict__ st, double epoch) {
+    if (threadIdx.x == 0) st[14] = epoch;
+}
+
 // the loss of the very first optimizer.step() (summed over the ranks in msg[0])
 __global__ void begin_kernel(const double* __restrict__ msg, double* __restrict__ st, int* __restrict__ flags) {
     if (threadIdx.x != 0) return;
@@ -246,7 +251,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     // verdicts in pinned, device-visible host memory (two slots, alternating with the trial number); the host polls the
     // sequence number -- no stream synchronisation, no copy
     static thread_local double* host_state = nullptr;
-    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped));
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));   // portable: one buffer per thread serves calls on any device
     double* report = nullptr;
     ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
     volatile double* hs_all = host_state;
@@ -296,6 +301,10 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
         return ISLAM_OK;
     };
 
+    int steps = 0, trials = 0, status = ISLAM_OK;
+    double loss = 0.0, damping = 1.0 / prm->radius, epoch = 1.0;
+    IterCfg A{nl, vl, nt, vt};            // the iteration whose verdict is awaited
+    auto run = [&]() -> int {
     // first linearisation and the loss of the initial iterate
     const Gate open{nullptr, 0.0};
     if (reproj && (rc = reproj_reduce_gated(nl, nullptr, Mloc, reproj, a, rp_lin, open, s)) != ISLAM_OK) return rc;
@@ -304,9 +313,6 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     if (world > 1 && (rc = red.sum(msg, 1, s)) != ISLAM_OK) return rc;
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, s, msg, state, flags);
 
-    IterCfg A{nl, vl, nt, vt};            // the iteration whose verdict is awaited
-    int steps = 0, trials = 0, status = ISLAM_OK;
-    double loss = 0.0, damping = 1.0 / prm->radius, epoch = 1.0;
     if ((rc = enqueue_iter(A, 1.0, epoch, false)) != ISLAM_OK) return rc;
     for (;;) {
         const double seq = (double)(trials + 1);
@@ -348,6 +354,20 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     hipLaunchKernelGGL(unpack_full_kernel, dim3((N * 10 + 255) / 256), dim3(256), 0, s, full, N, nodes, vels);
     ISLAM_LAUNCH_CHECK();
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return ISLAM_OK;
+    };
+    rc = run();
+    if (rc != ISLAM_OK) {
+        // A failed enqueue / collective / status wait leaves gated kernels (and possibly collectives) of the run-ahead chain in
+        // flight: they would still write the pinned verdict block and the scratch the NEXT call reuses.  Close the gate (any
+        // epoch no enqueued kernel carries) and drain the stream before handing the error up; the message of the original
+        // failure is kept.  After a collective error the peers may be blocked in their next collective: the caller must destroy
+        // (abort) the communicator.
+        hipLaunchKernelGGL(close_gate_kernel, dim3(1), dim3(64), 0, s, state, epoch + 2.0);
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        return rc;
+    }
     res->steps = steps; res->trials = trials; res->status = status; res->loss = loss; res->damping = damping;
     if (exchanged_bytes) *exchanged_bytes = xbytes;
     return ISLAM_OK;

@@ -273,7 +273,11 @@ class RcclComm:
                 ident = ident.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
             dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             raw = (ctypes.c_ubyte * 128)(*ident.cpu().tolist())
-            check(lib().islam_dist_comm_init(raw, self.world, self.rank, ctypes.byref(self.handle)))
+            # ncclCommInitRank binds the communicator to the HIP current device: join on THIS rank's device, whatever the
+            # caller's current device is (all ranks on device 0 would be a duplicate-GPU error or a hang)
+            idx = torch.device(device).index if device is not None else None
+            with torch.cuda.device(idx if idx is not None else torch.cuda.current_device()):
+                check(lib().islam_dist_comm_init(raw, self.world, self.rank, ctypes.byref(self.handle)))
 
     def close(self):
         from ._lib import check, lib

@@ -79,3 +79,14 @@ def test_edge_mask_argument_checks(cuda):
     with pytest.raises(RuntimeError):
         edges.edge_mask(torch.zeros(1, 3, 64, 64))                                # CPU tensor: no fallback
     assert edges.edge_mask(torch.zeros(0, 3, 64, 64, device=cuda)).shape == (0, 16, 16)
+
+
+def test_images_too_large_for_one_cu_take_the_tensor_op_path(cuda):
+    """More pixels than fit the LDS of one CU: same integer pipeline as device tensor ops, still bit-exact."""
+    from islam_amd._lib import lib
+    img = edge_test_image(5, B=1, H=192, W=256, amp=0.5, cells=32, boxes=3)
+    assert 192 * 256 > lib().islam_edge_mask_max_pixels()
+    _check(img, cuda, downscale=False)
+    big = edge_test_image(6, B=1, H=704, W=704, amp=0.5, cells=64, boxes=3)
+    assert (704 // 4) ** 2 > lib().islam_edge_mask_max_pixels()
+    _check(big, cuda)
