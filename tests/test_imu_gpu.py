@@ -70,3 +70,29 @@ def test_full_size_5000_frames(cuda):
     q = out[1][0]
     for k in range(0, 5000, 997):
         np.testing.assert_allclose(lie.quat_mul(out[1][k], mo[1][k]), out[1][k + 1], atol=1e-12)
+
+
+@pytest.mark.parametrize('tag,dtype,bound', [('f64', np.float64, 4.0), ('f32', np.float32, 4.0)])
+def test_gap_to_torch_op_arithmetic(cuda, tag, dtype, bound):
+    """"Bit-exact" above means: to the fdlibm contract shared with oracle/imu_preint.c.  The reference runs TORCH ops
+    (torch.sin / cos, cumsum, PyPose's doubling cumprod; imu_integrator.py:55-56,146): tests/golden/imu_torchops_*.npz holds that
+    op sequence's results (tests/golden/make_imu_torchops_golden.py -- a restatement, not a PyPose pin).  This test REPORTS the
+    maximal difference of islam_imu_preint against them in ulps of the row's largest component and bounds it."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'imu_torchops_%s.npz' % tag))
+    eps = np.finfo(dtype).eps
+    worst = {}
+    for name in ('ragged', 'car9_10', 'car33_7'):
+        init = dict(pos=z[name + '_init_pos'], rot=z[name + '_init_rot'], vel=z[name + '_init_vel'])
+        for motion in (False, True):
+            out = _run(cuda, z[name + '_dts'], z[name + '_gyros'], z[name + '_accels'], z[name + '_seg'], init,
+                       float(z[name + '_gravity']), motion, dtype)
+            m = name + ('_motion' if motion else '_world')
+            for o, k in zip(out, ('pos', 'rot', 'vel')):
+                g = z[m + '_' + k]
+                assert o.shape == g.shape and o.dtype == g.dtype
+                scale = np.ones((len(g), 1)) if k == 'rot' else np.maximum(np.abs(g).max(axis=-1, keepdims=True), np.finfo(dtype).tiny)
+                ulp = float((np.abs(o.astype(np.float64) - g.astype(np.float64)) / (eps * scale)).max())
+                worst[k] = max(worst.get(k, 0.0), ulp)
+    print('islam_imu_preint vs torch-op arithmetic (%s): max ulp pos %.3g rot %.3g vel %.3g' % (tag, worst['pos'], worst['rot'], worst['vel']))
+    assert max(worst.values()) <= bound, worst
