@@ -914,20 +914,41 @@ __device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSr
 constexpr int TW_ACC = 9 * 10;                                  // wave B's accumulation onto the right separator: [a][b], b = 9: g
 constexpr int LDS_TWISTED = 2 * LDS_PER_WAVE + TW_ACC + 2;      // doubles per workgroup
 
+// Helper wavefronts (HELP = true, bt_eliminate_tw_kernel: four wavefronts per segment).  Of the ~4400 clocks of a node step only
+// the pivots, the Schur update and the formation of the next node's columns lie on the k -> k+1 dependency; the factor / reciprocal
+// stores (address arithmetic + 18 store instructions per lane) and the accumulation onto the outer separator (two more column
+// reads + a 9-term dot product) do not.  Each sweeping wave therefore leaves the eliminated node -- all 28 columns, the D^-1-scaled
+// copies and the reciprocal pivots -- in an LDS stage (two stages, alternating with the node's parity) and a helper wave picks it
+// up one node step later: it streams the factor out with lane-contiguous 512-byte stores and keeps the separator accumulation.
+// One s_barrier per node step (all four waves execute the same number of barriers: the forward sweep's step count) hands a stage
+// over; the barrier after step h-1 is also where the forward sweep folds the reverse sweep's side in.
+constexpr int H_FST = 28 * XS;                                  // eliminated columns [L^T | U~ | F~ | y~]
+constexpr int H_XB = 19 * XS;                                   // D^-1 [U~ | F~ | y~]
+constexpr int H_STAGE = H_FST + H_XB + 10;                      // + reciprocal pivots (9, padded)
+constexpr int H_SWEEP = 2 * H_STAGE + 19 * XS;                  // two stages + Tn
+constexpr int LDS_TW4 = 2 * H_SWEEP + TW_ACC + 2;               // doubles per workgroup
+
+// workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: global prefetches and stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One directed sweep.  REV = false: nodes first, first+1, ...; REV = true: first, first-1, ...
 //   count      nodes eliminated by this wave
 //   has_spike  an outer separator exists (left for forward, right for reverse)
 //   merge_t    (forward only) after node step merge_t the next node is the MIDDLE node: wait for wave B and fold its
 //              contributions in (-1: one-sided)
 //   last_next  (forward only) node whose columns follow the last eliminated node (the right separator), -1: none
-template <bool REV>
-__device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDst& dst, int n, int p, int first, int count,
+//   nbar       (HELP) barriers every wave of the workgroup executes = node steps of the forward sweep
+//   L0         1 / 0: the level is known at compile time (level-0 instantiation: no composition loads, fewer registers); -1: runtime
+template <bool REV, bool HELP = false, int L0 = -1>
+__device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const LevelDst& dst, int n, int p, int first, int count,
                                               bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
                                               double* __restrict__ lds, const double* __restrict__ TnB,
-                                              double* __restrict__ accB, const Gate& gate) {
+                                              double* __restrict__ accB, const Gate& gate, int nbar = 0) {
     double* Xa = lds;
     double* Xb = lds + 19 * XS;
-    double* Tn = lds + 2 * 19 * XS;
+    double* Tn = lds + (HELP ? 2 * H_STAGE : 2 * 19 * XS);
+    LevelSrc src = src_in;
+    if (L0 >= 0) src.level0 = L0;
     [[maybe_unused]] const bool prb = lane == 0 && p == 1 && !src.level0 && src.Pprev > 500;      // probe build: level 1, segment 1
     [[maybe_unused]] const int pbase = REV ? 470 : 440;
     PROBE_WALL(prb, pbase);
@@ -938,7 +959,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
     int pa, pb;                                                     // left-separator accumulation F-^T D^-1 [F- | y-]
     pair_of(lane, pa, pb);
     if (lane >= 45) { pa = lane - 45; pb = 9; }
-    const bool acc_on = has_spike && lane < 54;
+    const bool acc_on = !HELP && has_spike && lane < 54;
     const bool use_nb = lane < 18 || lane == 27;
     const bool use_tn = lane < 9 || lane == 27 || (has_spike && lane >= 18 && lane < 27);
     const int tn_off = (lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
@@ -997,11 +1018,36 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
         }
         PROBE_WALL(prb, pbase + 3 + 5 * t);
-        if (lane >= 9 && lane < 28) {
-            double* xa = Xa + (lane - 9) * XS;
-            double* xb = Xb + (lane - 9) * XS;
+        if constexpr (HELP) {
+            // the eliminated node goes to the stage of its parity: all 28 columns (the helper streams them out as the factor),
+            // the scaled copies of the 19 right-hand columns, the reciprocal pivots
+            double* st = lds + (t & 1) * H_STAGE;
+            Xa = st + 9 * XS;
+            Xb = st + H_FST;
+            if (lane < 28) {
+                double* fc = st + lane * XS;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
+                for (int r = 0; r < 9; ++r) fc[r] = mcol[r];
+            }
+            if (lane >= 9 && lane < 28) {
+                double* xb = Xb + (lane - 9) * XS;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) xb[r] = mcol[r] * ipv[r];
+            }
+            if (lane < 9) {
+                double mine = 0.0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r)
+                    if (r == lane) mine = ipv[r];
+                st[H_FST + H_XB + lane] = mine;
+            }
+        } else {
+            if (lane >= 9 && lane < 28) {
+                double* xa = Xa + (lane - 9) * XS;
+                double* xb = Xb + (lane - 9) * XS;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
+            }
         }
         lds_sync();
         if (t_on) {
@@ -1022,7 +1068,8 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             ldcol(Xb + (9 + pb) * XS, cbv);
             accL += dot9r(ca, cbv);
         }
-        lds_sync();
+        if constexpr (HELP) lds_barrier();       // barrier t: stage + Tn complete; the helper takes node c from here
+        else lds_sync();
         PROBE_WALL(prb, pbase + 4 + 5 * t);
         __builtin_amdgcn_sched_barrier(0);
         // the next node's own columns; wave B never forms the middle node's (wave A does: its diagonal is damped once)
@@ -1031,15 +1078,17 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
             if (REV) combine_cols_rev(LS, src, nxt, lane, damping, raw, nb);
             else combine_cols(LS, src, nxt, n, lane, damping, raw, nb);
         }
-        if (lane < 28) {
-            double* f = dst.fac + (size_t)c * FAC + lane * 9;
+        if constexpr (!HELP) {
+            if (lane < 28) {
+                double* f = dst.fac + (size_t)c * FAC + lane * 9;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);
-        }
-        if (lane == 0) {
-            double* iv = dst.inv + (size_t)c * 9;
+                for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);
+            }
+            if (lane == 0) {
+                double* iv = dst.inv + (size_t)c * 9;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+                for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+            }
         }
         PROBE_WALL(prb, pbase + 5 + 5 * t);
         if (!last) {
@@ -1051,7 +1100,8 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
                 // the node just formed is the middle node: fold wave B's side in.  T_B(r, cb): r = middle unknown, cb < 9
                 // middle unknown (S update), cb = 9+j right-separator unknown j (its negative IS the coupling middle -> R,
                 // i.e. this wave's U columns), cb = 18 right-hand side
-                __syncthreads();
+                // (HELP: barrier t above is the rendezvous -- the reverse sweep finished its last step before it)
+                if constexpr (!HELP) __syncthreads();
                 double tb[9];
                 const int off = (lane < 9 ? lane : lane < 18 ? lane : 18) * XS;       // U lane 9+cu reads column 9+cu
                 ldcol(TnB + off, tb);
@@ -1066,6 +1116,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
         } else if (!REV) {
             if (has_right) {
                 const bool addB = merge_t >= 0;               // wave B accumulated onto the right separator as well
+                // (HELP: the reverse sweep's helper left that accumulation in accB before it arrived at this step's barrier)
                 for (int e = lane; e < 81; e += 64) {
                     const int r = e / 9, cc = e - r * 9;
                     dst.cR[(size_t)p * 81 + e] = Tn[cc * XS + r] + (addB ? accB[r * 10 + cc] : 0.0);
@@ -1085,27 +1136,90 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src, const LevelDs
         lds_sync();
         PROBE_WALL(prb, pbase + 6 + 5 * t);
     }
-    if (!REV) {
-        if (has_spike) {
-            if (lane < 45) {
-                dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
-                dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
-            } else if (lane < 54) {
-                dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
-            }
-        }
+    if constexpr (HELP) {
+        // the reverse sweep has fewer steps than the forward one: keep the workgroup's barrier count
+        for (int t = count; t < nbar; ++t) lds_barrier();
     } else {
-        // wave B: its last Tn stays in LDS for wave A; the accumulation onto the right separator goes next to it
-        if (lane < 45) {
-            accB[pa * 10 + pb] = has_spike ? accL : 0.0;
-            accB[pb * 10 + pa] = has_spike ? accL : 0.0;
-        } else if (lane < 54) {
-            accB[(lane - 45) * 10 + 9] = has_spike ? accL : 0.0;
+        if (!REV) {
+            if (has_spike) {
+                if (lane < 45) {
+                    dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
+                    dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
+                } else if (lane < 54) {
+                    dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
+                }
+            }
+        } else {
+            // wave B: its last Tn stays in LDS for wave A; the accumulation onto the right separator goes next to it
+            if (lane < 45) {
+                accB[pa * 10 + pb] = has_spike ? accL : 0.0;
+                accB[pb * 10 + pa] = has_spike ? accL : 0.0;
+            } else if (lane < 54) {
+                accB[(lane - 45) * 10 + 9] = has_spike ? accL : 0.0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     PROBE_WALL(prb, pbase + 29);
     if (bad && lane == 0) atomicOr(flags, 1);
+}
+
+// The helper wavefront (see H_STAGE): after barrier t it owns the stages of node t of both sweeps.  Per node:
+//   factor: 252 doubles, lane-contiguous (four 512-byte store instructions instead of nine 72-byte-strided ones per lane)
+//   reciprocal pivots: 9 doubles
+//   accumulation F~^T D^-1 [F~ | y~] onto the sweep's outer separator (entries as in the sweeping wave: pair_of)
+// After the last node it writes cL / cgL (the forward sweep's accumulation onto the left separator); the reverse sweep's sums are
+// left in accB BEFORE the workgroup's last barrier (the forward sweep adds them to cR / cgR after it).
+__device__ __forceinline__ void helper_node(const LevelDst& dst, int c, const double* __restrict__ st, int lane, bool acc_on, int pa, int pb,
+                                            double& accL) {
+    double* f = dst.fac + (size_t)c * FAC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        if (e < FAC) {
+            const int col = e / 9, row = e - col * 9;
+            __builtin_nontemporal_store(st[col * XS + row], &f[e]);
+        }
+    }
+    if (lane < 9) dst.inv[(size_t)c * 9 + lane] = st[H_FST + H_XB + lane];
+    if (acc_on) {
+        double ca[9], cbv[9];
+        ldcol(st + (18 + pa) * XS, ca);                  // F~ column pa
+        ldcol(st + H_FST + (9 + pb) * XS, cbv);          // D^-1 [F~ | y~] column pb
+        accL += dot9r(ca, cbv);
+    }
+}
+
+__device__ __forceinline__ void twisted_helper(const LevelDst& dst, int p, int firstA, int nA, bool has_left, int firstB, int nB,
+                                               bool has_right, int lane, const double* __restrict__ ldsA,
+                                               const double* __restrict__ ldsB, double* __restrict__ accB, const Gate& gate) {
+    if (gate_closed(gate)) return;
+    int pa, pb;
+    pair_of(lane, pa, pb);
+    if (lane >= 45) { pa = lane - 45; pb = 9; }
+    const bool onA = has_left && lane < 54, onB = has_right && lane < 54;
+    double accA = 0.0, accBv = 0.0;
+    for (int t = 0; t < nA; ++t) {
+        if (t == nA - 1) {                               // (nB < nA: the reverse sweep's last node was picked up a step ago)
+            if (lane < 45) {
+                accB[pa * 10 + pb] = has_right ? accBv : 0.0;
+                accB[pb * 10 + pa] = has_right ? accBv : 0.0;
+            } else if (lane < 54) {
+                accB[(lane - 45) * 10 + 9] = has_right ? accBv : 0.0;
+            }
+        }
+        lds_barrier();
+        helper_node(dst, firstA + t, ldsA + (t & 1) * H_STAGE, lane, onA, pa, pb, accA);
+        if (t < nB) helper_node(dst, firstB - t, ldsB + (t & 1) * H_STAGE, lane, onB, pa, pb, accBv);
+    }
+    if (has_left) {
+        if (lane < 45) {
+            dst.cL[(size_t)p * 81 + pa * 9 + pb] = accA;
+            dst.cL[(size_t)p * 81 + pb * 9 + pa] = accA;
+        } else if (lane < 54) {
+            dst.cgL[(size_t)p * 9 + (lane - 45)] = accA;
+        }
+    }
 }
 
 // middle index of a segment with cnt interior nodes (wave A: nodes 0..h incl. the middle, wave B: cnt-1 .. h+1)
@@ -1133,12 +1247,40 @@ __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const Lev
     }
 }
 
-__global__ __launch_bounds__(128) void bt_eliminate_tw_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
-                                                              int nseg, Gate gate) {
-    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
+// three wavefronts per segment: 0 = forward sweep, 1 = reverse sweep, 2 = the helper of both
+template <int L0>
+__device__ __forceinline__ void eliminate_twisted3(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
+                                                   int wave, int lane, double* __restrict__ lds_wg, const Gate& gate) {
+    const int stride = m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(m, n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + m;
+    const bool has_right = sR < n;
+    const bool tw = cnt >= 3;
+    const int h = twisted_mid(cnt);
+    const int nA = tw ? h + 1 : cnt, nB = tw ? cnt - 1 - h : 0;
+    double* ldsA = lds_wg;
+    double* ldsB = lds_wg + H_SWEEP;
+    double* accB = lds_wg + 2 * H_SWEEP;
+    if (wave == 0)
+        twisted_sweep<false, true, L0>(src, dst, n, p, c0, nA, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags, lane, ldsA,
+                                       ldsB + 2 * H_STAGE, accB, gate, nA);
+    else if (wave == 1) {
+        if (tw) twisted_sweep<true, true, L0>(src, dst, n, p, c0 + cnt - 1, nB, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB, gate, nA);
+        else if (!gate_closed(gate)) { for (int t = 0; t < nA; ++t) lds_barrier(); }
+    } else
+        twisted_helper(dst, p, c0, nA, has_left, c0 + cnt - 1, nB, has_right, lane, ldsA, ldsB, accB, gate);
+}
+
+// (level 0 of the N = 5001 tree has 834 segments, all of which must be resident at once: 3 waves per SIMD, i.e. <= 168 VGPRs)
+template <int L0>
+__global__ __launch_bounds__(192, L0 ? 3 : 2) void bt_eliminate_tw_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
+                                                                          int nseg, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_TW4];
     const int p = xcd_index(blockIdx.x, nseg);
     if (p < 0) return;
-    eliminate_twisted(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
+    eliminate_twisted3<L0>(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
 }
 
 #ifdef ISLAM_PROBE
@@ -2290,11 +2432,16 @@ static int next_serial() {
     return serial;
 }
 
-// the up-sweep launch of one level below the root: one workgroup per segment (two wavefronts when twisted)
+static void launch_tw(const LevelSrc& src, const LevelDst& dst, int n, int m, int* flags, int seg0, int nseg, Gate gate, hipStream_t s) {
+    if (src.level0) hipLaunchKernelGGL(bt_eliminate_tw_kernel<1>, dim3(xcd_grid(nseg)), dim3(192), 0, s, src, dst, n, m, flags, seg0, nseg, gate);
+    else hipLaunchKernelGGL(bt_eliminate_tw_kernel<0>, dim3(xcd_grid(nseg)), dim3(192), 0, s, src, dst, n, m, flags, seg0, nseg, gate);
+}
+
+// the up-sweep launch of one level below the root: one workgroup per segment (three wavefronts when twisted)
 static void launch_eliminate(const LevelPlan& L, bool tw, const LevelSrc& src, const LevelDst& dst, int* flags, hipStream_t s,
                              Gate gate) {
     if (tw)
-        hipLaunchKernelGGL(bt_eliminate_tw_kernel, dim3(xcd_grid(L.P)), dim3(128), 0, s, src, dst, L.n, L.m, flags, 0, L.P, gate);
+        launch_tw(src, dst, L.n, L.m, flags, 0, L.P, gate, s);
     else
         hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(L.P)), dim3(64), 0, s, src, dst, L.n, L.m, flags, 0, L.P, gate);
 }
@@ -2704,8 +2851,7 @@ int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double 
         LevelBufs ob = w.lv[l];
         if (l == R.xl) { ob.Dsep = xb.Dsep; ob.rsep = xb.rsep; ob.cL = xb.cL; ob.cR = xb.cR; ob.fill = xb.fill; ob.cgL = xb.cgL; ob.cgR = xb.cgR; }
         if (sp.twisted)
-            hipLaunchKernelGGL(bt_eliminate_tw_kernel, dim3(xcd_grid(R.nseg[l])), dim3(128), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n,
-                               sp.lv[l].m, flags, R.seg0[l], R.nseg[l], gate);
+            launch_tw(src, level_dst(ob, nullptr), sp.lv[l].n, sp.lv[l].m, flags, R.seg0[l], R.nseg[l], gate, s);
         else
             hipLaunchKernelGGL(bt_eliminate_kernel, dim3(xcd_grid(R.nseg[l])), dim3(64), 0, s, src, level_dst(ob, nullptr), sp.lv[l].n,
                                sp.lv[l].m, flags, R.seg0[l], R.nseg[l], gate);
