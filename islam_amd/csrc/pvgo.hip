@@ -58,7 +58,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 #ifdef ISLAM_PROBE
-__device__ long long islam_probe_buf[512];
+__device__ long long islam_probe_buf[1024];
 #define PROBE_AT(cond, slot) do { __builtin_amdgcn_sched_barrier(0); if (cond) islam_probe_buf[(slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PROBE_WALL(cond, slot) do { __builtin_amdgcn_sched_barrier(0); if (cond) islam_probe_buf[(slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -526,6 +526,8 @@ struct LevelSrc {
     const double* rhs0;
     const double* state;         // state[2] = damping
     double damping_override;     // used when state == nullptr
+    int hist;                    // 1: Hd keeps its UNDAMPED diagonal; the dampings of the current linearisation are applied on load
+                                 //    (state != nullptr: the list state[16 .. 16 + state[8]]; else damping_override, once)
     const double *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill;
     int Pprev;                   // number of segments of the previous level
 };
@@ -580,7 +582,27 @@ __device__ __forceinline__ void issue_cols(const LaneSrc& L, bool level0, int k,
     }
 }
 
-__device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s, int k, int n, int lane, double damping,
+// How the level-0 diagonal is damped (pp.optim.LM: A.diagonal().add_(A.diagonal() * damping), cumulative over the retries of a
+// step).  In place: one damping per solve, the damped value is written back for the next retry.  History (LevelSrc::hist): the
+// stored diagonal stays undamped and every solve applies the whole list -- same operations in the same order, bit for bit.
+struct Damp { double d; const double* list; int n; bool wb; };
+__device__ __forceinline__ Damp make_damp(const LevelSrc& s) {
+    Damp D;
+    D.wb = !s.hist;
+    D.list = (s.hist && s.state) ? s.state + STATE_HIST : nullptr;
+    D.n = D.list ? (int)s.state[8] + 1 : 0;
+    D.d = s.state ? s.state[2] : s.damping_override;
+    return D;
+}
+__device__ __forceinline__ double damp_apply(const Damp& D, double v) {
+    if (D.list) {
+        for (int i = 0; i < D.n; ++i) v = v + v * D.list[i];
+        return v;
+    }
+    return v + v * D.d;
+}
+
+__device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s, int k, int n, int lane, const Damp& damping,
                                              const RawCols& raw, double (&m)[9]) {
     if (s.level0) {
         // lanes that own no column (spike lanes, lanes >= 28) carry don't-care values: they are overwritten by the
@@ -590,10 +612,10 @@ __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = zeroU ? 0.0 : raw.a[r];
-            if (r == lane) { v = v + v * damping; dg = v; }   // A.diagonal().add_(A.diagonal()*damping), kept for retries
+            if (r == lane) { v = damp_apply(damping, v); dg = v; }   // A.diagonal().add_(A.diagonal()*damping), kept for retries
             m[r] = v;
         }
-        if (lane < 9) s.Hd[(size_t)k * 81 + lane * 10] = dg;
+        if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
     } else {
         const bool ua = L.isS || L.isG || (L.isU && (k + 1) < n);
         const bool ub = L.isS || L.isG;
@@ -729,7 +751,7 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     const bool has_left = p > 0;
     const int sR = c0 + m;
     const bool has_right = sR < n;
-    const double damping = src.state ? src.state[2] : src.damping_override;
+    const Damp damping = make_damp(src);
 
     // Schur-update work split, fixed per lane: entries (r, cb) = X[:,r] . D^-1 X[:,cb] for cb = g, g+7, g+14
     const int tr = lane % 9, tg = lane / 9;                         // lanes 0..62 (g <= 6); lane 63 idles
@@ -890,7 +912,7 @@ __device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) 
     return L;
 }
 
-__device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, double damping,
+__device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, const Damp& damping,
                                                  const RawCols& raw, double (&m)[9]) {
     if (s.level0) {
         const bool zeroU = L.isU && k <= 0;
@@ -898,10 +920,10 @@ __device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSr
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = zeroU ? 0.0 : raw.a[r];
-            if (r == lane) { v = v + v * damping; dg = v; }
+            if (r == lane) { v = damp_apply(damping, v); dg = v; }
             m[r] = v;
         }
-        if (lane < 9) s.Hd[(size_t)k * 81 + lane * 10] = dg;
+        if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
     } else {
         const bool ua = L.isS || L.isG || (L.isU && k > 0);
         const bool ub = L.isS || L.isG;
@@ -952,7 +974,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     [[maybe_unused]] const bool prb = lane == 0 && p == 1 && !src.level0 && src.Pprev > 500;      // probe build: level 1, segment 1
     [[maybe_unused]] const int pbase = REV ? 470 : 440;
     PROBE_WALL(prb, pbase);
-    const double damping = src.state ? src.state[2] : src.damping_override;
+    const Damp damping = make_damp(src);
     const int tr = lane % 9, tg = lane / 9;
     const bool t_on = tg < 7;
     const bool t_third = t_on && (tg + 14) < 19;
@@ -1285,7 +1307,7 @@ __global__ __launch_bounds__(192, L0 ? 3 : 2) void bt_eliminate_tw_kernel(LevelS
 
 #ifdef ISLAM_PROBE
 extern "C" int islam_probe_read(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_probe_buf), sizeof(long long) * 512) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_probe_buf), sizeof(long long) * 1024) == hipSuccess ? 0 : -2;
 }
 #endif
 
@@ -1911,7 +1933,9 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     q = wave_sum(q);
     if (threadIdx.x == 0) {
         *ticket = 0u;
-        lm_control(s, q, st, flags, tr, report, seq);
+        const bool failed = flags[0] != 0;
+        flags[0] = 0;
+        lm_control(s, q, st, failed, tr, report, seq);
     }
     PROBE_AT(threadIdx.x == 0, 207);
 }
@@ -1931,7 +1955,7 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     double* __restrict__ nodes_t, double* __restrict__ vels_t, double* part, double* st, int* flags, unsigned* ticket,
     TRParams tr, double* report, double seq, const double* __restrict__ red_lin, const double* __restrict__ red_trial,
     ReprojDev rp, LinWeights W, double* __restrict__ lin_o, double* __restrict__ Hd_o, double* __restrict__ Ho_o,
-    double* __restrict__ rhs_o, Gate gate) {
+    double* __restrict__ rhs_o, Gate gate, int* eflag2 = nullptr) {
     __shared__ double sl[64][LB_REC];
     __shared__ double s_sq;
     extern __shared__ __attribute__((aligned(16))) double lb_out[];
@@ -1962,7 +1986,10 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
         qsum = wave_sum(qsum);
         if (lane == 0) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lm_control(ssum, qsum, st, flags, tr, report, seq);
+            bool failed = flags[0] != 0;
+            flags[0] = 0;
+            if (eflag2) { failed = failed || *eflag2 != 0; *eflag2 = 0; }     // (level 0 of the solve ran inside trial_elim_kernel)
+            lm_control(ssum, qsum, st, failed, tr, report, seq);
         }
         PROBE_WALL(lane == 0, 421);
         return;
@@ -2070,11 +2097,280 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
     PROBE_WALL(pr, 410);
 }
 
+// ------------------------------------------------------------------------------------------
+// The LM loop's steady state in ONE launch per level-0 segment: trial step + loss / trust-region partial sums of trial t, the
+// linearisation at the trial point, AND the level-0 elimination of the next solve straight out of LDS.
+//
+// The elimination of step t+1 damps its diagonal with TrustRegion.update's output for trial t, which needs sums over ALL links --
+// a grid-wide dependency between the linearisation and the first pivot.  It is broken by SPECULATION: the next damping has three
+// possible values (radius x up / kept / x down); every workgroup assumes that the trial is accepted and that TrustRegion.update takes
+// the branch it took for the previous trial (speculated_damping: an LM run stays in one regime for many trials -- on the
+// 5000-frame bench graph the radius is kept on all ten).  The deciding workgroup (one extra workgroup, as in trial_lin_kernel) validates
+// the guess when the sums are in and bumps the run-ahead epoch otherwise (verdict 5, or any of the non-"accepted, continue"
+// verdicts): the launches queued behind this one (upper levels, down-sweep) turn into no-ops and the host redoes the solve on the
+// launched level-0 kernel from the linearisation this kernel wrote to global memory (undamped: LevelSrc::hist).
+//
+// Workgroup = segment p of level 0 (m interior nodes c0 .. c0+m-1, right separator c0+m), three wavefronts:
+//   wave 0  one lane per link c0-1 .. c0+m (the two outer links are shared with the neighbouring segments): retraction, residuals
+//           at the trial point, Jacobians, weighted per-link pieces -> LDS; trial iterate / lin record of the links it owns
+//   wave 1  trust-region term (J D)^T (2R + J D) of the owned links from the OLD linearisation; publishes both partial sums
+//   all     node blocks Hd / Ho / rhs of nodes c0 .. c0+m in LDS, one 3x3 sub-block per thread
+//   wave 2  copies the blocks to global memory (coalesced), then serves as the elimination's helper (twisted_helper)
+//   waves 0, 1  twisted elimination of the segment, columns read from the LDS blocks (eliminate_twisted3)
+// Saves per LM iteration: one launch (11 us), the 13.7 MB round trip of Hd / Ho / rhs through HBM on the critical path, and the
+// level-0 kernel's first dependent loads.
+constexpr int FZ_MAXM = BS_PAR_MAX;
+constexpr int FZ_LINKS = FZ_MAXM + 2;                      // links c0-1 .. c0+m
+constexpr int FZ_NODES = FZ_MAXM + 1;                      // nodes c0 .. c0+m
+constexpr int FZ_OFF_SUM = (FZ_LINKS * LB_REC + 1) & ~1;
+constexpr int FZ_OFF_HD = FZ_OFF_SUM + 2;
+constexpr int FZ_OFF_HO = (FZ_OFF_HD + FZ_NODES * 81 + 1) & ~1;
+constexpr int FZ_OFF_RHS = (FZ_OFF_HO + (FZ_NODES + 1) * 81 + 1) & ~1;
+constexpr int FZ_OFF_TW = (FZ_OFF_RHS + FZ_NODES * 9 + 1) & ~1;
+constexpr int FZ_LDS = FZ_OFF_TW + LDS_TW4;
+static_assert(FZ_OFF_HD % 2 == 0 && FZ_OFF_HO % 2 == 0 && FZ_OFF_RHS % 2 == 0 && FZ_OFF_TW % 2 == 0, "16-byte aligned LDS regions");
+
+struct FusedArgs {
+    const double *nodes, *vels, *dx, *poses, *drots, *dtrans, *dvels, *dts, *lin;    // iterate, step, measurements, OLD linearisation
+    int N;
+    double *nodes_t, *vels_t;                     // trial iterate
+    double* part;
+    double* st;
+    int* flags;
+    unsigned* ticket;
+    TRParams tr;
+    double* report;
+    double seq;
+    LinWeights W;
+    double *lin_o, *Hd_o, *Ho_o, *rhs_o;          // linearisation at the trial point (diagonal clamped, UNDAMPED)
+    LevelDst dst;                                 // level-0 factor and products
+    int m, P;                                     // level-0 segment length / count
+    int* eflag;                                   // solver-error word of THIS elimination
+    int* eflag_prev;                              // ... of the level-0 elimination of the solve whose trial is evaluated here
+};
+
+__device__ __forceinline__ M3<double> m3_zero() { return M3<double>{0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+
+__global__ __launch_bounds__(192, 3) void trial_elim_kernel(FusedArgs a, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[FZ_LDS];
+    double (*sl)[LB_REC] = reinterpret_cast<double (*)[LB_REC]>(lds);
+    double* s_sum = lds + FZ_OFF_SUM;
+    double* Hd_l = lds + FZ_OFF_HD;
+    double* Ho_l = lds + FZ_OFF_HO;
+    double* rhs_l = lds + FZ_OFF_RHS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int N = a.N, M = N - 1;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the deciding workgroup (see trial_lin_kernel): sums the partials in index order, LM decision, validates the speculation
+        if (wave != 0 || gate_closed(gate)) return;
+        const double d_spec = speculated_damping(a.st, a.tr);
+        __builtin_amdgcn_s_sleep(64);
+        if (lane == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)a.P) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { atomicOr(a.flags, 2); break; }     // never observed; a logic error must not hang the GPU
+            }
+        }
+        asm volatile("" ::: "memory");
+        double ssum = 0.0, qsum = 0.0;
+        for (int i = lane; i < a.P; i += 64) {
+            ssum += ld_coherent(&a.part[2 * i]);
+            qsum += ld_coherent(&a.part[2 * i + 1]);
+        }
+        ssum = wave_sum(ssum);
+        qsum = wave_sum(qsum);
+        if (lane == 0) {
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool failed = a.flags[0] != 0 || *a.eflag_prev != 0;
+            a.flags[0] = 0;
+            *a.eflag_prev = 0;
+            lm_control(ssum, qsum, a.st, failed, a.tr, a.report, a.seq, d_spec);
+        }
+        return;
+    }
+    const int p = xcd_index(blockIdx.x, a.P);
+    if (p < 0 || gate_closed(gate)) return;
+    const double d_spec = speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
+    const int m = a.m, stride = m + 1, c0 = p * stride;
+    [[maybe_unused]] const bool fpr = lane == 0 && (p == 1 || p == a.P / 2 || p == a.P - 2);     // probe build only
+    [[maybe_unused]] const int fpo = 600 + (p == 1 ? 0 : p == a.P / 2 ? 30 : 60) + 10 * wave;
+    PROBE_WALL(fpr, fpo);
+    const int L = c0 - 1 + lane;                                   // link of this lane (waves 0 and 1)
+    const bool valid = lane <= m + 1 && L >= 0 && L < M;
+    const bool owns = valid && lane >= 1 && lane <= stride;        // links c0 .. c0+m belong to this segment
+    if (wave == 0) {
+        double sq = 0.0, dt = 0.0;
+        SE3<double> Xi{}, Xj{};
+        V3<double> vi{}, vj{};
+        LinkRes r{};
+        if (valid) {
+            const double* di = a.dx + (size_t)L * 9;
+            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+            Xi = se3_mul(se3_exp(dri, dpi), se3_load(a.nodes + 7 * L));                    // LieTensor.add_
+            Xj = se3_mul(se3_exp(drj, dpj), se3_load(a.nodes + 7 * (L + 1)));
+            vi = ld3(a.vels + 3 * L) + dvi;
+            vj = ld3(a.vels + 3 * (L + 1)) + dvj;
+            dt = a.dts[L];
+            PROBE_WALL(fpr, fpo + 1);
+            r = link_residuals(Xi, Xj, vi, vj, se3_load(a.poses + 7 * L), ld4(a.drots + 4 * L), ld3(a.dtrans + 3 * L),
+                               ld3(a.dvels + 3 * L), dt);
+            PROBE_WALL(fpr, fpo + 2);
+            if (owns) {
+                sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+                se3_store(Xi, a.nodes_t + 7 * L);
+                a.vels_t[3 * L] = vi.x; a.vels_t[3 * L + 1] = vi.y; a.vels_t[3 * L + 2] = vi.z;
+                if (L == M - 1) {
+                    se3_store(Xj, a.nodes_t + 7 * (L + 1));
+                    a.vels_t[3 * L + 3] = vj.x; a.vels_t[3 * L + 4] = vj.y; a.vels_t[3 * L + 5] = vj.z;
+                }
+            }
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) s_sum[0] = sq;                 // published by wave 2 after the barrier below: this wave never waits for a store
+        if (valid) {
+            M3<double> G, C, B;
+            link_jacobians(r, G, C, B);
+            PROBE_WALL(fpr, fpo + 3);
+            link_emit(r, G, C, B, dt, L, M, owns, a.W, a.lin_o, sl[lane], nullptr, ReprojDev{}, Xi);
+        }
+        PROBE_WALL(fpr, fpo + 4);
+    } else if (wave == 1) {
+        double qd = 0.0;
+        if (owns) {
+            const double* di = a.dx + (size_t)L * 9;
+            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+            const double dtl = a.dts[L];
+            double rec[LIN_C];
+#pragma unroll
+            for (int c = 0; c < LIN_C; ++c) rec[c] = a.lin[(size_t)c * M + L];
+            const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+            const V3<double> ddr = drj - dri, ddp = dpj - dpi;
+            const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
+            const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+                R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+            qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+                 dot(j4, 2.0 * R4 + j4);
+        }
+        qd = wave_sum(qd);
+        if (lane == 0) s_sum[1] = qd;
+    }
+    lds_barrier();
+    PROBE_WALL(fpr, fpo + 5);
+    if (wave == 2 && lane == 0) {
+        // publish: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
+        st_coherent(&a.part[2 * p], s_sum[0]);
+        st_coherent(&a.part[2 * p + 1], s_sum[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- node blocks of nodes c0 .. c0+m (Hd, rhs) and of the couplings c0-1 .. c0+m-1 (Ho), one 3x3 sub-block per thread
+    {
+        const int tid = threadIdx.x, nb9 = stride * 9;
+        const double w1 = a.W.w1, w3 = a.W.w3;
+        const M3<double> I = m3_identity<double>();
+        if (tid < nb9) {
+            const int i = tid / 9, b = tid - i * 9, br = b / 3, bc = b - br * 3, k = c0 + i;
+            if (k < N) {
+                const double* a0 = sl[i];
+                const double* a1 = sl[i + 1];
+                const bool hp = k > 0, hn = k < M;
+                M3<double> blk = m3_zero();
+                const int which = br == bc ? br : (br + bc == 1 ? 3 : (br + bc == 2 ? 4 : 5));      // 0 rr, 1 pp, 2 vv, 3 rp/pr, 4 rv/vr, 5 pv/vp
+                if (which == 0) { if (hp) blk = blk + m3_load(a0); if (hn) blk = blk + m3_load(a1); }
+                else if (which == 1) { if (hp) blk = blk + m3_load(a0 + 18); if (hn) blk = blk + m3_load(a1 + 18); }
+                else if (which == 3) { if (hp) blk = blk + m3_load(a0 + 9); if (hn) blk = blk + m3_load(a1 + 9); if (br == 1) blk = transpose(blk); }
+                else if (which == 2) {
+                    double hvv = 0.0;
+                    if (hp) hvv += w1;
+                    if (hn) { const double d = a1[39]; hvv += w1 + w3 * d * d; }
+                    blk = hvv * I;
+                } else if (which == 4) { blk = (hn ? w3 * a1[39] : 0.0) * I; }
+                double o[9];
+                m3_store(blk, o);
+                if (br == bc) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) o[d * 4] = fmin(fmax(o[d * 4], a.W.vmin), a.W.vmax);      // A.diagonal().clamp_(min, max)
+                }
+                double* h = Hd_l + i * 81 + br * 27 + bc * 3;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) h[rr * 9 + cc] = o[rr * 3 + cc];
+            }
+        } else if (tid < 2 * nb9) {
+            const int t2 = tid - nb9, i = t2 / 9, b = t2 - i * 9, br = b / 3, bc = b - br * 3, k = c0 - 1 + i;     // coupling k -> k+1 = link k
+            if (k >= 0 && k < M) {
+                const double* a1 = sl[i];
+                M3<double> blk = m3_zero();
+                if (br == 0 && bc == 0) blk = -1.0 * m3_load(a1);
+                else if (br == 0 && bc == 1) blk = -1.0 * m3_load(a1 + 9);
+                else if (br == 1 && bc == 0) blk = -1.0 * transpose(m3_load(a1 + 9));
+                else if (br == 1 && bc == 1) blk = -1.0 * m3_load(a1 + 18);
+                else if (br == 2 && bc == 0) blk = (-w3 * a1[39]) * I;
+                else if (br == 2 && bc == 2) blk = (-w1) * I;
+                double o[9];
+                m3_store(blk, o);
+                double* h = Ho_l + i * 81 + br * 27 + bc * 3;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) h[rr * 9 + cc] = o[rr * 3 + cc];
+            }
+        } else if (tid < 2 * nb9 + stride) {
+            const int i = tid - 2 * nb9, k = c0 + i;
+            if (k < N) {
+                const double* a0 = sl[i];
+                const double* a1 = sl[i + 1];
+                V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
+                if (k > 0) {
+                    gr = gr + ld3(a0 + 27); gp = gp + ld3(a0 + 30);
+                    gv = gv - w1 * ld3(a0 + 33);
+                }
+                if (k < M) {
+                    const double d = a1[39];
+                    gr = gr - ld3(a1 + 27); gp = gp - ld3(a1 + 30);
+                    gv = gv + w1 * ld3(a1 + 33) - (w3 * d) * ld3(a1 + 36);
+                }
+                double* bb = rhs_l + i * 9;
+                bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
+                bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
+            }
+        }
+    }
+    PROBE_WALL(fpr, fpo + 6);
+    lds_barrier();
+    PROBE_WALL(fpr, fpo + 7);
+    if (wave == 2) {
+        // the linearisation to global memory, lane-contiguous: the fallback solves (reject, mis-speculated damping, failed solve)
+        // and the un-fused entry points read it from there
+        const int no = min(stride, N - c0);                               // nodes this segment owns
+        for (int e = lane; e < no * 81; e += 64) a.Hd_o[(size_t)c0 * 81 + e] = Hd_l[e];
+        for (int e = lane; e < no * 9; e += 64) a.rhs_o[(size_t)c0 * 9 + e] = rhs_l[e];
+        const int k0 = max(c0 - 1, 0), k1 = min(c0 + m - 1, M - 1);       // couplings this segment owns
+        const double* hs = Ho_l + (k0 - (c0 - 1)) * 81;
+        for (int e = lane; e < (k1 - k0 + 1) * 81; e += 64) a.Ho_o[(size_t)k0 * 81 + e] = hs[e];
+    }
+    LevelSrc src{};
+    src.level0 = 1;
+    src.Hd = Hd_l - (ptrdiff_t)c0 * 81;
+    src.Ho = Ho_l - (ptrdiff_t)(c0 - 1) * 81;
+    src.rhs0 = rhs_l - (ptrdiff_t)c0 * 9;
+    src.state = nullptr;
+    src.damping_override = d_spec;
+    src.hist = 1;
+    PROBE_WALL(fpr, fpo + 8);
+    eliminate_twisted3<1>(src, a.dst, N, m, p, a.eflag, wave, lane, lds + FZ_OFF_TW, Gate{nullptr, 0.0});
+    PROBE_WALL(fpr, fpo + 9);
+}
+
 // state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
 __global__ __launch_bounds__(64) void control_init_kernel(double* __restrict__ st, int* __restrict__ flags, double radius, double down) {
     const int t = threadIdx.x;
-    if (t < 16) st[t] = t == 2 ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
-    if (t < 4) flags[t] = 0;
+    if (t < STATE_DOUBLES) st[t] = (t == 2 || t == STATE_HIST) ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : (t == 14 || t == 15) ? 1.0 : 0.0;     // [15]: first guess "radius kept"
+    if (t < 8) flags[t] = 0;
 }
 
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
@@ -2363,7 +2659,7 @@ Workspace carve(void* base, int N) {
     w.lin = take((size_t)LIN_C * M);
     const int nlb = (N + LB_NODES - 1) / LB_NODES;     // workgroups of linbuild / trial_lin (>= nblk)
     w.loss_part = take(std::max(nblk, nlb) + 2);
-    w.part = take(2 * (size_t)std::max(nblk, nlb) + 2);
+    w.part = take(2 * (size_t)std::max(std::max(nblk, nlb), N / 4 + 8) + 2);      // (trial_elim_kernel: one pair per level-0 segment, segments >= 5 nodes)
     w.Hd = take((size_t)N * 81);
     w.Ho = take((size_t)N * 81);
     w.rhs = take((size_t)N * 9);
@@ -2376,8 +2672,8 @@ Workspace carve(void* base, int N) {
     w.dx = take((size_t)N * 9);
     w.nodes_t = take((size_t)N * 7);
     w.vels_t = take((size_t)N * 3);
-    w.state = take(16);
-    w.flags = (int*)take(2);
+    w.state = take(STATE_DOUBLES);
+    w.flags = (int*)take(4);         // [0] solver error of the launched levels, [2] ticket, [4], [5] solver error of the fused level-0 elimination (by parity)
     w.ready_bytes = align_up(((size_t)N / 3 + 64 * MAXL) * READY_STRIDE * sizeof(int));   // segments of all levels < N/4 + ...
     w.ready = (int*)take(w.ready_bytes / sizeof(double));
     int n = N;
@@ -2448,8 +2744,10 @@ static void launch_eliminate(const LevelPlan& L, bool tw, const LevelSrc& src, c
 
 // Enqueue levels [lbegin, nl): `first` describes the source of level lbegin (level-0 arrays, or the level-0 products when
 // lbegin == 1), xout receives the solution of level lbegin.  Big levels: one launch each way; levels >= sp.top: one launch.
+// skip_first: the elimination of level lbegin has been enqueued by the caller (trial_elim_kernel eliminates level 0 itself).
 int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const LevelSrc& first, const LevelBufs* first_prev,
-                   double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev, Gate gate = Gate{nullptr, 0.0}) {
+                   double* xout, int* flags, hipStream_t s, hipEvent_t* evs, int* nev, Gate gate = Gate{nullptr, 0.0},
+                   bool skip_first = false) {
     static bool lds_attr_set[64] = {};                       // per device: the attribute lives in the device's code object
     int dev_i = 0;
     ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
@@ -2470,6 +2768,7 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
     const bool sweep = (top == nl - 1) && (top > lbegin);      // root alone in the top kernel, at least one level below
     const bool tw = sp.twisted && sweep && lbegin == 0;
     for (int l = lbegin; l < top; ++l) {
+        if (l == lbegin && skip_first) continue;
         launch_eliminate(sp.lv[l], tw, src_of(l), level_dst(w.lv[l], x_of(l)), flags, s, gate);
         if (evs) (void)hipEventRecord(evs[ne++], s);
     }
@@ -2610,7 +2909,7 @@ int islam_pvgo_solve_chain(double* Hd, const double* Ho, const double* rhs, doub
                     islam_pvgo_workspace_bytes(N));
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 4 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     int rc = enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, s);
     if (rc != ISLAM_OK) return rc;
@@ -2643,7 +2942,7 @@ int islam_pvgo_solve_status(int N, void* workspace, size_t workspace_bytes, void
     int flag = 0;
     ISLAM_HIP_CHECK(hipMemcpyAsync(&flag, w.flags, sizeof(int), hipMemcpyDeviceToHost, s));
     ISLAM_HIP_CHECK(hipStreamSynchronize(s));
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 4 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     if (flag) return fail(ISLAM_ENOTPD, "islam_pvgo_solve_status: non-positive pivot (matrix not positive definite)");
     return ISLAM_OK;
@@ -2662,7 +2961,7 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     hipEvent_t evs[2 * MAXL + 2];
     for (auto& e : evs) ISLAM_HIP_CHECK(hipEventCreate(&e));
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.flags, 0, 4 * sizeof(double), s));
     int ne = 0;
     int rc = enqueue_solve(w, Hd, Ho, rhs, nullptr, damping, N, seg_len, dx, s, evs, &ne);
     if (rc != ISLAM_OK) return rc;
@@ -3159,6 +3458,113 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     int steps = 0, trials = 0, status = ISLAM_OK;
     double loss = 0.0, damping = damping0;
     double epoch = 1.0;
+    // ---- the fused loop (default): trial t, the linearisation at its trial point and the level-0 elimination of solve t+1 in
+    // ONE launch (trial_elim_kernel), under a speculated damping the deciding workgroup validates.  Plans it does not cover
+    // (one-sided levels, segments longer than FZ_MAXM, a single level), the reprojection factor and ISLAM_PVGO_NO_FUSE=1 take
+    // the launch-per-stage loop below.
+    SolvePlan sp;
+    plan_levels(N, prm->seg_len, sp, solve_twisted());
+    static const bool no_fuse = [] { const char* e = std::getenv("ISLAM_PVGO_FUSE"); return !(e && e[0] == '1'); }();     // (opt-in until it is faster)
+    const bool fused = !no_fuse && !reproj && sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM &&
+                       prm->reject < STATE_DOUBLES - STATE_HIST - 1;
+    if (fused) {
+        // every solve keeps the stored diagonal undamped and applies the damping history of the current linearisation (LevelSrc::hist)
+        auto enqueue_solve_hist = [&](int pb, double ep) -> int {
+            LevelSrc src{};
+            src.level0 = 1; src.Hd = HD[pb]; src.Ho = HO[pb]; src.rhs0 = RH[pb]; src.state = w.state; src.hist = 1;
+            return enqueue_levels(w, sp, 0, src, nullptr, w.dx, w.flags, s, nullptr, nullptr, Gate{w.state, ep});
+        };
+        int* const eflag_none = w.flags + 6;                 // a word nobody sets
+        // evaluates trial `seq` of iteration c (cur + dx -> tri); more: also eliminates level 0 of solve seq+1 and enqueues its upper
+        // levels + down-sweep (-> dx).  prev_fused: level 0 of solve `seq` ran inside the previous trial_elim_kernel.
+        auto enqueue_trial = [&](const IterCfg& c, double seq, double ep, bool more, bool prev_fused) -> int {
+            const Gate gate{w.state, ep};
+            double* rep_slot = report + 16 * ((long long)seq & 1);
+            int* eprev = prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none;
+            if (!more) {
+                hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb) + 1), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses,
+                                   drots, dtrans, dvels, dts, LIN[c.pb], N, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot,
+                                   seq, (const double*)nullptr, (const double*)nullptr, rp, W, LIN[1 - c.pb], HD[1 - c.pb], HO[1 - c.pb],
+                                   RH[1 - c.pb], gate, eprev);
+                ISLAM_LAUNCH_CHECK();
+                return ISLAM_OK;
+            }
+            FusedArgs fa{};
+            fa.nodes = c.cur_n; fa.vels = c.cur_v; fa.dx = w.dx; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans; fa.dvels = dvels;
+            fa.dts = dts; fa.lin = LIN[c.pb]; fa.N = N; fa.nodes_t = c.tri_n; fa.vels_t = c.tri_v; fa.part = w.part; fa.st = w.state;
+            fa.flags = w.flags; fa.ticket = ticket; fa.tr = tr; fa.report = rep_slot; fa.seq = seq; fa.W = W;
+            fa.lin_o = LIN[1 - c.pb]; fa.Hd_o = HD[1 - c.pb]; fa.Ho_o = HO[1 - c.pb]; fa.rhs_o = RH[1 - c.pb];
+            fa.dst = level_dst(w.lv[0], w.dx);
+            fa.m = sp.lv[0].m; fa.P = sp.lv[0].P;
+            fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
+            fa.eflag_prev = eprev;
+            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fa.P) + 1), dim3(192), 0, s, fa, gate);
+            LevelSrc none{};
+            none.level0 = 1;
+            return enqueue_levels(w, sp, 0, none, nullptr, w.dx, w.flags, s, nullptr, nullptr, gate, true);
+        };
+        enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
+        hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+        int rc = enqueue_solve_hist(A.pb, epoch);
+        if (rc != ISLAM_OK) return rc;
+        bool prev_fused = false;
+        for (;;) {
+            const double seq = (double)(trials + 1);
+            const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
+            // (an accepted trial that would be the last optimizer step anyway -- StopOnPlateau's step limit -- needs no next solve)
+            const bool more = steps + 1 < prm->max_steps;
+            rc = enqueue_trial(A, seq, epoch, more, prev_fused);
+            if (rc != ISLAM_OK) return rc;
+            volatile double* hs = hs_all + 16 * ((long long)seq & 1);
+            {
+                unsigned long spins = 0;
+                while (hs[15] != seq) {
+                    if (++spins > 400000000ul) {
+                        ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                        if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: no status from the device (trial %d)", trials + 1);
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            ++trials;
+            const int verdict = (int)hs[12];
+            damping = hs[2];
+            loss = hs[0];
+            steps = (int)hs[13];
+            if (trace && trials <= trace_cap && verdict != 3 && verdict != 4) {
+                trace[3 * (trials - 1)] = hs[6];
+                trace[3 * (trials - 1) + 1] = damping;
+                trace[3 * (trials - 1) + 2] = (verdict == 1) ? 0.0 : 1.0;
+            }
+            if (verdict == 0) {               // accepted, the speculated damping was right: solve seq+1 is already running
+                A = B;
+                prev_fused = true;
+                continue;
+            }
+            epoch += 1.0;                     // any other verdict bumped the device epoch: the launches queued behind are no-ops
+            if (verdict == 2) { A = B; break; }
+            if (verdict == 4) { status = ISLAM_ENOTPD; break; }
+            // the speculative level-0 elimination (if there was one) is void: clear its error word; the next solve runs on the
+            // launched kernels from the linearisation in global memory
+            if (more) ISLAM_HIP_CHECK(hipMemsetAsync(w.flags + 4 + (((long long)seq + 1) & 1), 0, sizeof(int), s));
+            if (verdict == 5) A = B;          // accepted with another damping: the trial point's linearisation is in the other buffers
+            if (verdict == 3) status = ISLAM_ENOTPD;      // "Linear solver failed. Breaking optimization step...": same iterate, same
+                                                          // (undamped) linearisation, StopOnPlateau's plateau counter ends the loop
+            rc = enqueue_solve_hist(A.pb, epoch);
+            if (rc != ISLAM_OK) return rc;
+            prev_fused = false;
+        }
+        if (A.cur_n != nodes) {
+            ISLAM_HIP_CHECK(hipMemcpyAsync(nodes, A.cur_n, (size_t)N * 7 * sizeof(double), hipMemcpyDeviceToDevice, s));
+            ISLAM_HIP_CHECK(hipMemcpyAsync(vels, A.cur_v, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        result->steps = steps;
+        result->trials = trials;
+        result->status = status;
+        result->loss = loss;
+        result->damping = damping;
+        return ISLAM_OK;
+    }
     enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
     int rc = enqueue_iter(A, 1.0, epoch);

@@ -67,8 +67,8 @@ __device__ __forceinline__ void decide(const double* __restrict__ msg, double* _
     if (halo && t < 7) nt[(size_t)halo_row * 7 + t] = halo[t];
     if (halo && t >= 7 && t < 10) vt[(size_t)halo_row * 3 + (t - 7)] = halo[t];
     if (t == 0) {
-        flags[0] = msg[2] > 0.0 ? 1 : 0;                                // a failed pivot on ANY rank fails the step everywhere
-        lm_control(msg[0], msg[1], st, flags, tr, report, seq);
+        flags[0] = 0;
+        lm_control(msg[0], msg[1], st, msg[2] > 0.0, tr, report, seq);   // a failed pivot on ANY rank fails the step everywhere
     }
 }
 
@@ -109,7 +109,7 @@ __global__ void decide_kernel(const double* __restrict__ msg, double* __restrict
 // state <- [damping = 1 / radius (TrustRegion), radius, down, run-ahead epoch 1], everything else zero
 __global__ void state_init_kernel(double* __restrict__ st, double radius, double down) {
     const int t = threadIdx.x;
-    if (t < 16) st[t] = t == 2 ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
+    if (t < STATE_DOUBLES) st[t] = (t == 2 || t == STATE_HIST) ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : t == 14 ? 1.0 : 0.0;
 }
 
 // error path: an epoch no enqueued chain carries turns everything still queued into no-ops
@@ -214,7 +214,7 @@ int islam_dist_comm_destroy(void* comm) {
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
     size_t d = a256(LIN_C * n) + a256(n / 8 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +
-               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(16) + 2 * a256(ISLAM_REPROJ_REC * n);
+               a256(2 * (n / 64 + 2)) + a256(3 + 10 * (size_t)world) + a256(10 * n) + 2 * a256(351 * (n / 5 + 2)) + a256(64) + a256(STATE_DOUBLES) + 2 * a256(ISLAM_REPROJ_REC * n);
     return d * sizeof(double) + 512;
 }
 
@@ -245,7 +245,7 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     double* ex_own = take(351 * (nn / 5 + 2));        // own rows of the exchange level, everything else stays zero (zeroed once)
     double* ex = world > 1 ? take(351 * (nn / 5 + 2)) : ex_own;      // the sum over the ranks
     int* flags = (int*)take(64);
-    double* state = take(16);
+    double* state = take(STATE_DOUBLES);
     double* rp_lin = take(ISLAM_REPROJ_REC * nn);      // reprojection factor: per-link reductions at the linearisation point ...
     double* rp_tri = take(ISLAM_REPROJ_REC * nn);      // ... and at the trial point
     // verdicts in pinned, device-visible host memory (two slots, alternating with the trial number); the host polls the

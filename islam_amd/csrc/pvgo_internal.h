@@ -16,11 +16,18 @@ __device__ __forceinline__ bool gate_closed(const Gate& g) { return g.ctl != nul
 
 // ------------------------------------------------------------------------------------------
 // state: [0] loss [1] last [2] damping [3] radius [4] down [5] quality [6] trial loss [7] qden
-//        [8] reject_count [9] accepted [10] error [11] has_loss
+//        [8] reject_count [9] accepted [10] error [11] has_loss [15] branch TrustRegion.update took last (speculated_damping)
+//        [16 .. 16 + reject_count] the dampings applied to the diagonal of the CURRENT linearisation, in order (PyPose's
+//        `A.diagonal().add_(A.diagonal() * damping)` is cumulative over the retries of one optimizer.step(): entry 0 is the damping of
+//        the step's first solve, every reject appends one) -- what a solve that keeps the stored diagonal untouched (LevelSrc::hist,
+//        the fused trial + elimination kernel) applies instead of damping in place
+constexpr int STATE_DOUBLES = 40;
+constexpr int STATE_HIST = 16;
 // report (host-visible copy written after every trial): same slots as seen by the step that just ran, [15] = sequence number
 //        [12] optimizer steps [13] plateau patience count [14] run-ahead epoch (Gate)
 // report[12] = verdict: 0 accepted & continue, 1 rejected (retry with more damping), 2 accepted & stop, 3 solver failed &
-// continue (same iterate, new linearisation), 4 solver failed & stop;  report[13] = optimizer steps so far
+// continue (same iterate, new linearisation), 4 solver failed & stop, 5 accepted & continue but the damping the run-ahead solve
+// speculated on is not the one TrustRegion.update produced (the solve must be redone);  report[13] = optimizer steps so far
 struct TRParams { double high, low, up, down, factor, rmin, rmax; int reject; int max_steps, patience; double decreasing; };
 
 // StopOnPlateau.step(loss) after a finished optimizer.step() (pvgo.py:172,177-180): returns 1 when the loop must stop
@@ -34,25 +41,40 @@ __device__ __forceinline__ int scheduler_step(double* __restrict__ st, const TRP
     return stop;
 }
 
+// The damping the NEXT solve will use if this trial is accepted and TrustRegion.update takes the same branch as it did for the
+// previous trial (state[15]: 0 radius x up, 1 radius kept, 2 radius x down; an LM run stays in one regime for many trials) --
+// what the fused trial + elimination kernel speculates on: it needs the damping before the grid-wide sums of the trial exist.
+// The same floating-point operations as lm_control, so a correct guess is bit-identical to the real update.
+__device__ __forceinline__ double speculated_damping(const double* __restrict__ st, const TRParams& tr) {
+    const int cls = (int)st[15];
+    double radius = 1.0 / st[2];
+    if (cls == 0) radius = tr.up * radius;
+    else if (cls == 2) radius = radius * st[4];
+    radius = fmax(tr.rmin, fmin(radius, tr.rmax));
+    return 1.0 / radius;
+}
+
 // pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
-__device__ inline void lm_control(double s, double q, double* __restrict__ st, int* flags, const TRParams& tr,
-                                  double* __restrict__ report, double seq) {
+// failed: a solver error was flagged for the solve whose trial this is.  d_spec >= 0: the solve of the next step is already running
+// with this damping; an accepted trial whose TrustRegion.update yields another damping closes the gate (verdict 5).
+__device__ inline void lm_control(double s, double q, double* __restrict__ st, bool failed, const TRParams& tr,
+                                  double* __restrict__ report, double seq, double d_spec = -1.0) {
     double rep[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) rep[i] = 0.0;
-    if (flags[0] != 0) {                 // solver failed: PyPose prints and breaks the step, nothing changes
-        flags[0] = 0;
+    if (failed) {                        // solver failed: PyPose prints and breaks the step, nothing changes
         rep[0] = st[0]; rep[1] = st[1]; rep[2] = st[2]; rep[8] = st[8]; rep[10] = 1.0;
         rep[12] = scheduler_step(st, tr, st[1], st[0], st[8]) ? 4.0 : 3.0;
         st[8] = 0.0;
+        st[STATE_HIST] = st[2];          // the next optimizer.step() rebuilds A and damps it once with the unchanged damping
         st[14] += 1.0;
     } else {
         const double last = st[1];
         const double quality = (last - s) / (-q);
         double radius = 1.0 / st[2], down = st[4];
-        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; }
-        else if (quality > tr.low) { down = tr.down; }
-        else { radius = radius * down; down = down * tr.factor; }
+        if (quality > tr.high) { radius = tr.up * radius; down = tr.down; st[15] = 0.0; }
+        else if (quality > tr.low) { down = tr.down; st[15] = 1.0; }
+        else { radius = radius * down; down = down * tr.factor; st[15] = 2.0; }
         down = fmax(tr.rmin, fmin(down, tr.rmax));
         radius = fmax(tr.rmin, fmin(radius, tr.rmax));
         st[3] = radius; st[4] = down; st[2] = 1.0 / radius; st[5] = quality; st[6] = s; st[7] = -q;
@@ -60,17 +82,20 @@ __device__ inline void lm_control(double s, double q, double* __restrict__ st, i
         if (last < s && st[8] < (double)tr.reject) {       // reject: the host keeps the old iterate, loss = last
             st[0] = last;
             st[8] += 1.0;
+            st[STATE_HIST + min((int)st[8], STATE_DOUBLES - STATE_HIST - 1)] = st[2];      // the retry damps the already damped diagonal once more
             rep[0] = last; rep[8] = st[8]; rep[9] = 0.0;
             rep[12] = 1.0;
             st[14] += 1.0;
         } else {                                           // step kept (also when the reject limit is exhausted)
             rep[0] = s; rep[8] = st[8]; rep[9] = 1.0;
             const int stop = scheduler_step(st, tr, last, s, st[8]);
-            rep[12] = stop ? 2.0 : 0.0;
-            if (stop) st[14] += 1.0;
+            const bool respec = !stop && d_spec >= 0.0 && st[2] != d_spec;
+            rep[12] = stop ? 2.0 : (respec ? 5.0 : 0.0);
+            if (stop || respec) st[14] += 1.0;
             st[0] = s;
             st[1] = s;                                     // next optimizer.step(): self.last = self.loss
             st[8] = 0.0;
+            st[STATE_HIST] = st[2];                        // a new linearisation: damped once, with the new damping
         }
     }
     rep[13] = st[12];

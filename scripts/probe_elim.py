@@ -16,7 +16,7 @@ t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
 Hd_d, Ho_d, rhs = t(Hd), t(Ho), t(rng.normal(size=(N, 9)))
 for _ in range(5): ops.pvgo_solve_chain(Hd_d.clone(), Ho_d, rhs, 1e-4)
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 512)()
+buf = (ctypes.c_longlong * 1024)()
 L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
 assert L.lib().islam_probe_read(buf) == 0
 b = list(buf)

@@ -1,4 +1,4 @@
-"""Wall-clock (100 MHz) probes of trial_lin_kernel inside the LM loop (libislam_probe.so, scripts/build_probe.sh)."""
+"""Wall-clock (100 MHz) probes of trial_elim_kernel inside the LM loop (libislam_probe.so): three segments x three waves."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import islam_amd._lib as L
@@ -15,12 +15,13 @@ for _ in range(3):
     res, _ = ops.pvgo_run_chain(n, v, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'], prm, workspace=ws)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 1024)()
-L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
-assert L.lib().islam_probe_read(buf) == 0
+fn = L.lib()._cdll.islam_probe_read
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf) == 0
 b = list(buf)
-t0 = b[400]
-us = lambda x: (x - t0) / 100.0
-names = ['entry', 'loads+retract', 'residuals', 'quality', 'sum+ticket', 'barrier1', 'node stores', 'jacobians', 'emit(lin+LDS)', 'barrier2', 'build+copy']
-for i, nm in enumerate(names):
-    print('block 40  %-14s %.2f us' % (nm, us(b[400 + i])))
-print('deciding wave: start %.2f  done %.2f us (relative to block 40 entry)' % (us(b[420]), us(b[421])))
+names = ['entry', 'trial point', 'residuals', 'jacobians', 'emit', 'barrier 1', 'blocks built', 'barrier 2', 'elim start', 'elim end']
+for seg, so in (('p=1', 0), ('p=P/2', 30), ('p=P-2', 60)):
+    t0 = min(b[600 + so + 10 * w] for w in range(3))
+    for w in range(3):
+        base = 600 + so + 10 * w
+        print('%s wave %d: ' % (seg, w) + '  '.join('%s %.2f' % (names[i], (b[base + i] - t0) / 100.0) for i in range(10) if b[base + i] >= t0))

@@ -14,7 +14,7 @@ for _ in range(3):
     n, v = prob['init_nodes'].clone(), prob['init_vels'].clone()
     res, _ = ops.pvgo_run_chain(n, v, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'], prm, workspace=ws)
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 512)()
+buf = (ctypes.c_longlong * 1024)()
 L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
 assert L.lib().islam_probe_read(buf) == 0
 b = list(buf)
