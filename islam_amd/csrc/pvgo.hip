@@ -1212,44 +1212,81 @@ __device__ __forceinline__ void helper_node(const LevelDst& dst, int c, const do
     }
 }
 
-__device__ __forceinline__ void twisted_helper(const LevelDst& dst, int p, int firstA, int nA, bool has_left, int firstB, int nB,
-                                               bool has_right, int lane, const double* __restrict__ ldsA,
-                                               const double* __restrict__ ldsB, double* __restrict__ accB, const Gate& gate) {
-    if (gate_closed(gate)) return;
+// middle index of a segment with cnt interior nodes (wave A: nodes 0..h incl. the middle, wave B: cnt-1 .. h+1)
+__host__ __device__ __forceinline__ int twisted_mid(int cnt) { return cnt >= 3 ? cnt / 2 : cnt - 1; }
+
+// One helper wave can serve several segments of a workgroup (NSEG; trial_elim_kernel: two): nbar = barriers the workgroup executes.
+struct HelpSeg { int p, firstA, nA, firstB, nB; bool has_left, has_right, on; const double *ldsA, *ldsB; double* accB; };
+
+template <int NSEG>
+__device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSeg (&sg)[NSEG], int nbar, int lane) {
     int pa, pb;
     pair_of(lane, pa, pb);
     if (lane >= 45) { pa = lane - 45; pb = 9; }
-    const bool onA = has_left && lane < 54, onB = has_right && lane < 54;
-    double accA = 0.0, accBv = 0.0;
-    for (int t = 0; t < nA; ++t) {
-        if (t == nA - 1) {                               // (nB < nA: the reverse sweep's last node was picked up a step ago)
-            if (lane < 45) {
-                accB[pa * 10 + pb] = has_right ? accBv : 0.0;
-                accB[pb * 10 + pa] = has_right ? accBv : 0.0;
-            } else if (lane < 54) {
-                accB[(lane - 45) * 10 + 9] = has_right ? accBv : 0.0;
+    double accA[NSEG], accBv[NSEG];
+#pragma unroll
+    for (int q = 0; q < NSEG; ++q) { accA[q] = 0.0; accBv[q] = 0.0; }
+    for (int t = 0; t < nbar; ++t) {
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q) {
+            if (sg[q].on && t == sg[q].nA - 1) {             // (nB < nA: the reverse sweep's last node was picked up a step ago)
+                double* accB = sg[q].accB;
+                if (lane < 45) {
+                    accB[pa * 10 + pb] = sg[q].has_right ? accBv[q] : 0.0;
+                    accB[pb * 10 + pa] = sg[q].has_right ? accBv[q] : 0.0;
+                } else if (lane < 54) {
+                    accB[(lane - 45) * 10 + 9] = sg[q].has_right ? accBv[q] : 0.0;
+                }
             }
         }
         lds_barrier();
-        helper_node(dst, firstA + t, ldsA + (t & 1) * H_STAGE, lane, onA, pa, pb, accA);
-        if (t < nB) helper_node(dst, firstB - t, ldsB + (t & 1) * H_STAGE, lane, onB, pa, pb, accBv);
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q) {
+            if (!sg[q].on) continue;
+            if (t < sg[q].nA) helper_node(dst, sg[q].firstA + t, sg[q].ldsA + (t & 1) * H_STAGE, lane, sg[q].has_left && lane < 54, pa, pb, accA[q]);
+            if (t < sg[q].nB) helper_node(dst, sg[q].firstB - t, sg[q].ldsB + (t & 1) * H_STAGE, lane, sg[q].has_right && lane < 54, pa, pb, accBv[q]);
+        }
     }
-    if (has_left) {
+#pragma unroll
+    for (int q = 0; q < NSEG; ++q) {
+        if (!sg[q].on || !sg[q].has_left) continue;
         if (lane < 45) {
-            dst.cL[(size_t)p * 81 + pa * 9 + pb] = accA;
-            dst.cL[(size_t)p * 81 + pb * 9 + pa] = accA;
+            dst.cL[(size_t)sg[q].p * 81 + pa * 9 + pb] = accA[q];
+            dst.cL[(size_t)sg[q].p * 81 + pb * 9 + pa] = accA[q];
         } else if (lane < 54) {
-            dst.cgL[(size_t)p * 9 + (lane - 45)] = accA;
+            dst.cgL[(size_t)sg[q].p * 9 + (lane - 45)] = accA[q];
         }
     }
 }
 
-// middle index of a segment with cnt interior nodes (wave A: nodes 0..h incl. the middle, wave B: cnt-1 .. h+1)
-__host__ __device__ __forceinline__ int twisted_mid(int cnt) { return cnt >= 3 ? cnt / 2 : cnt - 1; }
+// segment p of a level with n nodes cut into segments of m: what its sweeps and its helper need
+struct SegGeom { int c0, cnt, sR, h, nA, nB; bool has_left, has_right, tw; };
+__device__ __forceinline__ SegGeom seg_geom(int n, int m, int p) {
+    SegGeom g;
+    g.c0 = p * (m + 1);
+    g.cnt = min(m, n - g.c0);
+    g.has_left = p > 0;
+    g.sR = g.c0 + m;
+    g.has_right = g.sR < n;
+    g.tw = g.cnt >= 3;
+    g.h = twisted_mid(g.cnt);
+    g.nA = g.tw ? g.h + 1 : g.cnt;
+    g.nB = g.tw ? g.cnt - 1 - g.h : 0;
+    return g;
+}
+__device__ __forceinline__ HelpSeg help_seg(const SegGeom& g, int p, double* lds_seg) {
+    HelpSeg s;
+    s.p = p; s.firstA = g.c0; s.nA = g.nA; s.firstB = g.c0 + g.cnt - 1; s.nB = g.nB; s.has_left = g.has_left; s.has_right = g.has_right;
+    s.on = true; s.ldsA = lds_seg; s.ldsB = lds_seg + H_SWEEP; s.accB = lds_seg + 2 * H_SWEEP;
+    return s;
+}
 
+
+// uniform: every wave executes exactly one workgroup barrier whatever the segment looks like (several segments share a workgroup)
+template <int L0 = -1>
 __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
                                                   int wave, int lane, double* __restrict__ lds_wg,
-                                                  const Gate& gate = Gate{nullptr, 0.0}) {
+                                                  const Gate& gate = Gate{nullptr, 0.0}, bool uniform = false) {
     const int stride = m + 1;
     const int c0 = p * stride;
     const int cnt = min(m, n - c0);
@@ -1262,37 +1299,44 @@ __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const Lev
     double* ldsB = lds_wg + LDS_PER_WAVE;
     double* accB = lds_wg + 2 * LDS_PER_WAVE;
     if (wave == 0) {
-        twisted_sweep<false>(src, dst, n, p, c0, tw ? h + 1 : cnt, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags,
-                             lane, ldsA, ldsB + 2 * 19 * XS, accB, gate);
+        twisted_sweep<false, false, L0>(src, dst, n, p, c0, tw ? h + 1 : cnt, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags,
+                                        lane, ldsA, ldsB + 2 * 19 * XS, accB, gate);
+        if (uniform && !tw) __syncthreads();
     } else if (tw) {
-        twisted_sweep<true>(src, dst, n, p, c0 + cnt - 1, cnt - 1 - h, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB, gate);
+        twisted_sweep<true, false, L0>(src, dst, n, p, c0 + cnt - 1, cnt - 1 - h, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB, gate);
+    } else if (uniform) {
+        __syncthreads();
     }
+}
+
+// The two sweeps of segment p with helper hand-off (HELP): role 0 = forward, 1 = reverse.  nbar = barriers every wave of the
+// workgroup executes (>= this segment's forward step count; more when a workgroup holds segments of different lengths).
+template <int L0>
+__device__ __forceinline__ void sweep_with_helper(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags, int role, int lane,
+                                                  double* __restrict__ lds_seg, const Gate& gate, int nbar) {
+    const SegGeom g = seg_geom(n, m, p);
+    double* ldsA = lds_seg;
+    double* ldsB = lds_seg + H_SWEEP;
+    double* accB = lds_seg + 2 * H_SWEEP;
+    if (role == 0)
+        twisted_sweep<false, true, L0>(src, dst, n, p, g.c0, g.nA, g.has_left, g.tw ? g.h - 1 : -1, g.has_right ? g.sR : -1, g.has_right, flags,
+                                       lane, ldsA, ldsB + 2 * H_STAGE, accB, gate, nbar);
+    else if (g.tw)
+        twisted_sweep<true, true, L0>(src, dst, n, p, g.c0 + g.cnt - 1, g.nB, g.has_right, -1, -1, g.has_right, flags, lane, ldsB, nullptr, accB,
+                                      gate, nbar);
+    else if (!gate_closed(gate)) { for (int t = 0; t < nbar; ++t) lds_barrier(); }
 }
 
 // three wavefronts per segment: 0 = forward sweep, 1 = reverse sweep, 2 = the helper of both
 template <int L0>
 __device__ __forceinline__ void eliminate_twisted3(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
                                                    int wave, int lane, double* __restrict__ lds_wg, const Gate& gate) {
-    const int stride = m + 1;
-    const int c0 = p * stride;
-    const int cnt = min(m, n - c0);
-    const bool has_left = p > 0;
-    const int sR = c0 + m;
-    const bool has_right = sR < n;
-    const bool tw = cnt >= 3;
-    const int h = twisted_mid(cnt);
-    const int nA = tw ? h + 1 : cnt, nB = tw ? cnt - 1 - h : 0;
-    double* ldsA = lds_wg;
-    double* ldsB = lds_wg + H_SWEEP;
-    double* accB = lds_wg + 2 * H_SWEEP;
-    if (wave == 0)
-        twisted_sweep<false, true, L0>(src, dst, n, p, c0, nA, has_left, tw ? h - 1 : -1, has_right ? sR : -1, has_right, flags, lane, ldsA,
-                                       ldsB + 2 * H_STAGE, accB, gate, nA);
-    else if (wave == 1) {
-        if (tw) twisted_sweep<true, true, L0>(src, dst, n, p, c0 + cnt - 1, nB, has_right, -1, -1, has_right, flags, lane, ldsB, nullptr, accB, gate, nA);
-        else if (!gate_closed(gate)) { for (int t = 0; t < nA; ++t) lds_barrier(); }
-    } else
-        twisted_helper(dst, p, c0, nA, has_left, c0 + cnt - 1, nB, has_right, lane, ldsA, ldsB, accB, gate);
+    const SegGeom g = seg_geom(n, m, p);
+    if (wave < 2) sweep_with_helper<L0>(src, dst, n, m, p, flags, wave, lane, lds_wg, gate, g.nA);
+    else if (!gate_closed(gate)) {
+        const HelpSeg sg[1] = {help_seg(g, p, lds_wg)};
+        twisted_helper<1>(dst, sg, g.nA, lane);
+    }
 }
 
 // (level 0 of the N = 5001 tree has 834 segments, all of which must be resident at once: 3 waves per SIMD, i.e. <= 168 VGPRs)
@@ -1854,7 +1898,7 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
                                                     double* __restrict__ vels_t, double* part, double* st, int* flags,
                                                     unsigned* ticket, TRParams tr, double* report, double seq,
                                                     const double* __restrict__ red_lin, const double* __restrict__ red_trial,
-                                                    ReprojDev rp, int lin_stride, Gate gate) {
+                                                    ReprojDev rp, int lin_stride, Gate gate, int* eflag2 = nullptr) {
     if (gate_closed(gate)) return;
     const int nblk = (M + 63) / 64;
     const int blk = xcd_index(blockIdx.x, nblk);
@@ -1933,8 +1977,9 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     q = wave_sum(q);
     if (threadIdx.x == 0) {
         *ticket = 0u;
-        const bool failed = flags[0] != 0;
+        bool failed = flags[0] != 0;
         flags[0] = 0;
+        if (eflag2) { failed = failed || *eflag2 != 0; *eflag2 = 0; }     // (level 0 of the solve ran inside trial_elim_kernel)
         lm_control(s, q, st, failed, tr, report, seq);
     }
     PROBE_AT(threadIdx.x == 0, 207);
@@ -2098,37 +2143,52 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// The LM loop's steady state in ONE launch per level-0 segment: trial step + loss / trust-region partial sums of trial t, the
-// linearisation at the trial point, AND the level-0 elimination of the next solve straight out of LDS.
+// The LM loop's steady state in ONE launch: trial step + loss / trust-region partial sums of trial t, the linearisation at the
+// trial point, AND the level-0 elimination of the next solve straight out of LDS.
 //
 // The elimination of step t+1 damps its diagonal with TrustRegion.update's output for trial t, which needs sums over ALL links --
 // a grid-wide dependency between the linearisation and the first pivot.  It is broken by SPECULATION: the next damping has three
 // possible values (radius x up / kept / x down); every workgroup assumes that the trial is accepted and that TrustRegion.update takes
 // the branch it took for the previous trial (speculated_damping: an LM run stays in one regime for many trials -- on the
-// 5000-frame bench graph the radius is kept on all ten).  The deciding workgroup (one extra workgroup, as in trial_lin_kernel) validates
-// the guess when the sums are in and bumps the run-ahead epoch otherwise (verdict 5, or any of the non-"accepted, continue"
-// verdicts): the launches queued behind this one (upper levels, down-sweep) turn into no-ops and the host redoes the solve on the
-// launched level-0 kernel from the linearisation this kernel wrote to global memory (undamped: LevelSrc::hist).
+// 5000-frame bench graph the radius is kept on all ten).  The deciding workgroup (one extra workgroup, as in trial_lin_kernel)
+// validates the guess when the sums are in and bumps the run-ahead epoch otherwise (verdict 5, or any of the non-"accepted,
+// continue" verdicts): the launches queued behind this one (upper levels, down-sweep) turn into no-ops and the host redoes the
+// solve on the launched level-0 kernel from the linearisation this kernel wrote to global memory (undamped: LevelSrc::hist).
 //
-// Workgroup = segment p of level 0 (m interior nodes c0 .. c0+m-1, right separator c0+m), three wavefronts:
-//   wave 0  one lane per link c0-1 .. c0+m (the two outer links are shared with the neighbouring segments): retraction, residuals
-//           at the trial point, Jacobians, weighted per-link pieces -> LDS; trial iterate / lin record of the links it owns
-//   wave 1  trust-region term (J D)^T (2R + J D) of the owned links from the OLD linearisation; publishes both partial sums
-//   all     node blocks Hd / Ho / rhs of nodes c0 .. c0+m in LDS, one 3x3 sub-block per thread
-//   wave 2  copies the blocks to global memory (coalesced), then serves as the elimination's helper (twisted_helper)
-//   waves 0, 1  twisted elimination of the segment, columns read from the LDS blocks (eliminate_twisted3)
-// Saves per LM iteration: one launch (11 us), the 13.7 MB round trip of Hd / Ho / rhs through HBM on the critical path, and the
-// level-0 kernel's first dependent loads.
+// Workgroup = FZ_S = 4 CONSECUTIVE level-0 segments = one contiguous stretch of G = 4 (m+1) nodes, eight wavefronts, one workgroup
+// per CU (the first version gave every segment its own three-wave workgroup: 834 wavefronts each ran the whole SE(3) arithmetic of
+// its 7 links on 7 of 64 lanes, two or three of them per SIMD -- 20 us before the first pivot, scripts/probe_fused.py).  The
+// per-link arithmetic is cut along its natural seams so that no wavefront carries a long instruction stream:
+//   A  wave 0, one lane per NODE: retraction X <- Exp(dx) X (LieTensor.add_), the trial iterate goes to LDS and to global memory
+//   B  wave 0, one lane per LINK: pose-graph residual Log(P^-1 Xi^-1 Xj), its Jacobian blocks G, C and their weighted products
+//      wave 1, one lane per link: IMU rotation / velocity / translation residuals, B and its products   (concurrently)
+//      wave 2, one lane per link: trust-region term (J D)^T (2R + J D) from the OLD linearisation        (concurrently)
+//      wave 3: sums both partial sums over the workgroup's links and publishes them
+//   C  all waves: node blocks Hd / Ho / rhs of the stretch in LDS, one 3x3 sub-block per thread (type-major: a wave builds one or
+//      two kinds of block, no divergence); the same blocks go to global memory, lane-contiguous (fallback solves read them)
+//   D  waves 2s, 2s+1: twisted elimination of segment s, columns read from the LDS blocks (eliminate_twisted)
+// The sums of products are formed in the order of link_emit / nodes_build_copy, so the linearisation is bit-identical to
+// linbuild_kernel's.  Saves per LM iteration: one launch, the 13.7 MB round trip of Hd / Ho / rhs through HBM on the critical
+// path, and the level-0 kernel's first dependent loads.
+constexpr int FZ_S = 4;                                    // segments per workgroup
+constexpr int FZ_HELPERS = FZ_S / 2;                       // helper waves, two segments each
+constexpr int FZ_THREADS = (2 * FZ_S + FZ_HELPERS) * 64;
 constexpr int FZ_MAXM = BS_PAR_MAX;
-constexpr int FZ_LINKS = FZ_MAXM + 2;                      // links c0-1 .. c0+m
-constexpr int FZ_NODES = FZ_MAXM + 1;                      // nodes c0 .. c0+m
-constexpr int FZ_OFF_SUM = (FZ_LINKS * LB_REC + 1) & ~1;
-constexpr int FZ_OFF_HD = FZ_OFF_SUM + 2;
-constexpr int FZ_OFF_HO = (FZ_OFF_HD + FZ_NODES * 81 + 1) & ~1;
-constexpr int FZ_OFF_RHS = (FZ_OFF_HO + (FZ_NODES + 1) * 81 + 1) & ~1;
-constexpr int FZ_OFF_TW = (FZ_OFF_RHS + FZ_NODES * 9 + 1) & ~1;
-constexpr int FZ_LDS = FZ_OFF_TW + LDS_TW4;
-static_assert(FZ_OFF_HD % 2 == 0 && FZ_OFF_HO % 2 == 0 && FZ_OFF_RHS % 2 == 0 && FZ_OFF_TW % 2 == 0, "16-byte aligned LDS regions");
+constexpr int FZ_G = FZ_S * (FZ_MAXM + 1);                 // nodes of a workgroup's stretch (at most)
+constexpr int FZ_XT = 10;                                  // retracted node: t 3 | q 4 | v 3
+constexpr int FZ_RV = 35;                                  // pose-graph pieces of a link: Srr 9 | Srp 9 | Spp 9 | gr 3 | gp 3 | e.e 1 | pad
+constexpr int FZ_RI = 25;                                  // IMU pieces: Spp 9 | w3 rt 3 | gp 3 | rv 3 | rt 3 | dt 1 | rv.rv, er.er, rt.rt
+constexpr int fz_even(int x) { return (x + 1) & ~1; }
+constexpr int FZ_OFF_XT = 0;
+constexpr int FZ_OFF_SV = fz_even(FZ_OFF_XT + (FZ_G + 2) * FZ_XT);
+constexpr int FZ_OFF_SI = fz_even(FZ_OFF_SV + (FZ_G + 1) * FZ_RV);
+constexpr int FZ_OFF_SUM = fz_even(FZ_OFF_SI + (FZ_G + 1) * FZ_RI);
+constexpr int FZ_OFF_HD = FZ_OFF_SUM + 4;
+constexpr int FZ_OFF_HO = fz_even(FZ_OFF_HD + FZ_G * 81);
+constexpr int FZ_OFF_RHS = fz_even(FZ_OFF_HO + (FZ_G + 1) * 81);
+constexpr int FZ_OFF_TW = fz_even(FZ_OFF_RHS + FZ_G * 9);
+constexpr int FZ_LDS = FZ_OFF_TW + FZ_S * LDS_TW4;
+constexpr int FZ_LDS_BYTES = FZ_LDS * (int)sizeof(double);
 
 struct FusedArgs {
     const double *nodes, *vels, *dx, *poses, *drots, *dtrans, *dvels, *dts, *lin;    // iterate, step, measurements, OLD linearisation
@@ -2144,16 +2204,21 @@ struct FusedArgs {
     LinWeights W;
     double *lin_o, *Hd_o, *Ho_o, *rhs_o;          // linearisation at the trial point (diagonal clamped, UNDAMPED)
     LevelDst dst;                                 // level-0 factor and products
-    int m, P;                                     // level-0 segment length / count
+    int m, P, nwg;                                // level-0 segment length / count, workgroups (each takes <= FZ_S consecutive segments)
     int* eflag;                                   // solver-error word of THIS elimination
     int* eflag_prev;                              // ... of the level-0 elimination of the solve whose trial is evaluated here
 };
 
 __device__ __forceinline__ M3<double> m3_zero() { return M3<double>{0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ void put33(double* h, const M3<double>& b) {        // 3x3 block into a row-major 9-wide matrix
+    h[0] = b.a00; h[1] = b.a01; h[2] = b.a02; h[9] = b.a10; h[10] = b.a11; h[11] = b.a12; h[18] = b.a20; h[19] = b.a21; h[20] = b.a22;
+}
 
-__global__ __launch_bounds__(192, 3) void trial_elim_kernel(FusedArgs a, Gate gate) {
-    __shared__ __attribute__((aligned(16))) double lds[FZ_LDS];
-    double (*sl)[LB_REC] = reinterpret_cast<double (*)[LB_REC]>(lds);
+__global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, Gate gate) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* xt = lds + FZ_OFF_XT;
+    double* sv = lds + FZ_OFF_SV;
+    double* si = lds + FZ_OFF_SI;
     double* s_sum = lds + FZ_OFF_SUM;
     double* Hd_l = lds + FZ_OFF_HD;
     double* Ho_l = lds + FZ_OFF_HO;
@@ -2167,14 +2232,14 @@ __global__ __launch_bounds__(192, 3) void trial_elim_kernel(FusedArgs a, Gate ga
         __builtin_amdgcn_s_sleep(64);
         if (lane == 0) {
             int spins = 0;
-            while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)a.P) {
+            while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)a.nwg) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 22)) { atomicOr(a.flags, 2); break; }     // never observed; a logic error must not hang the GPU
             }
         }
         asm volatile("" ::: "memory");
         double ssum = 0.0, qsum = 0.0;
-        for (int i = lane; i < a.P; i += 64) {
+        for (int i = lane; i < a.nwg; i += 64) {
             ssum += ld_coherent(&a.part[2 * i]);
             qsum += ld_coherent(&a.part[2 * i + 1]);
         }
@@ -2189,150 +2254,205 @@ __global__ __launch_bounds__(192, 3) void trial_elim_kernel(FusedArgs a, Gate ga
         }
         return;
     }
-    const int p = xcd_index(blockIdx.x, a.P);
-    if (p < 0 || gate_closed(gate)) return;
+    const int wg = xcd_index(blockIdx.x, a.nwg);
+    if (wg < 0 || gate_closed(gate)) return;
     const double d_spec = speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
-    const int m = a.m, stride = m + 1, c0 = p * stride;
-    [[maybe_unused]] const bool fpr = lane == 0 && (p == 1 || p == a.P / 2 || p == a.P - 2);     // probe build only
-    [[maybe_unused]] const int fpo = 600 + (p == 1 ? 0 : p == a.P / 2 ? 30 : 60) + 10 * wave;
+    // the level's segments are dealt out evenly: workgroup wg takes segments [wg P / nwg, (wg+1) P / nwg) -- three or four of them
+    // on the 5000-frame graph, so that all 256 CUs share the level's pivots
+    const int seg0 = (int)(((long long)wg * a.P) / a.nwg), seg1 = (int)(((long long)(wg + 1) * a.P) / a.nwg);
+    const int m = a.m, stride = m + 1, G = (seg1 - seg0) * stride;
+    const int cb = seg0 * stride;                                // first node of the stretch; links cb-1 .. cb+G-1, nodes cb-1 .. cb+G
+    [[maybe_unused]] const bool fpr = lane == 0 && (wg == 1 || wg == a.nwg / 2);     // probe build only
+    [[maybe_unused]] const int fpo = 600 + (wg == 1 ? 0 : 100) + 12 * wave;
     PROBE_WALL(fpr, fpo);
-    const int L = c0 - 1 + lane;                                   // link of this lane (waves 0 and 1)
-    const bool valid = lane <= m + 1 && L >= 0 && L < M;
-    const bool owns = valid && lane >= 1 && lane <= stride;        // links c0 .. c0+m belong to this segment
+    // ---- A: retraction, one lane per node
     if (wave == 0) {
-        double sq = 0.0, dt = 0.0;
-        SE3<double> Xi{}, Xj{};
-        V3<double> vi{}, vj{};
-        LinkRes r{};
-        if (valid) {
-            const double* di = a.dx + (size_t)L * 9;
-            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
-            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
-            Xi = se3_mul(se3_exp(dri, dpi), se3_load(a.nodes + 7 * L));                    // LieTensor.add_
-            Xj = se3_mul(se3_exp(drj, dpj), se3_load(a.nodes + 7 * (L + 1)));
-            vi = ld3(a.vels + 3 * L) + dvi;
-            vj = ld3(a.vels + 3 * (L + 1)) + dvj;
-            dt = a.dts[L];
-            PROBE_WALL(fpr, fpo + 1);
-            r = link_residuals(Xi, Xj, vi, vj, se3_load(a.poses + 7 * L), ld4(a.drots + 4 * L), ld3(a.dtrans + 3 * L),
-                               ld3(a.dvels + 3 * L), dt);
-            PROBE_WALL(fpr, fpo + 2);
-            if (owns) {
-                sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
-                se3_store(Xi, a.nodes_t + 7 * L);
-                a.vels_t[3 * L] = vi.x; a.vels_t[3 * L + 1] = vi.y; a.vels_t[3 * L + 2] = vi.z;
-                if (L == M - 1) {
-                    se3_store(Xj, a.nodes_t + 7 * (L + 1));
-                    a.vels_t[3 * L + 3] = vj.x; a.vels_t[3 * L + 4] = vj.y; a.vels_t[3 * L + 5] = vj.z;
-                }
+        const int k = cb - 1 + lane;
+        if (lane < G + 2 && k >= 0 && k < N) {
+            const double* d = a.dx + (size_t)k * 9;
+            const SE3<double> X = se3_mul(se3_exp(ld3(d), ld3(d + 3)), se3_load(a.nodes + 7 * k));      // LieTensor.add_
+            const V3<double> v = ld3(a.vels + 3 * k) + ld3(d + 6);
+            double* o = xt + lane * FZ_XT;
+            se3_store(X, o);
+            o[7] = v.x; o[8] = v.y; o[9] = v.z;
+            if (lane >= 1 && lane <= G) {                            // the stretch's own nodes
+                se3_store(X, a.nodes_t + 7 * k);
+                a.vels_t[3 * k] = v.x; a.vels_t[3 * k + 1] = v.y; a.vels_t[3 * k + 2] = v.z;
             }
         }
-        sq = wave_sum(sq);
-        if (lane == 0) s_sum[0] = sq;                 // published by wave 2 after the barrier below: this wave never waits for a store
-        if (valid) {
-            M3<double> G, C, B;
-            link_jacobians(r, G, C, B);
-            PROBE_WALL(fpr, fpo + 3);
-            link_emit(r, G, C, B, dt, L, M, owns, a.W, a.lin_o, sl[lane], nullptr, ReprojDev{}, Xi);
-        }
-        PROBE_WALL(fpr, fpo + 4);
-    } else if (wave == 1) {
-        double qd = 0.0;
-        if (owns) {
-            const double* di = a.dx + (size_t)L * 9;
-            const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
-            const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
-            const double dtl = a.dts[L];
-            double rec[LIN_C];
-#pragma unroll
-            for (int c = 0; c < LIN_C; ++c) rec[c] = a.lin[(size_t)c * M + L];
-            const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
-            const V3<double> ddr = drj - dri, ddp = dpj - dpi;
-            const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
-            const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
-                R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
-            qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
-                 dot(j4, 2.0 * R4 + j4);
-        }
-        qd = wave_sum(qd);
-        if (lane == 0) s_sum[1] = qd;
     }
     lds_barrier();
-    PROBE_WALL(fpr, fpo + 5);
-    if (wave == 2 && lane == 0) {
-        // publish: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
-        st_coherent(&a.part[2 * p], s_sum[0]);
-        st_coherent(&a.part[2 * p + 1], s_sum[1]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- node blocks of nodes c0 .. c0+m (Hd, rhs) and of the couplings c0-1 .. c0+m-1 (Ho), one 3x3 sub-block per thread
+    PROBE_WALL(fpr, fpo + 1);
+    // ---- B: one lane per link j (link L = cb-1+j joins the nodes in xt[j], xt[j+1])
     {
-        const int tid = threadIdx.x, nb9 = stride * 9;
+        const int L = cb - 1 + lane;
+        const bool valid = lane <= G && L >= 0 && L < M;
+        const bool owns = valid && lane >= 1;                        // links cb .. cb+G-1 belong to this stretch
+        const double* xi = xt + lane * FZ_XT;
+        const double* xj = xi + FZ_XT;
+        if (wave == 0 && valid) {
+            const SE3<double> Xi = se3_load(xi), Xj = se3_load(xj);
+            const SE3<double> pre = se3_mul(se3_inv(se3_load(a.poses + 7 * L)), se3_inv(Xi));
+            V3<double> erho, ephi;
+            se3_log(se3_mul(pre, Xj), erho, ephi);
+            const M3<double> Ji = so3_Jl_inv(ephi);
+            const M3<double> R = qmat(pre.q);
+            const M3<double> Gm = Ji * R;
+            const M3<double> C = Ji * (skew(pre.t) * R - se3_Q(erho, ephi) * Gm);
+            if (owns) {
+                double* lo = a.lin_o + L;
+                lo[0] = erho.x; lo[(size_t)M] = erho.y; lo[(size_t)2 * M] = erho.z;
+                lo[(size_t)3 * M] = ephi.x; lo[(size_t)4 * M] = ephi.y; lo[(size_t)5 * M] = ephi.z;
+                double rec[18];
+                m3_store(Gm, rec);
+                m3_store(C, rec + 9);
+#pragma unroll
+                for (int c = 0; c < 18; ++c) lo[(size_t)(6 + c) * M] = rec[c];
+            }
+            const M3<double> Gt = transpose(Gm), Ct = transpose(C);
+            const M3<double> GtG = Gt * Gm;
+            double* o = sv + lane * FZ_RV;
+            m3_store(a.W.w0 * GtG + a.W.w3 * m3_identity<double>(), o);
+            m3_store(a.W.w0 * (Gt * C), o + 9);
+            m3_store(a.W.w0 * (Ct * C + GtG), o + 18);
+            const V3<double> gr = a.W.w0 * (Gt * erho), gp = a.W.w0 * (Ct * erho + Gt * ephi);
+            o[27] = gr.x; o[28] = gr.y; o[29] = gr.z; o[30] = gp.x; o[31] = gp.y; o[32] = gp.z;
+            o[33] = dot(erho, erho) + dot(ephi, ephi);
+        } else if (wave == 1 && valid) {
+            const V3<double> ti = ld3(xi), tj = ld3(xj), vi = ld3(xi + 7), vj = ld3(xj + 7);
+            const Q4<double> qi = ld4(xi + 3), qj = ld4(xj + 3);
+            const double dt = a.dts[L];
+            const V3<double> rv = ld3(a.dvels + 3 * L) - (vj - vi);
+            const Q4<double> rpre = qmul(qinv(ld4(a.drots + 4 * L)), qinv(qi));
+            const V3<double> er = so3_log(qmul(rpre, qj));
+            const V3<double> rt = (tj - ti) - (dt * vi + ld3(a.dtrans + 3 * L));
+            const M3<double> B = so3_Jl_inv(er) * qmat(rpre);
+            if (owns) {
+                double* lo = a.lin_o + L;
+                lo[(size_t)24 * M] = er.x; lo[(size_t)25 * M] = er.y; lo[(size_t)26 * M] = er.z;
+                double rec[9];
+                m3_store(B, rec);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) lo[(size_t)(27 + c) * M] = rec[c];
+                lo[(size_t)36 * M] = rv.x; lo[(size_t)37 * M] = rv.y; lo[(size_t)38 * M] = rv.z;
+                lo[(size_t)39 * M] = rt.x; lo[(size_t)40 * M] = rt.y; lo[(size_t)41 * M] = rt.z;
+            }
+            const M3<double> Bt = transpose(B);
+            double* o = si + lane * FZ_RI;
+            m3_store(a.W.w2 * (Bt * B), o);
+            const V3<double> w3rt = a.W.w3 * rt, gp = a.W.w2 * (Bt * er);
+            o[9] = w3rt.x; o[10] = w3rt.y; o[11] = w3rt.z; o[12] = gp.x; o[13] = gp.y; o[14] = gp.z;
+            o[15] = rv.x; o[16] = rv.y; o[17] = rv.z; o[18] = rt.x; o[19] = rt.y; o[20] = rt.z; o[21] = dt;
+            o[22] = dot(rv, rv); o[23] = dot(er, er); o[24] = dot(rt, rt);
+        } else if (wave == 2) {
+            // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
+            double qd = 0.0;
+            if (owns) {
+                const double* di = a.dx + (size_t)L * 9;
+                const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+                const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+                const double dtl = a.dts[L];
+                double rec[LIN_C];
+#pragma unroll
+                for (int c = 0; c < LIN_C; ++c) rec[c] = a.lin[(size_t)c * M + L];
+                const M3<double> Gm = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+                const V3<double> ddr = drj - dri, ddp = dpj - dpi;
+                const V3<double> j0 = Gm * ddr + C * ddp, j1 = Gm * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
+                const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+                    R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+                qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+                     dot(j4, 2.0 * R4 + j4);
+            }
+            qd = wave_sum(qd);
+            if (lane == 0) s_sum[1] = qd;
+        }
+    }
+    lds_barrier();
+    PROBE_WALL(fpr, fpo + 2);
+    if (wave == 3) {
+        // unweighted loss of the stretch's own links (the terms in the order of link_residuals' sum), then publish both partial
+        // sums: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
+        const int L = cb - 1 + lane;
+        double sq = 0.0;
+        if (lane >= 1 && lane <= G && L < M) {
+            const double* o = si + lane * FZ_RI;
+            sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) {
+            st_coherent(&a.part[2 * wg], sq);
+            st_coherent(&a.part[2 * wg + 1], s_sum[1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- C: node blocks.  Node i of the stretch (k = cb+i) takes link slots i (k-1) and i+1 (k); coupling i (k' = cb-1+i) is link slot i.
+    // One 3x3 sub-block per thread, 32 slots per kind of block: a half-wave builds ONE kind (9 of Hd, 9 of Ho, the right-hand side)
+    {
         const double w1 = a.W.w1, w3 = a.W.w3;
         const M3<double> I = m3_identity<double>();
-        if (tid < nb9) {
-            const int i = tid / 9, b = tid - i * 9, br = b / 3, bc = b - br * 3, k = c0 + i;
-            if (k < N) {
-                const double* a0 = sl[i];
-                const double* a1 = sl[i + 1];
+        for (int it = threadIdx.x; it < 19 * 32; it += FZ_THREADS) {
+            const int ty = it >> 5, i = it & 31;
+            if (ty < 9) {
+                const int br = ty / 3, bc = ty - br * 3, k = cb + i;
+                if (i >= G || k >= N) continue;
                 const bool hp = k > 0, hn = k < M;
+                const double* v0 = sv + i * FZ_RV;
+                const double* v1 = v0 + FZ_RV;
+                const double* i0 = si + i * FZ_RI;
+                const double* i1 = i0 + FZ_RI;
                 M3<double> blk = m3_zero();
-                const int which = br == bc ? br : (br + bc == 1 ? 3 : (br + bc == 2 ? 4 : 5));      // 0 rr, 1 pp, 2 vv, 3 rp/pr, 4 rv/vr, 5 pv/vp
-                if (which == 0) { if (hp) blk = blk + m3_load(a0); if (hn) blk = blk + m3_load(a1); }
-                else if (which == 1) { if (hp) blk = blk + m3_load(a0 + 18); if (hn) blk = blk + m3_load(a1 + 18); }
-                else if (which == 3) { if (hp) blk = blk + m3_load(a0 + 9); if (hn) blk = blk + m3_load(a1 + 9); if (br == 1) blk = transpose(blk); }
-                else if (which == 2) {
+                if (br == 0 && bc == 0) { if (hp) blk = blk + m3_load(v0); if (hn) blk = blk + m3_load(v1); }
+                else if (br + bc == 1) {
+                    if (hp) blk = blk + m3_load(v0 + 9);
+                    if (hn) blk = blk + m3_load(v1 + 9);
+                    if (br == 1) blk = transpose(blk);
+                } else if (br == 1 && bc == 1) {
+                    if (hp) blk = blk + (m3_load(v0 + 18) + m3_load(i0));
+                    if (hn) blk = blk + (m3_load(v1 + 18) + m3_load(i1));
+                } else if (br == 2 && bc == 2) {
                     double hvv = 0.0;
                     if (hp) hvv += w1;
-                    if (hn) { const double d = a1[39]; hvv += w1 + w3 * d * d; }
+                    if (hn) { const double d = i1[21]; hvv += w1 + w3 * d * d; }
                     blk = hvv * I;
-                } else if (which == 4) { blk = (hn ? w3 * a1[39] : 0.0) * I; }
-                double o[9];
-                m3_store(blk, o);
-                if (br == bc) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) o[d * 4] = fmin(fmax(o[d * 4], a.W.vmin), a.W.vmax);      // A.diagonal().clamp_(min, max)
+                } else if (br + bc == 2) { blk = (hn ? w3 * i1[21] : 0.0) * I; }
+                if (br == bc) {                                          // A.diagonal().clamp_(min, max)
+                    blk.a00 = fmin(fmax(blk.a00, a.W.vmin), a.W.vmax);
+                    blk.a11 = fmin(fmax(blk.a11, a.W.vmin), a.W.vmax);
+                    blk.a22 = fmin(fmax(blk.a22, a.W.vmin), a.W.vmax);
                 }
-                double* h = Hd_l + i * 81 + br * 27 + bc * 3;
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) h[rr * 9 + cc] = o[rr * 3 + cc];
-            }
-        } else if (tid < 2 * nb9) {
-            const int t2 = tid - nb9, i = t2 / 9, b = t2 - i * 9, br = b / 3, bc = b - br * 3, k = c0 - 1 + i;     // coupling k -> k+1 = link k
-            if (k >= 0 && k < M) {
-                const double* a1 = sl[i];
+                put33(Hd_l + i * 81 + br * 27 + bc * 3, blk);
+            } else if (ty < 18) {
+                const int b = ty - 9, br = b / 3, bc = b - br * 3, k = cb - 1 + i;    // coupling k -> k+1
+                if (i > G) continue;
                 M3<double> blk = m3_zero();
-                if (br == 0 && bc == 0) blk = -1.0 * m3_load(a1);
-                else if (br == 0 && bc == 1) blk = -1.0 * m3_load(a1 + 9);
-                else if (br == 1 && bc == 0) blk = -1.0 * transpose(m3_load(a1 + 9));
-                else if (br == 1 && bc == 1) blk = -1.0 * m3_load(a1 + 18);
-                else if (br == 2 && bc == 0) blk = (-w3 * a1[39]) * I;
-                else if (br == 2 && bc == 2) blk = (-w1) * I;
-                double o[9];
-                m3_store(blk, o);
-                double* h = Ho_l + i * 81 + br * 27 + bc * 3;
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) h[rr * 9 + cc] = o[rr * 3 + cc];
-            }
-        } else if (tid < 2 * nb9 + stride) {
-            const int i = tid - 2 * nb9, k = c0 + i;
-            if (k < N) {
-                const double* a0 = sl[i];
-                const double* a1 = sl[i + 1];
+                if (k >= 0 && k < M) {
+                    const double* v1 = sv + i * FZ_RV;
+                    const double* i1 = si + i * FZ_RI;
+                    if (br == 0 && bc == 0) blk = -1.0 * m3_load(v1);
+                    else if (br == 0 && bc == 1) blk = -1.0 * m3_load(v1 + 9);
+                    else if (br == 1 && bc == 0) blk = -1.0 * transpose(m3_load(v1 + 9));
+                    else if (br == 1 && bc == 1) blk = -1.0 * (m3_load(v1 + 18) + m3_load(i1));
+                    else if (br == 2 && bc == 0) blk = (-w3 * i1[21]) * I;
+                    else if (br == 2 && bc == 2) blk = (-w1) * I;
+                }
+                put33(Ho_l + i * 81 + br * 27 + bc * 3, blk);
+            } else {
+                const int k = cb + i;
+                if (i >= G || k >= N) continue;
+                const double* v0 = sv + i * FZ_RV;
+                const double* v1 = v0 + FZ_RV;
+                const double* i0 = si + i * FZ_RI;
+                const double* i1 = i0 + FZ_RI;
                 V3<double> gr{0, 0, 0}, gp{0, 0, 0}, gv{0, 0, 0};
                 if (k > 0) {
-                    gr = gr + ld3(a0 + 27); gp = gp + ld3(a0 + 30);
-                    gv = gv - w1 * ld3(a0 + 33);
+                    gr = gr + (ld3(v0 + 27) + ld3(i0 + 9)); gp = gp + (ld3(v0 + 30) + ld3(i0 + 12));
+                    gv = gv - w1 * ld3(i0 + 15);
                 }
                 if (k < M) {
-                    const double d = a1[39];
-                    gr = gr - ld3(a1 + 27); gp = gp - ld3(a1 + 30);
-                    gv = gv + w1 * ld3(a1 + 33) - (w3 * d) * ld3(a1 + 36);
+                    const double d = i1[21];
+                    gr = gr - (ld3(v1 + 27) + ld3(i1 + 9)); gp = gp - (ld3(v1 + 30) + ld3(i1 + 12));
+                    gv = gv + w1 * ld3(i1 + 15) - (w3 * d) * ld3(i1 + 18);
                 }
                 double* bb = rhs_l + i * 9;
                 bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
@@ -2340,30 +2460,47 @@ __global__ __launch_bounds__(192, 3) void trial_elim_kernel(FusedArgs a, Gate ga
             }
         }
     }
-    PROBE_WALL(fpr, fpo + 6);
     lds_barrier();
-    PROBE_WALL(fpr, fpo + 7);
-    if (wave == 2) {
-        // the linearisation to global memory, lane-contiguous: the fallback solves (reject, mis-speculated damping, failed solve)
-        // and the un-fused entry points read it from there
-        const int no = min(stride, N - c0);                               // nodes this segment owns
-        for (int e = lane; e < no * 81; e += 64) a.Hd_o[(size_t)c0 * 81 + e] = Hd_l[e];
-        for (int e = lane; e < no * 9; e += 64) a.rhs_o[(size_t)c0 * 9 + e] = rhs_l[e];
-        const int k0 = max(c0 - 1, 0), k1 = min(c0 + m - 1, M - 1);       // couplings this segment owns
-        const double* hs = Ho_l + (k0 - (c0 - 1)) * 81;
-        for (int e = lane; e < (k1 - k0 + 1) * 81; e += 64) a.Ho_o[(size_t)k0 * 81 + e] = hs[e];
-    }
+    PROBE_WALL(fpr, fpo + 3);
+    // ---- D: waves 2s, 2s+1 eliminate segment s of the stretch; helper wave 2 FZ_S + h serves segments 2h, 2h+1 (twisted_helper) after
+    // it has copied its half of the linearisation to global memory.  Every wave executes the same number of barriers: the forward
+    // step count of a full segment.
     LevelSrc src{};
     src.level0 = 1;
-    src.Hd = Hd_l - (ptrdiff_t)c0 * 81;
-    src.Ho = Ho_l - (ptrdiff_t)(c0 - 1) * 81;
-    src.rhs0 = rhs_l - (ptrdiff_t)c0 * 9;
+    src.Hd = Hd_l - (ptrdiff_t)cb * 81;
+    src.Ho = Ho_l - (ptrdiff_t)(cb - 1) * 81;
+    src.rhs0 = rhs_l - (ptrdiff_t)cb * 9;
     src.state = nullptr;
     src.damping_override = d_spec;
     src.hist = 1;
-    PROBE_WALL(fpr, fpo + 8);
-    eliminate_twisted3<1>(src, a.dst, N, m, p, a.eflag, wave, lane, lds + FZ_OFF_TW, Gate{nullptr, 0.0});
-    PROBE_WALL(fpr, fpo + 9);
+    const int nbar = m >= 3 ? m / 2 + 1 : m;
+    double* tw = lds + FZ_OFF_TW;
+    PROBE_WALL(fpr, fpo + 4);
+    if (wave < 2 * FZ_S) {
+        const int seg = wave >> 1, p = seg0 + seg;
+        if (p < seg1) sweep_with_helper<1>(src, a.dst, N, m, p, a.eflag, wave & 1, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
+        else { for (int t = 0; t < nbar; ++t) lds_barrier(); }
+    } else {
+        // the linearisation to global memory, lane-contiguous: the fallback solves (reject, mis-speculated damping, failed solve)
+        // and the final trial_lin_kernel read it from there
+        const int ht = threadIdx.x - 2 * FZ_S * 64, HT = FZ_HELPERS * 64;
+        const int no = min(G, N - cb);                                    // nodes this stretch owns
+        for (int e = ht; e < no * 81; e += HT) a.Hd_o[(size_t)cb * 81 + e] = Hd_l[e];
+        for (int e = ht; e < no * 9; e += HT) a.rhs_o[(size_t)cb * 9 + e] = rhs_l[e];
+        const int k0 = max(cb - 1, 0), k1 = min(cb + G - 2, M - 1);       // couplings this stretch owns (cb+G-1 is the next one's first)
+        const double* hs = Ho_l + (k0 - (cb - 1)) * 81;
+        for (int e = ht; e < (k1 - k0 + 1) * 81; e += HT) a.Ho_o[(size_t)k0 * 81 + e] = hs[e];
+        const int hw = wave - 2 * FZ_S;
+        HelpSeg sg[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int seg = 2 * hw + q, p = seg0 + seg;
+            if (p < seg1) sg[q] = help_seg(seg_geom(N, m, p), p, tw + seg * LDS_TW4);
+            else { sg[q] = HelpSeg{}; sg[q].on = false; }
+        }
+        twisted_helper<2>(a.dst, sg, nbar, lane);
+    }
+    PROBE_WALL(fpr, fpo + 5);
 }
 
 // state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
@@ -2659,7 +2796,7 @@ Workspace carve(void* base, int N) {
     w.lin = take((size_t)LIN_C * M);
     const int nlb = (N + LB_NODES - 1) / LB_NODES;     // workgroups of linbuild / trial_lin (>= nblk)
     w.loss_part = take(std::max(nblk, nlb) + 2);
-    w.part = take(2 * (size_t)std::max(std::max(nblk, nlb), N / 4 + 8) + 2);      // (trial_elim_kernel: one pair per level-0 segment, segments >= 5 nodes)
+    w.part = take(2 * (size_t)std::max(std::max(nblk, nlb), 1024) + 2);           // (trial_elim_kernel: one pair per workgroup, at most one workgroup per CU)
     w.Hd = take((size_t)N * 81);
     w.Ho = take((size_t)N * 81);
     w.rhs = take((size_t)N * 9);
@@ -3105,6 +3242,18 @@ static int reproj_dev_local(const islam_pvgo_reproj* r, int link0, ReprojDev& d)
     return ISLAM_OK;
 }
 
+static int device_cus() {
+    static int cus[64] = {};
+    int dev_i = 0;
+    if (hipGetDevice(&dev_i) != hipSuccess || dev_i < 0 || dev_i >= 64) return 0;
+    if (cus[dev_i] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_i) != hipSuccess) return 0;
+        cus[dev_i] = v;
+    }
+    return cus[dev_i];
+}
+
 // linbuild_kernel / trial_lin_kernel stage their node blocks in dynamic LDS above the default limit (once per device)
 static int ensure_linbuild_lds() {
     static bool lb_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
@@ -3464,10 +3613,22 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     // the launch-per-stage loop below.
     SolvePlan sp;
     plan_levels(N, prm->seg_len, sp, solve_twisted());
-    static const bool no_fuse = [] { const char* e = std::getenv("ISLAM_PVGO_FUSE"); return !(e && e[0] == '1'); }();     // (opt-in until it is faster)
+    static const bool no_fuse = [] { const char* e = std::getenv("ISLAM_PVGO_NO_FUSE"); return e && e[0] == '1'; }();
+    // (one workgroup of FZ_S segments per CU: the whole level must be resident at once)
+    // (the deciding workgroup is one more block with the same LDS footprint: it is dispatched to XCD 0, which must keep a CU free
+    // for it -- otherwise it starts when the first workgroup exits and the launch ends ~4 us late)
+    static const int fz_spare = [] { const char* e = std::getenv("ISLAM_FZ_SPARE"); return e ? std::atoi(e) : 16; }();      // (8 / 16 / 47 spare CUs: 63.3 / 62.9 / 62.9 us per LM iteration)
+    const int fz_nwg = std::min(sp.lv[0].P, std::max(device_cus() - fz_spare, 1));
     const bool fused = !no_fuse && !reproj && sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM &&
-                       prm->reject < STATE_DOUBLES - STATE_HIST - 1;
+                       prm->reject < STATE_DOUBLES - STATE_HIST - 1 && (sp.lv[0].P + fz_nwg - 1) / fz_nwg <= FZ_S;
     if (fused) {
+        static bool fz_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
+        int dev_i = 0;
+        ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+        if (dev_i >= 0 && dev_i < 64 && !fz_attr_set[dev_i]) {
+            ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_elim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES));
+            fz_attr_set[dev_i] = true;
+        }
         // every solve keeps the stored diagonal undamped and applies the damping history of the current linearisation (LevelSrc::hist)
         auto enqueue_solve_hist = [&](int pb, double ep) -> int {
             LevelSrc src{};
@@ -3481,11 +3642,10 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             const Gate gate{w.state, ep};
             double* rep_slot = report + 16 * ((long long)seq & 1);
             int* eprev = prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none;
-            if (!more) {
-                hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb) + 1), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses,
-                                   drots, dtrans, dvels, dts, LIN[c.pb], N, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot,
-                                   seq, (const double*)nullptr, (const double*)nullptr, rp, W, LIN[1 - c.pb], HD[1 - c.pb], HO[1 - c.pb],
-                                   RH[1 - c.pb], gate, eprev);
+            if (!more) {                     // nothing follows an accepted trial: the trial alone, no linearisation
+                hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, s, c.cur_n, c.cur_v, w.dx, poses, drots, dtrans,
+                                   dvels, dts, LIN[c.pb], M, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot, seq,
+                                   (const double*)nullptr, (const double*)nullptr, rp, M, gate, eprev);
                 ISLAM_LAUNCH_CHECK();
                 return ISLAM_OK;
             }
@@ -3495,10 +3655,10 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             fa.flags = w.flags; fa.ticket = ticket; fa.tr = tr; fa.report = rep_slot; fa.seq = seq; fa.W = W;
             fa.lin_o = LIN[1 - c.pb]; fa.Hd_o = HD[1 - c.pb]; fa.Ho_o = HO[1 - c.pb]; fa.rhs_o = RH[1 - c.pb];
             fa.dst = level_dst(w.lv[0], w.dx);
-            fa.m = sp.lv[0].m; fa.P = sp.lv[0].P;
+            fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
             fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
             fa.eflag_prev = eprev;
-            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fa.P) + 1), dim3(192), 0, s, fa, gate);
+            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
             LevelSrc none{};
             none.level0 = 1;
             return enqueue_levels(w, sp, 0, none, nullptr, w.dx, w.flags, s, nullptr, nullptr, gate, true);

@@ -19,9 +19,9 @@ fn = L.lib()._cdll.islam_probe_read
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
 b = list(buf)
-names = ['entry', 'trial point', 'residuals', 'jacobians', 'emit', 'barrier 1', 'blocks built', 'barrier 2', 'elim start', 'elim end']
-for seg, so in (('p=1', 0), ('p=P/2', 30), ('p=P-2', 60)):
-    t0 = min(b[600 + so + 10 * w] for w in range(3))
-    for w in range(3):
-        base = 600 + so + 10 * w
-        print('%s wave %d: ' % (seg, w) + '  '.join('%s %.2f' % (names[i], (b[base + i] - t0) / 100.0) for i in range(10) if b[base + i] >= t0))
+names = ['entry', 'retracted', 'links done', 'blocks built', 'elim start', 'elim end']
+for seg, so in (('wg=1', 0), ('wg=nwg/2', 100)):
+    t0 = min(b[600 + so + 12 * w] for w in range(10) if b[600 + so + 12 * w] > 0)
+    for w in range(10):
+        base = 600 + so + 12 * w
+        print('%s wave %d: ' % (seg, w) + '  '.join('%s %.2f' % (names[i], (b[base + i] - t0) / 100.0) for i in range(6) if b[base + i] >= t0))

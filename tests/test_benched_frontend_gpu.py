@@ -4,8 +4,8 @@
 
   (a) the fp32 eager networks driven through the ORACLE's glue, IMU pre-integration and PVGO (oracle/tartanvo.py, oracle/imu.py,
       oracle/pvgo.py): VO motions, PGO poses and the loss, within the bf16 bounds stated below;
-  (b) the same bf16 frozen nets with an EAGER pose head (no graphs, NCHW, device glue, no prefetch): the accumulated pose-head
-      gradients must be the same numbers (fp32 kernels of different layouts: 2e-3 of the largest entry).
+  (b) the same bf16 frozen nets and float64 host glue with an EAGER pose head (no graphs, NCHW, no prefetch): the accumulated
+      pose-head gradients must be the same numbers (fp32 kernels of different layouts: see the bound at the assertion).
 
 `miopen_find` (MIOpen's timing-based kernel search, a ~1.5 minute one-off) is the one bench switch left off here: it changes which
 fp32 kernel MIOpen picks for the pose head, nothing else.  Reference: TartanVO.py:90-198, train.py:200-299."""
@@ -27,6 +27,7 @@ LW = (1, 0.1, 10, 0.1)
 TOL_MOTION_T, TOL_MOTION_R = 8e-2, 3e-3          # VO motions: translation relative to its norm, rotation in rad
 TOL_POSE = 5e-2                                  # PGO poses: |Log(ref^-1 got)| relative to max(|Log(ref)|, 1)
 TOL_LOSS = 0.25                                  # rot_w * rot_loss + trans_w * trans_loss, relative
+GRAD_TOL = 5e-3                                  # pose-head gradients vs eager, relative to the largest entry of each tensor
 
 
 def _make(cuda, **kw):
@@ -76,19 +77,24 @@ def test_benched_configuration_two_bilevel_steps(cuda):
     assert all(torch.isfinite(g).all() for g in grads_b) and any(float(g.abs().sum()) > 0 for g in grads_b)
 
     # ---- (b) same frozen nets, eager pose head, device glue, sequential schedule: the gradients must agree
-    vo_e = _make(cuda, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16)
+    vo_e = _make(cuda, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True)
     loop_e = _loop(vo_e, tr)
     losses_e = [loop_e.step(seq[k]) for k in range(steps)]
     grads_e = [p.grad.detach().float().cpu() for p in vo_e.vonet.flowPoseNet.parameters()]
     np.testing.assert_allclose(np.asarray(loop_e.vo_motions, dtype=np.float64), motions_b, rtol=2e-3, atol=2e-5)       # fp32 pose head, NHWC graph replay vs NCHW eager kernels
     for k in range(steps):
         assert losses_b[k] == pytest.approx(losses_e[k], rel=2e-3)
-    worst = 0.0
-    for gb, ge in zip(grads_b, grads_e):
+    worst, cos_min = 0.0, 1.0
+    names = [n for n, _ in vo_b.vonet.flowPoseNet.named_parameters()]
+    for n, gb, ge in zip(names, grads_b, grads_e):
         assert gb.shape == ge.shape
-        worst = max(worst, float((gb - ge).abs().max()) / max(float(ge.abs().max()), 1e-30))
-    print('pose-head gradients, benched configuration vs eager: max |diff| / max |g| per tensor = %.3g' % worst)
-    assert worst <= 2e-3
+        rel = float((gb - ge).abs().max()) / max(float(ge.abs().max()), 1e-30)
+        cos = float((gb * ge).sum() / (gb.norm() * ge.norm()).clamp_min(1e-30))
+        if rel > 0.5 * max(worst, 1e-4):
+            print('   %-40s rel %.3g cos %.8f' % (n, rel, cos))
+        worst, cos_min = max(worst, rel), min(cos_min, cos)
+    print('pose-head gradients, benched configuration vs eager: max |diff| / max |g| per tensor = %.3g, min cosine %.8f' % (worst, cos_min))
+    assert worst <= GRAD_TOL and cos_min >= 1.0 - GRAD_TOL
     del vo_e, loop_e
 
     # ---- (a) fp32 eager networks -> oracle glue -> oracle IMU -> oracle PVGO
