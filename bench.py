@@ -31,9 +31,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOSS_WEIGHT = (1, 0.1, 10, 0.1)  # run_kitti.sh:5
 N_FRAMES = 5001
-# algorithmic HBM bytes per node of the dominant kernel (bt_eliminate level 0), DESIGN.md section 4:
-# read Hd 81 + Ho 81 + rhs 9, write fac 252 + inv 9 + damped diagonal 9  doubles
+# algorithmic HBM bytes per node of the launched level-0 elimination (bt_eliminate_tw_kernel<1>, first LM iteration and
+# fallback solves), DESIGN.md section 3.1: read Hd 81 + Ho 81 + rhs 9, write fac 252 + inv 9 + damped diagonal 9 doubles
 ELIM_BYTES_PER_NODE = (81 + 81 + 9 + 252 + 9 + 9) * 8
+# ... of the dominant kernel of the LM loop's steady state (trial_elim_kernel: trial + linearisation + level-0 elimination),
+# read nodes 7 + vels 3 + dx 9 + poses 7 + drots 4 + dtrans 3 + dvels 3 + dts 1 + old lin 42,
+# write trial iterate 7 + 3, lin 42, Hd 81 + Ho 81 + rhs 9 (the linearisation the fallback solves read), fac 252 + inv 9 doubles
+FUSED_BYTES_PER_NODE = (7 + 3 + 9 + 7 + 4 + 3 + 3 + 1 + 42 + 7 + 3 + 42 + 81 + 81 + 9 + 252 + 9) * 8
+PRODUCT_BYTES_PER_SEGMENT = 351 * 8       # separator blocks, Schur contributions, fill handed to level 1
 
 
 def build_problem(device, n_frames=N_FRAMES):
@@ -78,6 +83,61 @@ def eliminate_l0_burst(ops, Hd, Ho, rhs, N, levels, device, launches=40):
     return e0.elapsed_time(e1) * 1e3 / launches
 
 
+def trial_elim_burst(ops, prob, prm, N, device, launches=40):
+    """Average period (us) of back-to-back launches of trial_elim_kernel (islam_pvgo_trial_elim_burst: one pair of HIP events
+    on the launch stream around the burst, inside the library) + (segment length, segments, workgroups); None if the fused loop
+    does not cover this N."""
+    import ctypes
+    from islam_amd._lib import IslamHipError, c_float, c_int, c_size_t, check, lib, ptr, stream_ptr
+    ws, nbytes = ops.pvgo_workspace(N, device)
+    us, info = c_float(0.0), (c_int * 3)()
+    try:
+        check(lib().islam_pvgo_trial_elim_burst(ptr(prob['init_nodes']), ptr(prob['init_vels']), ptr(prob['vo']), ptr(prob['drots']),
+                                                ptr(prob['dtrans']), ptr(prob['dvels']), ptr(prob['dts']), N, ctypes.byref(prm), ptr(ws),
+                                                c_size_t(nbytes), launches, ctypes.byref(us), info, stream_ptr(device)))
+    except IslamHipError:
+        return None, None
+    return float(us.value), list(info)
+
+
+def committed_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_r03.json), valid only for the kernel source
+    they were taken on: the file records sha256(pvgo.hip)[:16]; a different source -> no traffic figure (never a stale one)."""
+    import hashlib
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_r03.json')
+    if not os.path.exists(tpath):
+        return None
+    t = json.load(open(tpath))
+    sha = hashlib.sha256(open(os.path.join(ROOT, 'islam_amd', 'csrc', 'pvgo.hip'), 'rb').read()).hexdigest()[:16]
+    if t.get('pvgo_hip_sha16') != sha:
+        return {'stale': True, 'note': 'profiles/traffic_r03.json was taken on pvgo.hip %s, this is %s: dropped' % (t.get('pvgo_hip_sha16'), sha)}
+    return t
+
+
+def cpu_dense_protocol(prob_host):
+    """SURVEY 8(d) CPU protocol for the faithful formulation (dense J / block_diag W / dense Cholesky as PyPose builds them,
+    oracle/pvgo.py mode='dense'): fp32 like the reference (pvgo.py:157-160) AND fp64, all host cores, 1 warm-up + median of 5 first
+    LM iterations per size, the largest size the bounded sample affords, and the power-law fit that extrapolates to N=5001 (which
+    needs > 60 GB and minutes per iteration)."""
+    from oracle import pvgo as opvgo
+    out = {'cores': os.cpu_count(), 'what': 'dense PyPose-style LM iteration, 1 warm-up + median of 5 (first optimizer.step of the loop)'}
+    for name, dt in (('f32', np.float32), ('f64', np.float64)):
+        rows = []
+        for n_small in (129, 257, 513):
+            small = {k: (v[:n_small] if k in ('init_nodes', 'init_vels') else v[:n_small - 1]) for k, v in prob_host.items()}
+            ts = []
+            for rep in range(6):
+                t1 = time.perf_counter()
+                o = opvgo.run_pvgo(**small, loss_weight=LOSS_WEIGHT, mode='dense', max_steps=1, return_optimizer=True, dtype=dt)
+                ts.append((time.perf_counter() - t1) / max(len(o[5].trace), 1))
+            rows.append((n_small, float(np.median(ts[1:]))))
+        (n1, t1_), (n2, t2_) = rows[-2], rows[-1]
+        expo = float(np.log(t2_ / t1_) / np.log(n2 / n1))
+        out[name] = {'iters_per_s': {str(n): 1.0 / t for n, t in rows}, 'largest_N': rows[-1][0], 'value': 1.0 / rows[-1][1],
+                     'fit_exponent': expo, 'extrapolated_iters_per_s_N5001': 1.0 / (t2_ * (5001.0 / n2) ** expo)}
+    return out
+
+
 def cpu_baseline(prob_host):
     """Oracle (CPU restatement of the PyPose LM, oracle/pvgo.py) on the host cores: banded mode at full size."""
     from oracle import pvgo as opvgo
@@ -98,20 +158,13 @@ def cpu_baseline(prob_host):
             break
     if ctx is not None:
         ctx.unregister() if hasattr(ctx, 'unregister') else None
-    # the faithful dense formulation (what PyPose builds) on a bounded sample: N=513
-    n_small = 513
-    small = {k: (v[:n_small] if k in ('init_nodes', 'init_vels') else v[:n_small - 1]) for k, v in prob_host.items()}
-    t1 = time.perf_counter()
-    out_d = opvgo.run_pvgo(**small, loss_weight=LOSS_WEIGHT, mode='dense', max_steps=1, return_optimizer=True)
-    dt_d = time.perf_counter() - t1
+    # the faithful dense formulation (what PyPose builds), SURVEY 8(d) protocol on a bounded sample
+    dense = cpu_dense_protocol(prob_host)
     return {
         'value': trials / dt, 'unit': 'LM iters/s', 'cores': 1, 'kind': 'port',
         'sample': 'oracle/pvgo.py banded (block-tridiagonal) mode, the full N=%d graph, %d full LM loops = %d LM iterations in '
-                  '%.1f s, 1 thread' % (prob_host['init_nodes'].shape[0], runs, trials, dt),
-        'dense_pypose_style': {'value': len(out_d[5].trace) / dt_d, 'unit': 'LM iters/s', 'N': n_small,
-                               'cores': os.cpu_count(),
-                               'sample': 'dense J / block_diag W / dense Cholesky as PyPose builds them, first optimizer.step '
-                                         'only, N=%d (N=5001 needs >60 GB)' % n_small},
+                  '%.1f s, 1 thread (more threads make the many tiny LAPACK calls slower)' % (prob_host['init_nodes'].shape[0], runs, trials, dt),
+        'dense_pypose_style': dense,
     }
 
 
@@ -324,12 +377,19 @@ def main():
         # (an event after every launch, as in the per-level table above, adds ~2 us to each)
         elim0_s = eliminate_l0_burst(ops, Hd, Ho, rhs, N, levels, device) * 1e-6
         kern['eliminate_L0_burst'] = round(elim0_s * 1e6, 2)
-        alg_bytes = ELIM_BYTES_PER_NODE * N + 351 * 8 * levels[0][2]       # + the per-segment products handed to level 1
-        achieved = alg_bytes / elim0_s / 1e9
-        traffic = None                   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_eliminate_L0.json')
-        if os.path.exists(tpath) and N == N_FRAMES:
-            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+        elim_bytes = ELIM_BYTES_PER_NODE * N + PRODUCT_BYTES_PER_SEGMENT * levels[0][2]     # + the per-segment products handed to level 1
+        # the dominant kernel of the LM loop's steady state: trial + linearisation + level-0 elimination in one launch
+        fused_us, fused_info = trial_elim_burst(ops, prob, prm, N, device)
+        tfile = committed_traffic() if N == N_FRAMES else None         # HBM bytes per launch from committed rocprofv3 PMC passes
+        tk = (tfile or {}).get('kernels', {}) if tfile and not tfile.get('stale') else {}
+        if fused_us:
+            dom_name, dom_s = 'trial_elim_kernel (trial + linearisation + level-0 elimination)', fused_us * 1e-6
+            alg_bytes = FUSED_BYTES_PER_NODE * N + PRODUCT_BYTES_PER_SEGMENT * levels[0][2]
+            traffic = tk.get('trial_elim_kernel', {}).get('traffic_bytes_per_launch')
+        else:                                                            # the fused loop does not cover this N
+            dom_name, dom_s, alg_bytes = 'bt_eliminate_tw_kernel (level 0)', elim0_s, elim_bytes
+            traffic = tk.get('bt_eliminate_tw_kernel_L0', {}).get('traffic_bytes_per_launch')
+        achieved = alg_bytes / dom_s / 1e9
         # a burst of whole solves (all launches back to back, one event pair): what the solve costs inside the LM loop
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         Hb = Hd.clone()
@@ -349,24 +409,34 @@ def main():
         sweep_bytes = (252 + 9 + 9) * 8 * n_all                         # factor rows + reciprocal pivots read, solution written
         sweep_key = [k for k in kern if 'downsweep' in k or k.startswith('top')]
         sweep_us = kern[sweep_key[0]] if sweep_key else None
-        trial_bytes = (28 + 135 + 29 + 28) * 8 * N                      # trial residual pass, H / g written, retraction, next linearisation
-        trial_us = max(us_iter - solve_us, 0.0) if world == 1 and not force_sharded else None
-        per_launch = {'bt_eliminate_tw_kernel_L0': {'bytes': alg_bytes, 'us': elim0_s * 1e6, 'frac': achieved / HBM_PEAK_GBS}}
+        def entry(name, nbytes, us, timing):
+            e = {'bytes': nbytes, 'us': us, 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 'timing': timing}
+            t = tk.get(name, {}).get('traffic_bytes_per_launch')
+            if t:                                                        # counter traffic vs algorithmic bytes (> 1: wasted re-reads)
+                e['traffic'] = t
+                e['traffic_over_algorithmic'] = t / nbytes
+            return e
+        per_launch = {'bt_eliminate_tw_kernel_L0': entry('bt_eliminate_tw_kernel_L0', elim_bytes, elim0_s * 1e6,
+                                                         'burst of 40 launches between one event pair; first LM iteration and fallback solves only')}
+        if fused_us:
+            per_launch['trial_elim_kernel'] = entry('trial_elim_kernel', alg_bytes, fused_us,
+                                                    'burst of 40 launches between one event pair (islam_pvgo_trial_elim_burst)')
+            per_launch['trial_elim_kernel']['segment_len_segments_workgroups'] = fused_info
         if sweep_us:
-            per_launch['bt_downsweep_kernel'] = {'bytes': sweep_bytes, 'us': sweep_us, 'frac': sweep_bytes / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                                 'timing': 'event pair around the single launch (adds ~2 us)'}
-        if trial_us:
-            per_launch['trial_lin_kernel'] = {'bytes': trial_bytes, 'us': trial_us, 'frac': trial_bytes / (trial_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                              'timing': 'LM iteration minus a burst-timed whole solve (%.2f us)' % solve_us}
+            per_launch['bt_downsweep_kernel'] = entry('bt_downsweep_kernel', sweep_bytes, sweep_us, 'event pair around the single launch (adds ~2 us)')
         iter_bytes = 5000 * N                                           # ~5.0 KB per node per LM iteration
-        roofline = {'bound': 'hbm', 'kernel': 'bt_eliminate_tw_kernel (level 0)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+        roofline = {'bound': 'hbm', 'kernel': dom_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': elim0_s * 1e6,
+                    'traffic_source': (None if traffic is None else 'profiles/traffic_r03.json (rocprofv3 PMC passes, separate FETCH_SIZE / WRITE_SIZE '
+                                       'runs of this command; valid for pvgo.hip sha256[:16] = %s)' % tfile.get('pvgo_hip_sha16')) if not (tfile or {}).get('stale')
+                                      else tfile['note'],
+                    'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': dom_s * 1e6,
                     'solve_launch_us': kern, 'solve_burst_us': solve_us, 'levels_n_m_P': levels,
                     'iteration': {'bytes': iter_bytes, 'us': us_iter, 'frac': iter_bytes / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                   'what': 'whole LM iteration (solve + trial + control + next linearisation), SURVEY 8(d) traffic model'},
                     'per_launch': per_launch,
-                    'note': 'latency-bound: %d dependent 9x9 block pivots on the critical path' % sum(l[1] for l in levels)}
+                    'note': 'latency / issue-bound: the up-sweep is a chain of dependent 9x9 block pivots (one wavefront per half segment), '
+                            'the SE(3) linearisation in front of it runs on 25 lanes per CU'}
         value = trials / elapsed
         out = {
             'metric': 'pvgo_lm_iters_per_sec', 'value': value, 'unit': 'LM iters/s', 'n_gpus': world, 'steps': args.steps,

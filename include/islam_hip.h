@@ -315,6 +315,15 @@ int islam_pvgo_solve_chain_timed(double* Hd, const double* Ho, const double* rhs
  * nothing else -- bench.py times a burst of these for the roofline figure.  Hd's diagonal is damped in place. */
 int islam_pvgo_eliminate_level0(double* Hd, const double* Ho, const double* rhs, double damping, int N,
                                 const int seg_len[2], void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement hook: the LM loop's dominant launch in its steady state -- trial step + loss / trust-region sums of a trial
+ * (pvgo.py:26-64, ppost.TrustRegion), the linearisation at the trial point and the level-0 elimination of the next damped solve
+ * (pp.optim.LM's J^T W J + Cholesky) in ONE kernel (trial_elim_kernel) -- after one linearisation and one solve of the given
+ * problem: `launches` back-to-back launches between one pair of HIP events on `stream`; *us_per_launch = average period.
+ * info[0..2] = (level-0 segment length, segments, workgroups).  ISLAM_EARG when the fused loop does not cover this N. */
+int islam_pvgo_trial_elim_burst(const double* nodes, const double* vels, const double* poses, const double* drots,
+                                const double* dtrans, const double* dvels, const double* dts, int N,
+                                const islam_pvgo_params* prm, void* workspace, size_t workspace_bytes, int launches,
+                                float* us_per_launch, int* info, void* stream);
 /* ---- multi-GPU building blocks (islam_amd/dist_pvgo.py; no reference counterpart: the reference is single-GPU).
  * plan9 (3*ISLAM_PVGO_MAX_LEVELS+1 ints) receives (nodes, segment length, segments) per level (unused = 0) and, last,
  * the first level that runs inside the single-workgroup top kernel; returns the level count. */

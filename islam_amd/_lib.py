@@ -97,6 +97,8 @@ SIGNATURES = {
                                                               ctypes.POINTER(c_int), c_void_p]),
     'islam_pvgo_eliminate_level0': (c_int, [c_void_p] * 3 + [c_double, c_int, ctypes.POINTER(c_int), c_void_p, c_size_t,
                                                              c_void_p]),
+    'islam_pvgo_trial_elim_burst': (c_int, [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams), c_void_p, c_size_t, c_int,
+                                                             ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_void_p]),
     'islam_pvgo_plan': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'islam_dist_unique_id': (c_int, [c_void_p]),
     'islam_dist_comm_init': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

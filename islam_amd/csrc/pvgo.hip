@@ -3795,4 +3795,66 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     return ISLAM_OK;
 }
 
+// Measurement hook (bench.py's roofline leg): the LM loop's dominant launch, trial_elim_kernel, exactly as islam_pvgo_run_chain
+// launches it in its steady state -- after one linearisation and one damped solve of the given problem (so that `dx` and the old
+// linearisation are real), `launches` back-to-back launches between ONE pair of HIP events on `stream`; *us_per_launch = their
+// average period.  info[0..2] = (level-0 segment length, segments, workgroups).  ISLAM_EARG when the fused loop does not apply
+// to this problem size (islam_pvgo_run_chain then runs the launch-per-stage loop).
+int islam_pvgo_trial_elim_burst(const double* nodes, const double* vels, const double* poses, const double* drots, const double* dtrans,
+                                const double* dvels, const double* dts, int N, const islam_pvgo_params* prm, void* workspace,
+                                size_t workspace_bytes, int launches, float* us_per_launch, int* info, void* stream) {
+    if (N < 2 || !prm || !us_per_launch || launches < 1) return fail(ISLAM_EARG, "islam_pvgo_trial_elim_burst: bad argument");
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_trial_elim_burst: workspace too small");
+    SolvePlan sp;
+    plan_levels(N, prm->seg_len, sp, solve_twisted());
+    const int fz_nwg = std::min(sp.lv[0].P, std::max(device_cus() - 16, 1));
+    if (!(sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM && (sp.lv[0].P + fz_nwg - 1) / fz_nwg <= FZ_S))
+        return fail(ISLAM_EARG, "islam_pvgo_trial_elim_burst: the fused loop does not cover N=%d", N);
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    hipStream_t s = as_stream(stream);
+    int rc = ensure_linbuild_lds();
+    if (rc != ISLAM_OK) return rc;
+    ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_elim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
+    const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
+    const int nlb = (N + LB_NODES - 1) / LB_NODES;
+    hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, nodes, vels, poses, drots, dtrans, dvels, dts, N,
+                       W, w.lin, w.loss_part, w.Hd, w.Ho, w.rhs, (const double*)nullptr, ReprojDev{}, Gate{nullptr, 0.0});
+    hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+    LevelSrc src{};
+    src.level0 = 1; src.Hd = w.Hd; src.Ho = w.Ho; src.rhs0 = w.rhs; src.state = w.state; src.hist = 1;
+    rc = enqueue_levels(w, sp, 0, src, nullptr, w.dx, w.flags, s, nullptr, nullptr);
+    if (rc != ISLAM_OK) return rc;
+    FusedArgs fa{};
+    fa.nodes = nodes; fa.vels = vels; fa.dx = w.dx; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans; fa.dvels = dvels; fa.dts = dts;
+    fa.lin = w.lin; fa.N = N; fa.nodes_t = w.nodes_t; fa.vels_t = w.vels_t; fa.part = w.part; fa.st = w.state; fa.flags = w.flags;
+    fa.ticket = reinterpret_cast<unsigned*>(w.flags + 2);
+    fa.tr = TRParams{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject, prm->max_steps, prm->patience,
+                     prm->decreasing};
+    fa.report = nullptr; fa.seq = 1.0; fa.W = W;
+    fa.lin_o = w.lin2; fa.Hd_o = w.Hd2; fa.Ho_o = w.Ho2; fa.rhs_o = w.rhs2;
+    fa.dst = level_dst(w.lv[0], w.dx);
+    fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
+    fa.eflag = w.flags + 4; fa.eflag_prev = w.flags + 6;
+    const Gate open{nullptr, 0.0};
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, open);
+    hipEvent_t e0, e1;
+    ISLAM_HIP_CHECK(hipEventCreate(&e0));
+    ISLAM_HIP_CHECK(hipEventCreate(&e1));
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    ISLAM_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, open);
+    ISLAM_HIP_CHECK(hipEventRecord(e1, s));
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    ISLAM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *us_per_launch = ms * 1e3f / (float)launches;
+    if (info) { info[0] = fa.m; info[1] = fa.P; info[2] = fa.nwg; }
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 }  // extern "C"

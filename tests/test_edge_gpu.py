@@ -74,8 +74,10 @@ def test_edge_mask_argument_checks(cuda):
     from islam_amd import _lib, edges
     with pytest.raises(_lib.IslamHipError):
         edges.edge_mask(torch.zeros(1, 3, 448, 642, device=cuda))                 # not a multiple of 4
+    from islam_amd import ops
     with pytest.raises(_lib.IslamHipError):
-        edges.edge_mask(torch.zeros(1, 3, 1024, 1024, device=cuda))               # 256x256 does not fit the LDS
+        ops.edge_mask(torch.zeros(1, 3, 1024, 1024, device=cuda))                 # 256x256 does not fit the LDS of one CU: the kernel refuses ...
+    assert edges.edge_mask(torch.zeros(1, 3, 1024, 1024, device=cuda)).shape == (1, 256, 256)      # ... and edges.edge_mask takes the tensor-op path
     with pytest.raises(RuntimeError):
         edges.edge_mask(torch.zeros(1, 3, 64, 64))                                # CPU tensor: no fallback
     assert edges.edge_mask(torch.zeros(0, 3, 64, 64, device=cuda)).shape == (0, 16, 16)
