@@ -168,7 +168,7 @@ def cpu_baseline(prob_host):
     }
 
 
-def vio_frames_per_sec(device, batch=8, steps=6, warmup=2):
+def vio_frames_per_sec(device, batch=8, steps=16, warmup=3):
     """Secondary metric of BASELINE.json ("stereo-VIO frames/sec", configs[1] shapes): the bilevel loop body of
     train.py:200-299 -- TartanVO forward at 448x640 (bf16 stereo net, HIP correlation/warp/scale), 2x IMU integrate,
     run_pvgo on the 9-node window, one-step backward -- on synthetic stereo pairs, random-init weights."""
@@ -266,6 +266,8 @@ def main():
             dist.init_process_group(backend)
 
     from islam_amd import ops
+    from islam_amd.miopen_pin import use_pinned_db
+    use_pinned_db()          # before the process's first convolution: the front-end's MIOpen kernels are pinned (islam_amd/miopen_pin.py)
     prob, tr = build_problem(device, args.frames)
     N = prob['init_nodes'].shape[0]
     prm = ops.pvgo_default_params(LOSS_WEIGHT, radius=1e4)

@@ -64,6 +64,8 @@ class TartanVO(nn.Module):
         # ~1-2 minutes longer, the stereo net then runs ~25 % faster (the heuristics pick split-K kernels that need
         # zero-fill and cast passes around them)
         if miopen_find:
+            from .miopen_pin import use_pinned_db
+            use_pinned_db()          # the search results of one MI355X run, shipped with the package: same kernels every run, no search
             torch.backends.cudnn.benchmark = True
         self.device_id = device_id
         self.correct_scale = correct_scale

@@ -2207,6 +2207,8 @@ struct FusedArgs {
     int m, P, nwg;                                // level-0 segment length / count, workgroups (each takes <= FZ_S consecutive segments)
     int* eflag;                                   // solver-error word of THIS elimination
     int* eflag_prev;                              // ... of the level-0 elimination of the solve whose trial is evaluated here
+    const double* loss_part0;                     // first trial of a run only: the partial sums of the initial loss (linbuild_kernel) --
+    int nlb0;                                     // the deciding wave does control_begin_kernel's job on the way (one launch less per run)
 };
 
 __device__ __forceinline__ M3<double> m3_zero() { return M3<double>{0, 0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -2245,11 +2247,17 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         }
         ssum = wave_sum(ssum);
         qsum = wave_sum(qsum);
+        double l0 = 0.0;
+        if (a.loss_part0) {                       // self.loss of the very first optimizer.step(): summed like control_begin_kernel does
+            for (int i = lane; i < a.nlb0; i += 64) l0 += a.loss_part0[i];
+            l0 = wave_sum(l0);
+        }
         if (lane == 0) {
             __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool failed = a.flags[0] != 0 || *a.eflag_prev != 0;
             a.flags[0] = 0;
             *a.eflag_prev = 0;
+            if (a.loss_part0) { a.st[0] = l0; a.st[1] = l0; a.st[8] = 0.0; a.st[11] = 1.0; a.st[12] = 0.0; a.st[13] = 0.0; }
             lm_control(ssum, qsum, a.st, failed, a.tr, a.report, a.seq, d_spec);
         }
         return;
@@ -3636,6 +3644,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             return enqueue_levels(w, sp, 0, src, nullptr, w.dx, w.flags, s, nullptr, nullptr, Gate{w.state, ep});
         };
         int* const eflag_none = w.flags + 6;                 // a word nobody sets
+        bool begin_pending = true;                           // the initial loss has not been summed into the state yet
         // evaluates trial `seq` of iteration c (cur + dx -> tri); more: also eliminates level 0 of solve seq+1 and enqueues its upper
         // levels + down-sweep (-> dx).  prev_fused: level 0 of solve `seq` ran inside the previous trial_elim_kernel.
         auto enqueue_trial = [&](const IterCfg& c, double seq, double ep, bool more, bool prev_fused) -> int {
@@ -3643,6 +3652,10 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             double* rep_slot = report + 16 * ((long long)seq & 1);
             int* eprev = prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none;
             if (!more) {                     // nothing follows an accepted trial: the trial alone, no linearisation
+                if (begin_pending) {
+                    hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+                    begin_pending = false;
+                }
                 hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, s, c.cur_n, c.cur_v, w.dx, poses, drots, dtrans,
                                    dvels, dts, LIN[c.pb], M, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot, seq,
                                    (const double*)nullptr, (const double*)nullptr, rp, M, gate, eprev);
@@ -3658,13 +3671,14 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
             fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
             fa.eflag_prev = eprev;
+            if (begin_pending) { fa.loss_part0 = w.loss_part; fa.nlb0 = nlb; begin_pending = false; }
             hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
             LevelSrc none{};
             none.level0 = 1;
             return enqueue_levels(w, sp, 0, none, nullptr, w.dx, w.flags, s, nullptr, nullptr, gate, true);
         };
         enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
-        hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+        // (the initial loss enters the state in the first trial's deciding wave: the first solve does not need it)
         int rc = enqueue_solve_hist(A.pb, epoch);
         if (rc != ISLAM_OK) return rc;
         bool prev_fused = false;
