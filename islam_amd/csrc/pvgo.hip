@@ -528,6 +528,7 @@ struct LevelSrc {
     double damping_override;     // used when state == nullptr
     int hist;                    // 1: Hd keeps its UNDAMPED diagonal; the dampings of the current linearisation are applied on load
                                  //    (state != nullptr: the list state[16 .. 16 + state[8]]; else damping_override, once)
+    const double* zero;          // one double that reads 0.0, in the address space of the arrays above (nullptr: islam_zero16)
     const double *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill;
     int Pprev;                   // number of segments of the previous level
 };
@@ -543,42 +544,57 @@ struct LevelDst {
 // (level 0: A only).  issue() only loads -- every lane runs the same 9/27 loads, disabled terms read valid
 // memory and are dropped by a select in combine() -- so the loads of node c+2 are in flight while node c
 // is being eliminated and are first touched one full node later.
+// Terms a lane does not take (a lane without a column, the B / C composition terms of a U lane, the coupling of the chain's last
+// node, the contribution of a segment that does not exist) are not masked value by value: the lane's POINTER goes to a double that
+// reads 0.0 (strides 0), the same loads are issued on every path and combine_cols is a plain a - b - c.  (The masks cost 54
+// v_cndmask per node step of the upper levels, a sixth of the sweep's instructions.)
 struct LaneSrc {
-    const double *A, *B, *C;
+    const double *A, *B, *C, *Z;
     int nsA, nsB, nsC;        // stride between nodes (doubles)
     int sa, sb, sc;           // stride between rows
     bool isS, isU, isG;
 };
 struct RawCols { double a[9], b[9], c[9]; };
+__device__ double islam_zero16[16];             // never written: reads 0.0
 
+// ZG: the caller provides LevelSrc::zero (sources in LDS: the pointer must stay in that address space)
+template <bool ZG = false>
 __device__ __forceinline__ LaneSrc lane_source(const LevelSrc& s, int lane) {
     LaneSrc L;
     L.isS = lane < 9; L.isU = lane >= 9 && lane < 18; L.isG = lane == 27;
+    L.Z = ZG ? s.zero : islam_zero16;
     const int cu = L.isU ? lane - 9 : 0, cs = L.isS ? lane : 0;
-    L.nsA = L.nsB = L.nsC = L.isG ? 9 : 81;
-    L.sa = L.sb = L.sc = L.isG ? 1 : 9;
+    const bool enA = L.isS || L.isU || L.isG, enBC = L.isS || L.isG;
+    L.nsA = enA ? (L.isG ? 9 : 81) : 0;
+    L.sa = enA ? (L.isG ? 1 : 9) : 0;
+    L.nsB = L.nsC = enBC ? (L.isG ? 9 : 81) : 0;
+    L.sb = L.sc = enBC ? (L.isG ? 1 : 9) : 0;
     if (s.level0) {
-        L.A = L.isU ? s.Ho + cu : L.isG ? s.rhs0 : s.Hd + cs;
+        L.A = !enA ? L.Z : L.isU ? s.Ho + cu : L.isG ? s.rhs0 : s.Hd + cs;
         L.B = L.C = L.A;
     } else {
-        L.A = L.isU ? s.fill + 81 + cu : L.isG ? s.rsep : s.Dsep + cs;      // U: fill[k+1]
-        L.B = L.isG ? s.cgR : s.cR + cs;
-        L.C = L.isG ? s.cgL + 9 : s.cL + 81 + cs;                            // contribution of segment k+1
+        L.A = !enA ? L.Z : L.isU ? s.fill + 81 + cu : L.isG ? s.rsep : s.Dsep + cs;      // U: fill[k+1]
+        L.B = !enBC ? L.Z : L.isG ? s.cgR : s.cR + cs;
+        L.C = !enBC ? L.Z : L.isG ? s.cgL + 9 : s.cL + 81 + cs;                            // contribution of segment k+1
     }
     return L;
 }
 
-__device__ __forceinline__ void issue_cols(const LaneSrc& L, bool level0, int k, RawCols& raw) {
-    const double* pa = L.A + (size_t)k * L.nsA;
+// offU: node k has no coupling on this sweep's far side (the chain ends there); offC: there is no segment k+1 to contribute
+__device__ __forceinline__ void issue_cols(const LaneSrc& L, bool level0, int k, bool offU, bool offC, RawCols& raw) {
+    const bool za = L.isU && offU;
+    const double* pa = za ? L.Z : L.A + (size_t)k * L.nsA;
+    const int sa = za ? 0 : L.sa;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) raw.a[r] = pa[r * L.sa];
+    for (int r = 0; r < 9; ++r) raw.a[r] = pa[r * sa];
     if (!level0) {
         const double* pb = L.B + (size_t)k * L.nsB;
-        const double* pc = L.C + (size_t)k * L.nsC;
+        const double* pc = offC ? L.Z : L.C + (size_t)k * L.nsC;
+        const int sc = offC ? 0 : L.sc;
 #pragma unroll
         for (int r = 0; r < 9; ++r) raw.b[r] = pb[r * L.sb];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) raw.c[r] = pc[r * L.sc];
+        for (int r = 0; r < 9; ++r) raw.c[r] = pc[r * sc];
     }
 }
 
@@ -607,21 +623,17 @@ __device__ __forceinline__ void combine_cols(const LaneSrc& L, const LevelSrc& s
     if (s.level0) {
         // lanes that own no column (spike lanes, lanes >= 28) carry don't-care values: they are overwritten by the
         // spike / never stored, so no per-element select is needed except at the chain's last node (no coupling)
-        const bool zeroU = L.isU && (k + 1) >= n;
         double dg = 0.0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            double v = zeroU ? 0.0 : raw.a[r];
+            double v = raw.a[r];
             if (r == lane) { v = damp_apply(damping, v); dg = v; }   // A.diagonal().add_(A.diagonal()*damping), kept for retries
             m[r] = v;
         }
         if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
     } else {
-        const bool ua = L.isS || L.isG || (L.isU && (k + 1) < n);
-        const bool ub = L.isS || L.isG;
-        const bool uc = ub && (k + 1) < s.Pprev;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) m[r] = (ua ? raw.a[r] : 0.0) - (ub ? raw.b[r] : 0.0) - (uc ? raw.c[r] : 0.0);
+        for (int r = 0; r < 9; ++r) m[r] = raw.a[r] - raw.b[r] - raw.c[r];       // (absent terms were loaded as 0.0: issue_cols)
     }
 }
 
@@ -738,7 +750,7 @@ __device__ __forceinline__ void backsub_run(const double* __restrict__ fac, cons
 
 // One wavefront per segment: eliminate the segment's interior nodes onto its two separators (LDL^T, no square roots).
 // LDS per wave: Xa = [U- | F- | y-] (rows of L^-1 [U F^T g]), Xb = D^-1 Xa, Tn = Xa^T D^-1 Xa entries for the next node
-constexpr int LDS_PER_WAVE = 3 * 19 * XS;
+constexpr int LDS_PER_WAVE = 3 * 19 * XS + XS;       // Xa | Xb | Tn (19 columns each) + one column of zeros behind Tn (twisted_sweep)
 
 __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
                                                   int lane, double* __restrict__ lds) {
@@ -771,7 +783,7 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
     const bool level0 = src.level0 != 0;
     double mcol[9], nb[9];
     RawCols raw;
-    issue_cols(LS, level0, c0, raw);
+    issue_cols(LS, level0, c0, (c0 + 1) >= n, (c0 + 1) >= src.Pprev, raw);
     // spike F^T: coupling (left separator rows, c0 cols) transposed; requested together with the first node's columns
     // (every lane loads from a valid address, lanes outside 18..26 / segments without a left separator discard it)
     double spike[9];
@@ -798,7 +810,7 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
         // prefetch: the columns of node c+1 are requested now and first touched after the whole elimination and Schur
         // update of node c (~1 us later).  Unconditional (index clamped) so that every path through the loop body issues
         // the same memory operations and the compiler can place an exact, late s_waitcnt.
-        issue_cols(LS, level0, min(c + 1, n - 1), raw);
+        { const int kn = min(c + 1, n - 1); issue_cols(LS, level0, kn, (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
         __builtin_amdgcn_sched_barrier(0);
         // ---- LDL^T elimination of the 9 unknowns of node c, applied to all 28 columns
         double ipv[9];
@@ -902,8 +914,9 @@ __device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const Lev
 // dependent node steps instead of cnt.  The products handed to the next level (cL, cR, fill, cgL, cgR, Dsep, rsep) and
 // the factor layout per node are those of eliminate_segment; a B-side node's U~ couples to the node on its LEFT and its
 // F~ to the right separator (backsub_twisted).  Segments with fewer than 3 interior nodes run one-sided on wave A.
+template <bool ZG = false>
 __device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) {
-    LaneSrc L = lane_source(s, lane);
+    LaneSrc L = lane_source<ZG>(s, lane);
     if (L.isU) {                                    // U' column cu of node k = coupling (k rows, k-1 col cu) = row cu of the
         const int cu = lane - 9;                    // block that couples k-1 -> k
         L.A = (s.level0 ? s.Ho - 81 : s.fill) + cu * 9;
@@ -915,21 +928,17 @@ __device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) 
 __device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, const Damp& damping,
                                                  const RawCols& raw, double (&m)[9]) {
     if (s.level0) {
-        const bool zeroU = L.isU && k <= 0;
         double dg = 0.0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            double v = zeroU ? 0.0 : raw.a[r];
+            double v = raw.a[r];
             if (r == lane) { v = damp_apply(damping, v); dg = v; }
             m[r] = v;
         }
         if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
     } else {
-        const bool ua = L.isS || L.isG || (L.isU && k > 0);
-        const bool ub = L.isS || L.isG;
-        const bool uc = ub && (k + 1) < s.Pprev;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) m[r] = (ua ? raw.a[r] : 0.0) - (ub ? raw.b[r] : 0.0) - (uc ? raw.c[r] : 0.0);
+        for (int r = 0; r < 9; ++r) m[r] = raw.a[r] - raw.b[r] - raw.c[r];
     }
 }
 
@@ -947,7 +956,7 @@ constexpr int LDS_TWISTED = 2 * LDS_PER_WAVE + TW_ACC + 2;      // doubles per w
 constexpr int H_FST = 28 * XS;                                  // eliminated columns [L^T | U~ | F~ | y~]
 constexpr int H_XB = 19 * XS;                                   // D^-1 [U~ | F~ | y~]
 constexpr int H_STAGE = H_FST + H_XB + 10;                      // + reciprocal pivots (9, padded)
-constexpr int H_SWEEP = 2 * H_STAGE + 19 * XS;                  // two stages + Tn
+constexpr int H_SWEEP = 2 * H_STAGE + 20 * XS;                  // two stages + Tn + one column of zeros
 constexpr int LDS_TW4 = 2 * H_SWEEP + TW_ACC + 2;               // doubles per workgroup
 
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: global prefetches and stores stay in flight)
@@ -970,7 +979,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     double* Xb = lds + 19 * XS;
     double* Tn = lds + (HELP ? 2 * H_STAGE : 2 * 19 * XS);
     LevelSrc src = src_in;
-    if (L0 >= 0) src.level0 = L0;
+    if (L0 >= 0) src.level0 = L0 != 0;              // (L0 = 2: level 0 out of LDS blocks, LevelSrc::zero given -- trial_elim_kernel)
     [[maybe_unused]] const bool prb = lane == 0 && p == 1 && !src.level0 && src.Pprev > 500;      // probe build: level 1, segment 1
     [[maybe_unused]] const int pbase = REV ? 470 : 440;
     PROBE_WALL(prb, pbase);
@@ -982,15 +991,17 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     pair_of(lane, pa, pb);
     if (lane >= 45) { pa = lane - 45; pb = 9; }
     const bool acc_on = !HELP && has_spike && lane < 54;
-    const bool use_nb = lane < 18 || lane == 27;
+    // a lane that takes no Schur-update column (U lanes, lanes without a column, the spike lanes of a sweep without an outer
+    // separator) reads the column of zeros behind Tn: the next node's columns are a plain nb - tcol on every lane
     const bool use_tn = lane < 9 || lane == 27 || (has_spike && lane >= 18 && lane < 27);
-    const int tn_off = (lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
-    const LaneSrc LS = REV ? lane_source_rev(src, lane) : lane_source(src, lane);
+    const int tn_off = (!use_tn ? 19 : lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
+    if (lane < XS) Tn[19 * XS + lane] = 0.0;
+    const LaneSrc LS = REV ? lane_source_rev<L0 == 2>(src, lane) : lane_source<L0 == 2>(src, lane);
     const bool level0 = src.level0 != 0;
     auto clampi = [&](int k) { return min(max(k, 0), n - 1); };
     double mcol[9], nb[9];
     RawCols raw;
-    issue_cols(LS, level0, first, raw);
+    issue_cols(LS, level0, first, REV ? first <= 0 : (first + 1) >= n, (first + 1) >= src.Pprev, raw);
     double spike[9];
     {
         const int jj = (lane >= 18 && lane < 27) ? lane - 18 : 0;
@@ -1026,7 +1037,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
         const bool last = (t == count - 1);
         PROBE_WALL(prb, pbase + 2 + 5 * t);
         const int nxt = REV ? c - 1 : ((last && last_next >= 0) ? last_next : c + 1);
-        issue_cols(LS, level0, clampi(nxt), raw);
+        { const int kn = clampi(nxt); issue_cols(LS, level0, kn, REV ? kn <= 0 : (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
         __builtin_amdgcn_sched_barrier(0);
         double ipv[9];
 #pragma unroll
@@ -1117,7 +1128,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
             double tcol[9];
             ldcol(Tn + tn_off, tcol);
 #pragma unroll
-            for (int r = 0; r < 9; ++r) mcol[r] = (use_nb ? nb[r] : 0.0) - (use_tn ? tcol[r] : 0.0);
+            for (int r = 0; r < 9; ++r) mcol[r] = nb[r] - tcol[r];       // (nb is 0.0 on lanes without a column of their own: lane_source)
             if (!REV && t == merge_t) {
                 // the node just formed is the middle node: fold wave B's side in.  T_B(r, cb): r = middle unknown, cb < 9
                 // middle unknown (S update), cb = 9+j right-separator unknown j (its negative IS the coupling middle -> R,
@@ -2273,6 +2284,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     [[maybe_unused]] const bool fpr = lane == 0 && (wg == 1 || wg == a.nwg / 2);     // probe build only
     [[maybe_unused]] const int fpo = 600 + (wg == 1 ? 0 : 100) + 12 * wave;
     PROBE_WALL(fpr, fpo);
+    if (threadIdx.x == 0) s_sum[2] = 0.0;                        // LevelSrc::zero of the elimination below (same address space as the blocks)
     // ---- A: retraction, one lane per node
     if (wave == 0) {
         const int k = cb - 1 + lane;
@@ -2481,12 +2493,13 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     src.state = nullptr;
     src.damping_override = d_spec;
     src.hist = 1;
+    src.zero = s_sum + 2;
     const int nbar = m >= 3 ? m / 2 + 1 : m;
     double* tw = lds + FZ_OFF_TW;
     PROBE_WALL(fpr, fpo + 4);
     if (wave < 2 * FZ_S) {
         const int seg = wave >> 1, p = seg0 + seg;
-        if (p < seg1) sweep_with_helper<1>(src, a.dst, N, m, p, a.eflag, wave & 1, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
+        if (p < seg1) sweep_with_helper<2>(src, a.dst, N, m, p, a.eflag, wave & 1, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
         else { for (int t = 0; t < nbar; ++t) lds_barrier(); }
     } else {
         // the linearisation to global memory, lane-contiguous: the fallback solves (reject, mis-speculated damping, failed solve)
