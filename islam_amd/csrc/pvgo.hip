@@ -2131,15 +2131,16 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
         __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PROBE_WALL(pr, 405);
-    if (wave == 0 && valid) {
-        if (owns) {
-            se3_store(Xi, nodes_t + 7 * L);
-            vels_t[3 * L] = vi.x; vels_t[3 * L + 1] = vi.y; vels_t[3 * L + 2] = vi.z;
-            if (L == M - 1) {
-                se3_store(Xj, nodes_t + 7 * (L + 1));
-                vels_t[3 * L + 3] = vj.x; vels_t[3 * L + 4] = vj.y; vels_t[3 * L + 5] = vj.z;
-            }
+    if (wave == 0 && valid && owns) {
+        se3_store(Xi, nodes_t + 7 * L);
+        vels_t[3 * L] = vi.x; vels_t[3 * L + 1] = vi.y; vels_t[3 * L + 2] = vi.z;
+        if (L == M - 1) {
+            se3_store(Xj, nodes_t + 7 * (L + 1));
+            vels_t[3 * L + 3] = vj.x; vels_t[3 * L + 4] = vj.y; vels_t[3 * L + 5] = vj.z;
         }
+    }
+    if (lin_o == nullptr) return;            // trial only (the last trial of a run: nothing is linearised at its trial point)
+    if (wave == 0 && valid) {
         PROBE_WALL(pr, 406);
         M3<double> G, C, B;
         link_jacobians(r, G, C, B);
@@ -2241,7 +2242,8 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     if (blockIdx.x == gridDim.x - 1) {
         // the deciding workgroup (see trial_lin_kernel): sums the partials in index order, LM decision, validates the speculation
         if (wave != 0 || gate_closed(gate)) return;
-        const double d_spec = speculated_damping(a.st, a.tr);
+        const bool first = a.dx == nullptr;
+        const double d_spec = first ? -1.0 : speculated_damping(a.st, a.tr);
         __builtin_amdgcn_s_sleep(64);
         if (lane == 0) {
             int spins = 0;
@@ -2265,6 +2267,10 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         }
         if (lane == 0) {
             __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (first) {                          // the linearisation of the initial iterate: its loss is the run's first `last`
+                a.st[0] = ssum; a.st[1] = ssum; a.st[8] = 0.0; a.st[11] = 1.0; a.st[12] = 0.0; a.st[13] = 0.0;
+                return;
+            }
             const bool failed = a.flags[0] != 0 || *a.eflag_prev != 0;
             a.flags[0] = 0;
             *a.eflag_prev = 0;
@@ -2275,7 +2281,10 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     }
     const int wg = xcd_index(blockIdx.x, a.nwg);
     if (wg < 0 || gate_closed(gate)) return;
-    const double d_spec = speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
+    // first: the run's first linearisation (no step yet: dx == nullptr) -- the iterate itself instead of a trial point, no
+    // trust-region term, no decision, and the elimination uses the initial damping (nothing to speculate on)
+    const bool first = a.dx == nullptr;
+    const double d_spec = first ? a.st[2] : speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
     // the level's segments are dealt out evenly: workgroup wg takes segments [wg P / nwg, (wg+1) P / nwg) -- three or four of them
     // on the 5000-frame graph, so that all 256 CUs share the level's pivots
     const int seg0 = (int)(((long long)wg * a.P) / a.nwg), seg1 = (int)(((long long)(wg + 1) * a.P) / a.nwg);
@@ -2289,9 +2298,13 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     if (wave == 0) {
         const int k = cb - 1 + lane;
         if (lane < G + 2 && k >= 0 && k < N) {
-            const double* d = a.dx + (size_t)k * 9;
-            const SE3<double> X = se3_mul(se3_exp(ld3(d), ld3(d + 3)), se3_load(a.nodes + 7 * k));      // LieTensor.add_
-            const V3<double> v = ld3(a.vels + 3 * k) + ld3(d + 6);
+            SE3<double> X = se3_load(a.nodes + 7 * k);
+            V3<double> v = ld3(a.vels + 3 * k);
+            if (!first) {
+                const double* d = a.dx + (size_t)k * 9;
+                X = se3_mul(se3_exp(ld3(d), ld3(d + 3)), X);                                              // LieTensor.add_
+                v = v + ld3(d + 6);
+            }
             double* o = xt + lane * FZ_XT;
             se3_store(X, o);
             o[7] = v.x; o[8] = v.y; o[9] = v.z;
@@ -2367,7 +2380,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         } else if (wave == 2) {
             // -(J D)^T (2 R + J D) with the UNWEIGHTED J, R of the linearisation point (ppost.TrustRegion.update)
             double qd = 0.0;
-            if (owns) {
+            if (owns && !first) {
                 const double* di = a.dx + (size_t)L * 9;
                 const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
                 const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
@@ -3664,14 +3677,15 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             const Gate gate{w.state, ep};
             double* rep_slot = report + 16 * ((long long)seq & 1);
             int* eprev = prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none;
-            if (!more) {                     // nothing follows an accepted trial: the trial alone, no linearisation
+            if (!more) {                     // nothing follows an accepted trial: the trial alone, no linearisation (lin_o = nullptr)
                 if (begin_pending) {
                     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
                     begin_pending = false;
                 }
-                hipLaunchKernelGGL(trial_kernel, dim3(xcd_grid((M + 63) / 64)), dim3(64), 0, s, c.cur_n, c.cur_v, w.dx, poses, drots, dtrans,
-                                   dvels, dts, LIN[c.pb], M, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot, seq,
-                                   (const double*)nullptr, (const double*)nullptr, rp, M, gate, eprev);
+                hipLaunchKernelGGL(trial_lin_kernel, dim3(xcd_grid(nlb) + 1), dim3(LB_THREADS), LB_DYN_BYTES, s, c.cur_n, c.cur_v, w.dx, poses,
+                                   drots, dtrans, dvels, dts, LIN[c.pb], N, c.tri_n, c.tri_v, w.part, w.state, w.flags, ticket, tr, rep_slot,
+                                   seq, (const double*)nullptr, (const double*)nullptr, rp, W, (double*)nullptr, (double*)nullptr,
+                                   (double*)nullptr, (double*)nullptr, gate, eprev);
                 ISLAM_LAUNCH_CHECK();
                 return ISLAM_OK;
             }
@@ -3690,11 +3704,28 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             none.level0 = 1;
             return enqueue_levels(w, sp, 0, none, nullptr, w.dx, w.flags, s, nullptr, nullptr, gate, true);
         };
-        enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
-        // (the initial loss enters the state in the first trial's deciding wave: the first solve does not need it)
-        int rc = enqueue_solve_hist(A.pb, epoch);
+        // the first solve: the same kernel in its `first` mode (dx = nullptr) linearises at the initial iterate, sums the initial loss
+        // and eliminates level 0 with the initial damping -- linbuild_kernel + the launched level-0 kernel only on the fallback paths
+        int rc;
+        {
+            const Gate gate{w.state, epoch};
+            FusedArgs fa{};
+            fa.nodes = A.cur_n; fa.vels = A.cur_v; fa.dx = nullptr; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans; fa.dvels = dvels;
+            fa.dts = dts; fa.lin = nullptr; fa.N = N; fa.nodes_t = A.tri_n; fa.vels_t = A.tri_v; fa.part = w.part; fa.st = w.state;
+            fa.flags = w.flags; fa.ticket = ticket; fa.tr = tr; fa.report = nullptr; fa.seq = 0.0; fa.W = W;
+            fa.lin_o = LIN[A.pb]; fa.Hd_o = HD[A.pb]; fa.Ho_o = HO[A.pb]; fa.rhs_o = RH[A.pb];
+            fa.dst = level_dst(w.lv[0], w.dx);
+            fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
+            fa.eflag = w.flags + 4 + 1;                          // solve 1
+            fa.eflag_prev = eflag_none;
+            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
+            LevelSrc none{};
+            none.level0 = 1;
+            rc = enqueue_levels(w, sp, 0, none, nullptr, w.dx, w.flags, s, nullptr, nullptr, gate, true);
+            begin_pending = false;
+        }
         if (rc != ISLAM_OK) return rc;
-        bool prev_fused = false;
+        bool prev_fused = true;
         for (;;) {
             const double seq = (double)(trials + 1);
             const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
