@@ -113,11 +113,16 @@ class TartanVO(nn.Module):
         """Software pipelining across batches: run the frozen part of forward(sample) -- flow + disparity, 95 % of the GPU
         time of a forward -- on a side stream NOW, while the caller is still busy with the previous batch (IMU, PVGO,
         backward: small kernels and host work that leave the GPU mostly idle).  forward(sample) on the same dict object
-        picks the result up.  Only when both nets are frozen (no autograd state; the reference detaches flow and disparity
+        picks the result up.  Several batches may be under way at once (one entry per sample dict; the side stream runs them in
+        the order they were asked for).  Only when both nets are frozen (no autograd state; the reference detaches flow and disparity
         anyway, TartanVO.py:109-110); returns False otherwise and forward() computes everything inline."""
         nets = (self.vonet.flowNet, self.vonet.stereoNet)
         if any(p.requires_grad for n in nets for p in n.parameters()):
             return False
+        if getattr(self, '_prefetched', None) is None:
+            self._prefetched = {}
+        if id(sample) in self._prefetched:         # already under way (prefetch depth > 1: BilevelLoop.step asks again)
+            return True
         dev = self.device_id
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=dev)
@@ -128,7 +133,7 @@ class TartanVO(nn.Module):
             flow, disp = self.vonet.frozen_forward(*imgs)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._prefetched = (sample, flow, disp, ev)
+        self._prefetched[id(sample)] = (sample, flow, disp, ev)
         return True
 
     def forward(self, sample, is_train=True, given_scale=None):
@@ -141,14 +146,13 @@ class TartanVO(nn.Module):
             img0_norm = sample['img0_norm'].cuda(dev, non_blocking=True)
             img0_r_norm = sample['img0_r_norm'].cuda(dev, non_blocking=True)
             frozen = None
-            pre = getattr(self, '_prefetched', None)
+            pre = (getattr(self, '_prefetched', None) or {}).pop(id(sample), None)
             if pre is not None and pre[0] is sample:
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(pre[3])
                 for t in pre[1:3]:
                     t.record_stream(cur)
                 frozen = (pre[1], pre[2])
-            self._prefetched = None
             intrinsic_calib = sample['intrinsic_calib']
             baseline = torch.linalg.norm(sample['extrinsic'][:, :3], dim=1)
             precalc_flow = sample['flow'] if 'flow' in sample else None

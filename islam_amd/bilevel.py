@@ -49,9 +49,11 @@ class BilevelLoop:
         self.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
 
     def step(self, sample, target='vo', next_sample=None):
-        """One pass of train.py:200-299 over one batch of ``batch_size`` frames.  ``next_sample``: the following batch;
-        its frozen flow / disparity forward is started on a side stream as soon as this batch's pose head is enqueued
-        (TartanVO.prefetch) and overlaps with this batch's IMU / PVGO / backward."""
+        """One pass of train.py:200-299 over one batch of ``batch_size`` frames.  ``next_sample``: the following batch (or a
+        tuple of the following batches, nearest first); their frozen flow / disparity forwards are queued on a side stream as
+        soon as this batch's pose head is enqueued (TartanVO.prefetch) and overlap with this batch's IMU / PVGO / backward.
+        With TWO batches ahead the side stream never runs dry: with one, nothing but the launch-bound pose head runs between
+        the end of batch k+1's frozen forward and the start of batch k+2's."""
         bs, dev = self.bs, self.device
         sync = (lambda: torch.cuda.current_stream().synchronize()) if next_sample is not None else torch.cuda.synchronize
         t0 = time.perf_counter()
@@ -66,7 +68,9 @@ class BilevelLoop:
             with torch.set_grad_enabled(target == 'vo'):
                 res = self.vo(sample)
             if next_sample is not None and hasattr(self.vo, 'prefetch'):
-                self.vo.prefetch(next_sample)
+                for nxt in (next_sample if isinstance(next_sample, (tuple, list)) else (next_sample,)):
+                    if nxt is not None:
+                        self.vo.prefetch(nxt)
             motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
             T_IL = self.T_IL.to(motions.device).to(motions.dtype)
             motions = T_IL @ motions @ T_IL.Inv()                                               # train.py:214-215

@@ -2402,23 +2402,8 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     }
     lds_barrier();
     PROBE_WALL(fpr, fpo + 2);
-    if (wave == 3) {
-        // unweighted loss of the stretch's own links (the terms in the order of link_residuals' sum), then publish both partial
-        // sums: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
-        const int L = cb - 1 + lane;
-        double sq = 0.0;
-        if (lane >= 1 && lane <= G && L < M) {
-            const double* o = si + lane * FZ_RI;
-            sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
-        }
-        sq = wave_sum(sq);
-        if (lane == 0) {
-            st_coherent(&a.part[2 * wg], sq);
-            st_coherent(&a.part[2 * wg + 1], s_sum[1]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    // (the two partial sums are published after the block build, by a helper wave: a wave that waits for its write-through stores
+    // here arrives ~1 us late at the barrier behind the build and holds the whole workgroup -- measured: blocks 1.4 -> 0.6 us)
     // ---- C: node blocks.  Node i of the stretch (k = cb+i) takes link slots i (k-1) and i+1 (k); coupling i (k' = cb-1+i) is link slot i.
     // One 3x3 sub-block per thread, 32 slots per kind of block: a half-wave builds ONE kind (9 of Hd, 9 of Ho, the right-hand side)
     {
@@ -2515,8 +2500,25 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         if (p < seg1) sweep_with_helper<2>(src, a.dst, N, m, p, a.eflag, wave & 1, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
         else { for (int t = 0; t < nbar; ++t) lds_barrier(); }
     } else {
+        if (wave == 2 * FZ_S + FZ_HELPERS - 1) {
+            // unweighted loss of the stretch's own links (the terms in the order of link_residuals' sum), then publish both partial
+            // sums: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
+            const int L = cb - 1 + lane;
+            double sq = 0.0;
+            if (lane >= 1 && lane <= G && L < M) {
+                const double* o = si + lane * FZ_RI;
+                sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) {
+                st_coherent(&a.part[2 * wg], sq);
+                st_coherent(&a.part[2 * wg + 1], s_sum[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         // the linearisation to global memory, lane-contiguous: the fallback solves (reject, mis-speculated damping, failed solve)
-        // and the final trial_lin_kernel read it from there
+        // read it from there
         const int ht = threadIdx.x - 2 * FZ_S * 64, HT = FZ_HELPERS * 64;
         const int no = min(G, N - cb);                                    // nodes this stretch owns
         for (int e = ht; e < no * 81; e += HT) a.Hd_o[(size_t)cb * 81 + e] = Hd_l[e];

@@ -66,13 +66,13 @@ def _loop(vo, tr):
 def test_benched_configuration_two_bilevel_steps(cuda):
     steps = 2
     tr = synthetic.car_trajectory(steps * B + 1, seed=3)
-    seq = _samples(cuda, steps + 1)
+    seq = _samples(cuda, steps + 2)
 
     # ---- the benched configuration, pipelined exactly like bench.py's timed loop
     vo_b = _make(cuda, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True, pose_channels_last=True,
                  graph_frozen=True, graph_pose=True)
     loop_b = _loop(vo_b, tr)
-    losses_b = [loop_b.step(seq[k], next_sample=seq[k + 1]) for k in range(steps)]
+    losses_b = [loop_b.step(seq[k], next_sample=(seq[k + 1], seq[k + 2])) for k in range(steps)]      # (a tuple: two batches ahead -- the deepest schedule BilevelLoop offers; bench.py runs one ahead)
     torch.cuda.synchronize()
     motions_b = np.asarray(loop_b.vo_motions, dtype=np.float64)
     poses_b = np.asarray(loop_b.pgo_poses, dtype=np.float64)
