@@ -1683,19 +1683,36 @@ __global__ __launch_bounds__(128, 2) void bt_downsweep_kernel(SweepArgs a, int* 
     if (gate_closed(gate)) return;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
+    // A root of exactly three nodes (the N = 5001 tree) never leaves the workgroup: its two sweeps run in the staged (HELP) form --
+    // no factor stores, no accumulations (no outer separators) -- and the back-substitution takes its factor rows straight from
+    // the three LDS stages (forward sweep: nodes 0, 1 in its two stages; reverse sweep: node 2).  Root published 8.8 -> 7.x us
+    // into the launch (scripts/probe_sweep.py).
+    const bool root3 = a.root_twisted && a.root_n == 3;
     if (threadIdx.x >= 64) {
-        if (b == 0 && a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 1, lane, lds);
+        if (b == 0 && root3) sweep_with_helper<0>(a.root_src, a.root_dst, 3, 3, 0, flags, 1, lane, lds, Gate{nullptr, 0.0}, 2);
+        else if (b == 0 && a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 1, lane, lds);
         return;
     }
     if (b == 0) {                                   // root: eliminate + solve
         PROBE_WALL(lane == 0, 300);
-        if (a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 0, lane, lds);
+        if (root3) sweep_with_helper<0>(a.root_src, a.root_dst, 3, 3, 0, flags, 0, lane, lds, Gate{nullptr, 0.0}, 2);
+        else if (a.root_twisted) eliminate_twisted(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, 0, lane, lds);
         else eliminate_segment(a.root_src, a.root_dst, a.root_n, a.root_n, 0, flags, lane, lds);
         PROBE_WALL(lane == 0, 301);
         double xn[9], xL[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
-        if (a.root_twisted) {
+        if (root3) {
+            lds_sync();
+            const int t = min(lane / 9, 2), r = lane - (lane / 9) * 9;          // lane 9t + r: row r of node t (lanes >= 27 duplicate node 2)
+            const double* st = t == 0 ? lds : t == 1 ? lds + H_STAGE : lds + H_SWEEP;
+            FacRow row;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { row.lt[i] = st[i * XS + r]; row.u[i] = st[(9 + i) * XS + r]; row.f[i] = st[(18 + i) * XS + r]; }
+            row.y = st[27 * XS + r];
+            row.iv = st[H_FST + H_XB + r];
+            backsub_par_run_tw(a.root_dst.x, 0, 3, lane, xn, xL, row);
+        } else if (a.root_twisted) {
             FacRow row;
             backsub_par_load(a.root_dst.fac, a.root_dst.inv, 0, a.root_n, lane, row);
             backsub_par_run_tw(a.root_dst.x, 0, a.root_n, lane, xn, xL, row);
@@ -1773,24 +1790,55 @@ __global__ __launch_bounds__(128, 2) void bt_downsweep_kernel(SweepArgs a, int* 
         const bool int0 = has_left && (q0 - base * ps) < P.m;
         const bool int1 = has_right && (q1 - s1 * ps) < P.m;
         const bool sh = s1 != base;                          // q1's producer segment is the next one: its U's are base, base+1
-        if (int0) wait_ready(a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE, a.serial, flags, lane);
-        if (int1 && (!int0 || sh)) wait_ready(a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE, a.serial, flags, lane);
-        PROBE_WALL(pr, po + 315 + 10 * li);                  // (probe build: G-ready words seen)
+        // ALL ready words this segment depends on are polled at once, one word per lane: lanes 0 / 1 the G-ready words of the (up to
+        // two) producer segments, lanes 2-4 the words of the (up to three) nodes of the level above the producer.  The rows of G are
+        // requested the moment their words are seen -- whichever side arrives first no longer delays the other by a round trip
+        // (the top pair sees the root's solution long before its producers' G, the bottom pair the other way round).
         const int rq = lane < 9 ? lane : lane - 9;           // row of G_q0 (lanes 0-8) / G_q1 (lanes 9-17)
         const bool mineint = lane < 9 ? int0 : (lane < 18 && int1);
         const bool minesep = lane < 9 ? (has_left && !int0) : (lane < 18 && has_right && !int1);
+        const int* myf = nullptr;
+        if (lane == 0 && int0) myf = a.ready + (size_t)(P.gflag0 + base) * READY_STRIDE;
+        if (lane == 1 && int1 && (!int0 || sh)) myf = a.ready + (size_t)(P.gflag0 + s1) * READY_STRIDE;
+        if (lane >= 2 && lane < 5) {
+            const int j = base - 1 + (lane - 2);
+            const bool dup = lane > 2 && j - 1 >= 0 && (j - 1) / P.up_stride == j / P.up_stride;      // same word as the lane before
+            if (j >= 0 && j < nup && !dup) myf = a.ready + (size_t)(P.up_flag0 + j / P.up_stride) * READY_STRIDE;
+        }
+        double tq[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tq[i] = 0.0;
+        bool g_issued = false;
+        for (int spins = 0;; ++spins) {
+            const int ok = myf ? (__hip_atomic_load(myf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.serial) : 1;
+            const unsigned long long seen = __ballot(ok);
+            const bool gok = (seen & 3ull) == 3ull, xok = (seen & 0x1cull) == 0x1cull;
+            if (gok && !g_issued) {
+                PROBE_WALL(pr, po + 315 + 10 * li);          // (probe build: G-ready words seen)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {                // both matrices, contiguous: six loads per lane, all in flight
+                    const int e = min(lane + 64 * i, 341);
+                    const bool first = e < 171;
+                    const double* gsrc = P.gx + (size_t)(first ? q0 : q1) * 171 + (first ? e : e - 171);
+                    tq[i] = (first ? int0 : int1) ? ld_coherent(gsrc) : 0.0;
+                }
+                g_issued = true;
+            }
+            if (gok && xok) break;
+            __builtin_amdgcn_s_sleep(ISLAM_POLL_SLEEP);
+            if (spins > (1 << 22)) { if (lane == 0) atomicOr(flags, 2); break; }     // never observed; keeps a logic error from hanging the GPU
+        }
+        asm volatile("" ::: "memory");
+        PROBE_WALL(pr, po + 311 + 10 * li);
+        double uv = 0.0;
+        {
+            const int j = base - 1 + lane / 9;
+            if (lane < 27 && j >= 0 && j < nup) uv = ld_coherent(&P.xsep[(size_t)(base - 1) * 9 + lane]);
+        }
         double gq[19];
         {
-            // both matrices through LDS with contiguous loads (six per lane), then every lane picks its row
+            // the matrices go through LDS, then every lane picks its row
             double* Gq = lds;                                // [2][171]
-            double tq[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {                    // all six loads in flight, then the LDS writes
-                const int e = min(lane + 64 * i, 341);
-                const bool first = e < 171;
-                const double* gsrc = P.gx + (size_t)(first ? q0 : q1) * 171 + (first ? e : e - 171);
-                tq[i] = (first ? int0 : int1) ? ld_coherent(gsrc) : 0.0;
-            }
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 if (lane + 64 * i < 342) Gq[lane + 64 * i] = tq[i];
@@ -1804,27 +1852,7 @@ __global__ __launch_bounds__(128, 2) void bt_downsweep_kernel(SweepArgs a, int* 
                     if (k == rq) gq[10 + k] = -1.0;
             }
         }
-#ifdef ISLAM_PROBE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PROBE_WALL(pr, po + 316 + 10 * li);                  // (probe build: rows of G arrived)
-#endif
-        // wait for the (up to three) nodes of the level above the producer
-        int lastf = -1;
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            const int j = base - 1 + sl;
-            if (j >= 0 && j < nup) {
-                const int f = P.up_flag0 + j / P.up_stride;
-                if (f != lastf) wait_ready(a.ready + (size_t)f * READY_STRIDE, a.serial, flags, lane);
-                lastf = f;
-            }
-        }
-        PROBE_WALL(pr, po + 311 + 10 * li);
-        double uv = 0.0;
-        {
-            const int j = base - 1 + lane / 9;
-            if (lane < 27 && j >= 0 && j < nup) uv = ld_coherent(&P.xsep[(size_t)(base - 1) * 9 + lane]);
-        }
+        PROBE_WALL(pr, po + 316 + 10 * li);                  // (probe build: rows of G in registers)
         const bool second = lane >= 9 && sh;                 // lanes of q1 when its segment is base+1: (UL, UR) = slots (1, 2)
         double xq = gq[0];
 #pragma unroll

@@ -17,8 +17,9 @@ Hd_d, Ho_d, rhs = t(Hd), t(Ho), t(rng.normal(size=(N, 9)))
 for _ in range(5): ops.pvgo_solve_chain(Hd_d.clone(), Ho_d, rhs, 1e-4)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 1024)()
-L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
-assert L.lib().islam_probe_read(buf) == 0
+fn = L.lib()._cdll.islam_probe_read
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf) == 0
 b = list(buf)
 print('prologue->loop start (cycles from slot0): n/a; per node phases in shader cycles (2.4 GHz):')
 for tnode in range(5):

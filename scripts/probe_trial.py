@@ -15,8 +15,9 @@ for _ in range(3):
     res, _ = ops.pvgo_run_chain(n, v, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'], prm, workspace=ws)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 1024)()
-L.lib().islam_probe_read.argtypes = [ctypes.c_void_p]
-assert L.lib().islam_probe_read(buf) == 0
+fn = L.lib()._cdll.islam_probe_read
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf) == 0
 b = list(buf)
 t0 = b[400]
 us = lambda x: (x - t0) / 100.0
