@@ -958,6 +958,11 @@ constexpr int H_XB = 19 * XS;                                   // D^-1 [U~ | F~
 constexpr int H_STAGE = H_FST + H_XB + 10;                      // + reciprocal pivots (9, padded)
 constexpr int H_SWEEP = 2 * H_STAGE + 20 * XS;                  // two stages + Tn + one column of zeros
 constexpr int LDS_TW4 = 2 * H_SWEEP + TW_ACC + 2;               // doubles per workgroup
+// PF (upper levels: bt_eliminate_tw_kernel<0>): the helper also FETCHES AND COMPOSES the next node's columns (27 global loads with
+// their address arithmetic and the a - b - c per lane -- a sixth of the sweeping wave's instructions, and the sweep is bound by
+// instruction issue) and leaves them in LDS, two buffers per sweep by step parity, 29 columns each (28 + one that reads 0.0).
+constexpr int H_NB = 29 * XS;
+constexpr int LDS_TW4_PF = LDS_TW4 + 4 * H_NB + 2;
 
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: global prefetches and stores stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -970,11 +975,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   last_next  (forward only) node whose columns follow the last eliminated node (the right separator), -1: none
 //   nbar       (HELP) barriers every wave of the workgroup executes = node steps of the forward sweep
 //   L0         1 / 0: the level is known at compile time (level-0 instantiation: no composition loads, fewer registers); -1: runtime
-template <bool REV, bool HELP = false, int L0 = -1>
+//   PF / nbst  (HELP, upper levels) the next node's columns come composed from the helper: nbst[2][H_NB], buffer t & 1 for step t
+template <bool REV, bool HELP = false, int L0 = -1, bool PF = false>
 __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const LevelDst& dst, int n, int p, int first, int count,
                                               bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
                                               double* __restrict__ lds, const double* __restrict__ TnB,
-                                              double* __restrict__ accB, const Gate& gate, int nbar = 0) {
+                                              double* __restrict__ accB, const Gate& gate, int nbar = 0,
+                                              const double* __restrict__ nbst = nullptr) {
     double* Xa = lds;
     double* Xb = lds + 19 * XS;
     double* Tn = lds + (HELP ? 2 * H_STAGE : 2 * 19 * XS);
@@ -1037,7 +1044,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
         const bool last = (t == count - 1);
         PROBE_WALL(prb, pbase + 2 + 5 * t);
         const int nxt = REV ? c - 1 : ((last && last_next >= 0) ? last_next : c + 1);
-        { const int kn = clampi(nxt); issue_cols(LS, level0, kn, REV ? kn <= 0 : (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
+        if constexpr (!PF) { const int kn = clampi(nxt); issue_cols(LS, level0, kn, REV ? kn <= 0 : (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
         __builtin_amdgcn_sched_barrier(0);
         double ipv[9];
 #pragma unroll
@@ -1108,7 +1115,8 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
         // the next node's own columns; wave B never forms the middle node's (wave A does: its diagonal is damped once)
         const bool want_next = REV ? !last : (nxt >= 0 && nxt < n && (!last || last_next >= 0));
         if (want_next) {
-            if (REV) combine_cols_rev(LS, src, nxt, lane, damping, raw, nb);
+            if constexpr (PF) ldcol(nbst + (t & 1) * H_NB + min(lane, 28) * XS, nb);      // composed by the helper before this step's barrier
+            else if (REV) combine_cols_rev(LS, src, nxt, lane, damping, raw, nb);
             else combine_cols(LS, src, nxt, n, lane, damping, raw, nb);
         }
         if constexpr (!HELP) {
@@ -1227,16 +1235,84 @@ __device__ __forceinline__ void helper_node(const LevelDst& dst, int c, const do
 __host__ __device__ __forceinline__ int twisted_mid(int cnt) { return cnt >= 3 ? cnt / 2 : cnt - 1; }
 
 // One helper wave can serve several segments of a workgroup (NSEG; trial_elim_kernel: two): nbar = barriers the workgroup executes.
-struct HelpSeg { int p, firstA, nA, firstB, nB; bool has_left, has_right, on; const double *ldsA, *ldsB; double* accB; };
+struct HelpSeg { int p, firstA, nA, firstB, nB; bool has_left, has_right, on; const double *ldsA, *ldsB; double* accB;
+                 int n, last_next; double *nbA, *nbB; };        // (PF: level size, the node behind the forward sweep's last one, the column buffers)
 
-template <int NSEG>
-__device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSeg (&sg)[NSEG], int nbar, int lane) {
+// PF: composes the columns the sweeps take next (see H_NB): the loads for step t+1 are issued right behind barrier t, the stage of
+// node t is streamed out while they fly, the columns are written before barrier t+1.
+template <bool REV>
+__device__ __forceinline__ bool pf_next(const HelpSeg& g, int t, int& k) {
+    int nxt;
+    bool want;
+    if (REV) { nxt = g.firstB - t - 1; want = t < g.nB - 1; }
+    else {
+        const bool last = t == g.nA - 1;
+        nxt = (last && g.last_next >= 0) ? g.last_next : g.firstA + t + 1;
+        want = t < g.nA && nxt < g.n && (!last || g.last_next >= 0);
+    }
+    k = min(max(nxt, 0), g.n - 1);
+    return want;
+}
+
+template <int NSEG, bool PF = false>
+__device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSeg (&sg)[NSEG], int nbar, int lane,
+                                               const LevelSrc* src = nullptr) {
     int pa, pb;
     pair_of(lane, pa, pb);
     if (lane >= 45) { pa = lane - 45; pb = 9; }
     double accA[NSEG], accBv[NSEG];
 #pragma unroll
     for (int q = 0; q < NSEG; ++q) { accA[q] = 0.0; accBv[q] = 0.0; }
+    [[maybe_unused]] LaneSrc LSA{}, LSB{};
+    [[maybe_unused]] RawCols rawA[NSEG], rawB[NSEG];
+    [[maybe_unused]] Damp nodamp{0.0, nullptr, 0, false};
+    // issue the loads of the columns step t takes next / compose them and leave them in buffer t & 1
+    [[maybe_unused]] auto pf_issue = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q) {
+            if (!sg[q].on) continue;
+            int k;
+            if (pf_next<false>(sg[q], t, k)) issue_cols(LSA, false, k, (k + 1) >= sg[q].n, (k + 1) >= src->Pprev, rawA[q]);
+            if (pf_next<true>(sg[q], t, k)) issue_cols(LSB, false, k, k <= 0, (k + 1) >= src->Pprev, rawB[q]);
+        }
+    };
+    [[maybe_unused]] auto pf_write = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q) {
+            if (!sg[q].on) continue;
+            int k;
+            double m[9];
+            if (pf_next<false>(sg[q], t, k)) {
+                combine_cols(LSA, *src, k, sg[q].n, lane, nodamp, rawA[q], m);
+                if (lane < 28) {
+                    double* o = sg[q].nbA + (t & 1) * H_NB + lane * XS;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) o[r] = m[r];
+                }
+            }
+            if (pf_next<true>(sg[q], t, k)) {
+                combine_cols_rev(LSB, *src, k, lane, nodamp, rawB[q], m);
+                if (lane < 28) {
+                    double* o = sg[q].nbB + (t & 1) * H_NB + lane * XS;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) o[r] = m[r];
+                }
+            }
+        }
+    };
+    if constexpr (PF) {
+        LSA = lane_source(*src, lane);
+        LSB = lane_source_rev(*src, lane);
+        pf_issue(0);
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q) {                     // the column lanes without a column of their own read: 0.0
+            if (sg[q].on && lane >= 28 && lane < 28 + XS) {
+                sg[q].nbA[28 * XS + lane - 28] = 0.0; sg[q].nbA[H_NB + 28 * XS + lane - 28] = 0.0;
+                sg[q].nbB[28 * XS + lane - 28] = 0.0; sg[q].nbB[H_NB + 28 * XS + lane - 28] = 0.0;
+            }
+        }
+        pf_write(0);
+    }
     for (int t = 0; t < nbar; ++t) {
 #pragma unroll
         for (int q = 0; q < NSEG; ++q) {
@@ -1251,12 +1327,14 @@ __device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSe
             }
         }
         lds_barrier();
+        if constexpr (PF) { if (t + 1 < nbar) pf_issue(t + 1); }
 #pragma unroll
         for (int q = 0; q < NSEG; ++q) {
             if (!sg[q].on) continue;
             if (t < sg[q].nA) helper_node(dst, sg[q].firstA + t, sg[q].ldsA + (t & 1) * H_STAGE, lane, sg[q].has_left && lane < 54, pa, pb, accA[q]);
             if (t < sg[q].nB) helper_node(dst, sg[q].firstB - t, sg[q].ldsB + (t & 1) * H_STAGE, lane, sg[q].has_right && lane < 54, pa, pb, accBv[q]);
         }
+        if constexpr (PF) { if (t + 1 < nbar) pf_write(t + 1); }
     }
 #pragma unroll
     for (int q = 0; q < NSEG; ++q) {
@@ -1285,10 +1363,11 @@ __device__ __forceinline__ SegGeom seg_geom(int n, int m, int p) {
     g.nB = g.tw ? g.cnt - 1 - g.h : 0;
     return g;
 }
-__device__ __forceinline__ HelpSeg help_seg(const SegGeom& g, int p, double* lds_seg) {
+__device__ __forceinline__ HelpSeg help_seg(const SegGeom& g, int p, double* lds_seg, int n = 0) {
     HelpSeg s;
     s.p = p; s.firstA = g.c0; s.nA = g.nA; s.firstB = g.c0 + g.cnt - 1; s.nB = g.nB; s.has_left = g.has_left; s.has_right = g.has_right;
     s.on = true; s.ldsA = lds_seg; s.ldsB = lds_seg + H_SWEEP; s.accB = lds_seg + 2 * H_SWEEP;
+    s.n = n; s.last_next = g.has_right ? g.sR : -1; s.nbA = lds_seg + LDS_TW4; s.nbB = lds_seg + LDS_TW4 + 2 * H_NB;
     return s;
 }
 
@@ -1322,7 +1401,7 @@ __device__ __forceinline__ void eliminate_twisted(const LevelSrc& src, const Lev
 
 // The two sweeps of segment p with helper hand-off (HELP): role 0 = forward, 1 = reverse.  nbar = barriers every wave of the
 // workgroup executes (>= this segment's forward step count; more when a workgroup holds segments of different lengths).
-template <int L0>
+template <int L0, bool PF = false>
 __device__ __forceinline__ void sweep_with_helper(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags, int role, int lane,
                                                   double* __restrict__ lds_seg, const Gate& gate, int nbar) {
     const SegGeom g = seg_geom(n, m, p);
@@ -1330,11 +1409,11 @@ __device__ __forceinline__ void sweep_with_helper(const LevelSrc& src, const Lev
     double* ldsB = lds_seg + H_SWEEP;
     double* accB = lds_seg + 2 * H_SWEEP;
     if (role == 0)
-        twisted_sweep<false, true, L0>(src, dst, n, p, g.c0, g.nA, g.has_left, g.tw ? g.h - 1 : -1, g.has_right ? g.sR : -1, g.has_right, flags,
-                                       lane, ldsA, ldsB + 2 * H_STAGE, accB, gate, nbar);
+        twisted_sweep<false, true, L0, PF>(src, dst, n, p, g.c0, g.nA, g.has_left, g.tw ? g.h - 1 : -1, g.has_right ? g.sR : -1, g.has_right,
+                                           flags, lane, ldsA, ldsB + 2 * H_STAGE, accB, gate, nbar, lds_seg + LDS_TW4);
     else if (g.tw)
-        twisted_sweep<true, true, L0>(src, dst, n, p, g.c0 + g.cnt - 1, g.nB, g.has_right, -1, -1, g.has_right, flags, lane, ldsB, nullptr, accB,
-                                      gate, nbar);
+        twisted_sweep<true, true, L0, PF>(src, dst, n, p, g.c0 + g.cnt - 1, g.nB, g.has_right, -1, -1, g.has_right, flags, lane, ldsB, nullptr,
+                                          accB, gate, nbar, lds_seg + LDS_TW4 + 2 * H_NB);
     else if (!gate_closed(gate)) { for (int t = 0; t < nbar; ++t) lds_barrier(); }
 }
 
@@ -1343,10 +1422,11 @@ template <int L0>
 __device__ __forceinline__ void eliminate_twisted3(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
                                                    int wave, int lane, double* __restrict__ lds_wg, const Gate& gate) {
     const SegGeom g = seg_geom(n, m, p);
-    if (wave < 2) sweep_with_helper<L0>(src, dst, n, m, p, flags, wave, lane, lds_wg, gate, g.nA);
+    constexpr bool PF = L0 == 0;                     // upper levels: the helper fetches and composes the next node's columns
+    if (wave < 2) sweep_with_helper<L0, PF>(src, dst, n, m, p, flags, wave, lane, lds_wg, gate, g.nA);
     else if (!gate_closed(gate)) {
-        const HelpSeg sg[1] = {help_seg(g, p, lds_wg)};
-        twisted_helper<1>(dst, sg, g.nA, lane);
+        const HelpSeg sg[1] = {help_seg(g, p, lds_wg, n)};
+        twisted_helper<1, PF>(dst, sg, g.nA, lane, &src);
     }
 }
 
@@ -1354,7 +1434,7 @@ __device__ __forceinline__ void eliminate_twisted3(const LevelSrc& src, const Le
 template <int L0>
 __global__ __launch_bounds__(192, L0 ? 3 : 2) void bt_eliminate_tw_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0,
                                                                           int nseg, Gate gate) {
-    __shared__ __attribute__((aligned(16))) double lds[LDS_TW4];
+    __shared__ __attribute__((aligned(16))) double lds[L0 ? LDS_TW4 : LDS_TW4_PF];
     const int p = xcd_index(blockIdx.x, nseg);
     if (p < 0) return;
     eliminate_twisted3<L0>(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
