@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libislam_hip.so')
+LIB_PATH = os.environ.get('ISLAM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libislam_hip.so')      # (ISLAM_HIP_LIB: A/B runs of two builds)
 _lib = None
 
 c_void_p, c_int, c_int64, c_double, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
