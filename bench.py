@@ -114,30 +114,6 @@ def committed_traffic():
     return t
 
 
-def cpu_dense_protocol(prob_host):
-    """SURVEY 8(d) CPU protocol for the faithful formulation (dense J / block_diag W / dense Cholesky as PyPose builds them,
-    oracle/pvgo.py mode='dense'): fp32 like the reference (pvgo.py:157-160) AND fp64, all host cores, 1 warm-up + median of 5 first
-    LM iterations per size, the largest size the bounded sample affords, and the power-law fit that extrapolates to N=5001 (which
-    needs > 60 GB and minutes per iteration, SURVEY F7)."""
-    from oracle import pvgo as opvgo
-    out = {'cores': os.cpu_count(), 'what': 'dense PyPose-style LM iteration, 1 warm-up + median of 5 (first optimizer.step of the loop)'}
-    for name, dt in (('f32', np.float32), ('f64', np.float64)):
-        rows = []
-        for n_small in (129, 257, 513):
-            small = {k: (v[:n_small] if k in ('init_nodes', 'init_vels') else v[:n_small - 1]) for k, v in prob_host.items()}
-            ts = []
-            for rep in range(6):
-                t1 = time.perf_counter()
-                o = opvgo.run_pvgo(**small, loss_weight=LOSS_WEIGHT, mode='dense', max_steps=1, return_optimizer=True, dtype=dt)
-                ts.append((time.perf_counter() - t1) / max(len(o[5].trace), 1))
-            rows.append((n_small, float(np.median(ts[1:]))))
-        (n1, t1_), (n2, t2_) = rows[-2], rows[-1]
-        expo = float(np.log(t2_ / t1_) / np.log(n2 / n1))
-        out[name] = {'iters_per_s': {str(n): 1.0 / t for n, t in rows}, 'largest_N': rows[-1][0], 'value': 1.0 / rows[-1][1],
-                     'fit_exponent': expo, 'extrapolated_iters_per_s_N5001': 1.0 / (t2_ * (5001.0 / n2) ** expo)}
-    return out
-
-
 def cpu_baseline(prob_host):
     """Oracle (CPU restatement of the PyPose LM, oracle/pvgo.py) on the host cores: banded mode at full size."""
     from oracle import pvgo as opvgo
@@ -166,6 +142,30 @@ def cpu_baseline(prob_host):
                   '%.1f s, 1 thread (more threads make the many tiny LAPACK calls slower)' % (prob_host['init_nodes'].shape[0], runs, trials, dt),
         'dense_pypose_style': dense,
     }
+
+
+def cpu_dense_protocol(prob_host):
+    """SURVEY 8(d) CPU protocol for the faithful formulation (dense J / block_diag W / dense Cholesky as PyPose builds them,
+    oracle/pvgo.py mode='dense'): fp32 like the reference (pvgo.py:157-160) AND fp64, all host cores, 1 warm-up + median of 5 first
+    LM iterations per size, the largest size the bounded sample affords, and the power-law fit that extrapolates to N=5001 (which
+    needs > 60 GB and minutes per iteration, SURVEY F7)."""
+    from oracle import pvgo as opvgo
+    out = {'cores': os.cpu_count(), 'what': 'dense PyPose-style LM iteration, 1 warm-up + median of 5 (first optimizer.step of the loop)'}
+    for name, dt in (('f32', np.float32), ('f64', np.float64)):
+        rows = []
+        for n_small in (129, 257, 513):
+            small = {k: (v[:n_small] if k in ('init_nodes', 'init_vels') else v[:n_small - 1]) for k, v in prob_host.items()}
+            ts = []
+            for rep in range(6):
+                t1 = time.perf_counter()
+                o = opvgo.run_pvgo(**small, loss_weight=LOSS_WEIGHT, mode='dense', max_steps=1, return_optimizer=True, dtype=dt)
+                ts.append((time.perf_counter() - t1) / max(len(o[5].trace), 1))
+            rows.append((n_small, float(np.median(ts[1:]))))
+        (n1, t1_), (n2, t2_) = rows[-2], rows[-1]
+        expo = float(np.log(t2_ / t1_) / np.log(n2 / n1))
+        out[name] = {'iters_per_s': {str(n): 1.0 / t for n, t in rows}, 'largest_N': rows[-1][0], 'value': 1.0 / rows[-1][1],
+                     'fit_exponent': expo, 'extrapolated_iters_per_s_N5001': 1.0 / (t2_ * (5001.0 / n2) ** expo)}
+    return out
 
 
 def vio_frames_per_sec(device, batch=8, steps=16, warmup=3):

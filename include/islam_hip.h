@@ -107,6 +107,16 @@ int islam_avgpool_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H,
  * y, res: (pixels, C) bf16 bits, C a multiple of 8; bias (C) fp32. */
 int islam_bias_act_add_nhwc_bf16(uint16_t* y, const float* bias, const uint16_t* res, long long pixels, int C, int relu,
                                  void* stream);
+/* The elementwise tail of the trainable pose head's convolutions (Network/VOFlowNet.py:42-157: conv + bias + ReLU, residual
+ * blocks conv + bias + shortcut + ReLU), fp32 channels-last (pixels x C, C a multiple of 4), one launch each way:
+ *   forward   y = act(x + bias[c] (+ res));  x may alias y
+ *   backward  gx = gy * (y > 0) (relu) or gy;  gbias[c] = sum over pixels of gx (deterministic two-stage sum); gx may alias gy.
+ * scratch: islam_bias_act_bwd_scratch_floats(pixels, C) floats; ticket: one zero-initialised word, left at zero. */
+int islam_bias_act_f32_nhwc(const float* x, const float* bias, const float* res, float* y, long long pixels, int C, int relu,
+                            void* stream);
+long long islam_bias_act_bwd_scratch_floats(long long pixels, int C);
+int islam_bias_act_bwd_f32_nhwc(const float* gy, const float* y, float* gx, float* gbias, float* scratch, unsigned* ticket,
+                                long long pixels, int C, int relu, void* stream);
 
 /* Train-mode BatchNorm2d (+ ReLU, + residual add) on a channels-last bf16 tensor -- the BatchNorm layers of the "frozen"
  * stereo feature extractor, which the reference still runs with batch statistics (TartanVO.py:90-91; Network/PSM/

@@ -59,6 +59,9 @@ SIGNATURES = {
     'islam_avgpool_nhwc_bf16': (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     'islam_resize_bilinear_nhwc_bf16_into': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'islam_bias_act_add_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
+    'islam_bias_act_f32_nhwc': (c_int, [c_void_p] * 4 + [ctypes.c_longlong, c_int, c_int, c_void_p]),
+    'islam_bias_act_bwd_scratch_floats': (ctypes.c_longlong, [ctypes.c_longlong, c_int]),
+    'islam_bias_act_bwd_f32_nhwc': (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_int, c_int, c_void_p]),
     'islam_bn_scratch_floats': (c_size_t, [c_int]),
     'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'islam_conv_nhwc_packed_elems': (c_size_t, [c_int] * 3),

@@ -12,6 +12,8 @@ state-dict keys and forward arithmetic, so the released checkpoints load unchang
 tests/test_nets_cpu.py checks key sets, shapes and forward outputs against golden vectors generated
 by importing the reference modules (tests/golden/make_net_golden.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -595,7 +597,29 @@ def _linear_relu(cin, cout):
     return nn.Sequential(nn.Linear(cin, cout), nn.ReLU(inplace=True))
 
 
+def _conv_nobias(conv, x):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _fused_tail_ok(x):
+    """The one-launch elementwise tail (ops.bias_act) serves fp32 channels-last activations on the device."""
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) \
+        and not torch.is_autocast_enabled()
+
+
+def _conv_relu_fused(seq, x):
+    """`_conv_relu` (conv + bias + ReLU) with the bias add and the ReLU in ONE launch forward and ONE backward (ops.bias_act)."""
+    from . import ops
+    conv = seq[0]
+    y = _conv_nobias(conv, x)
+    if not _fused_tail_ok(y) or conv.out_channels % 4:
+        return F.relu(y + conv.bias.view(1, -1, 1, 1))
+    return ops.bias_act(y, conv.bias, None, True)
+
+
 class _PoseBlock(nn.Module):
+    fused_tail = False           # set by VOFlowRes.set_fused_tail: same parameters, same state dict, fewer launches
+
     def __init__(self, cin, cout, stride, downsample):
         super().__init__()
         self.conv1 = _conv_relu(cin, cout, stride)
@@ -603,6 +627,14 @@ class _PoseBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if self.fused_tail and _fused_tail_ok(x):
+            from . import ops
+            h = _conv_relu_fused(self.conv1, x)
+            y = _conv_nobias(self.conv2, h)
+            sc = x if self.downsample is None else self.downsample(x)
+            if _fused_tail_ok(y) and _fused_tail_ok(sc):
+                return ops.bias_act(y, self.conv2.bias, sc, True)           # relu((conv2 + bias) + shortcut): one launch
+            return F.relu(y + self.conv2.bias.view(1, -1, 1, 1) + sc)
         y = self.conv2(self.conv1(x))
         return F.relu(y + (x if self.downsample is None else self.downsample(x)), inplace=True)
 
@@ -628,8 +660,21 @@ class VOFlowRes(nn.Module):
                 for p in part.parameters():
                     p.requires_grad = False
 
+    def set_fused_tail(self, on=True):
+        """Bias add + ReLU (+ shortcut add) behind every convolution of the encoder as one HIP launch forward and one backward
+        (islam_amd/csrc/pose_ops.hip) instead of 2-4 ATen launches each way; fp32 channels-last activations only (other inputs
+        take the plain modules).  Same parameters and state dict."""
+        self.fused_tail = bool(on)
+        for m in self.modules():
+            if isinstance(m, _PoseBlock):
+                m.fused_tail = bool(on)
+
     def forward(self, x, extrinsic=None):
-        x = self.feat_net(x)
+        if getattr(self, 'fused_tail', False) and _fused_tail_ok(x):
+            for i, m in enumerate(self.feat_net):
+                x = _conv_relu_fused(m, x) if i < 3 else m(x)
+        else:
+            x = self.feat_net(x)
         x = x.reshape(x.shape[0], -1)          # (= .view for the reference's NCHW activations; channels_last ones are re-laid out)
         return torch.cat((self.voflow_trans(x), self.voflow_rot(x)), 1)
 
@@ -666,6 +711,7 @@ class VONet(nn.Module):
         (~270 per step).  Same parameters, same state dict, same arithmetic up to MIOpen's kernel choice."""
         self.pose_channels_last = bool(on)
         self.flowPoseNet.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+        self.flowPoseNet.set_fused_tail(on and os.environ.get('ISLAM_POSE_NO_FUSED_TAIL') != '1')     # (channels-last activations: ops.bias_act applies)
 
     def set_frozen_dtype(self, dtype, flow_dtype=None):
         self.frozen_dtype, self.flow_dtype = dtype, flow_dtype

@@ -336,6 +336,54 @@ def bias_act_add_(y, bias32, res=None, relu=False):
     return y
 
 
+class _BiasActF32(torch.autograd.Function):
+    """y = act(x + bias[c] (+ res)) on fp32 channels-last conv outputs, one launch each way (islam_bias_act_f32_nhwc /
+    islam_bias_act_bwd_f32_nhwc): the elementwise tail of the trainable pose head's convolutions (Network/VOFlowNet.py:42-157)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, relu):
+        B, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        check(lib().islam_bias_act_f32_nhwc(ptr(x), ptr(bias), ptr(res), ptr(y), ctypes.c_longlong(B * H * W), C, int(bool(relu)),
+                                            stream_ptr(x.device)))
+        ctx.relu, ctx.has_res = bool(relu), res is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        B, C, H, W = y.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(gy, memory_format=torch.channels_last)
+        gb = torch.empty(C, dtype=torch.float32, device=y.device)
+        npix = B * H * W
+        scratch = torch.empty(int(lib().islam_bias_act_bwd_scratch_floats(ctypes.c_longlong(npix), C)), dtype=torch.float32, device=y.device)
+        check(lib().islam_bias_act_bwd_f32_nhwc(ptr(gy), ptr(y), ptr(gx), ptr(gb), ptr(scratch), ptr(_ticket(y.device)),
+                                                ctypes.c_longlong(npix), C, int(ctx.relu), stream_ptr(y.device)))
+        return gx, gb, (gx if ctx.has_res else None), None
+
+
+_TICKETS = {}
+
+
+def _ticket(device):
+    """One zero-initialised word per device for the kernels that fold partial sums in their last workgroup (they leave it at zero;
+    launches on one stream are ordered, so they can share it)."""
+    t = _TICKETS.get(device)
+    if t is None:
+        t = _TICKETS[device] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t
+
+
+def bias_act(x, bias, res=None, relu=True):
+    """act(x + bias[c] (+ res)) for an fp32 channels-last conv output, differentiable w.r.t. x, bias and res."""
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 4 == 0
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == torch.float32 and res.is_contiguous(memory_format=torch.channels_last)
+    return _BiasActF32.apply(x, bias, res, relu)
+
+
 def bn_train_(x, bn, relu=False, res=None):
     """nn.BatchNorm2d in training mode on a channels-last bf16 conv output, IN PLACE, with the ReLU and / or residual add
     that follows it folded in (islam_bn_train_nhwc_bf16).  ``bn``: the fp32 BatchNorm2d module (weight, bias, running

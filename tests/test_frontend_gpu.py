@@ -303,3 +303,50 @@ def test_pose_head_graph_replay_trains_like_eager(cuda):
     import gc
     gc.collect()
     torch.cuda.synchronize()
+
+
+def test_pose_head_fused_elementwise_tail(cuda):
+    """VOFlowRes.set_fused_tail (islam_bias_act_f32_nhwc / _bwd): bias + ReLU (+ shortcut) behind every encoder convolution in one
+    launch each way.  Same convolutions on the same inputs: the forward is the same sequence of fp32 additions (bit-equal pose), the
+    bias gradients are summed in another (fixed) order."""
+    from islam_amd import nets, ops
+    torch.manual_seed(7)
+    vn = nets.VONet(fix_parts=('flow', 'stereo'))
+    head = vn.flowPoseNet.to(cuda)
+    vn.set_pose_channels_last(True)
+    assert head.fused_tail
+    B = 3
+    flow = torch.randn(B, 2, 112, 160, device=cuda)
+    intr = torch.rand(B, 2, 112, 160, device=cuda)
+    frozen = (flow, torch.zeros(B, 1, 112, 160, device=cuda))
+
+    def run():
+        for p in head.parameters():
+            p.grad = None
+        _, _, pose = vn(None, None, None, None, intr, frozen=frozen)
+        (pose * torch.arange(1, 7, device=cuda)).sum().backward()
+        return pose.detach().clone(), [p.grad.detach().clone() for p in head.parameters()]
+    p1, g1 = run()
+    head.set_fused_tail(False)
+    p0, g0 = run()
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
+    for (name, _), a, b in zip(head.named_parameters(), g1, g0):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-6 * max(float(b.abs().max()), 1e-30) + 1e-12, msg=name)
+    # the op on its own: values, gradients w.r.t. all three inputs, odd pixel counts
+    for shape, with_res, relu in (((2, 32, 5, 7), False, True), ((3, 256, 2, 3), True, True), ((1, 64, 9, 11), True, False)):
+        g = torch.Generator(device='cpu').manual_seed(sum(shape))
+        mk = lambda *s: torch.randn(*s, generator=g).to(cuda)
+        x = mk(*shape).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bias = mk(shape[1]).requires_grad_(True)
+        res = mk(*shape).contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+        w = mk(*shape)
+        y = ops.bias_act(x, bias, res, relu)
+        ref = x + bias.view(1, -1, 1, 1) + (res if with_res else 0)
+        ref = torch.relu(ref) if relu else ref
+        assert torch.equal(y, ref)
+        gi = torch.autograd.grad((y * w).sum(), [x, bias] + ([res] if with_res else []))
+        gr = torch.autograd.grad((ref * w).sum(), [x, bias] + ([res] if with_res else []))
+        assert torch.equal(gi[0], gr[0]) and (not with_res or torch.equal(gi[2], gr[2]))
+        torch.testing.assert_close(gi[1], gr[1], rtol=1e-5, atol=1e-5)
+        gi2 = torch.autograd.grad((ops.bias_act(x, bias, res, relu) * w).sum(), [bias])
+        assert torch.equal(gi[1], gi2[0])                                   # fixed-order sums: the same bits every time
