@@ -121,7 +121,7 @@ def test_product_fails_loudly_without_gpu():
         IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')
 
 
-@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json'])
+@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json', 'bench_r03_final.json'])
 def test_committed_bench_line_follows_the_contract(name):
     """profiles/bench_rNN_final.json is the last `python bench.py` line of a round measured on the MI355X: one JSON object with
     the driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline; from round 2 on
@@ -138,6 +138,15 @@ def test_committed_bench_line_follows_the_contract(name):
         assert {'bt_eliminate_tw_kernel_L0', 'bt_downsweep_kernel', 'trial_lin_kernel'} <= set(pl)
         assert sum(v['us'] for v in pl.values()) < it['us']               # the three biggest launches fit inside the iteration
         assert 0 < d['stereo_vio']['mfma_frac'] < 1
+    if 'r03' in name:                 # round 3: the dominant launch is the fused trial + elimination kernel; traffic carries its provenance
+        it = d['roofline']['iteration']
+        assert abs(it['us'] - d['us_per_lm_iter']) < 1e-9 and it['bytes'] == 5000 * 5001
+        pl = d['roofline']['per_launch']
+        assert {'bt_eliminate_tw_kernel_L0', 'bt_downsweep_kernel', 'trial_elim_kernel'} <= set(pl)
+        assert 'trial_elim_kernel' in d['roofline']['kernel'] and d['roofline']['algorithmic_bytes_per_launch'] == pl['trial_elim_kernel']['bytes']
+        assert d['roofline']['traffic'] is None or 'pvgo.hip sha256' in d['roofline']['traffic_source']
+        dense = d['cpu_baseline']['dense_pypose_style']
+        assert {'f32', 'f64'} <= set(dense) and dense['cores'] >= 1 and dense['f32']['fit_exponent'] > 1
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
