@@ -1,0 +1,94 @@
+"""BASELINE configs[4] (whole trajectories in parallel) with the REAL networks on the GPU: two ranks (gloo, both on
+the one GPU of the test box), each a BilevelLoop over its own synthetic trajectory through TartanVO (HIP correlation / warp / scale /
+edge kernels, train-mode BatchNorm), IMU pre-integration, PVGO and the one-step backward; `TrajectoryParallel.end_epoch` all-reduces
+the accumulated pose-head gradients (one bucket) and steps Adam.  Checked against one process that runs both trajectories itself:
+same averaged gradients, replicas bit-identical after the step.  ("gloo CPU test + stub-net GPU test only".)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B = 2
+
+
+def _make():
+    from islam_amd.TartanVO import TartanVO
+    torch.manual_seed(0)
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=True)
+    with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
+        vo.vonet.stereoNet.conv_c13.weight.zero_()
+        vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
+    return vo
+
+
+def _loop(vo, traj):
+    from islam_amd import lietensor as pp, synthetic
+    from islam_amd.bilevel import BilevelLoop
+    from islam_amd.imu_integrator import IMUModule
+    tr = synthetic.car_trajectory(B + 1, seed=40 + traj)
+    imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], np.zeros(3), np.zeros(3), tr['init'], tr['gravity'],
+                    tr['rgb2imu_sync'], device='cuda', denoise_model_name=None, denoise_accel=True, denoise_gyro=False)
+    return BilevelLoop(vo, imu, pp.identity_SE3(), tr['init'], batch_size=B, device='cuda'), synthetic.stereo_batch(B, seed=70 + traj)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from islam_amd.dist_train import TrajectoryParallel, allreduce_gradients
+    vo = _make()
+    loop, sample = _loop(vo, rank)
+    tp = TrajectoryParallel(loop)
+    loss = tp.step(sample)
+    params = list(vo.vonet.flowPoseNet.parameters())
+    own = [p.grad.detach().clone().cpu() for p in params]
+    nb = allreduce_gradients(params, None, True)                       # what end_epoch does first (idempotent: the mean of equal values)
+    red = [p.grad.detach().clone().cpu() for p in params]
+    tp.end_epoch()
+    torch.save({'loss': loss, 'own': own, 'red': red, 'buckets': nb, 'w': [p.detach().clone().cpu() for p in params]},
+               os.path.join(out_dir, 't%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trajectory_parallel_bilevel_loop_with_real_nets(cuda, tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), 't%d.pt' % r)) for r in range(2)]
+    assert outs[0]['buckets'] == 1                                       # 60.5 MB of pose-head gradients: one collective
+    assert all(np.isfinite(o['loss']) for o in outs)
+    for a, b in zip(outs[0]['red'], outs[1]['red']):
+        assert torch.equal(a, b)                                         # every rank holds the same reduced gradient ...
+    for a, b in zip(outs[0]['w'], outs[1]['w']):
+        assert torch.equal(a, b)                                         # ... and the replicas stay bit-identical after Adam
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(outs[0]['own'], outs[1]['own']))      # the trajectories differ
+    # one process, both trajectories: the reduced gradient is the mean of the per-trajectory gradients
+    vo = _make()
+    w0 = [p.detach().clone().cpu() for p in vo.vonet.flowPoseNet.parameters()]
+    per = []
+    for traj in range(2):
+        for p in vo.vonet.flowPoseNet.parameters():
+            p.grad = None
+        loop, sample = _loop(vo, traj)
+        loop.step(sample)
+        per.append([p.grad.detach().clone().cpu() for p in vo.vonet.flowPoseNet.parameters()])
+    # (the bilevel gradient is a small difference of large terms -- entries of 1e-9 -- and MIOpen's split-K weight gradients are not
+    # bit-reproducible: two runs of the SAME trajectory agree to ~5e-3 of the largest entry; hence the loose bounds)
+    worst, cos_min = 0.0, 1.0
+    for g0, g1, red, own0 in zip(per[0], per[1], outs[0]['red'], outs[0]['own']):
+        want = 0.5 * (g0 + g1)
+        scale = max(float(want.abs().max()), 1e-30)
+        worst = max(worst, float((red - want).abs().max()) / scale)
+        cos_min = min(cos_min, float((red * want).sum() / (red.norm() * want.norm()).clamp_min(1e-30)))
+        assert float((own0 - g0).abs().max()) <= 3e-2 * max(float(g0.abs().max()), 1e-30)
+    assert worst <= 3e-2 and cos_min >= 0.999, (worst, cos_min)
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(outs[0]['w'], w0))                # the step moved the weights
