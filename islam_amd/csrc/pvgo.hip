@@ -3757,7 +3757,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     // the launch-per-stage loop below.
     SolvePlan sp;
     plan_levels(N, prm->seg_len, sp, solve_twisted());
-    static const bool no_fuse = [] { const char* e = std::getenv("ISLAM_PVGO_NO_FUSE"); return e && e[0] == '1'; }();
+    const bool no_fuse = [] { const char* e = std::getenv("ISLAM_PVGO_NO_FUSE"); return e && e[0] == '1'; }();      // (read per call: A/B tests)
     // (one workgroup of FZ_S segments per CU: the whole level must be resident at once)
     // (the deciding workgroup is one more block with the same LDS footprint: it is dispatched to XCD 0, which must keep a CU free
     // for it -- otherwise it starts when the first workgroup exits and the launch ends ~4 us late)

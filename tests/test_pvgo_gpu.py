@@ -316,3 +316,28 @@ def test_block_tridiagonal_solver_random_sizes_and_segment_lengths(cuda):
                 ab[9 + c - r, r:9 * (N - 1):9] = Ho[:N - 1, r, c]
         ref = sla.solveh_banded(ab, rhs.reshape(-1), lower=True).reshape(N, 9)
         assert np.abs(dx - ref).max() <= 1e-9 * np.abs(ref).max(), (case, N, seg)
+
+
+@pytest.mark.parametrize('F,seed,sig', [(1000, 3, 0.8), (5001, 5, 0.5), (5001, 6, 1.5), (777, 9, 3.0)])
+def test_fused_loop_equals_the_launch_per_stage_loop_on_reject_heavy_graphs(cuda, F, seed, sig, monkeypatch):
+    """islam_pvgo_run_chain's two loops on problems that make LM reject trials and change its damping at full size: the fused loop
+    (trial_elim_kernel: speculated damping, verdict 5 / reject / fallback solves from the undamped linearisation + damping history)
+    against the launch-per-stage loop (in-place cumulative damping) -- same accept / reject sequence, same dampings, same iterate."""
+    from islam_amd import ops
+    prob = _noisy_problem(F, seed, sig)
+    prm = ops.pvgo_default_params(LW, radius=1e4)
+    outs = []
+    for no_fuse in ('1', '0'):
+        monkeypatch.setenv('ISLAM_PVGO_NO_FUSE', no_fuse)
+        nodes, vels, poses, drots, dtrans, dvels, dts = _dev(prob, cuda)
+        res, trace = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, prm, trace_cap=256)
+        outs.append((res, np.asarray(trace)[:res.trials], nodes.cpu().numpy(), vels.cpu().numpy()))
+    (r0, t0, n0, v0), (r1, t1, n1, v1) = outs
+    assert (r1.trials, r1.steps, r1.status) == (r0.trials, r0.steps, r0.status)
+    np.testing.assert_array_equal(t1[:, 2], t0[:, 2])                       # accept / reject pattern
+    np.testing.assert_allclose(t1[:, 1], t0[:, 1], rtol=1e-12)              # dampings
+    np.testing.assert_allclose(t1[:, 0], t0[:, 0], rtol=1e-9)               # trial losses
+    np.testing.assert_allclose(n1, n0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v1, v0, rtol=0, atol=1e-8)
+    if sig >= 1.5:
+        assert r0.trials > r0.steps or len(set(np.round(t0[:, 1] / t0[0, 1], 6))) > 1      # rejects or a changing damping were exercised
