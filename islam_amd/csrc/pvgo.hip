@@ -989,7 +989,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     if (L0 >= 0) src.level0 = L0 != 0;              // (L0 = 2: level 0 out of LDS blocks, LevelSrc::zero given -- trial_elim_kernel)
     [[maybe_unused]] const bool prb = lane == 0 && p == 1 && !src.level0 && src.Pprev > 500;      // probe build: level 1, segment 1
     [[maybe_unused]] const int pbase = REV ? 470 : 440;
-    PROBE_WALL(prb, pbase);
+#ifdef ISLAM_PROBE
+    const long long t_entry = wall_clock64();
+#endif
     const Damp damping = make_damp(src);
     const int tr = lane % 9, tg = lane / 9;
     const bool t_on = tg < 7;
@@ -1030,6 +1032,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     // cannot change while this kernel runs (it is bumped by the previous iteration's trial kernel), so both wavefronts of
     // the workgroup take the same branch.
     if (gate_closed(gate)) return;
+#ifdef ISLAM_PROBE
+    if (prb) islam_probe_buf[pbase] = t_entry;
+#endif
     PROBE_WALL(prb, pbase + 1);
     if (REV) combine_cols_rev(LS, src, first, lane, damping, raw, mcol);
     else combine_cols(LS, src, first, n, lane, damping, raw, mcol);
@@ -1108,6 +1113,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
             ldcol(Xb + (9 + pb) * XS, cbv);
             accL += dot9r(ca, cbv);
         }
+        PROBE_WALL(prb, (REV ? 550 : 540) + t);  // (Schur update done, before the barrier)
         if constexpr (HELP) lds_barrier();       // barrier t: stage + Tn complete; the helper takes node c from here
         else lds_sync();
         PROBE_WALL(prb, pbase + 4 + 5 * t);
@@ -1300,6 +1306,8 @@ __device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSe
             }
         }
     };
+    [[maybe_unused]] const bool hprb = PF && lane == 0 && sg[0].p == 1 && src && src->Pprev > 500;      // probe build: level 1, segment 1
+    PROBE_WALL(hprb, 500);
     if constexpr (PF) {
         LSA = lane_source(*src, lane);
         LSB = lane_source_rev(*src, lane);
@@ -1313,6 +1321,7 @@ __device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSe
         }
         pf_write(0);
     }
+    PROBE_WALL(hprb, 501);
     for (int t = 0; t < nbar; ++t) {
 #pragma unroll
         for (int q = 0; q < NSEG; ++q) {
@@ -1326,7 +1335,9 @@ __device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSe
                 }
             }
         }
+        PROBE_WALL(hprb, 502 + 4 * t);
         lds_barrier();
+        PROBE_WALL(hprb, 503 + 4 * t);
         if constexpr (PF) { if (t + 1 < nbar) pf_issue(t + 1); }
 #pragma unroll
         for (int q = 0; q < NSEG; ++q) {
@@ -1334,7 +1345,9 @@ __device__ __forceinline__ void twisted_helper(const LevelDst& dst, const HelpSe
             if (t < sg[q].nA) helper_node(dst, sg[q].firstA + t, sg[q].ldsA + (t & 1) * H_STAGE, lane, sg[q].has_left && lane < 54, pa, pb, accA[q]);
             if (t < sg[q].nB) helper_node(dst, sg[q].firstB - t, sg[q].ldsB + (t & 1) * H_STAGE, lane, sg[q].has_right && lane < 54, pa, pb, accBv[q]);
         }
+        PROBE_WALL(hprb, 504 + 4 * t);
         if constexpr (PF) { if (t + 1 < nbar) pf_write(t + 1); }
+        PROBE_WALL(hprb, 505 + 4 * t);
     }
 #pragma unroll
     for (int q = 0; q < NSEG; ++q) {
@@ -2604,8 +2617,10 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     double* tw = lds + FZ_OFF_TW;
     PROBE_WALL(fpr, fpo + 4);
     if (wave < 2 * FZ_S) {
-        const int seg = wave >> 1, p = seg0 + seg;
-        if (p < seg1) sweep_with_helper<2>(src, a.dst, N, m, p, a.eflag, wave & 1, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
+        // waves s and FZ_S + s sweep segment s forwards / backwards: a workgroup's waves go to the CU's four SIMDs round-robin, so
+        // every SIMD gets one forward (three node steps) and one reverse sweep (two) instead of two of a kind
+        const int seg = wave % FZ_S, p = seg0 + seg;
+        if (p < seg1) sweep_with_helper<2>(src, a.dst, N, m, p, a.eflag, wave / FZ_S, lane, tw + seg * LDS_TW4, Gate{nullptr, 0.0}, nbar);
         else { for (int t = 0; t < nbar; ++t) lds_barrier(); }
     } else {
         if (wave == 2 * FZ_S + FZ_HELPERS - 1) {

@@ -1,9 +1,14 @@
 #!/bin/bash
-# builds islam_amd/lib/libislam_probe.so = the product library with -DISLAM_PROBE (phase timestamps)
+# builds islam_amd/lib/libislam_probe${SUFFIX}.so = the product library with -DISLAM_PROBE (phase timestamps) [+ EXTRA flags]
+# usage: scripts/build_probe.sh [SUFFIX [EXTRA_FLAGS...]]
 set -e
+SUFFIX=$1; shift || true
 cd "$(dirname "$0")/../islam_amd/csrc"
-mkdir -p /tmp/probe_obj
+O=/tmp/probe_obj$SUFFIX
+mkdir -p $O
 for f in abi pvgo corr_warp imu_preint scale_ls conv_mfma conv_nhwc edge_mask pvgo_dist pose_ops; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DISLAM_PROBE -c $f.hip -o /tmp/probe_obj/$f.o
+  if [ $f = pvgo ] || [ ! -f $O/$f.o ]; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DISLAM_PROBE "$@" -c $f.hip -o $O/$f.o
+  fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libislam_probe.so /tmp/probe_obj/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libislam_probe$SUFFIX.so $O/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
