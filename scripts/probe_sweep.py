@@ -2,7 +2,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import islam_amd._lib as L
-L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), 'libislam_probe.so')
+L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), 'libislam_probe%s.so' % os.environ.get('ISLAM_PROBE_SUFFIX', ''))
 import torch
 from islam_amd import ops
 import bench
