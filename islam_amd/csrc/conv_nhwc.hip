@@ -36,6 +36,14 @@
 #define ISLAM_CONV_PROBE 0
 #endif
 
+// ISLAM_CONV_PROBE=3 (scripts/conv_phase_probe.sh): phase timestamps of one workgroup's wave 0
+#if ISLAM_CONV_PROBE == 3
+__device__ long long islam_conv_probe_buf[128];
+#define CPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (cprb) islam_conv_probe_buf[(slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPROBE(slot) do { } while (0)
+#endif
+
 namespace {
 
 using namespace islam;
@@ -121,6 +129,12 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     const int tile = wtile % tiles, b = wtile / tiles;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int wo0 = tx * TW, ho0 = ty * TH, n0 = (sidx - wtile * nblk_n) * TN;
+    [[maybe_unused]] const bool cprb = tid == 0 && sidx == nwork / 2 + 3;
+    [[maybe_unused]] int cpi = 2;
+    CPROBE(0);
+#if ISLAM_CONV_PROBE == 3
+    if (cprb) islam_conv_probe_buf[124] = clock64();
+#endif
     // image b = (batch index, sub-grid row a, sub-grid column c); pixel (gy, gx) of it is full-resolution pixel (gy*d + a, gx*d + c)
     const int dd = sl.d * sl.d, bb = b / dd, sga = (b - bb * dd) / sl.d, sgc = b - bb * dd - sga * sl.d;
     const size_t img0 = ((size_t)(bb * H * sl.d + sga)) * sl.Wf + sgc;          // first pixel of the image, in full-resolution pixels
@@ -206,12 +220,17 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     const unsigned short* bbase = lin + ((size_t)(ROWS * wave) * IW + li) * PS + 8 * kg;
     const unsigned short* abase = lw + (size_t)li * PS + 8 * kg;
     fetch(0);
+    CPROBE(1);
     for (int c0 = 0; c0 < CinP; c0 += KC) {
+        CPROBE(cpi); ++cpi;
         __syncthreads();                                     // the previous chunk's operand reads are done
+        CPROBE(cpi); ++cpi;
 #if ISLAM_CONV_PROBE != 2
         stage(c0);
 #endif
+        CPROBE(cpi); ++cpi;
         __syncthreads();
+        CPROBE(cpi); ++cpi;
 #if ISLAM_CONV_PROBE != 2
         if (c0 + KC < CinP) fetch(c0 + KC);                  // in flight while this chunk is multiplied
 #endif
@@ -238,7 +257,9 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                             acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[p + r], acc[a][p], 0, 0, 0);
                 }
             }
+        CPROBE(cpi); ++cpi;
     }
+    CPROBE(120);
 
     // ---- epilogue.  D row (channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel x) = lane&31.  The tile goes through LDS
     // ([pixel][TN channels] bf16, rounded once) so that the stores are 16 bytes per lane along C -- consecutive lanes complete
@@ -333,6 +354,10 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             if (n0 + c < Cout) partial[((size_t)wtile * 2 + which) * Cout + n0 + c] = t;
         }
     }
+    CPROBE(121);
+#if ISLAM_CONV_PROBE == 3
+    if (cprb) islam_conv_probe_buf[125] = clock64();
+#endif
 }
 
 // tile of 64 pixels x 32 channels: reads are 256-byte rows of a channel plane, writes 64 bytes per pixel (16 bytes per lane)
@@ -396,6 +421,12 @@ int launch(const unsigned short* x, const unsigned short* wp, const float* in_af
 }  // namespace
 
 extern "C" {
+
+#if ISLAM_CONV_PROBE == 3
+int islam_conv_probe_read(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_conv_probe_buf), sizeof(long long) * 128) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
