@@ -2086,21 +2086,21 @@ __global__ __launch_bounds__(64) void trial_kernel(const double* __restrict__ no
     PROBE_AT(pr, 203);
     sq = wave_sum(sq);
     qd = wave_sum(qd);
-    if (threadIdx.x == 0 && blk >= 0) { part[2 * blk] = sq; part[2 * blk + 1] = qd; }
+    // (write-through stores + completion wait instead of a release fence -- an agent-scope fence walks the XCD's whole L2)
+    if (threadIdx.x == 0 && blk >= 0) { st_coherent(&part[2 * blk], sq); st_coherent(&part[2 * blk + 1], qd); }
     PROBE_AT(pr, 204);
     if (st == nullptr) return;           // stage-level call: no control
     // ---- last block takes the decision
     int last_block = 0;
     if (threadIdx.x == 0) {
-        __threadfence();                                              // publish this block's partial
-        last_block = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this block's partial sums are written through
+        last_block = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     }
     last_block = __builtin_amdgcn_readfirstlane(last_block);
     PROBE_AT(pr, 205);
     if (!last_block) return;
     PROBE_AT(threadIdx.x == 0, 206);
-    __threadfence();                                                  // acquire the other blocks' partials
-    double s = 0.0, q = 0.0;
+    double s = 0.0, q = 0.0;                                          // (agent-coherent loads of the other blocks' partial sums)
     for (int i = threadIdx.x; i < nblk; i += 64) {
         s += __hip_atomic_load(&part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q += __hip_atomic_load(&part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
