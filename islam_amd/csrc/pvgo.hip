@@ -1574,18 +1574,25 @@ __device__ __forceinline__ void backsub_par_run_tw(double* __restrict__ x, int c
 // factor rows broadcast from LDS.  What is left on the critical path once the separators arrive is one 18-term dot product per
 // lane instead of h+1 dependent 9-step triangular solves (1.45 -> ~0.2 us per level of the tree).
 // In: lane 9t+r holds FacRow `row` of node t (t < cnt <= BS_PAR_MAX).  Out: g = row r of G_t on lane 9t+r.
-constexpr int INF_FR = 30;                                  // doubles per (node, row) record in LDS: lt 9 | u 9 | f 9 | y | iv | pad
+constexpr int INF_FR = 22;                                  // doubles per (node, row) record in LDS: u 9 (+1) | f 9 (+1) | y | pad: 16-byte aligned pieces
+constexpr int INF_ND = 9 * 10 + 10;                         // per node: the transposed L^T block (column i = 9 doubles, stride 10) | reciprocal pivots 9 (+1)
 constexpr int INF_GS = 20;                                  // row stride of G in LDS (19 + pad)
-constexpr int LDS_INFLUENCE = 9 * BS_PAR_MAX * (INF_FR + INF_GS);
+constexpr int LDS_INFLUENCE = 9 * BS_PAR_MAX * (INF_FR + INF_GS) + BS_PAR_MAX * INF_ND;
 __device__ __forceinline__ void influence_tw(const FacRow& row, int cnt, int lane, double* __restrict__ lds, double (&g)[19]) {
     double* rec = lds;                                      // [9 * cnt][INF_FR]
     double* G = lds + 9 * BS_PAR_MAX * INF_FR;              // [9 * cnt][INF_GS]
+    double* nd = G + 9 * BS_PAR_MAX * INF_GS;               // [cnt][INF_ND]
+    // Layout for wide, mostly broadcast reads (the recurrences below are one wavefront's chain of LDS round trips and fp64 FMAs):
+    // a row's U~ and F~ are 16-byte aligned runs of nine, the entries of D L^T a triangular-solve step needs -- column i above the
+    // diagonal -- are contiguous in a transposed copy per node, and so are the node's reciprocal pivots.
     if (lane < 9 * cnt) {
         double* p = rec + lane * INF_FR;
+        const int t = lane / 9, r = lane - 9 * t;
+        double* n = nd + t * INF_ND;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { p[q] = row.lt[q]; p[9 + q] = row.u[q]; p[18 + q] = row.f[q]; }
-        p[27] = row.y;
-        p[28] = row.iv;
+        for (int q = 0; q < 9; ++q) { p[q] = row.u[q]; p[10 + q] = row.f[q]; n[q * 10 + r] = row.lt[q]; }
+        p[20] = row.y;
+        n[90 + r] = row.iv;
     }
     lds_sync();
     const int h = twisted_mid(cnt);
@@ -1595,27 +1602,36 @@ __device__ __forceinline__ void influence_tw(const FacRow& row, int cnt, int lan
     // right-hand side column c of node tn: kind 0 = middle, 1 = left of it (side A), 2 = right of it (side B)
     auto solve = [&](int tn, int kind, double (&X)[9]) {
         const double* R = rec + (size_t)tn * 9 * INF_FR;
+        const double* n = nd + (size_t)tn * INF_ND;
         double b[9];
 #pragma unroll
         for (int rr = 0; rr < 9; ++rr) {
             const double* p = R + rr * INF_FR;
             double v = 0.0;
-            if (cc == 0) v = p[27];
-            else if (cc < 10) v = kind != 2 ? p[18 + cc - 1] : 0.0;                      // F~ multiplies xL for the middle and side A
-            else v = kind == 0 ? p[9 + cc - 10] : (kind == 2 ? p[18 + cc - 10] : 0.0);   // middle: U~ multiplies xR; side B: F~ does
+            if (cc == 0) v = p[20];
+            else if (cc < 10) v = kind != 2 ? p[10 + cc - 1] : 0.0;                      // F~ multiplies xL for the middle and side A
+            else v = kind == 0 ? p[cc - 10] : (kind == 2 ? p[10 + cc - 10] : 0.0);       // middle: U~ multiplies xR; side B: F~ does
             if (kind != 0) {
+                double u[9];
+                ldcol(p, u);
 #pragma unroll
-                for (int q = 0; q < 9; ++q) v = fma(-p[9 + q], X[q], v);                 // - U~ G_neighbour
+                for (int q = 0; q < 9; ++q) v = fma(-u[q], X[q], v);                     // - U~ G_neighbour
             }
             b[rr] = v;
         }
+        double iv[9];
+        ldcol(n + 90, iv);
 #pragma unroll
         for (int i = 8; i >= 0; --i) {
-            const double xi = b[i] * R[i * INF_FR + 28];
+            const double xi = b[i] * iv[i];
             X[i] = xi;
+            if (i > 0) {
+                double lc[9];                                // column i of D L^T: rows 0 .. i-1 matter
+                ldcol(n + i * 10, lc);
 #pragma unroll
-            for (int rr = 0; rr < 9; ++rr)
-                if (rr < i) b[rr] = fma(-R[rr * INF_FR + i], xi, b[rr]);
+                for (int rr = 0; rr < 9; ++rr)
+                    if (rr < i) b[rr] = fma(-lc[rr], xi, b[rr]);
+            }
         }
     };
     double X[9];
