@@ -156,6 +156,16 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
  * H and W must be multiples of d. */
 int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
                          int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, int dilation, float slope, void* stream);
+/* ConvTranspose2d(Cin, Cout, kernel 4, stride 2, padding 1) + bias (+ ReLU, relu = 1) of the frozen stereo net's decoder --
+ * /root/reference/Network/StereoNet7.py:121-139 (deconv_c7_2, deconv_c7 ... deconv_c10) with the activation of :180-190 -- on the
+ * channels-last matrix-core kernel: four dense 2x2 convolutions, one per output parity class (a, c) of pixel (2y + a, 2x + c), taps
+ * K[r][s] = W[:, :, 3 - 2r - a, 3 - 2s - c].  x: (B,H,W,Cin) bf16; wpacked: islam_deconv_nhwc_packed_elems(Cin, Cout) bf16 elements,
+ * [class a*2+c][tap r*2+s][CoutP][CinP]; the result goes to channels [yoff, yoff + Cout) of y = (B,2H,2W,ytot) bf16 (the channel
+ * slice of the concatenation the decoder builds next).  bf16 operands, fp32 accumulation, output rounded to nearest even.
+ * Cin, Cout, ytot, yoff: multiples of 8. */
+size_t islam_deconv_nhwc_packed_elems(int Cin, int Cout);
+int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* bias, uint16_t* y, int ytot, int yoff, int B, int Cin,
+                                int H, int W, int Cout, int relu, void* stream);
 /* fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W) -> bf16 (nearest-even) channels [doff, doff + C) of dst (B,H,W,dtot);
  * channels up to the next multiple of 8 are zeroed.  Fills the mirror with what the non-convolution producers wrote. */
 int islam_nchw_f32_to_nhwc_bf16(const float* src, int stot, int soff, uint16_t* dst, int dtot, int doff, int B, int C, int H, int W,

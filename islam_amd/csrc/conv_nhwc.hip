@@ -97,7 +97,12 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // Dilation d > 1 (the flow net's context layers): a 3x3 convolution with dilation d is d*d independent dense 3x3 convolutions on the
 // sub-grids (a::d, c::d) of the image, so the kernel runs on B*d*d "images" of (H, W) = (Hf/d, Wf/d) pixels whose neighbours are
 // d pixels apart in memory (Hf, Wf must be multiples of d); Wf = full row length in pixels.
-struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; };
+// Transposed convolution (tc = 1, KS = 2: ConvTranspose2d(k = 4, s = 2, p = 1), the stereo net's decoder): output pixel (2y + a, 2x + c)
+// depends on the 2x2 input patch rows {y - 1 + a, y + a} x columns {x - 1 + c, x + c} only, so the layer is FOUR dense 2x2
+// convolutions, one per output parity class (a, c), each with its own taps K[r][s] = W[:, :, 3 - 2r - a, 3 - 2s - c].  The kernel runs
+// on B * 4 "images" (d = 2 decodes the class like a dilation sub-grid): the INPUT is the dense image with its origin shifted by
+// (a, c), the OUTPUT is the sub-grid (a::2, c::2) of the (2H, 2W) result, the weights are the class's slice of the packed array.
+struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; int tc; };
 
 template <int TN, int KS, int ROWS, int KC, bool FLOW>
 __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
@@ -138,7 +143,13 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
     // image b = (batch index, sub-grid row a, sub-grid column c); pixel (gy, gx) of it is full-resolution pixel (gy*d + a, gx*d + c)
     const int dd = sl.d * sl.d, bb = b / dd, sga = (b - bb * dd) / sl.d, sgc = b - bb * dd - sga * sl.d;
     const size_t img0 = ((size_t)(bb * H * sl.d + sga)) * sl.Wf + sgc;          // first pixel of the image, in full-resolution pixels
-    const unsigned short* xb = x + img0 * sl.xs + sl.xoff;
+    const bool tcm = sl.tc != 0;                             // transposed convolution: dense input image, output on a sub-grid
+    const int idil = tcm ? 1 : sl.d, iWf = tcm ? W : sl.Wf, oWf = tcm ? 2 * W : sl.Wf;
+    const int oy = tcm ? sga : 0, ox = tcm ? sgc : 0;        // origin shift of the 2x2 patch of parity class (sga, sgc)
+    const size_t in_img0 = tcm ? (size_t)bb * H * W : img0;
+    const size_t out_img0 = tcm ? ((size_t)(bb * 2 * H + sga)) * (2 * W) + sgc : img0;
+    if (tcm) wp += (size_t)(sga * 2 + sgc) * TAPS * CoutP * CinP;
+    const unsigned short* xb = x + in_img0 * sl.xs + sl.xoff;
 
     f32x16 acc[NT][ROWS];
 #pragma unroll
@@ -159,9 +170,9 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
         if (it < NPIX * (KC / 8)) {
             const int pix = it / OPP;
             const int yy = pix / IW, xx = pix - yy * IW;
-            const int gy = ho0 - P + yy, gx = wo0 - P + xx;
+            const int gy = ho0 - P + oy + yy, gx = wo0 - P + ox + xx;
             loff[k] = pix * PS + coct;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * sl.Wf + gx) * sl.d * sl.xs + coct;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * iWf + gx) * idil * sl.xs + coct;
         }
     });
     int woff[NWT], wlds[NWT];
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             }
     if (FLOW && !y) return;                                  // (uniform) no channels-last mirror asked for
     __syncthreads();
-    unsigned short* yb = y + img0 * sl.ys + sl.yoff;
+    unsigned short* yb = y + out_img0 * sl.ys + sl.yoff;
     const unsigned short* rb = res ? res + (size_t)b * H * W * Cout : nullptr;
     const int oct = tid % OCT, n = n0 + 8 * oct;
     float sm[8], sq[8];
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 sm[2 * i + 1] += hi; sq[2 * i + 1] = fmaf(hi, hi, sq[2 * i + 1]);
             }
         }
-        const size_t o = ((size_t)ho * sl.Wf + wo) * sl.d * sl.ys + n;
+        const size_t o = ((size_t)ho * oWf + wo) * sl.d * sl.ys + n;
         if (rb) {
             const u32x4 r = rv[k];
             v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
 template <int TN, int KS, int ROWS, int KC, bool FLOW = false>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
-           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0}) {
+           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0, 0}) {
     if (sl.xs == 0) { sl.xs = Cin; sl.ys = Cout; }           // dense tensors
     if (sl.Wf == 0) sl.Wf = W;
     constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS, PS = KC + 8;
@@ -475,6 +486,30 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 }
 
 
+// ConvTranspose2d(Cin, Cout, kernel 4, stride 2, padding 1) + bias (+ ReLU) of the frozen stereo net's decoder
+// (Network/StereoNet7.py:121-139 deconv_c7_2 ... deconv_c10, the ReLU of :180-190) on the kernel above: four 2x2 convolutions, one per
+// output parity class (see Slices).  x: (B,H,W,Cin) bf16; wpacked: [4 classes][4 taps][CoutP][CinP] bf16 (islam_amd/ops.py
+// pack_deconv_nhwc_weight); the result goes to channels [yoff, yoff + Cout) of y = (B,2H,2W,ytot) bf16 -- straight into the channel
+// slice of the concatenation the decoder builds next, no torch.cat copy of this half.  MIOpen ran these as bf16 implicit-GEMM
+// backward-data kernels (0.52 ms per forward at B = 8).
+size_t islam_deconv_nhwc_packed_elems(int Cin, int Cout) {
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    return (size_t)16 * CoutP * CinP;
+}
+
+int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* bias, uint16_t* y, int ytot, int yoff, int B, int Cin,
+                                int H, int W, int Cout, int relu, void* stream) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+    if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + Cout > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16: output slice %d+%d of %d", yoff, Cout, ytot);
+    if ((size_t)B * 4 * H * W * std::max(Cin, ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 2, W, 1};
+    hipStream_t s = (hipStream_t)stream;
+    return Cout > 32 ? launch<64, 2, 2, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl)
+                     : launch<32, 2, 4, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl);
+}
+
 // 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d + LeakyReLU(0.1),
 // :237-292) on the channels-last kernel above.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) mirror of the block's
 // concatenation buffer; the output goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what the
@@ -496,7 +531,7 @@ int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const u
     if ((size_t)B * H * W * std::max(std::max(xtot, mtot), ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: tensor too large for 32-bit offsets");
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     const int d = dilation;
-    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W};
+    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W, 0};
     hipStream_t s = (hipStream_t)stream;
     return Cout > 32 ? launch<64, 3, 2, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl)
                      : launch<32, 3, 4, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl);

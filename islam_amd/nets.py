@@ -249,6 +249,8 @@ HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '2'))
 # the flow net's DenseNet convolutions on the channels-last kernel through a bf16 mirror of the concatenation buffer (0: fp32 NCHW kernel)
 FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
+# the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
+HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 
 
 def _hip_conv_ok(conv, x, fused_1x1=False):
@@ -561,16 +563,40 @@ class StereoNet7(nn.Module):
         cat3 = pool(self.conv_c4(cat2))                                       # 1/16, 256
         cat4 = relu_pool(self.conv_c5(cat3))                                  # 1/32, 384
         x = act(self.conv_c6_2(relu_pool(self.conv_c6(cat4))))                # 1/64, 512
-        x = torch.cat((act(self.deconv_c7_2(x)), cat4), 1)
-        x = torch.cat((act(self.deconv_c7(x)), cat3), 1)
-        x = torch.cat((self.conv_c8(act(self.deconv_c8(x))), cat2), 1)
-        x = torch.cat((self.conv_c9(act(self.deconv_c9(x))), cat1), 1)
-        x = torch.cat((self.conv_c10(act(self.deconv_c10(x))), cat0), 1)
+        x = self._deconv_act(self.deconv_c7_2, x, cat4)
+        x = self._deconv_act(self.deconv_c7, x, cat3)
+        x = torch.cat((self.conv_c8(self._deconv_act(self.deconv_c8, x)), cat2), 1)
+        x = torch.cat((self.conv_c9(self._deconv_act(self.deconv_c9, x)), cat1), 1)
+        x = torch.cat((self.conv_c10(self._deconv_act(self.deconv_c10, x)), cat0), 1)
         if quarter:
             x = act(self._deconv_c11_quarter(x))
         else:
             x = act(self.deconv_c11(x))
         return self.conv_c13(act(self.conv_c12(x))), None
+
+    def _deconv_act(self, dc, x, skip=None):
+        """act(dc(x)), concatenated with ``skip`` when given (StereoNet7.py:180-190).  On the frozen bf16 channels-last execution
+        copy the 4x4 stride-2 transposed convolution runs on islam_deconv4x4s2_nhwc_bf16 -- four 2x2 convolutions on the matrix
+        cores, bias + ReLU in the epilogue, written straight into its channel slice of the concatenation (MIOpen ran these as
+        bf16 backward-data kernels whose output was then activated and copied by torch.cat)."""
+        act = self.actfun
+        co, ci = dc.out_channels, dc.in_channels
+        if (HIP_DECONV and act is F.relu and ops.fusable_nhwc_bf16(x, ci) and dc.weight.dtype == torch.bfloat16 and co % 8 == 0
+                and dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1) and dc.output_padding == (0, 0)
+                and dc.groups == 1 and dc.dilation == (1, 1)
+                and (skip is None or (ops.fusable_nhwc_bf16(skip, skip.shape[1]) and tuple(skip.shape[2:]) == (2 * x.shape[2], 2 * x.shape[3])))):
+            key = (dc.weight._version, dc.weight.data_ptr(), dc.bias._version, dc.bias.data_ptr())
+            hit = dc.__dict__.get('_nhwc_deconv')
+            if hit is None or hit[0] != key:
+                hit = dc.__dict__['_nhwc_deconv'] = (key, ops.pack_deconv_nhwc_weight(dc.weight), dc.bias.detach().float().contiguous())
+            out = None
+            if skip is not None:
+                out = torch.empty((x.shape[0], co + skip.shape[1], 2 * x.shape[2], 2 * x.shape[3]), dtype=x.dtype, device=x.device,
+                                  memory_format=torch.channels_last)
+                out[:, co:].copy_(skip)
+            return ops.deconv_nhwc(x, hit[1], hit[2], co, out=out, yoff=0, relu=True)
+        y = act(dc(x))
+        return y if skip is None else torch.cat((y, skip), 1)
 
     def _deconv_c11_quarter(self, x):
         """deconv_c11(x)[..., ::4, ::4].  ConvTranspose2d(k=4, s=2, p=1): out[o, oy, ox] = b[o] + sum_i sum_ky,kx x[i, (oy+1-ky)/2,

@@ -209,6 +209,38 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
     return y
 
 
+def pack_deconv_nhwc_weight(w):
+    """ConvTranspose2d weight (Cin, Cout, 4, 4) -> bf16 [4 classes][4 taps][CoutP][CinP] for islam_deconv4x4s2_nhwc_bf16: output parity
+    class (a, c), tap (r, s) of its 2x2 convolution = W[:, :, 3 - 2r - a, 3 - 2s - c] (stride 2, padding 1)."""
+    Cin, Cout = int(w.shape[0]), int(w.shape[1])
+    assert tuple(w.shape[2:]) == (4, 4)
+    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 63) // 64 * 64
+    p = torch.zeros((4, 4, CoutP, CinP), dtype=torch.bfloat16, device=w.device)
+    wt = w.detach().permute(2, 3, 1, 0).to(torch.bfloat16)            # (ky, kx, Cout, Cin)
+    for a in range(2):
+        for c in range(2):
+            for r in range(2):
+                for s_ in range(2):
+                    p[a * 2 + c, r * 2 + s_, :Cout, :Cin] = wt[3 - 2 * r - a, 3 - 2 * s_ - c]
+    assert p.numel() == lib().islam_deconv_nhwc_packed_elems(Cin, Cout)
+    return p.contiguous()
+
+
+def deconv_nhwc(x, packed, bias32, cout, out=None, yoff=0, relu=False):
+    """act(ConvTranspose2d(k=4, s=2, p=1)(x) + bias) of a channels-last bf16 tensor on islam_deconv4x4s2_nhwc_bf16, written into
+    channels [yoff, yoff + cout) of ``out`` (B, ytot, 2H, 2W) channels_last bf16 (allocated dense when None)."""
+    require_cuda(x, packed)
+    B, Cin, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and bias32.dtype == torch.float32
+    if out is None:
+        out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
+    assert out.shape[0] == B and tuple(out.shape[2:]) == (2 * H, 2 * W)
+    check(lib().islam_deconv4x4s2_nhwc_bf16(ptr(x), ptr(packed), ptr(bias32), ptr(out), int(out.shape[1]), int(yoff), B, Cin, H, W, int(cout),
+                                            int(bool(relu)), stream_ptr(x.device)))
+    return out
+
+
 def bn_finalize(folded, bn, count):
     """[256][2][C] partial sums -> (2*C) fp32 [scale | shift] of a train-mode nn.BatchNorm2d; its running statistics are
     updated like nn.BatchNorm2d would (islam_bn_finalize)."""

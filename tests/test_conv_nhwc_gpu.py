@@ -205,3 +205,53 @@ def test_dilated_flow_convolution_on_sub_grids(cuda, d, H, W, Cin, Cout):
     if Cin >= 16 and d <= 8:                                                                               # the fp32 NCHW kernel's range
         old = ops.conv3x3_mfma(xm.float().contiguous(), ops.pack_conv3x3_weight(w), b, Cout, 1, d, 0.1)
         assert float((y32 - old).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,skip_c,relu', [(2, 512, 7, 10, 512, 384, True), (1, 896, 14, 20, 320, 256, True), (2, 256, 37, 45, 64, 0, True),
+                                                        (1, 64, 16, 33, 128, 8, False), (3, 32, 5, 3, 72, 0, True)])
+def test_transposed_convolution_on_the_parity_classes(cuda, B, Cin, H, W, Cout, skip_c, relu):
+    """islam_deconv4x4s2_nhwc_bf16 (the stereo decoder's ConvTranspose2d(k=4, s=2, p=1) + bias + ReLU as four 2x2 convolutions, written
+    into a channel slice of the concatenation) against torch's conv_transpose2d in fp32 on the same bf16 operands."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=CL)
+    w = (torch.randn(Cin, Cout, 4, 4, generator=g) / (Cin * 4) ** 0.5).cuda().to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).cuda()
+    out = None
+    if skip_c:
+        out = torch.full((B, Cout + skip_c, 2 * H, 2 * W), 7.0, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=CL)
+    y = ops.deconv_nhwc(x, ops.pack_deconv_nhwc_weight(w), bias, Cout, out=out, yoff=0, relu=relu)
+    ref = F.conv_transpose2d(x.float(), w.float(), bias, stride=2, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    got = y[:, :Cout].float()
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    scale = float(ref.abs().max())
+    assert float((err - 0.5 * torch.pow(2.0, torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)).max()) <= 2e-5 * scale
+    if skip_c:
+        assert bool((y[:, Cout:] == 7.0).all())                      # the rest of the concatenation buffer is left alone
+
+
+def test_stereo_decoder_on_the_transposed_convolution_kernel(cuda):
+    """StereoNet7._deconv_act on the bf16 channels-last execution copy: HIP path == torch path (MIOpen + ReLU + torch.cat) within bf16
+    rounding, for a plain output and for one written into its concatenation."""
+    from islam_amd import nets
+    torch.manual_seed(3)
+    net = nets.StereoNet7().cuda().to(torch.bfloat16).to(memory_format=CL).eval()
+    x = torch.randn(2, 896, 14, 20, device='cuda').to(torch.bfloat16).contiguous(memory_format=CL)
+    skip = torch.randn(2, 256, 28, 40, device='cuda').to(torch.bfloat16).contiguous(memory_format=CL)
+    with torch.no_grad():
+        got = net._deconv_act(net.deconv_c7, x, skip)
+        old = nets.HIP_DECONV
+        nets.HIP_DECONV = False
+        try:
+            ref = net._deconv_act(net.deconv_c7, x, skip)
+        finally:
+            nets.HIP_DECONV = old
+        ref32 = torch.cat((F.relu(F.conv_transpose2d(x.float(), net.deconv_c7.weight.float(), net.deconv_c7.bias.float(), stride=2, padding=1)),
+                           skip.float()), 1)
+    assert got.shape == ref.shape == ref32.shape and got.is_contiguous(memory_format=CL)
+    e_hip = float((got.float() - ref32).abs().max()), float((ref.float() - ref32).abs().max())
+    assert e_hip[0] <= 1.0 * float(ref32.abs().max()) * 2 ** -8          # half a bf16 spacing at the output's scale
+    assert bool((got[:, 320:] == skip).all())
