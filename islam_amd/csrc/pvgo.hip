@@ -2430,6 +2430,8 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     [[maybe_unused]] const bool fpr = lane == 0 && (wg == 1 || wg == a.nwg / 2);     // probe build only
     [[maybe_unused]] const int fpo = 600 + (wg == 1 ? 0 : 100) + 12 * wave;
     PROBE_WALL(fpr, fpo);
+    // (probe build: entry / exit of every workgroup's wave 0 -- launch ramp and drain of the grid, scripts/probe_fused.py)
+    PROBE_WALL(threadIdx.x == 0 && blockIdx.x < 300, 300 + blockIdx.x);
     if (threadIdx.x == 0) s_sum[2] = 0.0;                        // LevelSrc::zero of the elimination below (same address space as the blocks)
     // ---- A: retraction, one lane per node
     if (wave == 0) {
@@ -2676,6 +2678,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         twisted_helper<2>(a.dst, sg, nbar, lane);
     }
     PROBE_WALL(fpr, fpo + 5);
+    PROBE_WALL(threadIdx.x == 0 && blockIdx.x < 300, 0 + blockIdx.x);
 }
 
 // state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
