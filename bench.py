@@ -240,6 +240,12 @@ def main():
     ap.add_argument('--no-frontend', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: libraries that print banners to file descriptor 1 while they initialise (RCCL's
+    # version / host block on rank 0) are pointed at stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -480,6 +486,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
 
 
