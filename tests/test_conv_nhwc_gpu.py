@@ -208,7 +208,7 @@ def test_dilated_flow_convolution_on_sub_grids(cuda, d, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize('B,Cin,H,W,Cout,skip_c,relu', [(2, 512, 7, 10, 512, 384, True), (1, 896, 14, 20, 320, 256, True), (2, 256, 37, 45, 64, 0, True),
-                                                        (1, 64, 16, 33, 128, 8, False), (3, 32, 5, 3, 72, 0, True)])
+                                                        (1, 64, 16, 33, 128, 8, False), (3, 32, 5, 3, 72, 0, True), (2, 64, 9, 20, 32, 0, True), (1, 40, 11, 37, 24, 16, False)])
 def test_transposed_convolution_on_the_parity_classes(cuda, B, Cin, H, W, Cout, skip_c, relu):
     """islam_deconv4x4s2_nhwc_bf16 (the stereo decoder's ConvTranspose2d(k=4, s=2, p=1) + bias + ReLU as four 2x2 convolutions, written
     into a channel slice of the concatenation) against torch's conv_transpose2d in fp32 on the same bf16 operands."""
