@@ -255,3 +255,22 @@ def test_stereo_decoder_on_the_transposed_convolution_kernel(cuda):
     e_hip = float((got.float() - ref32).abs().max()), float((ref.float() - ref32).abs().max())
     assert e_hip[0] <= 1.0 * float(ref32.abs().max()) * 2 ** -8          # half a bf16 spacing at the output's scale
     assert bool((got[:, 320:] == skip).all())
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout', [(3, 64, 40, 72, 128), (2, 128, 19, 50, 192), (1, 32, 33, 31, 72)])
+def test_statistics_of_layers_with_several_channel_blocks(cuda, B, Cin, H, W, Cout):
+    """Layers with more than one 64-channel output block launch in the XCD-aware order (a workgroup's pixel tile and channel block
+    come from its logical work index): the per-tile partial sums must still land on their tile's row -- the folded statistics equal
+    the sums over the stored output, and they are the same bits on every run."""
+    from islam_amd import ops
+    x, w = _mk(B, Cin, H, W, Cout, 3, seed=11)
+    wp = ops.pack_conv_nhwc_weight(w)
+    y, f = ops.conv_nhwc(x, wp, Cout, 3, stats=True)
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    assert float((y.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    s = f.view(256, 2, Cout).double().sum(0)
+    yd = y.double()
+    np.testing.assert_allclose(s[0].cpu().numpy(), yd.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(s[1].cpu().numpy(), (yd ** 2).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
+    y2, f2 = ops.conv_nhwc(x, wp, Cout, 3, stats=True)
+    assert torch.equal(f, f2) and torch.equal(y, y2)
