@@ -116,8 +116,7 @@ class TartanVO(nn.Module):
         picks the result up.  Several batches may be under way at once (one entry per sample dict; the side stream runs them in
         the order they were asked for).  Only when both nets are frozen (no autograd state; the reference detaches flow and disparity
         anyway, TartanVO.py:109-110); returns False otherwise and forward() computes everything inline."""
-        nets = (self.vonet.flowNet, self.vonet.stereoNet)
-        if any(p.requires_grad for n in nets for p in n.parameters()):
+        if self.vonet.frozen_nets_trainable():
             return False
         if getattr(self, '_prefetched', None) is None:
             self._prefetched = {}
@@ -127,7 +126,7 @@ class TartanVO(nn.Module):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=dev)
         self._side.wait_stream(torch.cuda.current_stream(dev))
-        self.vonet.train() if is_train else self.vonet.eval()
+        self.vonet.set_mode(is_train)
         with torch.cuda.stream(self._side), torch.no_grad():
             imgs = [sample[k].cuda(dev, non_blocking=True) for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm')]
             flow, disp = self.vonet.frozen_forward(*imgs)
@@ -137,7 +136,7 @@ class TartanVO(nn.Module):
         return True
 
     def forward(self, sample, is_train=True, given_scale=None):
-        self.vonet.train() if is_train else self.vonet.eval()               # BN batch statistics when training (F4)
+        self.vonet.set_mode(is_train)                                       # BN batch statistics when training (F4)
         with torch.set_grad_enabled(is_train):
             dev = self.device_id
             img0 = sample['img0'].cuda(dev, non_blocking=True)

@@ -743,6 +743,7 @@ class VONet(nn.Module):
         self.frozen_dtype, self.flow_dtype = dtype, flow_dtype
         self._exec = {}
         self._graphs = {}
+        self.__dict__.pop('_frozen_param_list', None)
 
     def _run_frozen(self, name, master, dtype, x, quarter=False):
         if dtype is None or any(p.requires_grad for p in master.parameters()):
@@ -768,6 +769,28 @@ class VONet(nn.Module):
         if getattr(self, '_graphs', None):
             torch.cuda.synchronize()            # no replay may still be in flight when the graphs and their memory pool go
         self._graphs = {}
+        self.__dict__.pop('_frozen_param_list', None)
+
+    def frozen_nets_trainable(self):
+        """True if any parameter of the flow / stereo nets requires grad.  Asked once or twice per batch on the host's critical path
+        (TartanVO.prefetch, frozen_forward): the flat parameter list is cached -- walking two module trees of ~900 modules through
+        nn.Module.parameters() cost ~1 ms per call -- and dropped by reset_graphs() / set_frozen_dtype()."""
+        ps = self.__dict__.get('_frozen_param_list')
+        if ps is None:
+            ps = self.__dict__['_frozen_param_list'] = [p for n in (self.flowNet, self.stereoNet) for p in n.parameters()]
+        return any(p.requires_grad for p in ps)
+
+    def set_mode(self, is_train):
+        """vonet.train() / vonet.eval() (TartanVO.py:91) without walking ~900 modules when nothing changes: nn.Module.train()
+        re-assigns `training` on every module of the tree (~1.5 ms of host time per call, twice per batch, in front of everything
+        the batch enqueues).  The walk is skipped only if the net and its three sub-nets already are in the mode this method
+        applied last; anything else -- a first call, a mode change, a sub-net switched by hand -- takes the full walk."""
+        is_train = bool(is_train)
+        if (self.__dict__.get('_mode_applied') is is_train and self.training == is_train and self.flowNet.training == is_train
+                and self.stereoNet.training == is_train and self.flowPoseNet.training == is_train):
+            return
+        self.train(is_train)
+        self.__dict__['_mode_applied'] = is_train
 
     def _frozen_graphed(self, imgs):
         key = (tuple(imgs[0].shape), imgs[0].device, self.stereoNet.training, self.flowNet.training, self.frozen_dtype, self.flow_dtype)
@@ -792,7 +815,7 @@ class VONet(nn.Module):
         """Flow + disparity (Network/VONet.py:28-34).  With both nets frozen this part carries no autograd state, so
         TartanVO.prefetch can run it for the NEXT batch on a side stream while the current batch is optimised."""
         if getattr(self, 'graph_frozen', False) and self.frozen_dtype is not None and self.flow_dtype is not None and \
-                not any(p.requires_grad for n in (self.flowNet, self.stereoNet) for p in n.parameters()):
+                not self.frozen_nets_trainable():
             return self._frozen_graphed((img0, img1, img0_norm, img0_r_norm))
         return self._frozen_eager(img0, img1, img0_norm, img0_r_norm)
 
