@@ -55,7 +55,11 @@ class BilevelLoop:
         With TWO batches ahead the side stream never runs dry: with one, nothing but the launch-bound pose head runs between
         the end of batch k+1's frozen forward and the start of batch k+2's."""
         bs, dev = self.bs, self.device
-        sync = (lambda: torch.cuda.current_stream().synchronize()) if next_sample is not None else torch.cuda.synchronize
+        # stage timing: the sequential schedule synchronises after every stage (self.timing = device-inclusive stage times); the
+        # pipelined one must not -- every hand-over to the host (pose -> host glue, IMU / PVGO results) synchronises by itself, and a
+        # barrier behind the backward would only stop the host from enqueueing the next batch while the GPU still runs this one's
+        # (self.timing then holds host times per stage)
+        sync = (lambda: None) if next_sample is not None else torch.cuda.synchronize
         t0 = time.perf_counter()
         motions = None
         if target != 'vo' and self.prev_vo_motions is not None:          # train.py:207-209: IMU epochs reuse last epoch's VO

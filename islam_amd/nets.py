@@ -806,10 +806,23 @@ class VONet(nn.Module):
                 static_out = self._frozen_eager(*static_in)
             st = self._graphs[key] = (g, static_in, static_out)
         g, static_in, static_out = st
+        # One launch of this graph in flight at a time: the host waits for the previous replay (and the clones of its outputs) before it
+        # queues the next one.  With two batches ahead the second replay used to be queued on the side stream while the first was
+        # still running, and on this stack (ROCm 7.0 hipGraphLaunch) that intermittently corrupted a few pixels of the FIRST replay's
+        # flow -- in about half of all fresh processes the stereo scale of one frame of the second batch moved by 3-4 %
+        # (scripts/debug/flaky_once.py; tests/test_benched_frontend_gpu.py was flaky for it).  bench.py's one-ahead schedule never
+        # overlaps two replays: there the wait returns at once.
+        prev = self.__dict__.get('_replay_done')
+        if prev is not None and os.environ.get('ISLAM_GRAPH_FENCE', '1') == '1':
+            prev.synchronize()
         for d, t in zip(static_in, imgs):
             d.copy_(t, non_blocking=True)
         g.replay()
-        return tuple(t.clone() for t in static_out)
+        out = tuple(t.clone() for t in static_out)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(imgs[0].device))
+        self.__dict__['_replay_done'] = ev
+        return out
 
     def frozen_forward(self, img0, img1, img0_norm, img0_r_norm):
         """Flow + disparity (Network/VONet.py:28-34).  With both nets frozen this part carries no autograd state, so
