@@ -111,6 +111,9 @@ class BilevelLoop:
         sync(); t3 = time.perf_counter()
 
         loss_bp = torch.cat((self.rot_w * rot_loss, self.trans_w * trans_loss))                # train.py:280
+        # the value that is returned: read BEFORE the backward is enqueued -- a device-to-host read behind it would wait for the
+        # whole backward pass, and the pipelined schedule wants the host back while the GPU still runs it
+        loss_value = float(loss_bp.detach().sum())
         if loss_bp.requires_grad:
             self._accumulate_gradients(loss_bp)
         sync(); t4 = time.perf_counter()
@@ -121,7 +124,7 @@ class BilevelLoop:
                                vel=pgo_vels_np[-1].astype(np.float64))
         for k, v in zip(('vo', 'imu', 'pgo', 'opt'), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             self.timing[k] += v
-        return float(loss_bp.detach().sum())
+        return loss_value
 
     def _accumulate_gradients(self, loss_bp):
         """loss_bp.backward(ones) (train.py:282-283) for the parameters the two optimizers own: the gradients of this batch are

@@ -36,13 +36,14 @@ torch.cuda.synchronize()
 loop.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
-pr.enable()
+if os.environ.get('NOPROF') != '1': pr.enable()
 for k in range(warmup, warmup + steps):
     loop.step(seq[k], next_sample=seq[k + 1])
-pr.disable()
+if os.environ.get('NOPROF') != '1': pr.disable()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print('pipelined: %.2f ms per batch (with cProfile on); stage wall ms per batch: %s' % (el / steps * 1e3, {k: round(v / steps * 1e3, 2) for k, v in loop.timing.items()}))
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
-print(s.getvalue()[:9000])
+if os.environ.get('NOPROF') != '1':
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+    print(s.getvalue()[:9000])
