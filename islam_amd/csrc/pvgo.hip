@@ -3797,7 +3797,10 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     // for it -- otherwise it starts when the first workgroup exits and the launch ends ~4 us late)
     static const int fz_spare = [] { const char* e = std::getenv("ISLAM_FZ_SPARE"); return e ? std::atoi(e) : 16; }();      // (8 / 16 / 47 spare CUs: 63.3 / 62.9 / 62.9 us per LM iteration)
     const int fz_nwg = std::min(sp.lv[0].P, std::max(device_cus() - fz_spare, 1));
-    const bool fused = !no_fuse && !reproj && sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM &&
+    // (small graphs -- the reference's own per-batch problem is 9 nodes, run_kitti.sh -- stay on the launch-per-stage loop: its launches
+    // are cheaper than the fused kernel's fixed cost and a rejected trial costs no mis-speculated chain.  Measured per run_pvgo, fused /
+    // launch-per-stage: N = 9 (18 trials) 1059 / 723 us, N = 65 206 / 190 us, N = 129 203 / 236 us, N = 513 443 / 508 us.)
+    const bool fused = !no_fuse && !reproj && N > 96 && sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM &&
                        prm->reject < STATE_DOUBLES - STATE_HIST - 1 && (sp.lv[0].P + fz_nwg - 1) / fz_nwg <= FZ_S;
     if (fused) {
         static bool fz_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
