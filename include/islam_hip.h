@@ -65,6 +65,11 @@ int islam_warp_mask(const float* x, const float* flow, float scale, float* out, 
  * gx (B,C,H,W) and gflow (B,2,H,W) must be ZERO-INITIALISED by the caller (atomic scatter). */
 int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const float* gout, float* gx, float* gflow,
                         int B, int C, int H, int W, void* stream);
+/* ConvTranspose2d(C, 2, kernel 4, stride 2, padding 1) + bias, fp32 NCHW: PWC-Net's `deconv%d` / `upfeat%d`
+ * (/root/reference/Network/PWC/PWCNet.py:61-63 and their uses in :260-291).  x: (B,C,H,W); w: (C,2,4,4) as nn.ConvTranspose2d stores it;
+ * the two output channels go to channels [coff, coff + 2) of y = (B,ytot,2H,2W).  Exact fp32 FMAs; channel sums in a fixed order. */
+int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
+                              void* stream);
 
 /* 3x3 convolution (+ bias + LeakyReLU) of the frozen flow network on the matrix cores (implicit GEMM, bf16 operands,
  * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:20-25 `conv()` (Conv2d k=3, padding = dilation, then

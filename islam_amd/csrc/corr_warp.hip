@@ -329,6 +329,103 @@ __global__ __launch_bounds__(256) void warp_mask_bwd_kernel(const float* __restr
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(C -> 2, kernel 4, stride 2, padding 1) + bias: PWC-Net's `deconv%d` (2 -> 2 channels: the up-sampled flow) and
+// `upfeat%d` (the whole DenseNet concatenation, up to 565 channels, -> 2) (Network/PWC/PWCNet.py:61-63, 260-291).  With two output
+// channels this is a memory-bound reduction over the input channels, not a GEMM: MIOpen ran the large ones as Winograd / implicit-GEMM
+// backward-data kernels at 0.4 TB/s (184 + 126 us at the 56x80 level, B = 8).  fp32 NCHW in and out, exact fp32 FMAs.
+// Output pixel (2y + a, 2x + c) = b[o] + sum_i sum_{r,s in {0,1}} x[i, y-1+a+r, x-1+c+s] W[i, o, 3-2r-a, 3-2s-c]: a thread owns input
+// pixel (y, x), i.e. the 2x2 output block x 2 channels (8 sums) over its 3x3 input neighbourhood; the sixteen waves of a workgroup split the
+// channels (i = wave, wave + 16, ...: a channel's 32 weights are wave-uniform scalar loads) and add their sums in wave order (deterministic).
+constexpr int UP2_WAVES = 16;                        // waves of a workgroup = channel classes (i mod 16): the reduction is latency-bound per wave
+__global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                         const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
+                                                                         int ytot, int coff) {
+    __shared__ float red[UP2_WAVES - 1][64][9];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: weights by scalar loads)
+    const int px = blockIdx.x * 64 + lane, py = blockIdx.y, b = blockIdx.z;
+    const bool on = px < W;
+    float acc[2][2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[o][a][c] = 0.0f;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * C * plane;
+    bool vy[3], vx[3];
+    int oy[3], ox[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int yy = py - 1 + d, xx = px - 1 + d;
+        vy[d] = yy >= 0 && yy < H; vx[d] = on && xx >= 0 && xx < W;
+        oy[d] = min(max(yy, 0), H - 1) * W; ox[d] = min(max(xx, 0), W - 1);
+    }
+    auto load9 = [&](int i, float (&v)[3][3]) {              // (clamped addresses: the same nine loads on every lane)
+        const float* xc = xb + (size_t)min(i, C - 1) * plane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[dy][dx] = xc[oy[dy] + ox[dx]];
+    };
+    auto fma32 = [&](int i, const float (&v)[3][3]) {
+        if (i >= C) return;                                   // (wave-uniform)
+        const float* wc = w + (size_t)i * 32;                 // [o][ky][kx], wave-uniform: scalar loads
+        float m[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) m[dy][dx] = (vy[dy] && vx[dx]) ? v[dy][dx] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx)
+                            acc[o][a][c] = fmaf(m[a + r][c + sx], wc[o * 16 + (3 - 2 * r - a) * 4 + (3 - 2 * sx - c)], acc[o][a][c]);
+    };
+    // two channels per iteration, the next pair's eighteen loads in flight while this pair is accumulated
+    float v0[3][3], v1[3][3], n0[3][3], n1[3][3];
+    load9(wave, v0);
+    load9(wave + UP2_WAVES, v1);
+    for (int i = wave; i < C; i += 2 * UP2_WAVES) {
+        load9(i + 2 * UP2_WAVES, n0);
+        load9(i + 3 * UP2_WAVES, n1);
+        fma32(i, v0);
+        fma32(i + UP2_WAVES, v1);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) { v0[dy][dx] = n0[dy][dx]; v1[dy][dx] = n1[dy][dx]; }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave - 1][lane][e] = acc[e >> 2][(e >> 1) & 1][e & 1];
+    }
+    __syncthreads();
+    if (wave == 0 && on) {
+        const int Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float* yo = y + ((size_t)b * ytot + coff + o) * Ho * Wo;
+            const float bo = bias ? bias[o] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float2 out;
+                float s0 = acc[o][a][0], s1 = acc[o][a][1];
+                for (int q = 0; q < UP2_WAVES - 1; ++q) { s0 += red[q][lane][o * 4 + a * 2]; s1 += red[q][lane][o * 4 + a * 2 + 1]; }
+                out.x = s0 + bo; out.y = s1 + bo;
+                *reinterpret_cast<float2*>(yo + (size_t)(2 * py + a) * Wo + 2 * px) = out;
+            }
+        }
+    }
+}
+
 extern "C" {
 
 size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
@@ -381,6 +478,15 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask_bwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
     dim3 grid((W + 63) / 64, (H + 3) / 4, B * ((C + WCH - 1) / WCH)), block(256);
     hipLaunchKernelGGL(warp_mask_bwd_kernel, grid, block, 0, as_stream(stream), x, flow, scale, gout, gx, gflow, C, H, W);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
+                              void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1 || coff < 0 || coff + 2 > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_to2_f32: bad argument (C=%d, %dx%d, slice %d+2 of %d)", C, H, W, coff, ytot);
+    dim3 grid((W + 63) / 64, H, B);
+    hipLaunchKernelGGL(deconv4x4s2_to2_kernel, grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, w, bias, y, C, H, W, ytot, coff);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

@@ -177,6 +177,15 @@ class PWCDCNet(nn.Module):
             off -= w
         return buf, None
 
+    def _up2(self, name, t):
+        """The 4x4 stride-2 transposed convolutions with TWO output channels (deconv / upfeat): a memory-bound channel reduction on
+        islam_deconv4x4s2_to2_f32 instead of MIOpen's backward-data kernels (ISLAM_FLOW_UP2=0: MIOpen)."""
+        dc = getattr(self, name)
+        if (FLOW_UP2 and t.is_cuda and t.dtype == torch.float32 and dc.out_channels == 2 and dc.kernel_size == (4, 4) and dc.stride == (2, 2)
+                and dc.padding == (1, 1) and dc.output_padding == (0, 0) and dc.groups == 1 and dc.weight.dtype == torch.float32):
+            return ops.deconv_to2(t.contiguous(), dc.weight.detach(), dc.bias.detach() if dc.bias is not None else None)
+        return dc(t)
+
     def forward_mfma(self, x):
         """Same network as forward(), no autograd: both images go through the pyramid as one batch, convolutions through
         _c(), concatenations through channel slices.  fp32 activations; bf16-rounded operands inside the convolutions."""
@@ -193,8 +202,8 @@ class PWCDCNet(nn.Module):
         flows = {}
         for l in range(5, 1, -1):
             flows[l + 1] = self._c('predict_flow%d' % (l + 1), x)
-            up_flow = getattr(self, 'deconv%d' % (l + 1))(flows[l + 1])
-            up_feat = getattr(self, 'upfeat%d' % (l + 1))(x)
+            up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
+            up_feat = self._up2('upfeat%d' % (l + 1), x)
             a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
             x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
@@ -249,6 +258,7 @@ HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '2'))
 # the flow net's DenseNet convolutions on the channels-last kernel through a bf16 mirror of the concatenation buffer (0: fp32 NCHW kernel)
 FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
+FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 

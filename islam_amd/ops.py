@@ -139,6 +139,20 @@ def scale_ls(disp, flow, pose7, intr4, baseline, edge, disp_th, depth_input=Fals
 
 
 # --------------------------------------------------------------------------- 3x3 convolution on the matrix cores
+def deconv_to2(x, weight, bias, out=None, coff=0):
+    """nn.ConvTranspose2d(C, 2, 4, 2, 1)(x) for fp32 NCHW tensors on islam_deconv4x4s2_to2_f32 (PWC-Net's deconv / upfeat layers), written
+    into channels [coff, coff + 2) of ``out`` (B, ytot, 2H, 2W) (allocated with two channels when None)."""
+    require_cuda(x, weight)
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and tuple(weight.shape) == (C, 2, 4, 4) and weight.dtype == torch.float32
+    if out is None:
+        out = torch.empty((B, 2, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == B and tuple(out.shape[2:]) == (2 * H, 2 * W)
+    check(lib().islam_deconv4x4s2_to2_f32(ptr(x), ptr(weight.contiguous()), ptr(bias), ptr(out), int(out.shape[1]), int(coff), B, C, H, W,
+                                          stream_ptr(x.device)))
+    return out
+
+
 def pack_conv3x3_weight(w):
     """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages.
     The kernel walks the input channels in chunks of 16; when Cin > 16 is not a multiple of 16 its last chunk reads the LAST

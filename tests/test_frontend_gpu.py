@@ -350,3 +350,22 @@ def test_pose_head_fused_elementwise_tail(cuda):
         torch.testing.assert_close(gi[1], gr[1], rtol=1e-5, atol=1e-5)
         gi2 = torch.autograd.grad((ops.bias_act(x, bias, res, relu) * w).sum(), [bias])
         assert torch.equal(gi[1], gi2[0])                                   # fixed-order sums: the same bits every time
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 2, 7, 10), (1, 565, 14, 20), (3, 149, 9, 67), (1, 5, 1, 1), (2, 64, 33, 130)])
+def test_two_channel_transposed_convolution(cuda, B, C, H, W):
+    """islam_deconv4x4s2_to2_f32 (PWC-Net's deconv / upfeat: ConvTranspose2d(C, 2, 4, 2, 1)) against torch in fp32, also into a channel
+    slice of a larger tensor, and bit-reproducible."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, C, H, W, generator=g).to(cuda)
+    w = (torch.randn(C, 2, 4, 4, generator=g) / (4 * C) ** 0.5).to(cuda)
+    b = torch.randn(2, generator=g).to(cuda)
+    want = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    got = ops.deconv_to2(x, w, b)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 2e-6 * max(float(want.abs().max()), 1.0)
+    buf = torch.full((B, 5, 2 * H, 2 * W), 3.0, device=cuda)
+    ops.deconv_to2(x, w, None, out=buf, coff=2)
+    assert torch.equal(buf[:, 2:4], ops.deconv_to2(x, w, None)) and bool((buf[:, :2] == 3.0).all()) and bool((buf[:, 4:] == 3.0).all())
+    assert torch.equal(got, ops.deconv_to2(x, w, b))
