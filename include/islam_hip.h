@@ -66,7 +66,7 @@ int islam_warp_mask(const float* x, const float* flow, float scale, float* out, 
 int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const float* gout, float* gx, float* gflow,
                         int B, int C, int H, int W, void* stream);
 /* ConvTranspose2d(C, 2, kernel 4, stride 2, padding 1) + bias, fp32 NCHW: PWC-Net's `deconv%d` / `upfeat%d`
- * (/root/reference/Network/PWC/PWCNet.py:61-63 and their uses in :260-291).  x: (B,C,H,W); w: (C,2,4,4) as nn.ConvTranspose2d stores it;
+ * (Network/PWC/PWCNet.py:55-56 `deconv()`, layers :113-114 ff., uses :259-268).  x: (B,C,H,W); w: (C,2,4,4) as nn.ConvTranspose2d stores it;
  * the two output channels go to channels [coff, coff + 2) of y = (B,ytot,2H,2W).  Exact fp32 FMAs; channel sums in a fixed order. */
 int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
                               void* stream);
