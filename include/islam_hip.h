@@ -70,6 +70,15 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
  * the two output channels go to channels [coff, coff + 2) of y = (B,ytot,2H,2W).  Exact fp32 FMAs; channel sums in a fixed order. */
 int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
                               void* stream);
+/* One level of PWC-Net's feature pyramid -- conv(k3, stride 2) + conv(k3) + conv(k3), each + bias + LeakyReLU(slope) -- in one
+ * launch (Network/PWC/PWCNet.py:81-86 conv1a/conv1aa/conv1b, conv2a/conv2aa/conv2b; :20-25 `conv()`; used at :213-218).  bf16 operands
+ * (round to nearest even), fp32 accumulation, fp32 bias / activation; intermediates stay in LDS.  x: (B,Cin,H,W) fp32 NCHW;
+ * y: (B,C,(H-1)/2+1,(W-1)/2+1) fp32 NCHW; wA/wB/wC: bf16 [C][ceil(9*SC/32)*32], K index = (ky*3+kx)*SC + c, SC = 4 for Cin <= 4 else
+ * Cin (wB, wC: SC = C), zero padded (islam_pyramid_packed_elems elements each; islam_amd/ops.py pack_pyramid_weight).
+ * Built for (Cin, C) = (3, 16) and (16, 32); anything else is ISLAM_EARG. */
+size_t islam_pyramid_packed_elems(int Cin, int Cout);
+int islam_flow_pyramid_level(const float* x, const uint16_t* wA, const float* bA, const uint16_t* wB, const float* bB, const uint16_t* wC,
+                             const float* bC, float* y, int B, int Cin, int H, int W, int C, float slope, void* stream);
 
 /* 3x3 convolution (+ bias + LeakyReLU) of the frozen flow network on the matrix cores (implicit GEMM, bf16 operands,
  * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:20-25 `conv()` (Conv2d k=3, padding = dilation, then

@@ -177,6 +177,17 @@ class PWCDCNet(nn.Module):
             off -= w
         return buf, None
 
+    def _pyramid_level(self, l, f):
+        """conv{l}a (stride 2), conv{l}aa, conv{l}b (PWCNet.py:81-86, :213-218) on islam_flow_pyramid_level; weights re-packed when the
+        fp32 masters change (ISLAM_FLOW_PYR=0: layer by layer)."""
+        convs = [getattr(self, 'conv%d%s' % (l, s))[0] for s in ('a', 'aa', 'b')]
+        cache = self.__dict__.setdefault('_pyr_cache', {})
+        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version) for c in convs)
+        hit = cache.get(l)
+        if hit is None or hit[0] != key:
+            hit = cache[l] = (key, [ops.pack_pyramid_weight(c.weight) for c in convs], [c.bias.detach().float().contiguous() for c in convs])
+        return ops.flow_pyramid_level(f, hit[1], hit[2], 0.1)
+
     def _up2(self, name, t):
         """The 4x4 stride-2 transposed convolutions with TWO output channels (deconv / upfeat): a memory-bound channel reduction on
         islam_deconv4x4s2_to2_f32 instead of MIOpen's backward-data kernels (ISLAM_FLOW_UP2=0: MIOpen)."""
@@ -193,8 +204,11 @@ class PWCDCNet(nn.Module):
         x = x.float()
         f, feats = torch.cat((x[:, 0:3], x[:, 3:6]), 0).contiguous(), []
         for l in range(1, 7):
-            for s in (('a', 'aa', 'b') if l < 6 else ('aa', 'a', 'b')):
-                f = self._c('conv%d%s' % (l, s), f)
+            if FLOW_PYR and l <= 2 and f.is_cuda:                # levels 1, 2: the three layers in one launch, intermediates in LDS
+                f = self._pyramid_level(l, f)
+            else:
+                for s in (('a', 'aa', 'b') if l < 6 else ('aa', 'a', 'b')):
+                    f = self._c('conv%d%s' % (l, s), f)
             feats.append(f)
         p1, p2 = [t[:B] for t in feats], [t[B:] for t in feats]
         lrelu = lambda t: F.leaky_relu(t, 0.1)
@@ -259,6 +273,7 @@ HIP_CONV_LEVEL = int(_os.environ.get('ISLAM_HIP_CONV', '2'))
 FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
+FLOW_PYR = _os.environ.get('ISLAM_FLOW_PYR', '1') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 

@@ -153,6 +153,34 @@ def deconv_to2(x, weight, bias, out=None, coff=0):
     return out
 
 
+def pack_pyramid_weight(w):
+    """(Cout, Cin, 3, 3) fp32 -> bf16 [Cout][ceil(9 * SC / 32) * 32] with K index = (ky * 3 + kx) * SC + c, SC = 4 for Cin <= 4 else Cin,
+    zero padded: the layout islam_flow_pyramid_level holds in registers (include/islam_hip.h)."""
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    assert tuple(w.shape[2:]) == (3, 3)
+    SC = 4 if Cin <= 4 else Cin
+    K = (9 * SC + 31) // 32 * 32
+    p = torch.zeros((Cout, K), dtype=torch.bfloat16, device=w.device)
+    t = torch.zeros((Cout, 9, SC), dtype=torch.bfloat16, device=w.device)
+    t[:, :, :Cin] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9, Cin).to(torch.bfloat16)
+    p[:, :9 * SC] = t.reshape(Cout, 9 * SC)
+    assert p.numel() == lib().islam_pyramid_packed_elems(Cin, Cout)
+    return p.contiguous()
+
+
+def flow_pyramid_level(x, packed, biases, slope=0.1):
+    """conv(k3, s2) + conv(k3) + conv(k3), each + bias + LeakyReLU(slope), of one pyramid level in one launch (fp32 NCHW in and out, bf16
+    operands).  packed / biases: the three layers' pack_pyramid_weight tensors / fp32 biases.  Inference only."""
+    require_cuda(x, *packed)
+    B, Cin, H, W = x.shape
+    C = int(biases[0].numel())
+    assert x.dtype == torch.float32 and x.is_contiguous() and len(packed) == 3 and len(biases) == 3
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib().islam_flow_pyramid_level(ptr(x), ptr(packed[0]), ptr(biases[0]), ptr(packed[1]), ptr(biases[1]), ptr(packed[2]), ptr(biases[2]),
+                                         ptr(y), B, Cin, H, W, C, float(slope), stream_ptr(x.device)))
+    return y
+
+
 def pack_conv3x3_weight(w):
     """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages.
     The kernel walks the input channels in chunks of 16; when Cin > 16 is not a multiple of 16 its last chunk reads the LAST

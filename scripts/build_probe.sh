@@ -6,7 +6,7 @@ SUFFIX=$1; shift || true
 cd "$(dirname "$0")/../islam_amd/csrc"
 O=/tmp/probe_obj$SUFFIX
 mkdir -p $O
-for f in abi pvgo corr_warp imu_preint scale_ls conv_mfma conv_nhwc edge_mask pvgo_dist pose_ops; do
+for f in abi pvgo corr_warp imu_preint scale_ls conv_mfma conv_nhwc edge_mask pvgo_dist pose_ops pyramid; do
   if [ $f = pvgo ] || [ ! -f $O/$f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DISLAM_PROBE "$@" -c $f.hip -o $O/$f.o
   fi

@@ -369,3 +369,31 @@ def test_two_channel_transposed_convolution(cuda, B, C, H, W):
     ops.deconv_to2(x, w, None, out=buf, coff=2)
     assert torch.equal(buf[:, 2:4], ops.deconv_to2(x, w, None)) and bool((buf[:, :2] == 3.0).all()) and bool((buf[:, 4:] == 3.0).all())
     assert torch.equal(got, ops.deconv_to2(x, w, b))
+
+
+@pytest.mark.parametrize('Cin,C,B,H,W', [(3, 16, 2, 64, 128), (3, 16, 1, 37, 71), (3, 16, 1, 2, 2), (16, 32, 2, 32, 64), (16, 32, 1, 45, 39),
+                                         (16, 32, 1, 3, 130)])
+def test_fused_pyramid_level(cuda, Cin, C, B, H, W):
+    """islam_flow_pyramid_level (conv s2 + conv + conv, each + bias + LeakyReLU(0.1), intermediates in LDS) against the three torch
+    convolutions evaluated in float64 on the SAME bf16-rounded operands (weights, input, and each intermediate activation rounded to
+    bf16 after the fp32 activation) -- what is left is the fp32 summation order and roundings that fall on the other side of a bf16 tie;
+    ragged sizes cover partial tiles and the zero padding of the intermediate tiles at the image border."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(100 * Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(cuda)
+    ws, bs = [], []
+    for cin in (Cin, C, C):
+        ws.append((torch.randn(C, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(cuda))
+        bs.append((0.1 * torch.randn(C, generator=g)).to(cuda))
+    r = lambda t: t.to(torch.bfloat16).double()
+    want = x
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(r(want), r(w), b.double(), stride=2 if i == 0 else 1, padding=1), 0.1).float()
+    got = ops.flow_pyramid_level(x, [ops.pack_pyramid_weight(w) for w in ws], bs, 0.1)
+    assert got.shape == want.shape
+    err = (got.double() - want.double()).abs()
+    scale = float(want.abs().max())
+    # a bf16 tie that rounds the other way moves one operand by 2^-8 relative: bounded by ~1e-2 of the output scale, rare
+    assert float(err.max()) <= 2e-2 * scale, float(err.max()) / scale
+    assert float((err > 1e-4 * scale).double().mean()) < 0.02, float((err > 1e-4 * scale).double().mean())
+    assert torch.equal(got, ops.flow_pyramid_level(x, [ops.pack_pyramid_weight(w) for w in ws], bs, 0.1))
