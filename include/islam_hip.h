@@ -70,6 +70,14 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
  * the two output channels go to channels [coff, coff + 2) of y = (B,ytot,2H,2W).  Exact fp32 FMAs; channel sums in a fixed order. */
 int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
                               void* stream);
+/* PWC-Net's flow head + up-sampled features of one level in ONE pass over the level's DenseNet concatenation:
+ *   flow = Conv2d(C, 2, kernel 3, padding 1)(x) + bf          (`predict_flow%d`, Network/PWC/PWCNet.py:111,124,137,150,163; no activation)
+ *   up   = ConvTranspose2d(C, 2, 4, 2, 1)(x) + bu              (`upfeat%d`, as islam_deconv4x4s2_to2_f32), into channels [upoff, upoff+2) of
+ *                                                               up = (B,uptot,2H,2W); wu == NULL: the head alone (level 2)
+ * x: (B,C,H,W) fp32; wf: [C][2][3][3] fp32 (the Conv2d weight with its first two axes swapped); flow: (B,2,H,W).  Exact fp32 FMAs
+ * (the reference's arithmetic; the matrix-core path rounded the head's operands to bf16), fixed summation order. */
+int islam_flow_head_up_f32(const float* x, const float* wf, const float* bf, float* flow, const float* wu, const float* bu, float* up, int uptot,
+                           int upoff, int B, int C, int H, int W, void* stream);
 /* One level of PWC-Net's feature pyramid -- conv(k3, stride 2) + conv(k3) + conv(k3), each + bias + LeakyReLU(slope) -- in one
  * launch (Network/PWC/PWCNet.py:81-86 conv1a/conv1aa/conv1b, conv2a/conv2aa/conv2b; :20-25 `conv()`; used at :213-218).  bf16 operands
  * (round to nearest even), fp32 accumulation, fp32 bias / activation; intermediates stay in LDS.  x: (B,Cin,H,W) fp32 NCHW;

@@ -338,20 +338,25 @@ __global__ __launch_bounds__(256) void warp_mask_bwd_kernel(const float* __restr
 // pixel (y, x), i.e. the 2x2 output block x 2 channels (8 sums) over its 3x3 input neighbourhood; the sixteen waves of a workgroup split the
 // channels (i = wave, wave + 16, ...: a channel's 32 weights are wave-uniform scalar loads) and add their sums in wave order (deterministic).
 constexpr int UP2_WAVES = 16;                        // waves of a workgroup = channel classes (i mod 16): the reduction is latency-bound per wave
+//
+// HEAD: the same pass also evaluates PWC-Net's flow head `predict_flow%d` = Conv2d(C -> 2, kernel 3, padding 1) + bias (PWCNet.py:111 ff.,
+// used right before `upfeat%d` on the SAME tensor): flow[o, y, x] = b[o] + sum_i sum_{dy,dx} x[i, y-1+dy, x-1+dx] Wf[o, i, dy, dx] is another
+// two sums over the nine values the lane already holds -- 18 more FMAs per channel instead of a second pass over up to 565 channels
+// (the head ran as a 64-output-channel matrix-core tile with 2 live channels: 54-180 us per level).  wf: [C][2][9] (re-packed on the host).
+// UP = false: the head alone (level 2 has no up-sampling behind it).
+template <bool HEAD, bool UP>
 __global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                          const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
-                                                                         int ytot, int coff) {
-    __shared__ float red[UP2_WAVES - 1][64][9];
+                                                                         int ytot, int coff, const float* __restrict__ wf,
+                                                                         const float* __restrict__ bf, float* __restrict__ flow) {
+    constexpr int NS = (UP ? 8 : 0) + (HEAD ? 2 : 0);
+    __shared__ float red[UP2_WAVES - 1][64][NS + 1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: weights by scalar loads)
     const int px = blockIdx.x * 64 + lane, py = blockIdx.y, b = blockIdx.z;
     const bool on = px < W;
-    float acc[2][2][2];
+    float acc[NS];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[o][a][c] = 0.0f;
+    for (int e = 0; e < NS; ++e) acc[e] = 0.0f;
     const size_t plane = (size_t)H * W;
     const float* xb = x + (size_t)b * C * plane;
     bool vy[3], vx[3];
@@ -369,25 +374,36 @@ __global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const f
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) v[dy][dx] = xc[oy[dy] + ox[dx]];
     };
-    auto fma32 = [&](int i, const float (&v)[3][3]) {
+    auto fma_all = [&](int i, const float (&v)[3][3]) {
         if (i >= C) return;                                   // (wave-uniform)
-        const float* wc = w + (size_t)i * 32;                 // [o][ky][kx], wave-uniform: scalar loads
         float m[3][3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) m[dy][dx] = (vy[dy] && vx[dx]) ? v[dy][dx] : 0.0f;
+        if constexpr (UP) {
+            const float* wc = w + (size_t)i * 32;             // [o][ky][kx], wave-uniform: scalar loads
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                        for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int sx = 0; sx < 2; ++sx)
-                            acc[o][a][c] = fmaf(m[a + r][c + sx], wc[o * 16 + (3 - 2 * r - a) * 4 + (3 - 2 * sx - c)], acc[o][a][c]);
+                            for (int sx = 0; sx < 2; ++sx)
+                                acc[o * 4 + a * 2 + c] = fmaf(m[a + r][c + sx], wc[o * 16 + (3 - 2 * r - a) * 4 + (3 - 2 * sx - c)], acc[o * 4 + a * 2 + c]);
+        }
+        if constexpr (HEAD) {
+            const float* wh = wf + (size_t)i * 18;            // [o][dy][dx]
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[(UP ? 8 : 0) + o] = fmaf(m[dy][dx], wh[o * 9 + dy * 3 + dx], acc[(UP ? 8 : 0) + o]);
+        }
     };
     // two channels per iteration, the next pair's eighteen loads in flight while this pair is accumulated
     float v0[3][3], v1[3][3], n0[3][3], n1[3][3];
@@ -396,8 +412,8 @@ __global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const f
     for (int i = wave; i < C; i += 2 * UP2_WAVES) {
         load9(i + 2 * UP2_WAVES, n0);
         load9(i + 3 * UP2_WAVES, n1);
-        fma32(i, v0);
-        fma32(i + UP2_WAVES, v1);
+        fma_all(i, v0);
+        fma_all(i + UP2_WAVES, v1);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -405,23 +421,30 @@ __global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const f
     }
     if (wave > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave - 1][lane][e] = acc[e >> 2][(e >> 1) & 1][e & 1];
+        for (int e = 0; e < NS; ++e) red[wave - 1][lane][e] = acc[e];
     }
     __syncthreads();
     if (wave == 0 && on) {
-        const int Ho = 2 * H, Wo = 2 * W;
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            float* yo = y + ((size_t)b * ytot + coff + o) * Ho * Wo;
-            const float bo = bias ? bias[o] : 0.0f;
+        for (int e = 0; e < NS; ++e)
+            for (int q = 0; q < UP2_WAVES - 1; ++q) acc[e] += red[q][lane][e];
+        if constexpr (UP) {
+            const int Ho = 2 * H, Wo = 2 * W;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                float2 out;
-                float s0 = acc[o][a][0], s1 = acc[o][a][1];
-                for (int q = 0; q < UP2_WAVES - 1; ++q) { s0 += red[q][lane][o * 4 + a * 2]; s1 += red[q][lane][o * 4 + a * 2 + 1]; }
-                out.x = s0 + bo; out.y = s1 + bo;
-                *reinterpret_cast<float2*>(yo + (size_t)(2 * py + a) * Wo + 2 * px) = out;
+            for (int o = 0; o < 2; ++o) {
+                float* yo = y + ((size_t)b * ytot + coff + o) * Ho * Wo;
+                const float bo = bias ? bias[o] : 0.0f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float2 out;
+                    out.x = acc[o * 4 + a * 2] + bo; out.y = acc[o * 4 + a * 2 + 1] + bo;
+                    *reinterpret_cast<float2*>(yo + (size_t)(2 * py + a) * Wo + 2 * px) = out;
+                }
             }
+        }
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) flow[((size_t)b * 2 + o) * plane + (size_t)py * W + px] = acc[(UP ? 8 : 0) + o] + (bf ? bf[o] : 0.0f);
         }
     }
 }
@@ -486,7 +509,23 @@ int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias,
                               void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1 || coff < 0 || coff + 2 > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_to2_f32: bad argument (C=%d, %dx%d, slice %d+2 of %d)", C, H, W, coff, ytot);
     dim3 grid((W + 63) / 64, H, B);
-    hipLaunchKernelGGL(deconv4x4s2_to2_kernel, grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, w, bias, y, C, H, W, ytot, coff);
+    hipLaunchKernelGGL((deconv4x4s2_to2_kernel<false, true>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, w, bias, y, C, H, W, ytot, coff,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+int islam_flow_head_up_f32(const float* x, const float* wf, const float* bf, float* flow, const float* wu, const float* bu, float* up, int uptot,
+                           int upoff, int B, int C, int H, int W, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1 || !wf || !flow) return fail(ISLAM_EARG, "islam_flow_head_up_f32: bad argument (C=%d, %dx%d)", C, H, W);
+    if (wu && (!up || upoff < 0 || upoff + 2 > uptot)) return fail(ISLAM_EARG, "islam_flow_head_up_f32: slice %d+2 of %d", upoff, uptot);
+    dim3 grid((W + 63) / 64, H, B);
+    if (wu)
+        hipLaunchKernelGGL((deconv4x4s2_to2_kernel<true, true>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, wu, bu, up, C, H, W, uptot, upoff,
+                           wf, bf, flow);
+    else
+        hipLaunchKernelGGL((deconv4x4s2_to2_kernel<true, false>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, C, H, W, 0, 0, wf, bf, flow);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

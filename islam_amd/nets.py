@@ -188,6 +188,25 @@ class PWCDCNet(nn.Module):
             hit = cache[l] = (key, [ops.pack_pyramid_weight(c.weight) for c in convs], [c.bias.detach().float().contiguous() for c in convs])
         return ops.flow_pyramid_level(f, hit[1], hit[2], 0.1)
 
+    def _head_up(self, l, x, up):
+        """(predict_flow{l}(x), upfeat{l}(x) or None): the level's flow head and its up-sampled features (PWCNet.py:259-268) in one pass
+        over the DenseNet buffer (islam_flow_head_up_f32, exact fp32).  ISLAM_FLOW_UP2=0: matrix-core head + MIOpen."""
+        head = getattr(self, 'predict_flow%d' % l)
+        dc = getattr(self, 'upfeat%d' % l) if up else None
+        ok = (FLOW_UP2 and x.is_cuda and x.dtype == torch.float32 and head.weight.dtype == torch.float32 and head.kernel_size == (3, 3)
+              and head.stride == (1, 1) and head.padding == (1, 1) and head.dilation == (1, 1) and head.out_channels == 2
+              and (dc is None or (dc.out_channels == 2 and dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1)
+                                  and dc.output_padding == (0, 0) and dc.weight.dtype == torch.float32)))
+        if not ok:
+            return self._c('predict_flow%d' % l, x), (self._up2('upfeat%d' % l, x) if up else None)
+        cache = self.__dict__.setdefault('_head_cache', {})
+        key = (head.weight._version, head.weight.data_ptr())
+        hit = cache.get(l)
+        if hit is None or hit[0] != key:
+            hit = cache[l] = (key, head.weight.detach().permute(1, 0, 2, 3).contiguous())
+        return ops.flow_head_up(x.contiguous(), hit[1], head.bias.detach(), dc.weight.detach() if up else None,
+                                dc.bias.detach() if up and dc.bias is not None else None)
+
     def _up2(self, name, t):
         """The 4x4 stride-2 transposed convolutions with TWO output channels (deconv / upfeat): a memory-bound channel reduction on
         islam_deconv4x4s2_to2_f32 instead of MIOpen's backward-data kernels (ISLAM_FLOW_UP2=0: MIOpen)."""
@@ -215,13 +234,12 @@ class PWCDCNet(nn.Module):
         x, mir = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
         flows = {}
         for l in range(5, 1, -1):
-            flows[l + 1] = self._c('predict_flow%d' % (l + 1), x)
+            flows[l + 1], up_feat = self._head_up(l + 1, x, True)
             up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
-            up_feat = self._up2('upfeat%d' % (l + 1), x)
             a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
             x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
-        flow2 = self._c('predict_flow2', x)
+        flow2 = self._head_up(2, x, False)[0]
         Hc, Wc = x.shape[2], x.shape[3]
         if mir is not None and all(Hc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0 and Wc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0
                                    for i in range(1, 7)):

@@ -153,6 +153,22 @@ def deconv_to2(x, weight, bias, out=None, coff=0):
     return out
 
 
+def flow_head_up(x, wf, bf, wu=None, bu=None):
+    """(Conv2d(C, 2, 3, 1, 1)(x), ConvTranspose2d(C, 2, 4, 2, 1)(x)) -- PWC-Net's predict_flow and upfeat of one level -- in one pass over
+    x (islam_flow_head_up_f32).  wf: the Conv2d weight re-laid out as [C][2][3][3] (``weight.permute(1, 0, 2, 3).contiguous()``);
+    wu / bu: the ConvTranspose2d's weight (C,2,4,4) / bias, or None for the head alone (returns (flow, None))."""
+    require_cuda(x, wf)
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and tuple(wf.shape) == (C, 2, 3, 3) and wf.is_contiguous() and wf.dtype == torch.float32
+    flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
+    up = None
+    if wu is not None:
+        assert tuple(wu.shape) == (C, 2, 4, 4) and wu.dtype == torch.float32 and wu.is_contiguous()
+        up = torch.empty((B, 2, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(lib().islam_flow_head_up_f32(ptr(x), ptr(wf), ptr(bf), ptr(flow), ptr(wu), ptr(bu), ptr(up), 2, 0, B, C, H, W, stream_ptr(x.device)))
+    return flow, up
+
+
 def pack_pyramid_weight(w):
     """(Cout, Cin, 3, 3) fp32 -> bf16 [Cout][ceil(9 * SC / 32) * 32] with K index = (ky * 3 + kx) * SC + c, SC = 4 for Cin <= 4 else Cin,
     zero padded: the layout islam_flow_pyramid_level holds in registers (include/islam_hip.h)."""

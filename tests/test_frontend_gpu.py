@@ -397,3 +397,27 @@ def test_fused_pyramid_level(cuda, Cin, C, B, H, W):
     assert float(err.max()) <= 2e-2 * scale, float(err.max()) / scale
     assert float((err > 1e-4 * scale).double().mean()) < 0.02, float((err > 1e-4 * scale).double().mean())
     assert torch.equal(got, ops.flow_pyramid_level(x, [ops.pack_pyramid_weight(w) for w in ws], bs, 0.1))
+
+
+@pytest.mark.parametrize('B,C,H,W,up', [(2, 529, 7, 10, True), (1, 149, 9, 67, True), (1, 33, 1, 1, True), (2, 565, 14, 20, False), (1, 5, 33, 130, False)])
+def test_flow_head_with_upsampled_features_in_one_pass(cuda, B, C, H, W, up):
+    """islam_flow_head_up_f32: Conv2d(C, 2, 3, 1, 1) and ConvTranspose2d(C, 2, 4, 2, 1) of the same tensor against torch in float64."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(cuda)
+    wh = (torch.randn(2, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(cuda)
+    bh = torch.randn(2, generator=g).to(cuda)
+    wu = (torch.randn(C, 2, 4, 4, generator=g) / (4 * C) ** 0.5).to(cuda)
+    bu = torch.randn(2, generator=g).to(cuda)
+    flow, upf = ops.flow_head_up(x, wh.permute(1, 0, 2, 3).contiguous(), bh, wu if up else None, bu if up else None)
+    want = torch.nn.functional.conv2d(x.double(), wh.double(), bh.double(), padding=1)
+    assert flow.shape == want.shape
+    assert float((flow.double() - want).abs().max()) <= 2e-6 * max(float(want.abs().max()), 1.0)
+    if up:
+        wantu = torch.nn.functional.conv_transpose2d(x.double(), wu.double(), bu.double(), stride=2, padding=1)
+        assert float((upf.double() - wantu).abs().max()) <= 2e-6 * max(float(wantu.abs().max()), 1.0)
+        assert torch.equal(upf, ops.deconv_to2(x, wu, bu))          # the same sums as the kernel without the head
+    else:
+        assert upf is None
+    again = ops.flow_head_up(x, wh.permute(1, 0, 2, 3).contiguous(), bh, wu if up else None, bu if up else None)
+    assert torch.equal(flow, again[0])
