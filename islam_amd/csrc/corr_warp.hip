@@ -449,6 +449,148 @@ __global__ __launch_bounds__(64 * UP2_WAVES) void deconv4x4s2_to2_kernel(const f
     }
 }
 
+// The same sums with FOUR pixels per lane (W % 4 == 0): a lane owns pixels (y, x0 .. x0+3); per channel and input row it requests one
+// 16-byte vector (columns x0 .. x0+3) + the two neighbours x0-1, x0+4 -- 9 requests per 4 pixels instead of 36.  With one pixel per
+// lane the kernel was bound by the request rate of the vector memory pipe (nine 4-byte requests per pixel and channel: 0.8-1.3 TB/s).
+// Workgroup = 8 waves (channel classes i mod 8) x a 64 x 4 pixel block (16 lanes along x, 4 along y).
+constexpr int HU_WAVES = 8;
+template <bool HEAD, bool UP>
+__global__ __launch_bounds__(64 * HU_WAVES) void head_up4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int C, int H, int W, int ytot, int coff,
+                                                                 const float* __restrict__ wf, const float* __restrict__ bf, float* __restrict__ flow) {
+    constexpr int NS = (UP ? 8 : 0) + (HEAD ? 2 : 0), HO = UP ? 8 : 0;
+    __shared__ float red[HU_WAVES - 1][64][NS + 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * 64 + (lane & 15) * 4, py = blockIdx.y * 4 + (lane >> 4), b = blockIdx.z;
+    const bool on = x0 < W && py < H;                        // (W % 4 == 0: the four pixels are inside together)
+    float acc[4][NS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < NS; ++e) acc[j][e] = 0.0f;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * C * plane;
+    bool vy[3];
+    int oy[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int yy = py - 1 + d;
+        vy[d] = on && yy >= 0 && yy < H;
+        oy[d] = min(max(yy, 0), H - 1) * W;
+    }
+    const int xq = min(x0, W - 4), xl = max(xq - 1, 0), xr = min(x0 + 4, W - 1);
+    const bool vl = x0 >= 1, vr = x0 + 4 < W;
+    auto load18 = [&](int i, float (&v)[3][6]) {             // (clamped addresses: the same nine requests on every lane)
+        const float* xc = xb + (size_t)min(i, C - 1) * plane;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float4 q = *reinterpret_cast<const float4*>(xc + oy[d] + xq);
+            v[d][0] = xc[oy[d] + xl]; v[d][1] = q.x; v[d][2] = q.y; v[d][3] = q.z; v[d][4] = q.w; v[d][5] = xc[oy[d] + xr];
+        }
+    };
+    auto fma_all = [&](int i, const float (&v)[3][6]) {
+        if (i >= C) return;                                   // (wave-uniform)
+        float m[3][6];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[d][k] = (vy[d] && (k == 0 ? vl : k == 5 ? vr : true)) ? v[d][k] : 0.0f;
+        if constexpr (UP) {
+            const float* wc = w + (size_t)i * 32;             // [o][ky][kx], wave-uniform: scalar loads
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int sx = 0; sx < 2; ++sx) {
+                                const float wv = wc[o * 16 + (3 - 2 * r - a) * 4 + (3 - 2 * sx - c)];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[j][o * 4 + a * 2 + c] = fmaf(m[a + r][j + c + sx], wv, acc[j][o * 4 + a * 2 + c]);
+                            }
+        }
+        if constexpr (HEAD) {
+            const float* wh = wf + (size_t)i * 18;            // [o][dy][dx]
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float wv = wh[o * 9 + dy * 3 + dx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][HO + o] = fmaf(m[dy][j + dx], wv, acc[j][HO + o]);
+                    }
+        }
+    };
+    float v[3][6], n[3][6];
+    load18(wave, v);
+    for (int i = wave; i < C; i += HU_WAVES) {               // the next channel's nine requests in flight while this one is accumulated
+        load18(i + HU_WAVES, n);
+        fma_all(i, v);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[d][k] = n[d][k];
+    }
+    for (int j = 0; j < 4; ++j) {                             // the waves' sums, added in wave order (deterministic), one pixel column at a time
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e) red[wave - 1][lane][e] = acc[j][e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                float t = acc[j][e];
+                for (int q = 0; q < HU_WAVES - 1; ++q) t += red[q][lane][e];
+                acc[j][e] = t;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != 0 || !on) return;
+    if constexpr (UP) {
+        const int Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float* yo = y + ((size_t)b * ytot + coff + o) * Ho * Wo;
+            const float bo = bias ? bias[o] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float4* dst = reinterpret_cast<float4*>(yo + (size_t)(2 * py + a) * Wo + 2 * x0);
+                dst[0] = make_float4(acc[0][o * 4 + a * 2] + bo, acc[0][o * 4 + a * 2 + 1] + bo, acc[1][o * 4 + a * 2] + bo, acc[1][o * 4 + a * 2 + 1] + bo);
+                dst[1] = make_float4(acc[2][o * 4 + a * 2] + bo, acc[2][o * 4 + a * 2 + 1] + bo, acc[3][o * 4 + a * 2] + bo, acc[3][o * 4 + a * 2 + 1] + bo);
+            }
+        }
+    }
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float bo = bf ? bf[o] : 0.0f;
+            *reinterpret_cast<float4*>(flow + ((size_t)b * 2 + o) * plane + (size_t)py * W + x0) =
+                make_float4(acc[0][HO + o] + bo, acc[1][HO + o] + bo, acc[2][HO + o] + bo, acc[3][HO + o] + bo);
+        }
+    }
+}
+
+template <bool HEAD, bool UP>
+static void launch_head_up(const float* x, const float* w, const float* bias, float* y, int C, int H, int W, int ytot, int coff, const float* wf,
+                           const float* bf, float* flow, int B, hipStream_t s) {
+    // four pixels per lane only on large maps (level 2: 112x160): below, a level has too few pixel blocks to hide the per-channel round trip
+    // and the one-pixel kernel's 4x more waves win (upfeat4, 28x40: 31 vs 134 us; upfeat3, 56x80: 111 vs 136 us; head of level 2: 254 vs 186 us)
+    const bool quad = (size_t)H * W >= 8192 && (W & 3) == 0 && ((uintptr_t)x & 15) == 0 && (!UP || (((uintptr_t)y & 15) == 0)) && (!HEAD || (((uintptr_t)flow & 15) == 0));
+    if (quad)
+        hipLaunchKernelGGL((head_up4_kernel<HEAD, UP>), dim3((W + 63) / 64, (H + 3) / 4, B), dim3(64 * HU_WAVES), 0, s, x, w, bias, y, C, H, W, ytot, coff,
+                           wf, bf, flow);
+    else
+        hipLaunchKernelGGL((deconv4x4s2_to2_kernel<HEAD, UP>), dim3((W + 63) / 64, H, B), dim3(64 * UP2_WAVES), 0, s, x, w, bias, y, C, H, W, ytot, coff,
+                           wf, bf, flow);
+}
+
 extern "C" {
 
 size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
@@ -508,9 +650,7 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
 int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
                               void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1 || coff < 0 || coff + 2 > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_to2_f32: bad argument (C=%d, %dx%d, slice %d+2 of %d)", C, H, W, coff, ytot);
-    dim3 grid((W + 63) / 64, H, B);
-    hipLaunchKernelGGL((deconv4x4s2_to2_kernel<false, true>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, w, bias, y, C, H, W, ytot, coff,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    launch_head_up<false, true>(x, w, bias, y, C, H, W, ytot, coff, nullptr, nullptr, nullptr, B, as_stream(stream));
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -519,13 +659,8 @@ int islam_flow_head_up_f32(const float* x, const float* wf, const float* bf, flo
                            int upoff, int B, int C, int H, int W, void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1 || !wf || !flow) return fail(ISLAM_EARG, "islam_flow_head_up_f32: bad argument (C=%d, %dx%d)", C, H, W);
     if (wu && (!up || upoff < 0 || upoff + 2 > uptot)) return fail(ISLAM_EARG, "islam_flow_head_up_f32: slice %d+2 of %d", upoff, uptot);
-    dim3 grid((W + 63) / 64, H, B);
-    if (wu)
-        hipLaunchKernelGGL((deconv4x4s2_to2_kernel<true, true>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, wu, bu, up, C, H, W, uptot, upoff,
-                           wf, bf, flow);
-    else
-        hipLaunchKernelGGL((deconv4x4s2_to2_kernel<true, false>), grid, dim3(64 * UP2_WAVES), 0, as_stream(stream), x, (const float*)nullptr,
-                           (const float*)nullptr, (float*)nullptr, C, H, W, 0, 0, wf, bf, flow);
+    if (wu) launch_head_up<true, true>(x, wu, bu, up, C, H, W, uptot, upoff, wf, bf, flow, B, as_stream(stream));
+    else launch_head_up<true, false>(x, nullptr, nullptr, nullptr, C, H, W, 0, 0, wf, bf, flow, B, as_stream(stream));
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }

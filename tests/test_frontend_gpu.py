@@ -399,7 +399,8 @@ def test_fused_pyramid_level(cuda, Cin, C, B, H, W):
     assert torch.equal(got, ops.flow_pyramid_level(x, [ops.pack_pyramid_weight(w) for w in ws], bs, 0.1))
 
 
-@pytest.mark.parametrize('B,C,H,W,up', [(2, 529, 7, 10, True), (1, 149, 9, 67, True), (1, 33, 1, 1, True), (2, 565, 14, 20, False), (1, 5, 33, 130, False)])
+@pytest.mark.parametrize('B,C,H,W,up', [(2, 529, 7, 10, True), (1, 149, 9, 67, True), (1, 33, 1, 1, True), (2, 565, 14, 20, False), (1, 5, 33, 130, False),
+                                        (1, 37, 66, 128, True), (2, 21, 112, 160, False), (1, 9, 127, 68, True)])   # (large maps: four pixels per lane)
 def test_flow_head_with_upsampled_features_in_one_pass(cuda, B, C, H, W, up):
     """islam_flow_head_up_f32: Conv2d(C, 2, 3, 1, 1) and ConvTranspose2d(C, 2, 4, 2, 1) of the same tensor against torch in float64."""
     from islam_amd import ops
