@@ -49,6 +49,10 @@ int islam_abi_version(void);
  * with scratch the channels are split over workgroups and summed in a fixed order (deterministic). */
 size_t islam_corr81_scratch_bytes(int B, int C, int H, int W);
 int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream);
+/* The same correlation followed by LeakyReLU(slope), written into channels [ooff, ooff + 81) of out = (B,otot,H,W): PWC-Net's
+ * `corr = self.leakyRELU(corr)` and the torch.cat that follows (Network/PWC/PWCNet.py:232-234, 260-262) without the two extra passes. */
+int islam_corr81_fwd_act(const float* f1, const float* f2, float* out, int otot, int ooff, float slope, int B, int C, int H, int W, void* scratch,
+                         void* stream);
 
 /* Correlation backward.  Replaces correlation.py:334-383 with kernels updateGradFirst (:105-167) and
  * updateGradSecond (:169-233).  g1 and/or g2 may be NULL (needs_input_grad false). */

@@ -49,6 +49,7 @@ SIGNATURES = {
     'islam_warp_mask': (c_int, [c_void_p, c_void_p, c_float, c_void_p] + [c_int] * 4 + [c_void_p]),
     'islam_warp_mask_bwd': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     'islam_deconv4x4s2_to2_f32': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    'islam_corr81_fwd_act': (c_int, [c_void_p] * 3 + [c_int, c_int, c_float] + [c_int] * 4 + [c_void_p, c_void_p]),
     'islam_flow_head_up_f32': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'islam_pyramid_packed_elems': (c_size_t, [c_int, c_int]),
     'islam_flow_pyramid_level': (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),

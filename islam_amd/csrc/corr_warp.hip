@@ -38,7 +38,7 @@ constexpr int STG1 = (CC * TH * TW + NT - 1) / NT;       // (f1 tile)
 // every slice writes its partial sum to `part[slice]` and corr81_reduce_kernel adds the slices in index order.
 __global__ __launch_bounds__(NT) void corr81_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                          float* __restrict__ out, float* __restrict__ part, int B, int C,
-                                                         int H, int W, int nslice, int cps) {
+                                                         int H, int W, int nslice, int cps, int otot, int ooff, float slope) {
     __shared__ __attribute__((aligned(16))) float s1[CC * TH * TW];
     __shared__ __attribute__((aligned(16))) float s2[CC * F2H * F2RS];
     const int tx = threadIdx.x, ty = threadIdx.y, dyi = threadIdx.z;      // 16 x 4 x 9
@@ -122,28 +122,34 @@ __global__ __launch_bounds__(NT) void corr81_fwd_kernel(const float* __restrict_
     const int gy = y0 + ty, gx = x0 + 2 * tx;
     if (gy < H && gx < W) {
         const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
-        float* dst = nslice == 1 ? out : part + (size_t)slice * B * 81 * plane;
-        float* ob = dst + ((size_t)b * 81 + (size_t)dyi * 9) * plane + (size_t)gy * W + gx;
+        // single slice: straight into channels [ooff, ooff + 81) of the (B, otot, H, W) destination, LeakyReLU(slope) applied (slope 1: none)
+        float* ob = (nslice == 1 ? out + ((size_t)b * otot + ooff + (size_t)dyi * 9) * plane
+                                 : part + (size_t)slice * B * 81 * plane + ((size_t)b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
+        const float sl = nslice == 1 ? slope : 1.0f;
+        auto act = [&](float v) { return v > 0.0f ? v : v * sl; };
         const bool pair = (gx + 1 < W) && ((((size_t)gy * W + gx) & 1) == 0) && ((plane & 1) == 0);   // 8-byte aligned pair
 #pragma unroll
         for (int dx = 0; dx < 9; ++dx) {
             if (pair) {
-                *reinterpret_cast<float2*>(ob + (size_t)dx * plane) = make_float2(acc0[dx] * sc, acc1[dx] * sc);
+                *reinterpret_cast<float2*>(ob + (size_t)dx * plane) = make_float2(act(acc0[dx] * sc), act(acc1[dx] * sc));
             } else {
-                ob[(size_t)dx * plane] = acc0[dx] * sc;
-                if (gx + 1 < W) ob[(size_t)dx * plane + 1] = acc1[dx] * sc;
+                ob[(size_t)dx * plane] = act(acc0[dx] * sc);
+                if (gx + 1 < W) ob[(size_t)dx * plane + 1] = act(acc1[dx] * sc);
             }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void corr81_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
-                                                             int nslice, float inv_c) {
+                                                             int nslice, float inv_c, size_t img /* 81 * H * W */, int otot, int ooff,
+                                                             float slope) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = part[i];
     for (int k = 1; k < nslice; ++k) s += part[(size_t)k * n + i];       // fixed order: deterministic
-    out[i] = s * inv_c;
+    s *= inv_c;
+    const size_t b = i / img, rem = i - b * img;
+    out[(b * otot + ooff) * (img / 81) + rem] = s > 0.0f ? s : s * slope;
 }
 
 // gradient w.r.t. the first input:  g1[b,c,y,x] = (1/C) sum_{p,o} gout[b,(p+4)*9+(o+4),y,x] * f2[b,c,y+p,x+o]
@@ -601,8 +607,8 @@ size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
     return (size_t)nslice * B * 81 * H * W * sizeof(float);
 }
 
-int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream) {
-    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_corr81_fwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
+static int corr81_launch(const float* f1, const float* f2, float* out, int otot, int ooff, float slope, int B, int C, int H, int W, void* scratch,
+                         void* stream) {
     const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int chunks = (C + CC - 1) / CC;
     int nslice = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
@@ -610,14 +616,26 @@ int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C,
     const int cps = ((chunks + nslice - 1) / nslice) * CC;              // channels per slice (whole chunks)
     nslice = (C + cps - 1) / cps;
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
-    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps);
+    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
     if (nslice > 1) {
         const size_t n = (size_t)B * 81 * H * W;
         hipLaunchKernelGGL(corr81_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
-                           (const float*)scratch, out, n, nslice, 1.0f / (float)C);
+                           (const float*)scratch, out, n, nslice, 1.0f / (float)C, (size_t)81 * H * W, otot, ooff, slope);
     }
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_corr81_fwd: bad shape (%d,%d,%d,%d)", B, C, H, W);
+    return corr81_launch(f1, f2, out, 81, 0, 1.0f, B, C, H, W, scratch, stream);
+}
+
+int islam_corr81_fwd_act(const float* f1, const float* f2, float* out, int otot, int ooff, float slope, int B, int C, int H, int W, void* scratch,
+                         void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1 || ooff < 0 || ooff + 81 > otot)
+        return fail(ISLAM_EARG, "islam_corr81_fwd_act: bad argument (%d,%d,%d,%d), slice %d+81 of %d", B, C, H, W, ooff, otot);
+    return corr81_launch(f1, f2, out, otot, ooff, slope, B, C, H, W, scratch, stream);
 }
 
 int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/islam_hip.h"
 #include "common.h"
@@ -217,8 +218,21 @@ int islam_flow_pyramid_level(const float* x, const uint16_t* wA, const float* bA
     if (B < 1 || H < 2 || W < 2) return fail(ISLAM_EARG, "islam_flow_pyramid_level: bad shape B=%d H=%d W=%d", B, H, W);
     if ((size_t)B * std::max(Cin, C) * H * W >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_flow_pyramid_level: tensor too large for 32-bit offsets");
     hipStream_t s = as_stream(stream);
-    if (Cin == 3 && C == 16) return launch_level<3, 4, 16, 16, 32, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
-    if (Cin == 16 && C == 32) return launch_level<16, 16, 32, 8, 16, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+    static const int variant = [] { const char* e = std::getenv("ISLAM_PYR_TILE"); return e ? std::atoi(e) : 0; }();   // (A/B runs)
+    if (Cin == 3 && C == 16) {
+        if (variant == 1) return launch_level<3, 4, 16, 8, 32, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 2) return launch_level<3, 4, 16, 16, 32, 512>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 3) return launch_level<3, 4, 16, 16, 16, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 4) return launch_level<3, 4, 16, 32, 32, 512>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        return launch_level<3, 4, 16, 16, 32, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+    }
+    if (Cin == 16 && C == 32) {
+        if (variant == 1) return launch_level<16, 16, 32, 8, 32, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 2) return launch_level<16, 16, 32, 8, 32, 512>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 3) return launch_level<16, 16, 32, 16, 16, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        if (variant == 4) return launch_level<16, 16, 32, 16, 16, 512>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+        return launch_level<16, 16, 32, 8, 16, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
+    }
     return fail(ISLAM_EARG, "islam_flow_pyramid_level: (Cin, C) = (%d, %d); built for PWC-Net's levels 1 and 2: (3, 16), (16, 32)", Cin, C);
 }
 

@@ -162,6 +162,11 @@ class PWCDCNet(nn.Module):
         for p in pieces:
             buf[:, o:o + p.shape[1]].copy_(p)
             o += p.shape[1]
+        return self._dense_run(l, buf, od)
+
+    def _dense_run(self, l, buf, od):
+        """The five convolutions of level l's DenseNet block on a buffer whose last ``od`` channels (the block's input) are filled."""
+        B, tot, H, W = buf.shape
         off = tot - od
         if FLOW_NHWC and off % 8 == 0 and all(w % 8 == 0 for w in self.DENSE):
             totp = off + (od + 7) // 8 * 8
@@ -188,7 +193,7 @@ class PWCDCNet(nn.Module):
             hit = cache[l] = (key, [ops.pack_pyramid_weight(c.weight) for c in convs], [c.bias.detach().float().contiguous() for c in convs])
         return ops.flow_pyramid_level(f, hit[1], hit[2], 0.1)
 
-    def _head_up(self, l, x, up):
+    def _head_up(self, l, x, up, up_out=None, up_coff=0):
         """(predict_flow{l}(x), upfeat{l}(x) or None): the level's flow head and its up-sampled features (PWCNet.py:259-268) in one pass
         over the DenseNet buffer (islam_flow_head_up_f32, exact fp32).  ISLAM_FLOW_UP2=0: matrix-core head + MIOpen."""
         head = getattr(self, 'predict_flow%d' % l)
@@ -198,14 +203,17 @@ class PWCDCNet(nn.Module):
               and (dc is None or (dc.out_channels == 2 and dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1)
                                   and dc.output_padding == (0, 0) and dc.weight.dtype == torch.float32)))
         if not ok:
-            return self._c('predict_flow%d' % l, x), (self._up2('upfeat%d' % l, x) if up else None)
+            uf = self._up2('upfeat%d' % l, x) if up else None
+            if up_out is not None:
+                up_out[:, up_coff:up_coff + 2].copy_(uf)
+            return self._c('predict_flow%d' % l, x), uf
         cache = self.__dict__.setdefault('_head_cache', {})
         key = (head.weight._version, head.weight.data_ptr())
         hit = cache.get(l)
         if hit is None or hit[0] != key:
             hit = cache[l] = (key, head.weight.detach().permute(1, 0, 2, 3).contiguous())
         return ops.flow_head_up(x.contiguous(), hit[1], head.bias.detach(), dc.weight.detach() if up else None,
-                                dc.bias.detach() if up and dc.bias is not None else None)
+                                dc.bias.detach() if up and dc.bias is not None else None, up_out=up_out, up_coff=up_coff)
 
     def _up2(self, name, t):
         """The 4x4 stride-2 transposed convolutions with TWO output channels (deconv / upfeat): a memory-bound channel reduction on
@@ -231,12 +239,32 @@ class PWCDCNet(nn.Module):
             feats.append(f)
         p1, p2 = [t[:B] for t in feats], [t[B:] for t in feats]
         lrelu = lambda t: F.leaky_relu(t, 0.1)
-        x, mir = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
+        direct = FLOW_UP2 and x.is_cuda                     # producers write straight into the level's concatenation buffer
+        nd = sum(self.DENSE)
+        if direct:
+            a6 = p1[5].contiguous()
+            buf = torch.empty((a6.shape[0], nd + 81, a6.shape[2], a6.shape[3]), dtype=torch.float32, device=x.device)
+            ops.corr81_act(a6, p2[5].contiguous(), buf, nd, 0.1)
+            x, mir = self._dense_run(6, buf, 81)
+        else:
+            x, mir = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
         flows = {}
         for l in range(5, 1, -1):
+            a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
+            if direct:
+                # [conv4 .. conv0 | corr 81 | features ca | up_flow 2 | up_feat 2] (PWCNet.py:260-262 torch.cat order)
+                ca = a.shape[1]
+                buf = torch.empty((a.shape[0], nd + 81 + ca + 4, a.shape[2], a.shape[3]), dtype=torch.float32, device=x.device)
+                flows[l + 1], _ = self._head_up(l + 1, x, True, up_out=buf, up_coff=nd + 81 + ca + 2)
+                up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
+                warped = warp_fn(b2, up_flow, self.WARP_SCALE[l])
+                ops.corr81_act(a, warped, buf, nd, 0.1)
+                buf[:, nd + 81:nd + 81 + ca].copy_(a)
+                buf[:, nd + 81 + ca:nd + 81 + ca + 2].copy_(up_flow)
+                x, mir = self._dense_run(l, buf, 81 + ca + 4)
+                continue
             flows[l + 1], up_feat = self._head_up(l + 1, x, True)
             up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
-            a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
             x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
         flow2 = self._head_up(2, x, False)[0]

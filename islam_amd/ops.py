@@ -30,6 +30,21 @@ def corr81_forward(first, second):
     return out
 
 
+def corr81_act(first, second, out, coff, slope=0.1):
+    """LeakyReLU_slope(corr81(first, second)) written into channels [coff, coff + 81) of ``out`` (B, Ctot, H, W) fp32 -- the head of
+    PWC-Net's DenseNet concatenation without the activation and copy passes (islam_corr81_fwd_act).  Inference only."""
+    require_cuda(first, second, out)
+    assert first.is_contiguous() and second.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32
+    assert first.dtype == torch.float32 and second.dtype == torch.float32 and first.shape == second.shape
+    B, C, H, W = first.shape
+    assert out.shape[0] == B and tuple(out.shape[2:]) == (H, W)
+    nbytes = lib().islam_corr81_scratch_bytes(B, C, H, W)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=first.device) if nbytes else None
+    check(lib().islam_corr81_fwd_act(ptr(first), ptr(second), ptr(out), int(out.shape[1]), int(coff), float(slope), B, C, H, W, ptr(scratch),
+                                     stream_ptr(first.device)))
+    return out
+
+
 def corr81_backward(first, second, grad_out, need_first=True, need_second=True):
     """Network/PWC/correlation.py:334-383."""
     require_cuda(first, second, grad_out)
@@ -153,7 +168,7 @@ def deconv_to2(x, weight, bias, out=None, coff=0):
     return out
 
 
-def flow_head_up(x, wf, bf, wu=None, bu=None):
+def flow_head_up(x, wf, bf, wu=None, bu=None, up_out=None, up_coff=0):
     """(Conv2d(C, 2, 3, 1, 1)(x), ConvTranspose2d(C, 2, 4, 2, 1)(x)) -- PWC-Net's predict_flow and upfeat of one level -- in one pass over
     x (islam_flow_head_up_f32).  wf: the Conv2d weight re-laid out as [C][2][3][3] (``weight.permute(1, 0, 2, 3).contiguous()``);
     wu / bu: the ConvTranspose2d's weight (C,2,4,4) / bias, or None for the head alone (returns (flow, None))."""
@@ -164,8 +179,13 @@ def flow_head_up(x, wf, bf, wu=None, bu=None):
     up = None
     if wu is not None:
         assert tuple(wu.shape) == (C, 2, 4, 4) and wu.dtype == torch.float32 and wu.is_contiguous()
-        up = torch.empty((B, 2, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    check(lib().islam_flow_head_up_f32(ptr(x), ptr(wf), ptr(bf), ptr(flow), ptr(wu), ptr(bu), ptr(up), 2, 0, B, C, H, W, stream_ptr(x.device)))
+        if up_out is not None:              # into channels [up_coff, up_coff + 2) of a larger (B, Ctot, 2H, 2W) tensor
+            assert up_out.dtype == torch.float32 and up_out.is_contiguous() and up_out.shape[0] == B and tuple(up_out.shape[2:]) == (2 * H, 2 * W)
+            up = up_out
+        else:
+            up, up_coff = torch.empty((B, 2, 2 * H, 2 * W), dtype=torch.float32, device=x.device), 0
+    check(lib().islam_flow_head_up_f32(ptr(x), ptr(wf), ptr(bf), ptr(flow), ptr(wu), ptr(bu), ptr(up), int(up.shape[1]) if up is not None else 0,
+                                       int(up_coff), B, C, H, W, stream_ptr(x.device)))
     return flow, up
 
 

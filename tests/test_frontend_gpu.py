@@ -422,3 +422,17 @@ def test_flow_head_with_upsampled_features_in_one_pass(cuda, B, C, H, W, up):
         assert upf is None
     again = ops.flow_head_up(x, wh.permute(1, 0, 2, 3).contiguous(), bh, wu if up else None, bu if up else None)
     assert torch.equal(flow, again[0])
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 196, 7, 10), (1, 32, 33, 70), (2, 16, 112, 160)])
+def test_correlation_with_activation_into_a_channel_slice(cuda, B, C, H, W):
+    """islam_corr81_fwd_act == LeakyReLU(islam_corr81_fwd) bit for bit, in its channel slice, both with one and with several channel
+    slices of the reduction; the rest of the destination is untouched."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C)
+    a, b = torch.randn(B, C, H, W, generator=g).to(cuda), torch.randn(B, C, H, W, generator=g).to(cuda)
+    want = torch.nn.functional.leaky_relu(ops.corr81_forward(a, b), 0.1)
+    buf = torch.full((B, 81 + 7, H, W), 3.0, device=cuda)
+    ops.corr81_act(a, b, buf, 5, 0.1)
+    assert torch.equal(buf[:, 5:86], want)
+    assert bool((buf[:, :5] == 3.0).all()) and bool((buf[:, 86:] == 3.0).all())
