@@ -50,7 +50,7 @@ int islam_abi_version(void);
 size_t islam_corr81_scratch_bytes(int B, int C, int H, int W);
 int islam_corr81_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, void* scratch, void* stream);
 /* The same correlation followed by LeakyReLU(slope), written into channels [ooff, ooff + 81) of out = (B,otot,H,W): PWC-Net's
- * `corr = self.leakyRELU(corr)` and the torch.cat that follows (Network/PWC/PWCNet.py:232-234, 260-262) without the two extra passes. */
+ * `corr = self.leakyRELU(corr)` and the torch.cat that follows (Network/PWC/PWCNet.py:225-227, 255-258) without the two extra passes. */
 int islam_corr81_fwd_act(const float* f1, const float* f2, float* out, int otot, int ooff, float slope, int B, int C, int H, int W, void* scratch,
                          void* stream);
 
@@ -75,7 +75,7 @@ int islam_warp_mask_bwd(const float* x, const float* flow, float scale, const fl
 int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias, float* y, int ytot, int coff, int B, int C, int H, int W,
                               void* stream);
 /* PWC-Net's flow head + up-sampled features of one level in ONE pass over the level's DenseNet concatenation:
- *   flow = Conv2d(C, 2, kernel 3, padding 1)(x) + bf          (`predict_flow%d`, Network/PWC/PWCNet.py:111,124,137,150,163; no activation)
+ *   flow = Conv2d(C, 2, kernel 3, padding 1)(x) + bf          (`predict_flow%d`, Network/PWC/PWCNet.py:112,122,132,142,152; no activation)
  *   up   = ConvTranspose2d(C, 2, 4, 2, 1)(x) + bu              (`upfeat%d`, as islam_deconv4x4s2_to2_f32), into channels [upoff, upoff+2) of
  *                                                               up = (B,uptot,2H,2W); wu == NULL: the head alone (level 2)
  * x: (B,C,H,W) fp32; wf: [C][2][3][3] fp32 (the Conv2d weight with its first two axes swapped); flow: (B,2,H,W).  Exact fp32 FMAs
@@ -83,7 +83,7 @@ int islam_deconv4x4s2_to2_f32(const float* x, const float* w, const float* bias,
 int islam_flow_head_up_f32(const float* x, const float* wf, const float* bf, float* flow, const float* wu, const float* bu, float* up, int uptot,
                            int upoff, int B, int C, int H, int W, void* stream);
 /* One level of PWC-Net's feature pyramid -- conv(k3, stride 2) + conv(k3) + conv(k3), each + bias + LeakyReLU(slope) -- in one
- * launch (Network/PWC/PWCNet.py:81-86 conv1a/conv1aa/conv1b, conv2a/conv2aa/conv2b; :20-25 `conv()`; used at :213-218).  bf16 operands
+ * launch (Network/PWC/PWCNet.py:78-83 conv1a/conv1aa/conv1b, conv2a/conv2aa/conv2b; :16-20 `conv()`; used at :240-243).  bf16 operands
  * (round to nearest even), fp32 accumulation, fp32 bias / activation; intermediates stay in LDS.  x: (B,Cin,H,W) fp32 NCHW;
  * y: (B,C,(H-1)/2+1,(W-1)/2+1) fp32 NCHW; wA/wB/wC: bf16 [C][ceil(9*SC/32)*32], K index = (ky*3+kx)*SC + c, SC = 4 for Cin <= 4 else
  * Cin (wB, wC: SC = C), zero padded (islam_pyramid_packed_elems elements each; islam_amd/ops.py pack_pyramid_weight).
@@ -93,7 +93,7 @@ int islam_flow_pyramid_level(const float* x, const uint16_t* wA, const float* bA
                              const float* bC, float* y, int B, int Cin, int H, int W, int C, float slope, void* stream);
 
 /* 3x3 convolution (+ bias + LeakyReLU) of the frozen flow network on the matrix cores (implicit GEMM, bf16 operands,
- * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:20-25 `conv()` (Conv2d k=3, padding = dilation, then
+ * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:16-20 `conv()` (Conv2d k=3, padding = dilation, then
  * LeakyReLU(0.1)) for inference:  y[b, coff+n, ho, wo] = act(bias[n] + sum w[n,c,r,s] x[b, c, ho*stride + (r-1)*dil,
  * wo*stride + (s-1)*dil]),  act(v) = v >= 0 ? v : slope*v  (slope = 1: no activation).
  * x: channels [xoff, xoff+Cin) of a (B,xtot,H,W) fp32 NCHW buffer; y: channels [coff, coff+Cout) of a (B,ytot,Ho,Wo) fp32
@@ -171,7 +171,7 @@ int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout);
 size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout);
 int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
                          uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
-/* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d + LeakyReLU(0.1),
+/* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),
  * :237-292 the blocks) on the channels-last kernel.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) MIRROR of the block's
  * concatenation buffer; the result goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what correlation /
  * warp / transposed convolutions / flow heads read -- and, when ymir != NULL, as bf16 into channels [moff, moff + Cout) of the

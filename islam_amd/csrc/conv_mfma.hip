@@ -1,7 +1,7 @@
 // conv_mfma.hip -- 3x3 convolution of the frozen PWC-Net flow network as an implicit GEMM on the CDNA4 matrix cores.
 //
 // Replaces, for the frozen (inference-only) flow network, what the reference runs through cuDNN
-// (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d(k=3, padding=dilation) + LeakyReLU(0.1), :208-292 the network):
+// (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d(k=3, padding=dilation) + LeakyReLU(0.1), :208-292 the network):
 //   y[b, coff+n, ho, wo] = act( bias[n] + sum_{c,r,s} w[n,c,r,s] * x[b, c, ho*S + r*D - D, wo*S + s*D - D] )
 // x, y stay fp32 NCHW (the layout of the correlation / warp kernels and of torch.cat); operands are rounded to bf16 when
 // they are staged in LDS and accumulated in fp32 (v_mfma_f32_32x32x16_bf16) -- BASELINE config 2 "bf16 nets".  Bias and

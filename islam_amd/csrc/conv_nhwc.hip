@@ -510,7 +510,7 @@ int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, cons
                      : launch<32, 2, 4, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl);
 }
 
-// 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:20-25 `conv()` = Conv2d + LeakyReLU(0.1),
+// 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),
 // :237-292) on the channels-last kernel above.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) mirror of the block's
 // concatenation buffer; the output goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what the
 // correlation / warp / transposed-convolution / flow-head consumers read -- and, when ymir is given, as bf16 into channels

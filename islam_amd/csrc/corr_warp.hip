@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void warp_mask_bwd_kernel(const float* __restr
 // channels (i = wave, wave + 16, ...: a channel's 32 weights are wave-uniform scalar loads) and add their sums in wave order (deterministic).
 constexpr int UP2_WAVES = 16;                        // waves of a workgroup = channel classes (i mod 16): the reduction is latency-bound per wave
 //
-// HEAD: the same pass also evaluates PWC-Net's flow head `predict_flow%d` = Conv2d(C -> 2, kernel 3, padding 1) + bias (PWCNet.py:111 ff.,
+// HEAD: the same pass also evaluates PWC-Net's flow head `predict_flow%d` = Conv2d(C -> 2, kernel 3, padding 1) + bias (PWCNet.py:112 ff.,
 // used right before `upfeat%d` on the SAME tensor): flow[o, y, x] = b[o] + sum_i sum_{dy,dx} x[i, y-1+dy, x-1+dx] Wf[o, i, dy, dx] is another
 // two sums over the nine values the lane already holds -- 18 more FMAs per channel instead of a second pass over up to 565 channels
 // (the head ran as a 64-output-channel matrix-core tile with 2 live channels: 54-180 us per level).  wf: [C][2][9] (re-packed on the host).

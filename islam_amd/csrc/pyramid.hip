@@ -1,7 +1,7 @@
 // One level of PWC-Net's feature pyramid in ONE launch (frozen flow net, bf16 operands / fp32 accumulation like islam_conv3x3_mfma).
 //
-// Reference: Network/PWC/PWCNet.py:81-98 (conv1a, conv1aa, conv1b ... = conv(k=3, stride 2) + two conv(k=3, stride 1), each
-// Conv2d + LeakyReLU(0.1), :20-25) and their use at :213-230.  At the two large levels (16 channels at 1/2 resolution, 32 at 1/4) the three
+// Reference: Network/PWC/PWCNet.py:78-95 (conv1a, conv1aa, conv1b ... = conv(k=3, stride 2) + two conv(k=3, stride 1), each
+// Conv2d + LeakyReLU(0.1), :16-20) and their use at :240-251.  At the two large levels (16 channels at 1/2 resolution, 32 at 1/4) the three
 // layers are memory traffic, not arithmetic: launched one by one they move the level's fp32 activation through HBM five times
 // (0.33 + 0.19 ms of the 4.3 ms flow forward at B = 8, half of it MIOpen's stride-2 kernel + a bias launch + a LeakyReLU launch).
 // Here a workgroup produces a TH x TW tile of the level's output from the (2(TH+4)+1) x (2(TW+4)+1) source patch it depends on:

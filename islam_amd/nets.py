@@ -118,7 +118,7 @@ class PWCDCNet(nn.Module):
         return hit[1], hit[2], hit[3]
 
     def _c(self, name, x, out=None, coff=0, xoff=0):
-        """One `conv()` block (PWCNet.py:20-25).  Stride-1 layers with dilation <= 8 and >= 16 input channels run on the HIP
+        """One `conv()` block (PWCNet.py:16-20).  Stride-1 layers with dilation <= 8 and >= 16 input channels run on the HIP
         kernel (1.3-4.5x MIOpen's fp32 Winograd there, scripts/conv_bench.py); the stride-2 pyramid heads and the dilation-16
         context layer (its halo tile does not fit the prefetch registers) stay on MIOpen."""
         packed, bias, conv = self._packed(name)
@@ -183,7 +183,7 @@ class PWCDCNet(nn.Module):
         return buf, None
 
     def _pyramid_level(self, l, f):
-        """conv{l}a (stride 2), conv{l}aa, conv{l}b (PWCNet.py:81-86, :213-218) on islam_flow_pyramid_level; weights re-packed when the
+        """conv{l}a (stride 2), conv{l}aa, conv{l}b (PWCNet.py:78-83, :240-243) on islam_flow_pyramid_level; weights re-packed when the
         fp32 masters change (ISLAM_FLOW_PYR=0: layer by layer)."""
         convs = [getattr(self, 'conv%d%s' % (l, s))[0] for s in ('a', 'aa', 'b')]
         cache = self.__dict__.setdefault('_pyr_cache', {})
@@ -194,7 +194,7 @@ class PWCDCNet(nn.Module):
         return ops.flow_pyramid_level(f, hit[1], hit[2], 0.1)
 
     def _head_up(self, l, x, up, up_out=None, up_coff=0):
-        """(predict_flow{l}(x), upfeat{l}(x) or None): the level's flow head and its up-sampled features (PWCNet.py:259-268) in one pass
+        """(predict_flow{l}(x), upfeat{l}(x) or None): the level's flow head and its up-sampled features (PWCNet.py:216-222) in one pass
         over the DenseNet buffer (islam_flow_head_up_f32, exact fp32).  ISLAM_FLOW_UP2=0: matrix-core head + MIOpen."""
         head = getattr(self, 'predict_flow%d' % l)
         dc = getattr(self, 'upfeat%d' % l) if up else None
@@ -252,7 +252,7 @@ class PWCDCNet(nn.Module):
         for l in range(5, 1, -1):
             a, b2 = p1[l - 1].contiguous(), p2[l - 1].contiguous()
             if direct:
-                # [conv4 .. conv0 | corr 81 | features ca | up_flow 2 | up_feat 2] (PWCNet.py:260-262 torch.cat order)
+                # [conv4 .. conv0 | corr 81 | features ca | up_flow 2 | up_feat 2] (PWCNet.py:227 torch.cat order)
                 ca = a.shape[1]
                 buf = torch.empty((a.shape[0], nd + 81 + ca + 4, a.shape[2], a.shape[3]), dtype=torch.float32, device=x.device)
                 flows[l + 1], _ = self._head_up(l + 1, x, True, up_out=buf, up_coff=nd + 81 + ca + 2)
