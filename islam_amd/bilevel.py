@@ -19,6 +19,9 @@ from .pvgo import run_pvgo
 from .transformation import motion2pose_pypose, pose2motion_pypose
 
 
+import os as _os
+PREFETCH_FIRST = _os.environ.get('ISLAM_PREFETCH_FIRST', '1') == '1'
+
 class BilevelLoop:
     def __init__(self, tartanvo, imu_module, rgb2imu_pose, imu_init, loss_weight=(1, 0.1, 10, 0.1), rot_w=1.0,
                  trans_w=0.1, lr=3e-6, batch_size=8, device='cuda:0', train_imu_denoiser=False):
@@ -50,8 +53,10 @@ class BilevelLoop:
 
     def step(self, sample, target='vo', next_sample=None):
         """One pass of train.py:200-299 over one batch of ``batch_size`` frames.  ``next_sample``: the following batch (or a
-        tuple of the following batches, nearest first); their frozen flow / disparity forwards are queued on a side stream as
-        soon as this batch's pose head is enqueued (TartanVO.prefetch) and overlap with this batch's IMU / PVGO / backward.
+        tuple of the following batches, nearest first); their frozen flow / disparity forwards are queued on a side stream
+        (TartanVO.prefetch) -- one batch ahead: BEFORE this batch's pose head, whose host glue synchronises with the device twice
+        (queued behind it the GPU sat idle for ~2 ms per batch: 511 -> ~600 frames/s) -- and overlap with this batch's pose head /
+        IMU / PVGO / backward.
         With TWO batches ahead the side stream never runs dry: with one, nothing but the launch-bound pose head runs between
         the end of batch k+1's frozen forward and the start of batch k+2's."""
         bs, dev = self.bs, self.device
@@ -69,12 +74,20 @@ class BilevelLoop:
         if motions is None:
             # a VO forward inside an IMU epoch (first epoch, or a short slice of last epoch's motions) must not leave gradients
             # on the pose head: the next 'vo' epoch's optimizer.step() would apply them (the IMU epoch never zeroes them)
+            def prefetch_next():
+                if next_sample is not None and hasattr(self.vo, 'prefetch'):
+                    for nxt in (next_sample if isinstance(next_sample, (tuple, list)) else (next_sample,)):
+                        if nxt is not None:
+                            self.vo.prefetch(nxt)
+            # the next batch's frozen forward is queued BEFORE this batch's pose head and host glue (ISLAM_PREFETCH_FIRST=0: behind them; the glue
+            # synchronises with the device twice; queued behind it, the side stream sat idle for ~2 ms per batch)
+            first = PREFETCH_FIRST and not isinstance(next_sample, (tuple, list))
+            if first:
+                prefetch_next()
             with torch.set_grad_enabled(target == 'vo'):
                 res = self.vo(sample)
-            if next_sample is not None and hasattr(self.vo, 'prefetch'):
-                for nxt in (next_sample if isinstance(next_sample, (tuple, list)) else (next_sample,)):
-                    if nxt is not None:
-                        self.vo.prefetch(nxt)
+            if not first:
+                prefetch_next()
             motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
             T_IL = self.T_IL.to(motions.device).to(motions.dtype)
             motions = T_IL @ motions @ T_IL.Inv()                                               # train.py:214-215

@@ -320,6 +320,8 @@ FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
 FLOW_PYR = _os.environ.get('ISLAM_FLOW_PYR', '1') == '1'
+# capture the frozen flow and stereo nets as two parallel branches of the HIP graph (0: one after the other)
+FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '0') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 
@@ -873,8 +875,9 @@ class VONet(nn.Module):
                     self._frozen_eager(*static_in)
             torch.cuda.synchronize(imgs[0].device)
             g = torch.cuda.CUDAGraph()
+            fork = torch.cuda.Stream(imgs[0].device) if FROZEN_FORK else None        # (created outside the capture)
             with torch.no_grad(), torch.cuda.graph(g):
-                static_out = self._frozen_eager(*static_in)
+                static_out = self._frozen_eager(*static_in, fork=fork)
             st = self._graphs[key] = (g, static_in, static_out)
         g, static_in, static_out = st
         # One launch of this graph in flight at a time: the host waits for the previous replay (and the clones of its outputs) before it
@@ -903,7 +906,19 @@ class VONet(nn.Module):
             return self._frozen_graphed((img0, img1, img0_norm, img0_r_norm))
         return self._frozen_eager(img0, img1, img0_norm, img0_r_norm)
 
-    def _frozen_eager(self, img0, img1, img0_norm, img0_r_norm):
+    def _frozen_eager(self, img0, img1, img0_norm, img0_r_norm, fork=None):
+        if fork is not None:
+            # the two nets are independent: captured as two parallel branches of the graph (fork / join on a second stream), the
+            # launch-bound stretches of one (pyramid levels 3-6 and the small decoder levels of the flow net, the hourglass stack of the
+            # stereo net) run beside the large convolutions of the other
+            cur = torch.cuda.current_stream(img0.device)
+            fork.wait_stream(cur)
+            with torch.cuda.stream(fork):
+                disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1), quarter=True)[0]
+                disp = disp.float().contiguous()
+            flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0].float().contiguous()
+            cur.wait_stream(fork)
+            return flow, disp
         flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0]
         # Network/VONet.py:33-34 keeps disp[..., ::4, ::4] (nearest, scale 1/4): only those pixels are computed (StereoNet7.forward)
         disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1), quarter=True)[0]
