@@ -168,7 +168,7 @@ def cpu_dense_protocol(prob_host):
     return out
 
 
-def vio_frames_per_sec(device, batch=8, steps=16, warmup=3):
+def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps = 0.2 s gave +-4 % run to run; 64: +-0.6 %)
     """Secondary metric of BASELINE.json ("stereo-VIO frames/sec", configs[1] shapes): the bilevel loop body of
     train.py:200-299 -- TartanVO forward at 448x640 (bf16 stereo net, HIP correlation/warp/scale), 2x IMU integrate,
     run_pvgo on the 9-node window, one-step backward -- on synthetic stereo pairs, random-init weights."""
