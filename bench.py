@@ -182,7 +182,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                   pose_dtype=torch.bfloat16 if os.environ.get('ISLAM_POSE_BF16') == '1' else None,   # measured: 330 vs 325 frames/s -- not worth the numerics
 
                   graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1',
-                  graph_pose=os.environ.get('ISLAM_NO_GRAPH') != '1')
+                  graph_pose=False if os.environ.get('ISLAM_NO_GRAPH') == '1' else (True if os.environ.get('ISLAM_POSE_GRAPH') == 'callables' else 'accumulate'))
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
         vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)

@@ -86,7 +86,9 @@ class TartanVO(nn.Module):
             self.vonet.set_pose_channels_last(True)
         if graph_frozen:        # the frozen flow + disparity forward replays from a HIP graph (VONet.set_graph_frozen)
             self.vonet.set_graph_frozen(True)
-        self.vonet.graph_pose = bool(graph_pose)     # forward + backward of the trainable pose head as HIP graphs
+        # forward + backward of the trainable pose head as HIP graphs; 'accumulate': the backward node adds the parameter gradients to
+        # .grad itself (nets._PoseGraph; torch.autograd.grad callers list vonet.pose_graph_leaf() among their inputs)
+        self.vonet.graph_pose = 'accumulate' if graph_pose == 'accumulate' else bool(graph_pose)
         self.vonet.pose_dtype = pose_dtype           # bf16 autocast for the trainable pose head (fp32 master weights)
 
     def load_model(self, model, modelname):

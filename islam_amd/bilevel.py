@@ -148,7 +148,10 @@ class BilevelLoop:
                   for grp in opt.param_groups for p in grp['params'] if p.requires_grad]
         if not params:                               # everything frozen: nothing to accumulate (autograd.grad rejects an empty list)
             return
-        grads = torch.autograd.grad(loss_bp, params, torch.ones_like(loss_bp), allow_unused=True)
+        # a pose head on nets._PoseGraph accumulates its own gradients inside its backward node; its leaf is listed so that the engine
+        # runs that node (its parameters then come back as unused)
+        leaf = getattr(getattr(getattr(self.vo, 'vonet', None), '_pose_graph', None), 'leaf', None)
+        grads = torch.autograd.grad(loss_bp, params + ([leaf] if leaf is not None else []), torch.ones_like(loss_bp), allow_unused=True)[:len(params)]
         acc, new = [], []
         for p, g in zip(params, grads):
             if g is None:

@@ -929,7 +929,15 @@ class VONet(nn.Module):
         x = torch.cat([flow, intrinsic], 1)
         if self.pose_channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        if self.graph_pose and self.flowPoseNet.training and torch.is_grad_enabled():
+        if self.graph_pose == 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled() and x.is_cuda:
+            # forward and backward as two HIP graphs whose backward node adds the parameter gradients to .grad itself (_PoseGraph)
+            with self._pose_autocast():
+                pg = self.__dict__.get('_pose_graph')
+                if pg is None:
+                    pg = self.__dict__['_pose_graph'] = _PoseGraph(self.flowPoseNet, x)
+                    self._pose_graphed = tuple(x.shape)
+                pose = _PoseGraphFn.apply(x, pg.leaf, pg) if tuple(x.shape) == self._pose_graphed else self.flowPoseNet(x)
+        elif self.graph_pose and self.flowPoseNet.training and torch.is_grad_enabled():
             # forward AND backward of the trainable pose head replay from two captured HIP graphs
             # (torch.cuda.make_graphed_callables patches the module's forward; eval mode keeps the eager path, and so does a
             # batch of another shape, e.g. the last one of an epoch)
@@ -949,6 +957,67 @@ class VONet(nn.Module):
         if self.pose_dtype is None:
             return contextlib.nullcontext()
         return torch.autocast('cuda', dtype=self.pose_dtype, cache_enabled=False)   # (no weight-cast cache: graph capture)
+
+
+class _PoseGraph:
+    """Forward and backward of the trainable pose head as two captured HIP graphs (what torch.cuda.make_graphed_callables builds), driven
+    by an autograd node that ACCUMULATES the parameter gradients itself instead of handing ~110 tensors back to the autograd engine: per
+    returned gradient the engine does stream bookkeeping (event record + wait) and runs a capture hook or an AccumulateGrad node -- 1-2 ms
+    of host time per backward, at the end of the batch where nothing else keeps the GPU busy (scripts/vio_gpu_busy.py: 1.3 ms without a
+    running kernel per pipelined step).  Same arithmetic as AccumulateGrad: p.grad <- p.grad + g in fp32 (first time: a copy).
+    ``leaf`` is a zero-dimensional tensor that requires grad: it keeps the node in the graph, and a caller that asks
+    torch.autograd.grad for explicit inputs must list it (BilevelLoop._accumulate_gradients does) or the engine prunes the node."""
+
+    def __init__(self, net, x):
+        dev = x.device
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.static_x = x.detach().clone()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                    # MIOpen's kernel choice and lazy initialisation: outside the capture
+            for _ in range(3):
+                y = net(self.static_x)
+                torch.autograd.grad(y, self.params, torch.ones_like(y), allow_unused=True)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd, pool=pool):
+            self.static_y = net(self.static_x)
+        self.static_gy = torch.zeros_like(self.static_y)
+        self.bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd, pool=pool):
+            self.static_grads = torch.autograd.grad(self.static_y, self.params, self.static_gy, allow_unused=True)
+        self.leaf = torch.zeros((), device=dev, requires_grad=True)
+        self.zero = torch.zeros((), device=dev)
+
+
+class _PoseGraphFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, leaf, pg):
+        pg.static_x.copy_(x)
+        pg.fwd.replay()
+        ctx.pg = pg
+        return pg.static_y.detach().clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        pg = ctx.pg
+        pg.static_gy.copy_(gy)
+        pg.bwd.replay()
+        acc, new = [], []
+        for p, g in zip(pg.params, pg.static_grads):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g.detach().clone()              # (static buffer of the graph: never keep it)
+            else:
+                acc.append(p.grad)
+                new.append(g)
+        if acc:
+            torch._foreach_add_(acc, new)
+        return None, pg.zero, None
 
 
 class _HalfExec:

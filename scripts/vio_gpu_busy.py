@@ -14,7 +14,7 @@ device = torch.device('cuda:0')
 batch = 8
 torch.manual_seed(0)
 vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16,
-              host_glue=True, miopen_find=True, pose_channels_last=True, graph_frozen=True, graph_pose=True)
+              host_glue=True, miopen_find=True, pose_channels_last=True, graph_frozen=True, graph_pose='accumulate')
 with torch.no_grad():
     vo.vonet.stereoNet.conv_c13.weight.zero_(); vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
 steps, warmup = 6, 4
@@ -61,3 +61,10 @@ print('idle gaps > 40 us inside one step (offset us, gap us, kernel before -> ke
 for r in rows:
     print('  %8.0f  %6.0f   %s  ->  %s' % r)
 print('sum of those gaps: %.0f us' % sum(r[1] for r in rows))
+if os.environ.get('GAP_CONTEXT') == '1':          # the launches around every gap, with start offsets and durations
+    for off, gap, _, _ in rows:
+        g0 = lo + off
+        print('--- gap at %.0f us (%.0f us)' % (off, gap))
+        near = [e for e in ev if g0 - 400 <= e[0] <= g0 + gap + 300]
+        for a, b, n in near[-40:]:
+            print('   %9.0f  +%6.1f  %s' % (a - lo, b - a, n[:70]))

@@ -14,7 +14,7 @@ device = torch.device('cuda:0')
 batch = 8
 torch.manual_seed(0)
 vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16,
-              host_glue=True, miopen_find=True, pose_channels_last=True, graph_frozen=True, graph_pose=True)
+              host_glue=True, miopen_find=True, pose_channels_last=True, graph_frozen=True, graph_pose='accumulate')
 with torch.no_grad():
     vo.vonet.stereoNet.conv_c13.weight.zero_(); vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
 steps, warmup = 12, 4

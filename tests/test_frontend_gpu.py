@@ -261,9 +261,12 @@ def test_pose_head_channels_last_is_the_same_function(cuda):
     torch.testing.assert_close(p2, p0, rtol=1e-3, atol=1e-5)
 
 
-def test_pose_head_graph_replay_trains_like_eager(cuda):
+@pytest.mark.parametrize('mode', [True, 'accumulate'])
+def test_pose_head_graph_replay_trains_like_eager(cuda, mode):
     """VONet.graph_pose: forward and backward of the trainable pose head replayed from HIP graphs give the eager pose and
-    parameter gradients, keep following the optimizer's in-place updates, and leave other batch shapes on the eager path."""
+    parameter gradients, keep following the optimizer's in-place updates, and leave other batch shapes on the eager path.
+    'accumulate': the backward node adds the gradients to .grad itself (nets._PoseGraph) -- also on top of gradients that are
+    already there (second backward without zero_grad)."""
     from islam_amd import nets
     torch.manual_seed(7)
     B = 2
@@ -272,7 +275,7 @@ def test_pose_head_graph_replay_trains_like_eager(cuda):
     vb.load_state_dict(va.state_dict())
     for v in (va, vb):
         v.flowPoseNet.to(cuda).train()
-    vb.graph_pose = True
+    vb.graph_pose = mode
     opt = [torch.optim.SGD(v.flowPoseNet.parameters(), lr=1e-3) for v in (va, vb)]
     wts = torch.arange(1, 7, device=cuda, dtype=torch.float32)
     for it in range(3):
@@ -284,6 +287,9 @@ def test_pose_head_graph_replay_trains_like_eager(cuda):
             o.zero_grad(set_to_none=True)
             _, _, pose = v(None, None, None, None, intr, frozen=frozen)
             (pose * wts).sum().backward()
+            if it == 1:                                          # accumulation onto existing gradients
+                _, _, pose2 = v(None, None, None, None, intr, frozen=frozen)
+                (pose2 * wts).sum().backward()
             poses.append(pose.detach().clone())
             grads.append([p.grad.detach().clone() for p in v.flowPoseNet.parameters()])
             o.step()
