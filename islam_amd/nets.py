@@ -164,8 +164,10 @@ class PWCDCNet(nn.Module):
             o += p.shape[1]
         return self._dense_run(l, buf, od)
 
-    def _dense_run(self, l, buf, od):
-        """The five convolutions of level l's DenseNet block on a buffer whose last ``od`` channels (the block's input) are filled."""
+    def _dense_run(self, l, buf, od, keep32=True):
+        """The five convolutions of level l's DenseNet block on a buffer whose last ``od`` channels (the block's input) are filled.
+        keep32=False: the convolutions write the bf16 mirror only (no fp32 NCHW copy of their outputs: nobody reads it when the
+        flow head and the up-sampled features are taken from the mirror, _head_up_mirror)."""
         B, tot, H, W = buf.shape
         off = tot - od
         if FLOW_NHWC and off % 8 == 0 and all(w % 8 == 0 for w in self.DENSE):
@@ -174,7 +176,7 @@ class PWCDCNet(nn.Module):
             ops.nchw_to_nhwc_mirror(buf, off, od, mir, off)            # the block's input (correlation, features, flow, up-features)
             for i, w in enumerate(self.DENSE):
                 packed, bias, conv = self._packed_flow('conv%d_%d' % (l, i), totp - off)
-                ops.conv_nhwc_flow(mir, off, totp - off, packed, bias, buf, off - w, w, 0.1, ymir=mir, moff=off - w)
+                ops.conv_nhwc_flow(mir, off, totp - off, packed, bias, buf if keep32 else None, off - w, w, 0.1, ymir=mir, moff=off - w)
                 off -= w
             return buf, mir
         for i, w in enumerate(self.DENSE):
@@ -215,6 +217,49 @@ class PWCDCNet(nn.Module):
         return ops.flow_head_up(x.contiguous(), hit[1], head.bias.detach(), dc.weight.detach() if up else None,
                                 dc.bias.detach() if up and dc.bias is not None else None, up_out=up_out, up_coff=up_coff)
 
+    def _head_up_mirror(self, l, mir, tot, up, up_out=None, up_coff=0):
+        """predict_flow{l} and upfeat{l} (PWCNet.py:216-222) as ONE 3x3 convolution of the level's bf16 channels-last mirror on the
+        matrix-core kernel: the transposed convolution's output pixel (2y+a, 2x+c) is a 2x2 sub-window of the 3x3 neighbourhood of input
+        pixel (y, x) (K[a+r, c+s] = W[:, o, 3-2r-a, 3-2s-c], zero elsewhere), so its 2 channels x 4 parity classes are 8 output channels
+        of a stride-1 3x3 convolution, the flow head's two are channels 8, 9 (padded to 16), and a pixel shuffle puts the 8 back on the
+        2H x 2W grid.  bf16 operands (the mirror is what the DenseNet convolutions consumed; the head ran with bf16 operands before, the
+        transposed convolution's weights are rounded here for the first time).  Returns (flow (B,2,H,W) fp32, up-sampled features or None)."""
+        head = getattr(self, 'predict_flow%d' % l)
+        dc = getattr(self, 'upfeat%d' % l) if up else None
+        cache = self.__dict__.setdefault('_headm_cache', {})
+        key = (head.weight._version, head.weight.data_ptr(), None if dc is None else (dc.weight._version, dc.weight.data_ptr()), mir.shape[1])
+        hit = cache.get(l)
+        if hit is None or hit[0] != key:
+            C = head.weight.shape[1]
+            w = torch.zeros((16, mir.shape[1], 3, 3), dtype=torch.float32, device=mir.device)     # (zero rows for the mirror's padding channels)
+            b = torch.zeros(16, dtype=torch.float32, device=mir.device)
+            w[8:10, :C] = head.weight.detach()
+            b[8:10] = head.bias.detach()
+            if dc is not None:
+                wu = dc.weight.detach()                                                             # (C, 2, 4, 4)
+                for o in range(2):
+                    for a in range(2):
+                        for c in range(2):
+                            for r in range(2):
+                                for q in range(2):
+                                    w[o * 4 + a * 2 + c, :C, a + r, c + q] = wu[:, o, 3 - 2 * r - a, 3 - 2 * q - c]
+                            if dc.bias is not None:
+                                b[o * 4 + a * 2 + c] = dc.bias.detach()[o]
+            hit = cache[l] = (key, ops.pack_conv_nhwc_weight(w.to(torch.bfloat16)), b)
+        B, _, H, W = mir.shape
+        y = torch.empty((B, 16, H, W), dtype=torch.float32, device=mir.device)
+        ops.conv_nhwc_flow(mir, 0, mir.shape[1], hit[1], hit[2], y, 0, 16, 1.0)
+        flow = y[:, 8:10].contiguous()
+        upf = None
+        if up:
+            src = y[:, :8].view(B, 2, 2, 2, H, W).permute(0, 1, 4, 2, 5, 3)                        # (B, o, H, a, W, c)
+            if up_out is not None:
+                up_out[:, up_coff:up_coff + 2].view(B, 2, H, 2, W, 2).copy_(src)
+                upf = up_out
+            else:
+                upf = src.reshape(B, 2, 2 * H, 2 * W)
+        return flow, upf
+
     def _up2(self, name, t):
         """The 4x4 stride-2 transposed convolutions with TWO output channels (deconv / upfeat): a memory-bound channel reduction on
         islam_deconv4x4s2_to2_f32 instead of MIOpen's backward-data kernels (ISLAM_FLOW_UP2=0: MIOpen)."""
@@ -245,7 +290,7 @@ class PWCDCNet(nn.Module):
             a6 = p1[5].contiguous()
             buf = torch.empty((a6.shape[0], nd + 81, a6.shape[2], a6.shape[3]), dtype=torch.float32, device=x.device)
             ops.corr81_act(a6, p2[5].contiguous(), buf, nd, 0.1)
-            x, mir = self._dense_run(6, buf, 81)
+            x, mir = self._dense_run(6, buf, 81, keep32=not FLOW_HEAD_MIRROR)
         else:
             x, mir = self._dense_mfma(6, [lrelu(corr_fn(p1[5].contiguous(), p2[5].contiguous()))])
         flows = {}
@@ -255,19 +300,22 @@ class PWCDCNet(nn.Module):
                 # [conv4 .. conv0 | corr 81 | features ca | up_flow 2 | up_feat 2] (PWCNet.py:227 torch.cat order)
                 ca = a.shape[1]
                 buf = torch.empty((a.shape[0], nd + 81 + ca + 4, a.shape[2], a.shape[3]), dtype=torch.float32, device=x.device)
-                flows[l + 1], _ = self._head_up(l + 1, x, True, up_out=buf, up_coff=nd + 81 + ca + 2)
+                if FLOW_HEAD_MIRROR and mir is not None:
+                    flows[l + 1], _ = self._head_up_mirror(l + 1, mir, x.shape[1], True, up_out=buf, up_coff=nd + 81 + ca + 2)
+                else:
+                    flows[l + 1], _ = self._head_up(l + 1, x, True, up_out=buf, up_coff=nd + 81 + ca + 2)
                 up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
                 warped = warp_fn(b2, up_flow, self.WARP_SCALE[l])
                 ops.corr81_act(a, warped, buf, nd, 0.1)
                 buf[:, nd + 81:nd + 81 + ca].copy_(a)
                 buf[:, nd + 81 + ca:nd + 81 + ca + 2].copy_(up_flow)
-                x, mir = self._dense_run(l, buf, 81 + ca + 4)
+                x, mir = self._dense_run(l, buf, 81 + ca + 4, keep32=not FLOW_HEAD_MIRROR)
                 continue
             flows[l + 1], up_feat = self._head_up(l + 1, x, True)
             up_flow = self._up2('deconv%d' % (l + 1), flows[l + 1])
             warped = warp_fn(b2, up_flow.contiguous(), self.WARP_SCALE[l])
             x, mir = self._dense_mfma(l, [lrelu(corr_fn(a, warped)), a, up_flow, up_feat])
-        flow2 = self._head_up(2, x, False)[0]
+        flow2 = self._head_up_mirror(2, mir, x.shape[1], False)[0] if (direct and FLOW_HEAD_MIRROR and mir is not None) else self._head_up(2, x, False)[0]
         Hc, Wc = x.shape[2], x.shape[3]
         if mir is not None and all(Hc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0 and Wc % getattr(self, 'dc_conv%d' % i)[0].dilation[0] == 0
                                    for i in range(1, 7)):
@@ -320,6 +368,8 @@ FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
 FLOW_PYR = _os.environ.get('ISLAM_FLOW_PYR', '1') == '1'
+# flow head + up-sampled features of a level as one 3x3 convolution of the bf16 mirror; the DenseNet convolutions then skip their fp32 copies
+FLOW_HEAD_MIRROR = _os.environ.get('ISLAM_FLOW_HEAD_MIRROR', '1') == '1'
 # capture the frozen flow and stereo nets as two parallel branches of the HIP graph (0: one after the other)
 FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '0') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)

@@ -442,3 +442,38 @@ def test_correlation_with_activation_into_a_channel_slice(cuda, B, C, H, W):
     ops.corr81_act(a, b, buf, 5, 0.1)
     assert torch.equal(buf[:, 5:86], want)
     assert bool((buf[:, :5] == 3.0).all()) and bool((buf[:, 86:] == 3.0).all())
+
+
+@pytest.mark.parametrize('H,W,up', [(14, 20, True), (9, 23, True), (28, 40, False)])
+def test_flow_head_and_upsampled_features_from_the_mirror(cuda, H, W, up):
+    """PWCDCNet._head_up_mirror (predict_flow + upfeat as ONE 3x3 matrix-core convolution of the bf16 channels-last mirror, the
+    transposed convolution's four parity classes as output channels + pixel shuffle) against torch's Conv2d / ConvTranspose2d in float64
+    on the same bf16 operands, also into a channel slice of a larger buffer."""
+    from islam_amd import nets
+    torch.manual_seed(3)
+    net = nets.PWCDCNet().to(cuda)
+    l = 5
+    head, dc = net.predict_flow5, net.upfeat5
+    with torch.no_grad():
+        for p in list(head.parameters()) + list(dc.parameters()):
+            p.copy_(torch.randn_like(p) * (0.02 if p.dim() > 1 else 0.5))
+    C = head.weight.shape[1]
+    Cp = (C + 7) // 8 * 8
+    B = 2
+    mir = torch.zeros((B, Cp, H, W), dtype=torch.bfloat16, device=cuda).contiguous(memory_format=torch.channels_last)
+    mir[:, :C] = torch.randn(B, C, H, W, device=cuda).to(torch.bfloat16)
+    r = lambda t: t.detach().to(torch.bfloat16).double()
+    x64 = mir[:, :C].double()
+    want_flow = torch.nn.functional.conv2d(x64, r(head.weight), head.bias.double(), padding=1)
+    flow, upf = net._head_up_mirror(l, mir, C, up)
+    scale = float(want_flow.abs().max())
+    assert float((flow.double() - want_flow).abs().max()) <= 2e-5 * scale + 1e-6
+    if up:
+        want_up = torch.nn.functional.conv_transpose2d(x64, r(dc.weight), dc.bias.double(), stride=2, padding=1)
+        assert tuple(upf.shape) == tuple(want_up.shape)
+        assert float((upf.double() - want_up).abs().max()) <= 2e-5 * float(want_up.abs().max()) + 1e-6
+        buf = torch.full((B, 7, 2 * H, 2 * W), 3.0, device=cuda)
+        net._head_up_mirror(l, mir, C, True, up_out=buf, up_coff=4)
+        assert torch.equal(buf[:, 4:6], upf) and bool((buf[:, :4] == 3.0).all()) and bool((buf[:, 6:] == 3.0).all())
+    else:
+        assert upf is None
