@@ -534,7 +534,13 @@ class feature_extraction(nn.Module):
             feat = torch.cat(pieces, 1)
             if self.bigger:
                 feat = torch.cat((ops.resize_bilinear(feat, [hw[0] * 2, hw[1] * 2], align_corners=True), o0), 1)
-        return self.lastconv[2](_cbn(self.lastconv[0], feat, relu=True))
+        last = self.lastconv[2]                               # Conv2d(128, 32, 1, bias=False) behind (convbn, ReLU)
+        y = _cbn(self.lastconv[0], feat, relu=True, defer=True)
+        if isinstance(y, _Pending) and last.bias is None and _hip_conv_ok(last, y.raw, fused_1x1=True):
+            # BatchNorm + ReLU of the 352 -> 128 convolution applied while the 1x1 convolution stages its input: no apply pass over the
+            # 128-channel half-resolution tensor (94 us) and no MIOpen / CK launch (94 us) -- one launch of the channels-last kernel
+            return ops.conv_nhwc(y.raw, _packed_nhwc(last), last.out_channels, 1, in_affine=y.affine)
+        return last(y.materialize() if isinstance(y, _Pending) else y)
 
 
 class _HGConv(nn.Module):

@@ -54,10 +54,26 @@ BF16_OPERANDS = (8e-2, 3e-2, 1e-2)        # islam_conv3x3_mfma path: max, rms, |
 BF16_STEREO = (6e-2, 3e-2, 2.5e-2)        # bf16 execution copy of the stereo net: max, rms, |bias|
 
 
-def _within(got, ref, bounds, what=''):
+def _within(got, ref, bounds, what='', flips=False):
+    """max / rms / bias of the error within ``bounds``.  flips=True (outputs behind PWC-Net's warp): the warp zeroes a feature pixel
+    when its validity mask drops below 0.9999 (PWCNet.py:195-206) -- a DISCONTINUITY of the reference network.  A rounding-level change
+    of the up-sampled flow can flip that decision for a pixel on the edge, and the 3x3 / dilated convolutions behind it spread the
+    difference over its neighbourhood: on the 128x192 vector one flipped pixel of the level-2 warp puts 7 of 1536 pixels of the
+    full-resolution flow above 5e-2 (max 1.08e-1) while rms and bias stay inside their bounds (scripts/debug/flow0_outliers.py; which
+    way the pixel falls depends on MIOpen's choice of fp32 kernels for the stride-2 pyramid layers, which differs between machines of
+    the pool).  So for those outputs the maximum may exceed its bound on at most 1 % of the pixels, and never 3x the bound; rms and
+    bias keep their bounds -- a wrong kernel moves those."""
     mx, rms, bias = _stats(got, ref)
     print('%s: max %.3e rms %.3e bias %+.3e' % (what, mx, rms, bias))
-    assert mx <= bounds[0] and rms <= bounds[1] and abs(bias) <= bounds[2], (what, mx, rms, bias)
+    assert rms <= bounds[1] and abs(bias) <= bounds[2], (what, mx, rms, bias)
+    if mx > bounds[0] and flips:
+        r = np.asarray(ref, np.float64)
+        e = np.abs(got.detach().float().cpu().numpy().astype(np.float64) - r) / max(np.abs(r).max(), 1e-3)
+        frac = float((e > bounds[0]).mean())
+        print('%s: %.2f %% of the elements above %.1e' % (what, 100 * frac, bounds[0]))
+        assert frac <= 0.01 and mx <= 3 * bounds[0], (what, mx, frac)
+    else:
+        assert mx <= bounds[0], (what, mx, rms, bias)
     return mx
 
 
@@ -113,7 +129,7 @@ def test_flow_net_matrix_core_path_matches_reference(cuda):
     net = fill_state_dict(nets.PWCDCNet()).to(cuda).eval()
     with torch.no_grad():
         flows, _ = net.forward_mfma(make_input('pwc').to(cuda))
-    errs = [_within(f, ref['flow%d' % i], BF16_OPERANDS, 'flow%d' % i) for i, f in enumerate(flows)]
+    errs = [_within(f, ref['flow%d' % i], BF16_OPERANDS, 'flow%d' % i, flips=True) for i, f in enumerate(flows)]
     assert max(errs) > 1e-5                  # it IS the reduced-precision path (the fp32 path sits at ~1e-6)
 
 
@@ -179,7 +195,7 @@ def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph):
         rm0 = vn.stereoNet.state_dict()[key].clone()
         with torch.no_grad():
             flow, disp, pose = vn(*args)
-        _within(flow, ref['flow'], BF16_OPERANDS, 'flow')
+        _within(flow, ref['flow'], BF16_OPERANDS, 'flow', flips=True)
         _within(disp, ref['disp'], BF16_STEREO, 'disp')
         assert _relmax(pose, ref['pose']) <= 1e-2, rep     # pose head (fp32) fed with that flow (measured 7e-4)
         assert not torch.equal(vn.stereoNet.state_dict()[key], rm0)
