@@ -221,9 +221,9 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                     'implicit-GEMM kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load; pooling / up-sample+add / SPP '
                     'kernels), the decoder\'s transposed convolutions on the same kernel, the four stride-2 convolutions on MIOpen / CK; '
                     'flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, fp32 accumulate; DenseNet blocks on the channels-last kernel '
-                    'through a bf16 mirror of the fp32 buffer), pyramid levels 1-2 as one fused three-layer launch each, flow heads + '
-                    'two-channel transposed convolutions as fp32 channel reductions, stride-2 layers of levels 3-6 on MIOpen; pose head '
-                    'fp32 (trainable, MIOpen with a pinned solution set)',
+                    'through a bf16 mirror of the fp32 buffer), pyramid levels 1-2 as one fused three-layer launch each, flow head + '
+                    'up-sampled features of a level as one convolution of the mirror, stride-2 layers of levels 3-6 on MIOpen; pose head '
+                    'fp32 (trainable, MIOpen with a pinned solution set; forward / backward as HIP graphs)',
             'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
             'ms_per_batch': el / steps * 1e3,
             'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
