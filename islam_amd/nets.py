@@ -370,8 +370,9 @@ FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
 FLOW_PYR = _os.environ.get('ISLAM_FLOW_PYR', '1') == '1'
 # flow head + up-sampled features of a level as one 3x3 convolution of the bf16 mirror; the DenseNet convolutions then skip their fp32 copies
 FLOW_HEAD_MIRROR = _os.environ.get('ISLAM_FLOW_HEAD_MIRROR', '1') == '1'
-# capture the frozen flow and stereo nets as two parallel branches of the HIP graph (0: one after the other)
-FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '0') == '1'
+# capture the frozen flow and stereo nets as two parallel branches of the HIP graph (0: one after the other): forward-only +11 %,
+# sequential bilevel step +6 %, pipelined step unchanged (scripts/vio_only.py, five runs each)
+FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '1') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 
