@@ -118,13 +118,15 @@ class PWCDCNet(nn.Module):
         return hit[1], hit[2], hit[3]
 
     def _c(self, name, x, out=None, coff=0, xoff=0):
-        """One `conv()` block (PWCNet.py:16-20).  Stride-1 layers with dilation <= 8 and >= 16 input channels run on the HIP
-        kernel (1.3-4.5x MIOpen's fp32 Winograd there, scripts/conv_bench.py); the stride-2 pyramid heads and the dilation-16
-        context layer (its halo tile does not fit the prefetch registers) stay on MIOpen."""
+        """One `conv()` block (PWCNet.py:16-20).  Layers with dilation <= 8 and >= 16 input channels run on the HIP kernel (1.3-4.5x
+        MIOpen's fp32 Winograd on the stride-1 layers, scripts/conv_bench.py; the stride-2 heads of pyramid levels 3-6 for the launches
+        they save: MIOpen's kernel + layout transposes + a bias and a LeakyReLU launch each, and because MIOpen's choice of kernel for
+        them differs between machines); what is left for MIOpen: the dilation-16 layer when the sub-grid path does not apply."""
         packed, bias, conv = self._packed(name)
         act = isinstance(getattr(self, name), nn.Sequential)
-        if conv.stride[0] == 1 and conv.dilation[0] <= 8 and conv.in_channels >= 16:
-            return ops.conv3x3_mfma(x, packed, bias, conv.out_channels, 1, conv.dilation[0], 0.1 if act else 1.0, out, coff, xoff)
+        if (conv.stride[0] == 1 or (FLOW_S2_HIP and conv.stride[0] == 2 and conv.dilation[0] == 1)) and conv.dilation[0] <= 8 \
+                and conv.in_channels >= 16:
+            return ops.conv3x3_mfma(x, packed, bias, conv.out_channels, conv.stride[0], conv.dilation[0], 0.1 if act else 1.0, out, coff, xoff)
         xin = x if xoff == 0 else x[:, xoff:]
         y = conv(xin)
         y = F.leaky_relu(y, 0.1) if act else y
@@ -368,6 +370,8 @@ FLOW_NHWC = _os.environ.get('ISLAM_FLOW_NHWC', '1') == '1'
 HIP_CONV_MAX_C = int(_os.environ.get('ISLAM_HIP_CONV_MAX_C', '512'))
 FLOW_UP2 = _os.environ.get('ISLAM_FLOW_UP2', '1') == '1'
 FLOW_PYR = _os.environ.get('ISLAM_FLOW_PYR', '1') == '1'
+# stride-2 layers of pyramid levels 3-6 on islam_conv3x3_mfma (bias + LeakyReLU in the launch) instead of MIOpen + bias + activation launches
+FLOW_S2_HIP = _os.environ.get('ISLAM_FLOW_S2_HIP', '1') == '1'
 # flow head + up-sampled features of a level as one 3x3 convolution of the bf16 mirror; the DenseNet convolutions then skip their fp32 copies
 FLOW_HEAD_MIRROR = _os.environ.get('ISLAM_FLOW_HEAD_MIRROR', '1') == '1'
 # capture the frozen flow and stereo nets as two parallel branches of the HIP graph (0: one after the other): forward-only +11 %,
