@@ -278,19 +278,43 @@ namespace {
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
+// element index -> (channel octet, x, y, image) of a (B, Ho, Wo, C8) tensor.  32-bit arithmetic whenever the count allows: a 64-bit
+// integer division is a ~100-instruction software routine on the GPU, and six of them per 16-byte output made the element-wise kernels
+// below issue-bound instead of memory-bound.
+struct Idx4 { int cg, ox, oy, b; long long pix; };
+__device__ __forceinline__ Idx4 split4(long long i, long long total, int C8, int Wo, int Ho) {
+    Idx4 r;
+    if (total <= 0x7fffffffLL) {
+        unsigned p = (unsigned)i;
+        r.cg = (int)(p % (unsigned)C8); p /= (unsigned)C8;
+        r.pix = p;
+        r.ox = (int)(p % (unsigned)Wo); p /= (unsigned)Wo;
+        r.oy = (int)(p % (unsigned)Ho);
+        r.b = (int)(p / (unsigned)Ho);
+    } else {
+        long long p = i;
+        r.cg = (int)(p % C8); p /= C8;
+        r.pix = p;
+        r.ox = (int)(p % Wo); p /= Wo;
+        r.oy = (int)(p % Ho);
+        r.b = (int)(p / Ho);
+    }
+    return r;
+}
+__device__ __forceinline__ int octet_of(long long i, long long total, int C8) {
+    return total <= 0x7fffffffLL ? (int)((unsigned)i % (unsigned)C8) : (int)(i % C8);
+}
+
+
 __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8,
                                                                         int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                                         int align, long long total, int yC8, int yoff8,
                                                                         const uint4* __restrict__ add) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int cg = (int)(i % C8);
-    long long p = i / C8;
-    const long long opix = p;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    const Idx4 ix = split4(i, total, C8, Wo, Ho);
+    const int cg = ix.cg, ox = ix.ox, oy = ix.oy, b = ix.b;
+    const long long opix = ix.pix;
     float fy, fx;
     if (align) {
         fy = sh * oy;
@@ -328,12 +352,8 @@ __global__ __launch_bounds__(256) void maxpool2_nhwc_bf16_kernel(const uint4* __
                                                                  int Ho, int Wo, int relu, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int cg = (int)(i % C8);
-    long long p = i / C8;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    const Idx4 ix = split4(i, total, C8, Wo, Ho);
+    const int cg = ix.cg, ox = ix.ox, oy = ix.oy, b = ix.b;
     const uint4* base = x + (((size_t)b * Hi + 2 * oy) * Wi + 2 * ox) * C8 + cg;
     const uint4 a = base[0], bq = base[C8], c = base[(size_t)Wi * C8], d = base[(size_t)Wi * C8 + C8];
     auto mx = [&](unsigned va, unsigned vb, unsigned vc, unsigned vd) {
@@ -355,12 +375,8 @@ __global__ __launch_bounds__(256) void block_mean_nhwc_bf16_kernel(const uint4* 
                                                                    int Ho, int Wo, int k, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int cg = (int)(i % C8);
-    long long p = i / C8;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    const Idx4 ix = split4(i, total, C8, Wo, Ho);
+    const int cg = ix.cg, ox = ix.ox, oy = ix.oy, b = ix.b;
     const uint4* base = x + (((size_t)b * Hi + (size_t)k * oy) * Wi + (size_t)k * ox) * C8 + cg;
     float acc[8];
 #pragma unroll
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(256) void bias_act_add_nhwc_bf16_kernel(uint4* __re
                                                                      const uint4* __restrict__ res, int C8, int relu, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c0 = (int)(i % C8) * 8;
+    const int c0 = octet_of(i, total, C8) * 8;
     const uint4 v = y[i];
     uint4 r = make_uint4(0, 0, 0, 0);
     if (res) r = res[i];
@@ -586,7 +602,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
                                                        const float* __restrict__ scale_shift, int C8, int relu, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int C = C8 * 8, c0 = (int)(i % C8) * 8;
+    const int C = C8 * 8, c0 = octet_of(i, total, C8) * 8;
     const uint4 v = x[i];
     uint4 r = make_uint4(0, 0, 0, 0);
     if (res) r = res[i];
