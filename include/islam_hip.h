@@ -120,6 +120,10 @@ int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, 
  * like the two separate ops.  add, y: (B,Ho,Wo,C). */
 int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                         int align_corners, void* stream);
+/* The same into channels [yoff, yoff+C) of y = (B,Ho,Wo,ytot): the hourglass's half of the decoder's concatenations
+ * (Network/StereoNet7.py:129-138 `x = self.conv_c8(x); x = torch.cat((x, cat2), dim=1)` ...) is written in place. */
+int islam_resize_bilinear_add_nhwc_bf16_into(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho,
+                                             int Wo, int align_corners, int ytot, int yoff, void* stream);
 /* MaxPool2d(2, 2) / F.max_pool2d(kernel_size=2) of a channels-last bf16 tensor (hourglass.py:52, StereoNet7.py:117-125), relu != 0:
  * of relu(x) (the two commute); (B,H,W,C) -> (B,H/2,W/2,C), C a multiple of 8. */
 int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int relu, void* stream);
@@ -183,7 +187,7 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const uint16_t* wpacked, const float* bias, float* y32, int ytot,
                          int coff, uint16_t* ymir, int mtot, int moff, int B, int H, int W, int Cout, int dilation, float slope, void* stream);
 /* ConvTranspose2d(Cin, Cout, kernel 4, stride 2, padding 1) + bias (+ ReLU, relu = 1) of the frozen stereo net's decoder --
- * /root/reference/Network/StereoNet7.py:121-139 (deconv_c7_2, deconv_c7 ... deconv_c10) with the activation of :180-190 -- on the
+ * Network/StereoNet7.py:78-90 (deconv_c7_2, deconv_c7 ... deconv_c10) with the activation and concatenation of :121-136 -- on the
  * channels-last matrix-core kernel: four dense 2x2 convolutions, one per output parity class (a, c) of pixel (2y + a, 2x + c), taps
  * K[r][s] = W[:, :, 3 - 2r - a, 3 - 2s - c].  x: (B,H,W,Cin) bf16; wpacked: islam_deconv_nhwc_packed_elems(Cin, Cout) bf16 elements,
  * [class a*2+c][tap r*2+s][CoutP][CinP]; the result goes to channels [yoff, yoff + Cout) of y = (B,2H,2W,ytot) bf16 (the channel

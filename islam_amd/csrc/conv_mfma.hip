@@ -432,6 +432,14 @@ extern "C" int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint
     return resize_bilinear_launch(x, add, y, B, C, Hi, Wi, Ho, Wo, align_corners, C, 0, stream);
 }
 
+// the same into channels [yoff, yoff + C) of a (B,Ho,Wo,ytot) tensor: the decoder's torch.cat((conv_c8(...), skip), 1) etc.
+// (StereoNet7.py:129-138) without copying the hourglass's half of the concatenation
+extern "C" int islam_resize_bilinear_add_nhwc_bf16_into(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi,
+                                                        int Ho, int Wo, int align_corners, int ytot, int yoff, void* stream) {
+    if (!add) return fail(ISLAM_EARG, "islam_resize_bilinear_add_nhwc_bf16_into: null addend");
+    return resize_bilinear_launch(x, add, y, B, C, Hi, Wi, Ho, Wo, align_corners, ytot, yoff, stream);
+}
+
 // MaxPool2d(2, 2) / F.max_pool2d(kernel_size=2) of a channels-last bf16 tensor, optionally of relu(x) (StereoNet7.py:117-125
 // `pool(act(conv(x)))`, hourglass.py:52 pool1); (B,H,W,C) -> (B,H/2,W/2,C)
 extern "C" int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int relu, void* stream) {

@@ -487,7 +487,7 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 
 
 // ConvTranspose2d(Cin, Cout, kernel 4, stride 2, padding 1) + bias (+ ReLU) of the frozen stereo net's decoder
-// (Network/StereoNet7.py:121-139 deconv_c7_2 ... deconv_c10, the ReLU of :180-190) on the kernel above: four 2x2 convolutions, one per
+// (Network/StereoNet7.py:78-90 deconv_c7_2 ... deconv_c10, their ReLU and concatenation at :121-136) on the kernel above: four 2x2 convolutions, one per
 // output parity class (see Slices).  x: (B,H,W,Cin) bf16; wpacked: [4 classes][4 taps][CoutP][CinP] bf16 (islam_amd/ops.py
 // pack_deconv_nhwc_weight); the result goes to channels [yoff, yoff + Cout) of y = (B,2H,2W,ytot) bf16 -- straight into the channel
 // slice of the concatenation the decoder builds next, no torch.cat copy of this half.  MIOpen ran these as bf16 implicit-GEMM

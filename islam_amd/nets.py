@@ -607,15 +607,25 @@ class Hourglass(nn.Module):
         self.low3 = _HGResidual(nf, nf)
         self.up2 = nn.Upsample(scale_factor=2, mode='bilinear')
 
-    def forward(self, x):
+    def forward(self, x, cat_with=None):
+        """cat_with: a tensor the caller concatenates behind the result (torch.cat((hourglass(x), cat_with), 1)); on the bf16
+        channels-last path the result is written straight into its half of that concatenation, which is returned."""
         u = self.up1(x)
         fused = ops.fusable_nhwc_bf16(u, u.shape[1])
         low = self.low3(self.low2(ops.maxpool2(u) if fused else self.pool1(u)))
         # self.up2 = nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False); HIP kernels for bf16 channels-last:
         # pooling, and the up-sampling with the addition of u in the same pass
         if fused and ops.fusable_nhwc_bf16(low, low.shape[1]) and (low.shape[2] * 2, low.shape[3] * 2) == tuple(u.shape[2:]):
-            return ops.resize_bilinear_add(low, u)
-        return u + ops.resize_bilinear(low, (low.shape[2] * 2, low.shape[3] * 2), align_corners=False)
+            if cat_with is not None and ops.fusable_nhwc_bf16(cat_with, cat_with.shape[1]) and cat_with.shape[2:] == u.shape[2:]:
+                c = u.shape[1]
+                out = torch.empty((u.shape[0], c + cat_with.shape[1], u.shape[2], u.shape[3]), dtype=u.dtype, device=u.device,
+                                  memory_format=torch.channels_last)
+                out[:, c:].copy_(cat_with)
+                return ops.resize_bilinear_add(low, u, out=out, coff=0)
+            y = ops.resize_bilinear_add(low, u)
+        else:
+            y = u + ops.resize_bilinear(low, (low.shape[2] * 2, low.shape[3] * 2), align_corners=False)
+        return y if cat_with is None else torch.cat((y, cat_with), 1)
 
 
 class SSP(nn.Module):
@@ -699,9 +709,9 @@ class StereoNet7(nn.Module):
         x = act(self.conv_c6_2(relu_pool(self.conv_c6(cat4))))                # 1/64, 512
         x = self._deconv_act(self.deconv_c7_2, x, cat4)
         x = self._deconv_act(self.deconv_c7, x, cat3)
-        x = torch.cat((self.conv_c8(self._deconv_act(self.deconv_c8, x)), cat2), 1)
-        x = torch.cat((self.conv_c9(self._deconv_act(self.deconv_c9, x)), cat1), 1)
-        x = torch.cat((self.conv_c10(self._deconv_act(self.deconv_c10, x)), cat0), 1)
+        x = self.conv_c8(self._deconv_act(self.deconv_c8, x), cat_with=cat2)     # = torch.cat((conv_c8(...), cat2), 1), StereoNet7.py:129-138
+        x = self.conv_c9(self._deconv_act(self.deconv_c9, x), cat_with=cat1)
+        x = self.conv_c10(self._deconv_act(self.deconv_c10, x), cat_with=cat0)
         if quarter:
             x = act(self._deconv_c11_quarter(x))
         else:
@@ -709,7 +719,7 @@ class StereoNet7(nn.Module):
         return self.conv_c13(act(self.conv_c12(x))), None
 
     def _deconv_act(self, dc, x, skip=None):
-        """act(dc(x)), concatenated with ``skip`` when given (StereoNet7.py:180-190).  On the frozen bf16 channels-last execution
+        """act(dc(x)), concatenated with ``skip`` when given (StereoNet7.py:121-136).  On the frozen bf16 channels-last execution
         copy the 4x4 stride-2 transposed convolution runs on islam_deconv4x4s2_nhwc_bf16 -- four 2x2 convolutions on the matrix
         cores, bias + ReLU in the epilogue, written straight into its channel slice of the concatenation (MIOpen ran these as
         bf16 backward-data kernels whose output was then activated and copied by torch.cat)."""

@@ -399,11 +399,18 @@ def conv_nhwc_flow(xm, xoff, cin, packed, bias, y32, coff, cout, slope, ymir=Non
     return y32 if y32 is not None else ymir
 
 
-def resize_bilinear_add(x, add, align_corners=False):
+def resize_bilinear_add(x, add, align_corners=False, out=None, coff=0):
     """add + F.interpolate(x, add's size, mode='bilinear') in one pass over channels-last bf16 tensors
-    (islam_resize_bilinear_add_nhwc_bf16: the hourglass's `up1 + up2(low)`)."""
+    (islam_resize_bilinear_add_nhwc_bf16: the hourglass's `up1 + up2(low)`).  ``out``: write into out[:, coff:coff+C] of a larger
+    channels-last bf16 tensor (a concatenation under construction) and return ``out``."""
     B, C, Hi, Wi = x.shape
     assert fusable_nhwc_bf16(x, C) and fusable_nhwc_bf16(add, C) and add.shape[:2] == x.shape[:2]
+    if out is not None:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == B
+        assert tuple(out.shape[2:]) == tuple(add.shape[2:])
+        check(lib().islam_resize_bilinear_add_nhwc_bf16_into(ptr(x), ptr(add), ptr(out), B, C, Hi, Wi, int(add.shape[2]), int(add.shape[3]),
+                                                             int(bool(align_corners)), int(out.shape[1]), int(coff), stream_ptr(x.device)))
+        return out
     y = torch.empty_like(add)
     check(lib().islam_resize_bilinear_add_nhwc_bf16(ptr(x), ptr(add), ptr(y), B, C, Hi, Wi, int(add.shape[2]), int(add.shape[3]),
                                                     int(bool(align_corners)), stream_ptr(x.device)))
