@@ -64,8 +64,9 @@ class TartanVO(nn.Module):
         # ~1-2 minutes longer, the stereo net then runs ~25 % faster (the heuristics pick split-K kernels that need
         # zero-fill and cast passes around them)
         if miopen_find:
-            from .miopen_pin import use_pinned_db
+            from .miopen_pin import use_pinned_db, check_pinned_db
             use_pinned_db()          # the search results of one MI355X run, shipped with the package: same kernels every run, no search
+            check_pinned_db(device_id)   # warns (raises under ISLAM_MIOPEN_PIN_STRICT=1) when the set belongs to another MIOpen build / device
             torch.backends.cudnn.benchmark = True
         self.device_id = device_id
         self.correct_scale = correct_scale
@@ -137,9 +138,12 @@ class TartanVO(nn.Module):
         self._prefetched[id(sample)] = (sample, flow, disp, ev)
         return True
 
-    def forward(self, sample, is_train=True, given_scale=None):
+    def forward(self, sample, is_train=True, given_scale=None, need_grad=None):
+        """need_grad (default: is_train): whether the forward builds autograd state.  is_train alone selects the BatchNorm mode (F4);
+        a caller that wants train-mode statistics but no gradient (the VO forward of an IMU epoch, train.py:207-212) passes
+        need_grad=False -- no autograd graph, and a graphed pose head (graph_pose) does not replay its training graph."""
         self.vonet.set_mode(is_train)                                       # BN batch statistics when training (F4)
-        with torch.set_grad_enabled(is_train):
+        with torch.set_grad_enabled(is_train if need_grad is None else bool(need_grad)):
             dev = self.device_id
             img0 = sample['img0'].cuda(dev, non_blocking=True)
             img1 = sample['img1'].cuda(dev, non_blocking=True)

@@ -84,8 +84,17 @@ class BilevelLoop:
             first = PREFETCH_FIRST and not isinstance(next_sample, (tuple, list))
             if first:
                 prefetch_next()
-            with torch.set_grad_enabled(target == 'vo'):
-                res = self.vo(sample)
+            # no autograd state for the VO forward of an IMU epoch (TartanVO.forward opens its own grad mode: an outer
+            # torch.set_grad_enabled would not reach it)
+            if self.__dict__.get('_vo_takes_need_grad') is None:
+                import inspect
+                fwd = getattr(self.vo, 'forward', self.vo)
+                self._vo_takes_need_grad = 'need_grad' in inspect.signature(fwd).parameters
+            if self._vo_takes_need_grad:
+                res = self.vo(sample, need_grad=(target == 'vo'))
+            else:                                                  # a VO front-end without the flag (stand-ins in tests)
+                with torch.set_grad_enabled(target == 'vo'):
+                    res = self.vo(sample)
             if not first:
                 prefetch_next()
             motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
@@ -150,7 +159,8 @@ class BilevelLoop:
             return
         # a pose head on nets._PoseGraph accumulates its own gradients inside its backward node; its leaf is listed so that the engine
         # runs that node (its parameters then come back as unused)
-        leaf = getattr(getattr(getattr(self.vo, 'vonet', None), '_pose_graph', None), 'leaf', None)
+        vonet = getattr(self.vo, 'vonet', None)
+        leaf = vonet.pose_graph_leaf() if hasattr(vonet, 'pose_graph_leaf') else None
         grads = torch.autograd.grad(loss_bp, params + ([leaf] if leaf is not None else []), torch.ones_like(loss_bp), allow_unused=True)[:len(params)]
         acc, new = [], []
         for p, g in zip(params, grads):

@@ -9,22 +9,66 @@ consults it before searching; `islam_amd/miopen_db/` holds the find-db of one se
 MIOpen).  `use_pinned_db()` points MIOPEN_USER_DB_PATH at a writable copy of it, so every process picks the SAME kernels and skips
 the search (first forward + backward 49 s -> 9 s).  Another device / MIOpen build simply does not find its key in there and
 searches as before.  Must run before the process's first convolution (MIOpen reads the variable when its handle is created)."""
+import atexit
 import os
+import re
 import shutil
 import tempfile
+import warnings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DB_DIR = os.path.join(_HERE, 'miopen_db')
+_state = {'dir': None}
+
+
+def pinned_keys():
+    """[(arch, n_cu, (major, minor, patch), build tag)] of the shipped find-db files (`gfx950100.HIP.3_5_0_<tag>.ufdb.txt`:
+    device name + CU count in hex, backend, MIOpen version, build tag)."""
+    out = []
+    for f in sorted(os.listdir(DB_DIR)):
+        m = re.match(r'^(gfx[0-9a-f]{3})([0-9a-f]+)\.HIP\.(\d+)_(\d+)_(\d+)_(.+)\.ufdb\.txt$', f)
+        if m:
+            out.append((m.group(1), int(m.group(2), 16), (int(m.group(3)), int(m.group(4)), int(m.group(5))), m.group(6)))
+    return out
+
+
+def check_pinned_db(device=0, strict=None):
+    """Does the shipped find-db belong to the MIOpen build and device this process runs on?  MIOpen looks its records up under a
+    file name made of device + version + build tag: on any other build the pinned set is silently ignored and the timing-based search
+    (different kernels run to run) is back.  Returns (ok, message); warns when not ok, raises under ISLAM_MIOPEN_PIN_STRICT=1 /
+    strict=True.  The build tag is not exposed through torch, so the check covers architecture, CU count and the version triple."""
+    import torch
+    strict = os.environ.get('ISLAM_MIOPEN_PIN_STRICT') == '1' if strict is None else strict
+    v = torch.backends.cudnn.version()                       # MIOpen on ROCm: major * 1e6 + minor * 1e3 + patch
+    have = None if v is None else (v // 1000000, (v // 1000) % 1000, v % 1000)
+    prop = torch.cuda.get_device_properties(device)
+    arch = getattr(prop, 'gcnArchName', '').split(':')[0]
+    ncu = prop.multi_processor_count
+    keys = pinned_keys()
+    ok = any(a == arch and n == ncu and (have is None or ver == have) for a, n, ver, _ in keys)
+    msg = 'pinned MIOpen find-db %s; running %s with %d CUs, MIOpen %s' % (
+        ['%s/%d CUs/%d.%d.%d' % (a, n, *ver) for a, n, ver, _ in keys], arch, ncu, '?' if have is None else '%d.%d.%d' % have)
+    if not ok:
+        msg = 'islam_amd.miopen_pin: NO MATCH -- ' + msg + ': MIOpen will search (timing-based, not reproducible run to run)'
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg)
+    return ok, msg
 
 
 def use_pinned_db():
-    """Returns the directory MIOpen will use (an explicit MIOPEN_USER_DB_PATH of the caller always wins)."""
+    """Returns the directory MIOpen will use (an explicit MIOPEN_USER_DB_PATH of the caller always wins).  The shipped files are copied
+    into a FRESH private directory of this process (mkdtemp, mode 0700, removed at exit): MIOpen appends what it finds to its user
+    db, and a shared, predictable /tmp path would both drift from the shipped set and be open to pre-creation by another user."""
     if os.environ.get('MIOPEN_USER_DB_PATH'):
-        return os.environ['MIOPEN_USER_DB_PATH']
-    dst = os.path.join(tempfile.gettempdir(), 'islam_miopen_db_%d' % os.getuid())
-    os.makedirs(dst, exist_ok=True)
+        if _state['dir'] is None or os.environ['MIOPEN_USER_DB_PATH'] != _state['dir']:
+            return os.environ['MIOPEN_USER_DB_PATH']
+        return _state['dir']
+    dst = tempfile.mkdtemp(prefix='islam_miopen_db_')
     for f in os.listdir(DB_DIR):
-        if f.endswith('.txt') and not os.path.exists(os.path.join(dst, f)):
+        if f.endswith('.txt'):
             shutil.copyfile(os.path.join(DB_DIR, f), os.path.join(dst, f))
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
     os.environ['MIOPEN_USER_DB_PATH'] = dst
+    _state['dir'] = dst
     return dst

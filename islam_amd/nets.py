@@ -229,7 +229,9 @@ class PWCDCNet(nn.Module):
         head = getattr(self, 'predict_flow%d' % l)
         dc = getattr(self, 'upfeat%d' % l) if up else None
         cache = self.__dict__.setdefault('_headm_cache', {})
-        key = (head.weight._version, head.weight.data_ptr(), None if dc is None else (dc.weight._version, dc.weight.data_ptr()), mir.shape[1])
+        bkey = lambda m: None if m is None or m.bias is None else (m.bias._version, m.bias.data_ptr())
+        key = (head.weight._version, head.weight.data_ptr(), bkey(head), None if dc is None else (dc.weight._version, dc.weight.data_ptr()),
+               bkey(dc), mir.shape[1])
         hit = cache.get(l)
         if hit is None or hit[0] != key:
             C = head.weight.shape[1]
@@ -880,6 +882,7 @@ class VONet(nn.Module):
         and otherwise wrap every convolution (forward, data- and weight-gradient) in layout-transposing launches
         (~270 per step).  Same parameters, same state dict, same arithmetic up to MIOpen's kernel choice."""
         self.pose_channels_last = bool(on)
+        self._drop_pose_graph()                      # a captured pose-head graph holds the old layout
         self.flowPoseNet.to(memory_format=torch.channels_last if on else torch.contiguous_format)
         self.flowPoseNet.set_fused_tail(on and os.environ.get('ISLAM_POSE_NO_FUSED_TAIL') != '1')     # (channels-last activations: ops.bias_act applies)
 
@@ -914,6 +917,7 @@ class VONet(nn.Module):
             torch.cuda.synchronize()            # no replay may still be in flight when the graphs and their memory pool go
         self._graphs = {}
         self.__dict__.pop('_frozen_param_list', None)
+        self._drop_pose_graph()
 
     def frozen_nets_trainable(self):
         """True if any parameter of the flow / stereo nets requires grad.  Asked once or twice per batch on the host's critical path
@@ -1000,15 +1004,22 @@ class VONet(nn.Module):
         x = torch.cat([flow, intrinsic], 1)
         if self.pose_channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        if self.graph_pose == 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled() and x.is_cuda:
-            # forward and backward as two HIP graphs whose backward node adds the parameter gradients to .grad itself (_PoseGraph)
+        if self.graph_pose == 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled() and x.is_cuda and not x.requires_grad:
+            # forward and backward as two HIP graphs whose backward node adds the parameter gradients to .grad itself (_PoseGraph).
+            # Only for an input that carries no gradient (frozen flow net: the reference detaches flow behind the pose head,
+            # TartanVO.py:109, so with a TRAINABLE flow net the pose loss must reach it -- that case takes the eager branch below).
             with self._pose_autocast():
                 pg = self.__dict__.get('_pose_graph')
+                plist = pg.all_params if pg is not None else list(self.flowPoseNet.parameters())
+                key = (tuple(x.shape), self.pose_dtype, self.pose_channels_last, tuple(p.requires_grad for p in plist))
+                if pg is not None and pg.key != key and tuple(x.shape) == pg.key[0]:
+                    pg = None                                  # pose_dtype / layout / requires_grad changed: capture again
                 if pg is None:
                     pg = self.__dict__['_pose_graph'] = _PoseGraph(self.flowPoseNet, x)
+                    pg.key = key
                     self._pose_graphed = tuple(x.shape)
                 pose = _PoseGraphFn.apply(x, pg.leaf, pg) if tuple(x.shape) == self._pose_graphed else self.flowPoseNet(x)
-        elif self.graph_pose and self.flowPoseNet.training and torch.is_grad_enabled():
+        elif self.graph_pose and self.graph_pose != 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled():
             # forward AND backward of the trainable pose head replay from two captured HIP graphs
             # (torch.cuda.make_graphed_callables patches the module's forward; eval mode keeps the eager path, and so does a
             # batch of another shape, e.g. the last one of an epoch)
@@ -1022,6 +1033,18 @@ class VONet(nn.Module):
             with self._pose_autocast():
                 pose = self.flowPoseNet(x)
         return flow, disp, pose.float()
+
+    def pose_graph_leaf(self):
+        """The zero-dimensional leaf that keeps the graphed pose head's backward node alive (graph_pose='accumulate'): callers of
+        torch.autograd.grad(loss, inputs) list it among ``inputs`` or the engine prunes the node and the head gets no gradient.
+        None while no graph has been captured."""
+        pg = self.__dict__.get('_pose_graph')
+        return None if pg is None else pg.leaf
+
+    def _drop_pose_graph(self):
+        self.__dict__.pop('_pose_graph', None)
+        if self.graph_pose == 'accumulate':
+            self._pose_graphed = None
 
     def _pose_autocast(self):
         import contextlib
@@ -1041,7 +1064,8 @@ class _PoseGraph:
 
     def __init__(self, net, x):
         dev = x.device
-        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.all_params = list(net.parameters())
+        self.params = [p for p in self.all_params if p.requires_grad]
         self.static_x = x.detach().clone()
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
@@ -1062,19 +1086,28 @@ class _PoseGraph:
             self.static_grads = torch.autograd.grad(self.static_y, self.params, self.static_gy, allow_unused=True)
         self.leaf = torch.zeros((), device=dev, requires_grad=True)
         self.zero = torch.zeros((), device=dev)
+        self.pending = False                             # a forward replay whose backward has not run yet
+        self.key = None
 
 
 class _PoseGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, leaf, pg):
+        # the backward graph reads the activations the LAST forward replay left in the graph's static buffers: a second forward
+        # before the pending backward would silently hand that backward the wrong activations
+        if pg.pending:
+            raise RuntimeError('graph_pose="accumulate": forward replayed while the previous forward still awaits its backward '
+                               '(run forwards that need no gradient under torch.no_grad() / TartanVO(..., need_grad=False))')
         pg.static_x.copy_(x)
         pg.fwd.replay()
         ctx.pg = pg
+        pg.pending = True
         return pg.static_y.detach().clone()
 
     @staticmethod
     def backward(ctx, gy):
         pg = ctx.pg
+        pg.pending = False
         pg.static_gy.copy_(gy)
         pg.bwd.replay()
         acc, new = [], []
