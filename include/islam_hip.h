@@ -196,6 +196,18 @@ int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const u
 size_t islam_deconv_nhwc_packed_elems(int Cin, int Cout);
 int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* bias, uint16_t* y, int ytot, int yoff, int B, int Cin,
                                 int H, int W, int Cout, int relu, void* stream);
+/* One Residual module of the stereo net's hourglass stacks in ONE launch -- Network/PSM/hourglass.py:28-52 (`Residual.forward`),
+ * instantiated by Network/PSM/hourglass.py:53-77 / Network/StereoNet7.py:56-90:
+ *   y = conv3(relu(conv2(relu(conv1(relu(x)))))) + res ;  conv1 1x1 Cin -> h, conv2 3x3 h -> h (padding 1), conv3 1x1 h -> Cout,
+ *   h = Cout / 2, every convolution with a bias; res = x when Cin == Cout, else skip_layer(x) computed by the caller
+ *   (islam_conv_nhwc_bf16, 1x1 of the raw x).  The two h-channel intermediates never leave LDS; rounding points as the layer-by-layer
+ *   path: t1 = relu(bf16(. + b1)), t2 = relu(bf16(. + b2)), y = bf16(bf16(. + b3) + res); bf16 operands, fp32 accumulation.
+ * x (B,H,W,Cin), res / y (B,H,W,Cout) bf16 bits; Cin a multiple of 32, Cout a multiple of 64, Cout <= 256.
+ * wpacked: islam_hg_residual_packed_elems(Cin, Cout) bf16 elements = the per-K-stage LDS operand images the kernel copies with
+ * LDS-DMA (layout: csrc/hourglass.hip `Plan`; built by islam_amd/ops.py pack_hg_residual); bias: fp32 [b1 (h) | b2 (h) | b3 (Cout)]. */
+size_t islam_hg_residual_packed_elems(int Cin, int Cout);
+int islam_hg_residual_nhwc_bf16(const uint16_t* x, const uint16_t* res, uint16_t* y, const uint16_t* wpacked, const float* bias, int B, int Cin,
+                                int H, int W, int Cout, void* stream);
 /* fp32 NCHW channels [soff, soff + C) of src (B,stot,H,W) -> bf16 (nearest-even) channels [doff, doff + C) of dst (B,H,W,dtot);
  * channels up to the next multiple of 8 are zeroed.  Fills the mirror with what the non-convolution producers wrote. */
 int islam_nchw_f32_to_nhwc_bf16(const float* src, int stot, int soff, uint16_t* dst, int dtot, int doff, int B, int C, int H, int W,

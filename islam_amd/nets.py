@@ -381,6 +381,10 @@ FLOW_HEAD_MIRROR = _os.environ.get('ISLAM_FLOW_HEAD_MIRROR', '1') == '1'
 FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '1') == '1'
 # the stereo decoder's 4x4 stride-2 transposed convolutions on the channels-last kernel (0: MIOpen + torch.cat, for A/B runs)
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
+# hourglass Residual modules as one launch each (0: three convolution launches, for A/B runs); only for maps of at most
+# ISLAM_HG_FUSED_MAX_PIXELS pixels per image
+HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
+HG_FUSED_MAX_PIXELS = int(_os.environ.get('ISLAM_HG_FUSED_MAX_PIXELS', str(1 << 30)))
 
 
 def _hip_conv_ok(conv, x, fused_1x1=False):
@@ -588,7 +592,26 @@ class _HGResidual(nn.Module):
         self.skip_layer = _HGConv(cin, cout, 1)
         self.need_skip = cin != cout
 
+    def _fused_pack(self):
+        """packed weights + [b1 | b2 | b3] for islam_hg_residual_nhwc_bf16, rebuilt when the execution copy's parameters change"""
+        cs = (self.conv1.conv, self.conv2.conv, self.conv3.conv)
+        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in cs)
+        hit = self.__dict__.get('_fused')
+        if hit is None or hit[0] != key:
+            hit = self.__dict__['_fused'] = (key, ops.pack_hg_residual(*(c.weight for c in cs)),
+                                             torch.cat([c.bias.detach().float() for c in cs]).contiguous())
+        return hit[1], hit[2]
+
     def forward(self, x):
+        c1, c3 = self.conv1.conv, self.conv3.conv
+        if (HG_FUSED and ops.fusable_nhwc_bf16(x, c1.in_channels) and c1.weight.dtype == torch.bfloat16 and c1.in_channels % 32 == 0
+                and c3.out_channels % 64 == 0 and c3.out_channels <= 256 and c1.out_channels * 2 == c3.out_channels
+                and x.shape[2] * x.shape[3] <= HG_FUSED_MAX_PIXELS):
+            # the whole module in ONE launch, intermediates in LDS (islam_hg_residual_nhwc_bf16); the 1x1 skip convolution of the two
+            # modules that change the channel count stays a launch of its own and comes in as the residual
+            res = self.skip_layer.run(x) if self.need_skip else None
+            packed, b = self._fused_pack()
+            return ops.hg_residual(x, packed, b, c3.out_channels, res)
         if ops.fusable_nhwc_bf16(x, self.conv1.conv.out_channels) and self.conv3.conv.out_channels % 8 == 0:
             res = self.skip_layer.run(x) if self.need_skip else x
             y = self.conv2.run(self.conv1.run(x, relu=True, in_relu=True), relu=True)      # relu(x) rides on conv1's input staging
