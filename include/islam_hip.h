@@ -202,9 +202,10 @@ int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, cons
  *   h = Cout / 2, every convolution with a bias; res = x when Cin == Cout, else skip_layer(x) computed by the caller
  *   (islam_conv_nhwc_bf16, 1x1 of the raw x).  The two h-channel intermediates never leave LDS; rounding points as the layer-by-layer
  *   path: t1 = relu(bf16(. + b1)), t2 = relu(bf16(. + b2)), y = bf16(bf16(. + b3) + res); bf16 operands, fp32 accumulation.
- * x (B,H,W,Cin), res / y (B,H,W,Cout) bf16 bits; Cin a multiple of 32, Cout a multiple of 64, Cout <= 256.
- * wpacked: islam_hg_residual_packed_elems(Cin, Cout) bf16 elements = the per-K-stage LDS operand images the kernel copies with
- * LDS-DMA (layout: csrc/hourglass.hip `Plan`; built by islam_amd/ops.py pack_hg_residual); bias: fp32 [b1 (h) | b2 (h) | b3 (Cout)]. */
+ * x (B,H,W,Cin), res / y (B,H,W,Cout) bf16 bits; Cin, Cout multiples of 64 up to 256 (Cout = 64 with Cin = 64 only: res must be x).
+ * wpacked: islam_hg_residual_packed_elems(Cin, Cout) bf16 elements = the weights as MFMA A fragments (64 lanes x 8 bf16 each) in
+ * the order the waves consume them (layout: csrc/hourglass.hip; built by islam_amd/ops.py pack_hg_residual); bias: fp32
+ * [b1 (h) | b2 (h) | b3 (Cout)]. */
 size_t islam_hg_residual_packed_elems(int Cin, int Cout);
 int islam_hg_residual_nhwc_bf16(const uint16_t* x, const uint16_t* res, uint16_t* y, const uint16_t* wpacked, const float* bias, int B, int Cin,
                                 int H, int W, int Cout, void* stream);

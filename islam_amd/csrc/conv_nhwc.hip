@@ -79,10 +79,11 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {      // round-to-n
 }
 __device__ __forceinline__ float lo16(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float hi16(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+// ReLU of packed bf16: a negative bf16 is a negative int16 (sign-magnitude), so max(., 0) on the int16 lanes is the ReLU: ONE v_pk_max_i16 per pair
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu2(unsigned t) {
-    if (t & 0x8000u) t &= 0xffff0000u;
-    if (t & 0x80000000u) t &= 0x0000ffffu;
-    return t;
+    const s16x2_t z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, t), z));
 }
 
 // Register blocking: a wave owns ROWS pixel rows x TN channels; for a horizontal tap offset s it reads the ROWS + K - 1 halo rows
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
             wlds[k] = row * PS + coct;
         }
     });
-    uint4 pre[NIN];
+    u32x4 pre[NIN];                                          // (native vectors: see u32x4)
     u32x4 prew[NWT];
     float4 as0 = {1, 1, 1, 1}, as1 = as0, ah0 = {0, 0, 0, 0}, ah1 = ah0;     // the chunk's BatchNorm scale / shift, fetched with it
     auto fetch = [&](int c0) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
         }
         static_for<0, NIN>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            pre[k] = *reinterpret_cast<const uint4*>(xb + ((cok && goff[k] >= 0) ? (size_t)goff[k] + c0 : (size_t)0));   // masked: any valid address
+            pre[k] = *reinterpret_cast<const u32x4*>(xb + ((cok && goff[k] >= 0) ? (size_t)goff[k] + c0 : (size_t)0));   // masked: any valid address
         });
         static_for<0, NWT>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
         const float4 s0 = as0, s1 = as1, h0 = ah0, h1 = ah1;
         static_for<0, NIN>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            uint4 v = pre[k];
+            u32x4 v = pre[k];
             if (in_affine) {
                 v.x = relu2(pack2(fmaf(lo16(v.x), s0.x, h0.x), fmaf(hi16(v.x), s0.y, h0.y)));
                 v.y = relu2(pack2(fmaf(lo16(v.y), s0.z, h0.z), fmaf(hi16(v.y), s0.w, h0.w)));
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short
                 v.w = relu2(pack2(fmaf(lo16(v.w), s1.z, h1.z), fmaf(hi16(v.w), s1.w, h1.w)));
             }
             else if (in_relu) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }     // ReLU of the input on load
-            if (!(cok && goff[k] >= 0)) v = make_uint4(0, 0, 0, 0);      // zero padding of the NORMALISED activation
-            *reinterpret_cast<uint4*>(lin + loff[k]) = v;
+            if (!(cok && goff[k] >= 0)) v = u32x4{0, 0, 0, 0};           // zero padding of the NORMALISED activation
+            *reinterpret_cast<u32x4*>(lin + loff[k]) = v;
         });
         static_for<0, NWT>([&](auto kk) {
             constexpr int k = decltype(kk)::value;

@@ -28,6 +28,21 @@
 #include "../../include/islam_hip.h"
 #include "common.h"
 
+// scripts/hg_probe.sh builds an experiment variant (never the product library) that timestamps the phases of one workgroup
+#ifndef ISLAM_HG_PROBE
+#define ISLAM_HG_PROBE 0
+#endif
+#if ISLAM_HG_PROBE
+__device__ long long islam_hg_probe_buf[64];
+#define HPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (hprb) islam_hg_probe_buf[(slot) + 16 * wave] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HPROBE(slot) do { } while (0)
+#endif
+
+// scheduling fence for vector-memory and matrix instructions (LLVM sched_barrier mask: VALU, SALU and DS may cross): keeps a prefetch
+// where the source issues it -- the machine scheduler otherwise sinks global loads next to their first use to save registers
+#define VMEM_PIN() __builtin_amdgcn_sched_barrier(0x386)
+
 namespace {
 
 using namespace islam;
@@ -43,9 +58,9 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 
 constexpr int TH = 8, TW = 16, DW = TW + 2, DH = TH + 2, ND = DH * DW, NT1 = (ND + 31) / 32, NDP = NT1 * 32;   // 180 -> 192 slots
 constexpr int NOUT = TH * TW;                       // 128 output pixels = 4 N tiles
-constexpr int KC = 32, PS = KC + 8;                 // channels per K stage; elements per staged row (80-byte stride)
+
 constexpr int THREADS = 256;
-constexpr int PIECE = 512;                          // elements per LDS-DMA wave instruction (1 KiB)
+
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -61,262 +76,255 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 __device__ __forceinline__ float lo16(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float hi16(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+// ReLU of packed bf16: a negative bf16 is a negative int16 (sign-magnitude), so max(., 0) on the int16 lanes is the ReLU: ONE v_pk_max_i16 per pair
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu2(unsigned t) {
-    if (t & 0x8000u) t &= 0xffff0000u;
-    if (t & 0x80000000u) t &= 0x0000ffffu;
-    return t;
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, t), z));
 }
+__device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_elementwise_max(v, z);
+}
+__device__ __attribute__((aligned(16))) unsigned islam_hg_zero[4];      // 16 bytes of zeros: what LDS-DMA lanes of out-of-image pixels copy
 
-__host__ __device__ constexpr int round_piece(int elems) { return (elems + PIECE - 1) / PIECE * PIECE; }
-__host__ __device__ constexpr int taps_per_stage(int MT) { return MT == 1 ? 9 : 3; }
-
-// Packed weights (islam_hg_residual_packed_elems): [phase-1 stages: Cin/32][phase-2 stages: (h/32) * (9/TPS)][phase-3 stages:
-// passes * (h/32)], every stage the LDS image [rows][PS] of its A operand, rounded up to whole 1-KiB pieces:
-//   phase 1, chunk c:            rows n < h:               W1[n][32c ...]
-//   phase 2, chunk c, group g:   rows tl*h + n, tl < TPS:  W2[n][32c ...][tap g*TPS + tl]
-//   phase 3, pass p, chunk c:    rows n < PMR:             W3[128p + n][32c ...]   (PMR = min(Cout, 128); zero rows past Cout)
-struct Plan {
-    int S1, S2, S3, sb1, sb2, sb3, pmr, npass;       // stage counts, stage sizes in elements, rows per phase-3 pass
+// Wider modules (Cout = 128 / 192 / 256, h = Cout / 2 = 32 MT): a wave OWNS output-channel tiles.  Wave (mg, ng) computes M tile
+// mg of phases 1 / 2 (and M tiles mg, mg + MT of phase 3) for the N tiles of its pixel group ng, so the weight rows it multiplies
+// with are its own: it loads them straight from global memory (L2) as MFMA A fragments -- the host packs them in consumption
+// order, 1 KiB = one fragment of all 64 lanes per load -- through a small register ring, several fragments ahead.  No weight ever
+// touches LDS and no barrier separates K steps: LDS holds activations only (the whole relu(x) patch, t1, t2, the output staging
+// tile), and the workgroup meets at four barriers (patch staged, t1, t2, output tile).  [A first version streamed the weights
+// through LDS by LDS-DMA, double-buffered, one barrier per K stage: bound by the DMA round trip per stage, 37 us for a 256-channel
+// module on a 14 x 20 map.]  MT = 4: four waves, one M tile each, all N tiles; MT = 3: three waves; MT = 2: four waves = 2 M tiles x 2
+// pixel groups.
+// Packed weights, fragments of 512 elements ([64 lanes][8], lane = (li = lane & 31, kg = lane >> 5)):
+//   phase 1: [mg < MT][ks < Cin/16]                 W1[32 mg + li][16 ks + 8 kg ...]
+//   phase 2: [mg < MT][c < MT][tap < 9][ks2 < 2]    W2[32 mg + li][32 c + 16 ks2 + 8 kg ...][tap]
+//   phase 3: [m3 < 2 MT][ks < h/16]                 W3[32 m3 + li][16 ks + 8 kg ...]
+template <int MT> struct Geo {
+    static constexpr int WAVES = MT == 3 ? 3 : 4, NG = MT == 2 ? 2 : 1, THREADS_ = 64 * WAVES;
+    static constexpr int HC = 32 * MT, T1S = HC + 8, COUT = 2 * HC, OS = COUT + 8;
+    static constexpr int N1 = NT1 / NG, N2 = 4 / NG;        // N tiles per wave in phase 1, phases 2 / 3
 };
-__host__ __device__ inline Plan make_plan(int Cin, int h, int Cout) {
-    const int MT = h / 32, tps = taps_per_stage(MT);
-    Plan p;
-    p.pmr = Cout < 128 ? Cout : 128;
-    p.npass = (Cout + 127) / 128;
-    p.S1 = Cin / KC; p.S2 = MT * (9 / tps); p.S3 = p.npass * MT;
-    p.sb1 = round_piece(h * PS); p.sb2 = round_piece(tps * h * PS); p.sb3 = round_piece(p.pmr * PS);
-    return p;
-}
 
 template <int MT>
-__global__ __launch_bounds__(THREADS) void hg_residual_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
-                                                               unsigned short* __restrict__ y, const unsigned short* __restrict__ wpk,
-                                                               const float* __restrict__ bias, int Cin, int Cout, int H, int W,
-                                                               int tiles_x, int tiles, int t1_elems, int ra_elems, int wbuf_elems) {
+__global__ __launch_bounds__(Geo<MT>::THREADS_, (MT == 2 ? 2 : 1)) void hg_residual_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                                                         unsigned short* __restrict__ y, const unsigned short* __restrict__ wpk,
+                                                                         const float* __restrict__ bias, int Cin, int H, int W, int tiles_x,
+                                                                         int tiles, int rx_elems) {
+    using G = Geo<MT>;
+    constexpr int HC = G::HC, T1S = G::T1S, COUT = G::COUT, OS = G::OS, NG = G::NG, N1 = G::N1, N2 = G::N2, NTH = G::THREADS_;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    constexpr int HC = 32 * MT, T1S = HC + 8, TPS = taps_per_stage(MT);
-    unsigned short* t1 = lds;                                // [NDP][T1S]; phase 3: the output staging tile [NOUT][pmr + 8]
-    unsigned short* ra = lds + t1_elems;                     // phase 1: two x-chunk buffers [NDP][PS]; then t2 [NOUT][T1S]
-    unsigned short* wb = ra + ra_elems;                      // two weight stage buffers
+    unsigned short* rx = lds;                                // phase 1: raw x patch [NDP][Cin + 8]; then t2 [NOUT][T1S] at its start
+    unsigned short* t1 = lds + rx_elems;                     // [NDP][T1S]
+    unsigned short* t2 = rx;
+    unsigned short* ot = t1 + NDP * T1S - NOUT * OS;         // the output tile ends where t1 ends: over t1 (dead by then) and the patch's tail, clear of t2
     const int tid = threadIdx.x, lane = tid & 63, kg = lane >> 5, li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mg = wave % MT, ng = wave / MT;
     const int b = blockIdx.x / tiles, tile = blockIdx.x - b * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int ho0 = ty * TH, wo0 = tx * TW;
-    const Plan pl = make_plan(Cin, HC, Cout);
-    const int S = pl.S1 + pl.S2 + pl.S3;
+    const int XS = Cin + 8, F1 = Cin / 16;
     const unsigned short* xb = x + (size_t)b * H * W * Cin;
+    const bf16x8* wq = reinterpret_cast<const bf16x8*>(wpk) + lane;          // fragment f of this lane: wq[64 f]
+    const bf16x8* w1 = wq + (size_t)64 * mg * F1;
+    const bf16x8* w2 = wq + (size_t)64 * (MT * F1 + mg * MT * 18);
+    const bf16x8* w3 = wq + (size_t)64 * (MT * F1 + MT * MT * 18);
 
-    // ---- LDS-DMA of weight stage g into buffer g & 1: wave w copies pieces w, w + 4, ... (lane-linear 1-KiB pieces)
-    auto issue = [&](int g) {
-        int off, n;
-        if (g < pl.S1) { off = g * pl.sb1; n = pl.sb1; }
-        else if (g < pl.S1 + pl.S2) { off = pl.S1 * pl.sb1 + (g - pl.S1) * pl.sb2; n = pl.sb2; }
-        else { off = pl.S1 * pl.sb1 + pl.S2 * pl.sb2 + (g - pl.S1 - pl.S2) * pl.sb3; n = pl.sb3; }
-        const unsigned short* src = wpk + off + lane * 8;
-        unsigned short* dst = wb + (g & 1) * wbuf_elems;
-        for (int p = wave * PIECE; p < n; p += 4 * PIECE)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + p), (lds_ptr_t)(dst + p), 16, 0, 0);
-    };
+    [[maybe_unused]] const bool hprb = lane == 0 && blockIdx.x == gridDim.x / 2;
+    HPROBE(0);
+    // ALL weight fragments of phase 1 (Cin / 16 <= 16): in flight while the patch is staged
+    bf16x8 a1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a1[i] = w1[64 * (i < F1 ? i : 0)];
 
-    // ---- phase 1 staging map: slot q of the 10 x 18 patch <-> (q / 18, q % 18); 192 slots x 4 octets = 768 items, 3 per thread
-    constexpr int NXI = NDP * (KC / 8) / THREADS;            // 3
-    const int coct = 8 * (tid & 3);
-    int goff[NXI], loff[NXI];
-    static_for<0, NXI>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const int q = (tid + k * THREADS) >> 2;
-        const int qy = q / DW, qx = q - qy * DW;
-        const int gy = ho0 - 1 + qy, gx = wo0 - 1 + qx;
-        loff[k] = q * PS + coct;
-        goff[k] = (q < ND && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * Cin + coct : -1;
-    });
-    u32x4 pre[NXI];
-    auto fetch_x = [&](int c0) {
-        static_for<0, NXI>([&](auto kk) {
-            constexpr int k = decltype(kk)::value;
-            pre[k] = *reinterpret_cast<const u32x4*>(xb + (goff[k] >= 0 ? (size_t)goff[k] + c0 : (size_t)0));
-        });
-    };
-    auto stage_x = [&](unsigned short* dst) {
-        static_for<0, NXI>([&](auto kk) {
-            constexpr int k = decltype(kk)::value;
-            u32x4 v = pre[k];
-            v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w);       // conv1 reads relu(x) (hourglass.py:44)
-            if (goff[k] < 0) v = u32x4{0, 0, 0, 0};
-            *reinterpret_cast<u32x4*>(dst + loff[k]) = v;
-        });
-    };
-
-    f32x16 acc[2][4];                                        // phase 1: [N tile of the wave][M tile]; phases 2, 3: [0][M tile]
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][a][i] = 0.0f;
-    };
-    zero_acc();
-    issue(0);
-    fetch_x(0);
-
-    // ================= phase 1: t1 = relu(bf16(W1 relu(x) + b1)) on the 180-pixel patch =================
-    const int nmy1 = wave + 4 < NT1 ? 2 : 1;                 // N tiles wave, wave + 4
-    for (int g = 0; g < pl.S1; ++g) {
-        unsigned short* xs = ra + (g & 1) * (NDP * PS);
-        stage_x(xs);                                         // (its previous readers passed the barrier of stage g - 1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of weight stage g have landed
-        __syncthreads();
-        if (g + 1 < S) issue(g + 1);
-        if (g + 1 < pl.S1) fetch_x((g + 1) * KC);
-        const unsigned short* wsb = wb + (g & 1) * wbuf_elems;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[MT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const bf16x8*>(wsb + (a * 32 + li) * PS + 16 * ks + 8 * kg);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t < nmy1) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(xs + ((wave + 4 * t) * 32 + li) * PS + 16 * ks + 8 * kg);
-#pragma unroll
-                    for (int a = 0; a < MT; ++a) acc[t][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[t][a], 0, 0, 0);
-                }
-            }
+    // biases -> LDS (read at the three epilogues; 64 VGPRs if held)
+    float* bl = reinterpret_cast<float*>(t1 + NDP * T1S);
+    for (int i = tid; i < 2 * COUT; i += NTH) bl[i] = bias[i];
+    // ---- the RAW x patch, all channels, by LDS-DMA (no VGPRs, every piece in flight at once): LDS row = Cin / 8 data slots of 16
+    // bytes + one padding slot; a wave instruction fills 64 consecutive slots, lane by lane, each lane from its own global address --
+    // its pixel's channel octet, or 16 bytes of zeros for the padding slot and for pixels outside the image.  The ReLU of
+    // hourglass.py:44 is applied when phase 1 reads its B operands (one v_pk_max_i16 per register).
+    {
+        const int SPR = (Cin >> 3) + 1, NS = NDP * SPR, npiece = (NS + 63) >> 6;
+        const int dstep = (64 * G::WAVES) / SPR, rstep = 64 * G::WAVES - dstep * SPR;
+        int sidx = 64 * wave + lane;
+        int row = sidx / SPR, slot = sidx - row * SPR;
+        for (int pc = wave; pc < npiece; pc += G::WAVES) {
+            const int qy = row / DW, qx = row - qy * DW;
+            const int gy = ho0 - 1 + qy, gx = wo0 - 1 + qx;
+            const bool in = row < ND && slot < SPR - 1 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const unsigned short* src = in ? xb + (size_t)(gy * W + gx) * Cin + 8 * slot : reinterpret_cast<const unsigned short*>(islam_hg_zero);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(rx + pc * 512), 16, 0, 0);
+            row += dstep; slot += rstep;
+            if (slot >= SPR) { slot -= SPR; ++row; }
         }
     }
-    // epilogue 1.  D row (channel) = (reg & 3) + 8 (reg >> 2) + 4 kg, D col (pixel slot) = li
-    {
-        f32x4 bv[MT * 4];
-        static_for<0, MT * 4>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            bv[i] = *reinterpret_cast<const f32x4*>(bias + (i / 4) * 32 + 8 * (i % 4) + 4 * kg);
-        });
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t < nmy1) {
-                const int q = (wave + 4 * t) * 32 + li;
-                const int qy = q / DW, qx = q - qy * DW;
-                const int gy = ho0 - 1 + qy, gx = wo0 - 1 + qx;
-                const bool in = q < ND && gy >= 0 && gy < H && gx >= 0 && gx < W;
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const f32x4 bq = bv[a * 4 + gq];
-                        unsigned p0 = relu2(pack2(acc[t][a][4 * gq] + bq.x, acc[t][a][4 * gq + 1] + bq.y));
-                        unsigned p1 = relu2(pack2(acc[t][a][4 * gq + 2] + bq.z, acc[t][a][4 * gq + 3] + bq.w));
-                        if (!in) { p0 = 0; p1 = 0; }         // conv2's zero padding is a zero of ITS input, not relu(b1)
-                        *reinterpret_cast<uint2*>(t1 + (size_t)q * T1S + a * 32 + 8 * gq + 4 * kg) = make_uint2(p0, p1);
-                    }
-            }
-        }
-    }
-    zero_acc();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces have landed
+    HPROBE(1);
+    __syncthreads();                                         // barrier 1: patch staged
+    HPROBE(2);
 
-    // ================= phase 2: t2 = relu(bf16(W2 * t1 + b2)) on the 128 output pixels =================
-    // N tile of the wave = tile rows 2 wave, 2 wave + 1.  Second-row lanes take pixel x = (li - 18) mod 16, so that the patch rows a
-    // 16-lane group of ds_read_b128 touches stay distinct mod 16 (t1's row pitch is 18 pixels): conflict-free operand reads.
-    const int py2 = 2 * wave + (li >> 4), px2 = li < 16 ? li : ((li - 18) & 15);
-    const unsigned short* b2base = t1 + (size_t)(py2 * DW + px2) * T1S + 8 * kg;
-    for (int g2 = 0; g2 < pl.S2; ++g2) {
-        const int g = pl.S1 + g2;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                     // (first pass: also publishes t1)
-        if (g + 1 < S) issue(g + 1);
-        const unsigned short* wsb = wb + (g & 1) * wbuf_elems;
-        const int c = g2 / (9 / TPS), tg = g2 - c * (9 / TPS);
+    // ================= phase 1: t1 = relu(bf16(W1 relu(x) + b1)), this wave's 32 channels x N1 pixel tiles =================
+    {
+        f32x16 acc[N1];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int n = 0; n < N1; ++n)
 #pragma unroll
-            for (int tl = 0; tl < TPS; ++tl) {
-                const int tap = tg * TPS + tl, r = tap / 3, s = tap - 3 * r;
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b2base + (size_t)(r * DW + s) * T1S + c * 32 + 16 * ks);
+            for (int i = 0; i < 16; ++i) acc[n][i] = 0.0f;
+        const unsigned short* bb = rx + (size_t)(ng * 32 + li) * XS + 8 * kg;       // N tile ng + NG n: rows 32 (ng + NG n) + li
 #pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(wsb + ((tl * MT + a) * 32 + li) * PS + 16 * ks + 8 * kg);
-                    acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][a], 0, 0, 0);
+        for (int i = 0; i < 16; ++i)
+            if (i < F1) {                                    // (uniform)
+#pragma unroll
+                for (int n = 0; n < N1; ++n) {
+                    const bf16x8 bf = relu8(*reinterpret_cast<const bf16x8*>(bb + (size_t)(NG * n * 32) * XS + 16 * i));
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], bf, acc[n], 0, 0, 0);
                 }
             }
-    }
-    unsigned short* t2 = ra;                                 // (the x-chunk buffers are dead since the end of phase 1)
-    {
-        f32x4 bv[MT * 4];
-        static_for<0, MT * 4>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            bv[i] = *reinterpret_cast<const f32x4*>(bias + HC + (i / 4) * 32 + 8 * (i % 4) + 4 * kg);
-        });
-        const int p = py2 * TW + px2;
+        HPROBE(3);
+        f32x4 bv[4];
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const f32x4*>(bl + 32 * mg + 8 * gq + 4 * kg);
+#pragma unroll
+        for (int n = 0; n < N1; ++n) {
+            const int q = (ng + NG * n) * 32 + li;
+            const int qy = q / DW, qx = q - qy * DW;
+            const int gy = ho0 - 1 + qy, gx = wo0 - 1 + qx;
+            const bool in = q < ND && gy >= 0 && gy < H && gx >= 0 && gx < W;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 bq = bv[a * 4 + gq];
-                const unsigned p0 = relu2(pack2(acc[0][a][4 * gq] + bq.x, acc[0][a][4 * gq + 1] + bq.y));
-                const unsigned p1 = relu2(pack2(acc[0][a][4 * gq + 2] + bq.z, acc[0][a][4 * gq + 3] + bq.w));
-                *reinterpret_cast<uint2*>(t2 + (size_t)p * T1S + a * 32 + 8 * gq + 4 * kg) = make_uint2(p0, p1);
+                unsigned p0 = relu2(pack2(acc[n][4 * gq] + bv[gq].x, acc[n][4 * gq + 1] + bv[gq].y));
+                unsigned p1 = relu2(pack2(acc[n][4 * gq + 2] + bv[gq].z, acc[n][4 * gq + 3] + bv[gq].w));
+                if (!in) { p0 = 0; p1 = 0; }                 // conv2's zero padding is a zero of ITS input, not relu(b1)
+                *reinterpret_cast<uint2*>(t1 + (size_t)q * T1S + 32 * mg + 8 * gq + 4 * kg) = make_uint2(p0, p1);
             }
+        }
     }
+    // first fragments of phase 2: requested before the barrier
+    constexpr int F2 = MT * 18, D2 = 18;                     // fragments of phase 2 per wave, ring depth: one 32-channel chunk ahead
+    bf16x8 ring[D2];
+#pragma unroll
+    for (int i = 0; i < D2; ++i) ring[i] = w2[64 * i];
+    VMEM_PIN();
+    HPROBE(4);
+    __syncthreads();                                         // barrier 2: t1 complete (the patch is dead)
+    HPROBE(5);
 
-    // ================= phase 3: y = bf16(bf16(W3 * t2 + b3) + res), pmr channels per pass =================
-    const int p3 = wave * 32 + li;                           // natural pixel order: t2's row pitch is 16 pixels
-    const unsigned short* b3base = t2 + (size_t)p3 * T1S + 8 * kg;
-    const int OS = pl.pmr + 8;                               // staging tile row stride (elements)
-    unsigned short* ot = t1;
-    const int OCT = pl.pmr / 8;                              // channel octets per pixel and pass
-    for (int ps = 0; ps < pl.npass; ++ps) {
-        const int n0 = ps * 128;
-        const int mt3 = (Cout - n0 < 128 ? Cout - n0 : 128) / 32;     // live M tiles of this pass (uniform)
+    // ================= phase 2: t2 = relu(bf16(W2 * t1 + b2)) =================
+    // N tile = tile rows 2 nt, 2 nt + 1.  Second-row lanes take pixel x = (li - 18) mod 16, so that the patch rows a 16-lane group of
+    // ds_read_b128 touches stay distinct mod 16 (t1's row pitch is 18 pixels): conflict-free operand reads.
+    const int pyl = li >> 4, px2 = li < 16 ? li : ((li - 18) & 15);
+    {
+        f32x16 acc[N2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int n = 0; n < N2; ++n)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][a][i] = 0.0f;
-        for (int c = 0; c < MT; ++c) {
-            const int g = pl.S1 + pl.S2 + ps * MT + c;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                 // (first stage: also publishes t2; later passes: the stores below are done)
-            if (g + 1 < S) issue(g + 1);
-            const unsigned short* wsb = wb + (g & 1) * wbuf_elems;
+            for (int i = 0; i < 16; ++i) acc[n][i] = 0.0f;
+        const unsigned short* bb = t1 + (size_t)((2 * ng * N2 + pyl) * DW + px2) * T1S + 8 * kg;      // N tile nt = ng N2 + n: + 2 n rows
+        static_for<0, F2>([&](auto ff) {
+            constexpr int f = decltype(ff)::value;
+            constexpr int c = f / 18, tap = (f % 18) / 2, ks2 = f % 2, r = tap / 3, s_ = tap % 3;
+            const bf16x8 af = ring[f % D2];
+            if constexpr (f + D2 < F2) ring[f % D2] = w2[64 * (f + D2)];
+            VMEM_PIN();                                      // (the scheduler otherwise sinks every load next to its use: one load in flight)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b3base + c * 32 + 16 * ks);
+            for (int n = 0; n < N2; ++n) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bb + (size_t)((2 * n + r) * DW + s_) * T1S + 32 * c + 16 * ks2);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[n], 0, 0, 0);
+            }
+        });
+        HPROBE(6);
+        f32x4 bv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    if (a < mt3) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(wsb + (a * 32 + li) * PS + 16 * ks + 8 * kg);
-                        acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][a], 0, 0, 0);
-                    }
+        for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const f32x4*>(bl + HC + 32 * mg + 8 * gq + 4 * kg);
+#pragma unroll
+        for (int n = 0; n < N2; ++n) {
+            const int p = (2 * (ng * N2 + n) + pyl) * TW + px2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const unsigned p0 = relu2(pack2(acc[n][4 * gq] + bv[gq].x, acc[n][4 * gq + 1] + bv[gq].y));
+                const unsigned p1 = relu2(pack2(acc[n][4 * gq + 2] + bv[gq].z, acc[n][4 * gq + 3] + bv[gq].w));
+                *reinterpret_cast<uint2*>(t2 + (size_t)p * T1S + 32 * mg + 8 * gq + 4 * kg) = make_uint2(p0, p1);
             }
         }
-        // epilogue 3: through LDS (t1 is dead) so that the stores are 16 bytes per lane along C
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (a < mt3)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 2 * HC + n0 + a * 32 + 8 * gq + 4 * kg);
-                    *reinterpret_cast<uint2*>(ot + (size_t)p3 * OS + a * 32 + 8 * gq + 4 * kg) =
-                        make_uint2(pack2(acc[0][a][4 * gq] + bq.x, acc[0][a][4 * gq + 1] + bq.y),
-                                   pack2(acc[0][a][4 * gq + 2] + bq.z, acc[0][a][4 * gq + 3] + bq.w));
-                }
-        __syncthreads();
-        const int nitem = NOUT * OCT;
-        for (int it = tid; it < nitem; it += THREADS) {
-            const int px = it / OCT, oc = it - px * OCT;
-            const int ho = ho0 + (px >> 4), wo = wo0 + (px & 15), n = n0 + 8 * oc;
-            if (ho >= H || wo >= W || n >= Cout) continue;
-            const size_t o = (((size_t)b * H + ho) * W + wo) * Cout + n;
-            const u32x4 r = *reinterpret_cast<const u32x4*>(res + o);
-            u32x4 v = *reinterpret_cast<const u32x4*>(ot + (size_t)px * OS + 8 * oc);
-            v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
-            v.y = pack2(lo16(v.y) + lo16(r.y), hi16(v.y) + hi16(r.y));
-            v.z = pack2(lo16(v.z) + lo16(r.z), hi16(v.z) + hi16(r.z));
-            v.w = pack2(lo16(v.w) + lo16(r.w), hi16(v.w) + hi16(r.w));
-            *reinterpret_cast<u32x4*>(y + o) = v;
-        }
-        // (the next pass's first barrier orders these reads of the staging tile before its epilogue writes)
     }
+    // all fragments of phase 3 for this wave's two M tiles (2 x h/16 <= 16 fragments)
+    constexpr int F3 = HC / 16;
+    bf16x8 a3[2][F3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < F3; ++ks) a3[m][ks] = w3[64 * ((mg + MT * m) * F3 + ks)];
+    VMEM_PIN();
+    HPROBE(7);
+    __syncthreads();                                         // barrier 3: t2 complete
+    HPROBE(8);
+    // the residual values of all this thread's output items: requested now, used behind barrier 4
+    constexpr int OCT = COUT / 8, NIT = (NOUT * OCT + NTH - 1) / NTH;
+    u32x4 rv[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int it = tid + u * NTH, px = it / OCT, oc = it - px * OCT;
+        const int ho = ho0 + (px >> 4), wo = wo0 + (px & 15);
+        const bool ok = it < NOUT * OCT && ho < H && wo < W;
+        rv[u] = *reinterpret_cast<const u32x4*>(res + (ok ? (((size_t)b * H + ho) * W + wo) * COUT + 8 * oc : (size_t)0));
+    }
+    VMEM_PIN();
+
+    // ================= phase 3: y = bf16(bf16(W3 * t2 + b3) + res) =================
+    {
+        f32x16 acc[2][N2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < N2; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+        const unsigned short* bb = t2 + (size_t)(ng * N2 * 32 + li) * T1S + 8 * kg;      // natural pixel order: t2's pitch is 16 pixels
+#pragma unroll
+        for (int ks = 0; ks < F3; ++ks)
+#pragma unroll
+            for (int n = 0; n < N2; ++n) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bb + (size_t)(n * 32) * T1S + 16 * ks);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[m][ks], bf, acc[m][n], 0, 0, 0);
+            }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ch = 32 * (mg + MT * m);
+            f32x4 bv[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const f32x4*>(bl + 2 * HC + ch + 8 * gq + 4 * kg);
+#pragma unroll
+            for (int n = 0; n < N2; ++n) {
+                const int p = (ng * N2 + n) * 32 + li;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<uint2*>(ot + (size_t)p * OS + ch + 8 * gq + 4 * kg) =
+                        make_uint2(pack2(acc[m][n][4 * gq] + bv[gq].x, acc[m][n][4 * gq + 1] + bv[gq].y),
+                                   pack2(acc[m][n][4 * gq + 2] + bv[gq].z, acc[m][n][4 * gq + 3] + bv[gq].w));
+            }
+        }
+    }
+    HPROBE(9);
+    __syncthreads();                                         // barrier 4: output tile staged
+    HPROBE(10);
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int it = tid + u * NTH, px = it / OCT, oc = it - px * OCT;
+        const int ho = ho0 + (px >> 4), wo = wo0 + (px & 15);
+        if (it >= NOUT * OCT || ho >= H || wo >= W) continue;
+        u32x4 v = *reinterpret_cast<const u32x4*>(ot + (size_t)px * OS + 8 * oc);
+        const u32x4 r = rv[u];
+        v.x = pack2(lo16(v.x) + lo16(r.x), hi16(v.x) + hi16(r.x));
+        v.y = pack2(lo16(v.y) + lo16(r.y), hi16(v.y) + hi16(r.y));
+        v.z = pack2(lo16(v.z) + lo16(r.z), hi16(v.z) + hi16(r.z));
+        v.w = pack2(lo16(v.w) + lo16(r.w), hi16(v.w) + hi16(r.w));
+        *reinterpret_cast<u32x4*>(y + (((size_t)b * H + ho) * W + wo) * COUT + 8 * oc) = v;
+    }
+    HPROBE(11);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -517,22 +525,13 @@ int launch64(const unsigned short* x, unsigned short* y, const unsigned short* w
     return ISLAM_OK;
 }
 
-struct LdsPlan { int t1, ra, wbuf; size_t bytes; };
-LdsPlan lds_plan(int Cin, int h, int Cout) {
-    const Plan p = make_plan(Cin, h, Cout);
-    LdsPlan l;
-    l.t1 = std::max(NDP * (h + 8), NOUT * (p.pmr + 8));
-    l.ra = std::max(2 * NDP * PS, NOUT * (h + 8));
-    l.wbuf = std::max(p.sb1, std::max(p.sb2, p.sb3));
-    l.t1 = (l.t1 + 7) / 8 * 8; l.ra = (l.ra + 7) / 8 * 8;
-    l.bytes = ((size_t)l.t1 + l.ra + 2 * (size_t)l.wbuf) * sizeof(unsigned short);
-    return l;
-}
-
 template <int MT>
 int launch(const unsigned short* x, const unsigned short* res, unsigned short* y, const unsigned short* wpk, const float* bias, int B, int Cin,
-           int Cout, int H, int W, hipStream_t s) {
-    const LdsPlan l = lds_plan(Cin, 32 * MT, Cout);
+           int H, int W, hipStream_t s) {
+    using G = Geo<MT>;
+    const int npiece = (NDP * (Cin / 8 + 1) + 63) / 64;      // whole 1-KiB LDS-DMA pieces of the patch
+    const int rx = std::max(npiece * 512, NOUT * G::T1S + NOUT * G::OS - NDP * G::T1S);      // t2 | ... | output tile (ends with t1) must not overlap
+    const size_t lds = ((size_t)rx + (size_t)NDP * G::T1S) * sizeof(unsigned short) + (size_t)2 * G::COUT * sizeof(float);
     int dev = 0;
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
@@ -540,9 +539,10 @@ int launch(const unsigned short* x, const unsigned short* res, unsigned short* y
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)hg_residual_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev] = true;
     }
+    if (lds > 160 * 1024) return fail(ISLAM_EARG, "islam_hg_residual_nhwc_bf16: %zu bytes of LDS for Cin=%d, Cout=%d", lds, Cin, G::COUT);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    hipLaunchKernelGGL((hg_residual_kernel<MT>), dim3(tiles_x * tiles_y * B), dim3(THREADS), l.bytes, s, x, res, y, wpk, bias, Cin, Cout, H, W,
-                       tiles_x, tiles_x * tiles_y, l.t1, l.ra, l.wbuf);
+    hipLaunchKernelGGL((hg_residual_kernel<MT>), dim3(tiles_x * tiles_y * B), dim3(G::THREADS_), lds, s, x, res, y, wpk, bias, Cin, H, W, tiles_x,
+                       tiles_x * tiles_y, rx);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -551,17 +551,23 @@ int launch(const unsigned short* x, const unsigned short* res, unsigned short* y
 
 extern "C" {
 
+#if ISLAM_HG_PROBE
+int islam_hg_probe_read(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_hg_probe_buf), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+
 size_t islam_hg_residual_packed_elems(int Cin, int Cout) {
-    if (Cin < 32 || (Cin & 31) || Cout < 64 || (Cout & 63) || Cout > 256) return 0;
+    if (Cin < 64 || (Cin & 63) || Cout < 64 || (Cout & 63) || Cout > 256 || (Cout == 64 && Cin != 64)) return 0;
     if (Cin == 64 && Cout == 64) return (size_t)L_NFRAG * 512;       // register-resident fragments (hg_residual64_kernel)
-    const Plan p = make_plan(Cin, Cout / 2, Cout);
-    return (size_t)p.S1 * p.sb1 + (size_t)p.S2 * p.sb2 + (size_t)p.S3 * p.sb3;
+    const int MT = Cout / 64;
+    return (size_t)512 * (MT * (Cin / 16) + 18 * MT * MT + 2 * MT * 2 * MT);
 }
 
 int islam_hg_residual_nhwc_bf16(const uint16_t* x, const uint16_t* res, uint16_t* y, const uint16_t* wpacked, const float* bias, int B, int Cin,
                                 int H, int W, int Cout, void* stream) {
-    if (B < 1 || H < 1 || W < 1 || Cin < 32 || (Cin & 31) || Cout < 64 || (Cout & 63) || Cout > 256)
-        return fail(ISLAM_EARG, "islam_hg_residual_nhwc_bf16: bad shape (Cin=%d a multiple of 32, Cout=%d a multiple of 64 up to 256)", Cin, Cout);
+    if (B < 1 || H < 1 || W < 1 || Cin < 64 || (Cin & 63) || Cin > 256 || Cout < 64 || (Cout & 63) || Cout > 256 || (Cout == 64 && Cin != 64))
+        return fail(ISLAM_EARG, "islam_hg_residual_nhwc_bf16: bad shape (Cin=%d, Cout=%d: multiples of 64 up to 256; Cout = 64 with Cin = 64 only)", Cin, Cout);
     if (!x || !res || !y || !wpacked || !bias) return fail(ISLAM_EARG, "islam_hg_residual_nhwc_bf16: null argument");
     if ((size_t)B * H * W * std::max(Cin, Cout) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_hg_residual_nhwc_bf16: tensor too large for 32-bit offsets");
     hipStream_t s = (hipStream_t)stream;
@@ -570,10 +576,9 @@ int islam_hg_residual_nhwc_bf16(const uint16_t* x, const uint16_t* res, uint16_t
         return launch64(x, y, wpacked, bias, B, H, W, s);
     }
     switch (Cout / 64) {
-        case 1: return launch<1>(x, res, y, wpacked, bias, B, Cin, Cout, H, W, s);
-        case 2: return launch<2>(x, res, y, wpacked, bias, B, Cin, Cout, H, W, s);
-        case 3: return launch<3>(x, res, y, wpacked, bias, B, Cin, Cout, H, W, s);
-        default: return launch<4>(x, res, y, wpacked, bias, B, Cin, Cout, H, W, s);
+        case 2: return launch<2>(x, res, y, wpacked, bias, B, Cin, H, W, s);
+        case 3: return launch<3>(x, res, y, wpacked, bias, B, Cin, H, W, s);
+        default: return launch<4>(x, res, y, wpacked, bias, B, Cin, H, W, s);
     }
 }
 

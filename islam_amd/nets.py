@@ -604,8 +604,9 @@ class _HGResidual(nn.Module):
 
     def forward(self, x):
         c1, c3 = self.conv1.conv, self.conv3.conv
-        if (HG_FUSED and ops.fusable_nhwc_bf16(x, c1.in_channels) and c1.weight.dtype == torch.bfloat16 and c1.in_channels % 32 == 0
-                and c3.out_channels % 64 == 0 and c3.out_channels <= 256 and c1.out_channels * 2 == c3.out_channels
+        if (HG_FUSED and ops.fusable_nhwc_bf16(x, c1.in_channels) and c1.weight.dtype == torch.bfloat16 and c1.in_channels % 64 == 0
+                and c1.in_channels <= 256 and c3.out_channels % 64 == 0 and c3.out_channels <= 256 and c1.out_channels * 2 == c3.out_channels
+                and (c3.out_channels > 64 or c1.in_channels == 64)
                 and x.shape[2] * x.shape[3] <= HG_FUSED_MAX_PIXELS):
             # the whole module in ONE launch, intermediates in LDS (islam_hg_residual_nhwc_bf16); the 1x1 skip convolution of the two
             # modules that change the channel count stays a launch of its own and comes in as the residual

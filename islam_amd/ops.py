@@ -288,50 +288,31 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
 
 
 def pack_hg_residual(w1, w2, w3):
-    """Weights of one hourglass Residual (hourglass.py:28-40: conv1 (h,Cin,1,1), conv2 (h,h,3,3), conv3 (Cout,h,1,1)) as the sequence
-    of per-K-stage LDS operand images islam_hg_residual_nhwc_bf16 copies with LDS-DMA (csrc/hourglass.hip `Plan`): every stage is
-    [rows][40] bf16 (32 channels of the stage's chunk + 16 bytes of zero padding), rounded up to whole 1-KiB pieces."""
+    """Weights of one hourglass Residual (hourglass.py:28-40: conv1 (h,Cin,1,1), conv2 (h,h,3,3), conv3 (Cout,h,1,1)) as the MFMA A
+    fragments islam_hg_residual_nhwc_bf16 loads (1 KiB each: 64 lanes x 8 bf16), in the order its waves consume them
+    (csrc/hourglass.hip)."""
     h, Cin, Cout = int(w1.shape[0]), int(w1.shape[1]), int(w3.shape[0])
-    assert tuple(w2.shape) == (h, h, 3, 3) and int(w3.shape[1]) == h and Cout == 2 * h and h % 32 == 0 and Cin % 32 == 0
+    assert tuple(w2.shape) == (h, h, 3, 3) and int(w3.shape[1]) == h and Cout == 2 * h and h % 32 == 0 and Cin % 64 == 0
     MT = h // 32
-    tps = 9 if MT == 1 else 3
     dev = w1.device
     bf = torch.bfloat16
-
-    def img(rows):
-        R = rows.shape[0]
-        buf = torch.zeros((R, 40), dtype=bf, device=dev)
-        buf[:, :32] = rows.to(bf)
-        n = (R * 40 + 511) // 512 * 512
-        out = torch.zeros(n, dtype=bf, device=dev)
-        out[:R * 40] = buf.reshape(-1)
-        return out
-
     W1, W3 = w1.detach().reshape(h, Cin), w3.detach().reshape(Cout, h)
     W2 = w2.detach()
+    # one MFMA A fragment = [64 lanes][8] bf16: lane (li = lane & 31, kg = lane >> 5) holds row r0 + li, columns k0 + 8 kg ... + 8
+    li = torch.arange(64, device=dev) & 31
+    kk = (torch.arange(64, device=dev) >> 5)[:, None] * 8 + torch.arange(8, device=dev)[None, :]      # (64, 8): 8 kg + j
+    frag = lambda M, r0, k0: M[(r0 + li)[:, None], k0 + kk]
     if Cin == 64 and Cout == 64:
-        # hg_residual64_kernel keeps the module's weights in registers: [26 fragments][64 lanes][8], lane = (li = lane & 31, kg = lane >> 5)
-        li = torch.arange(64, device=dev) & 31
-        kk = (torch.arange(64, device=dev) >> 5)[:, None] * 8 + torch.arange(8, device=dev)[None, :]      # (64, 8): 8 kg + j
-        frag = lambda M, r0, ks: M[(r0 + li)[:, None], 16 * ks + kk]
-        fr = [frag(W1, 0, ks) for ks in range(4)]
-        fr += [frag(W2[:, :, t // 3, t % 3], 0, ks) for t in range(9) for ks in range(2)]
-        fr += [frag(W3, 32 * a, ks) for a in range(2) for ks in range(2)]
-        packed = torch.stack(fr).to(bf).reshape(-1).contiguous()
-        assert packed.numel() == lib().islam_hg_residual_packed_elems(Cin, Cout)
-        return packed
-    st = [img(W1[:, 32 * c:32 * c + 32]) for c in range(Cin // 32)]
-    for c in range(MT):
-        for g in range(9 // tps):
-            st.append(img(torch.cat([W2[:, 32 * c:32 * c + 32, t // 3, t % 3] for t in range(g * tps, (g + 1) * tps)], 0)))
-    pmr = min(Cout, 128)
-    for p in range((Cout + 127) // 128):
-        live = min(Cout - 128 * p, 128)
-        for c in range(MT):
-            rows = torch.zeros((pmr, 32), dtype=W3.dtype, device=dev)
-            rows[:live] = W3[128 * p:128 * p + live, 32 * c:32 * c + 32]
-            st.append(img(rows))
-    packed = torch.cat(st).contiguous()
+        # hg_residual64_kernel keeps the module's weights in registers: 26 fragments
+        fr = [frag(W1, 0, 16 * ks) for ks in range(4)]
+        fr += [frag(W2[:, :, t // 3, t % 3], 0, 16 * ks) for t in range(9) for ks in range(2)]
+        fr += [frag(W3, 32 * a, 16 * ks) for a in range(2) for ks in range(2)]
+    else:
+        # hg_residual_kernel: every wave streams the fragments of ITS output-channel tile in consumption order
+        fr = [frag(W1, 32 * mg, 16 * ks) for mg in range(MT) for ks in range(Cin // 16)]
+        fr += [frag(W2[:, :, t // 3, t % 3], 32 * mg, 32 * c + 16 * ks) for mg in range(MT) for c in range(MT) for t in range(9) for ks in range(2)]
+        fr += [frag(W3, 32 * m3, 16 * ks) for m3 in range(2 * MT) for ks in range(h // 16)]
+    packed = torch.stack(fr).to(bf).reshape(-1).contiguous()
     assert packed.numel() == lib().islam_hg_residual_packed_elems(Cin, Cout), (packed.numel(), Cin, Cout)
     return packed
 
