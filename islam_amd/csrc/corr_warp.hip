@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -137,6 +139,113 @@ __global__ __launch_bounds__(NT) void corr81_fwd_kernel(const float* __restrict_
                 if (gx + 1 < W) ob[(size_t)dx * plane + 1] = act(acc1[dx] * sc);
             }
         }
+    }
+}
+
+// Four pixels per lane (same arithmetic, same argument meaning as corr81_fwd_kernel above, which stays for
+// W % 4 != 0).  The one-pixel-pair form issues per channel and lane six 8-byte LDS reads for 18 FMAs and stages its tiles with
+// 4-byte global loads and LDS writes: it is bound by instruction issue (LDS + vector-memory requests), 72 us for the level-2 call
+// (83 MB: 0.14 of the HBM roof).  Here a workgroup owns a 32 x 8 pixel tile, a lane four horizontally adjacent pixels x nine
+// horizontal displacements of its wave's vertical displacement (36 accumulators): per channel ONE 16-byte read of f1 and three of
+// the f2 halo row feed 36 FMAs; tiles are staged with 16-byte global loads / LDS writes, results leave as 16-byte stores
+// (128-byte row segments of a displacement plane).  Needs W % 4 == 0 and 16-byte aligned tensors.
+constexpr int TW4 = 32, TH4 = 8, F2W4 = TW4 + 8, F2H4 = TH4 + 8;
+constexpr int Q2 = (CC * F2H4 * (F2W4 / 4) + NT - 1) / NT;     // float4 items of the f2 halo tile per thread (2560 / 576 -> 5)
+constexpr int Q1 = (CC * TH4 * (TW4 / 4) + NT - 1) / NT;       // float4 items of the f1 tile per thread (1024 / 576 -> 2)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          float* __restrict__ out, float* __restrict__ part, int B, int C,
+                                                          int H, int W, int nslice, int cps, int otot, int ooff, float slope) {
+    __shared__ __attribute__((aligned(16))) float s1[CC * TH4 * TW4];
+    __shared__ __attribute__((aligned(16))) float s2[CC * F2H4 * F2W4];
+    const int tid = threadIdx.x, lane = tid & 63, dyi = tid >> 6;        // 9 waves = 9 vertical displacements
+    const int tx = lane & 7, ty = lane >> 3;                              // pixels 4 tx ... 4 tx + 3 of tile row ty
+    const int b = blockIdx.z / nslice, slice = blockIdx.z - b * nslice;
+    const int c_begin = slice * cps, c_end = min(C, c_begin + cps);
+    const int x0 = blockIdx.x * TW4, y0 = blockIdx.y * TH4;
+    const size_t plane = (size_t)H * W;
+    const float* f1b = f1 + (size_t)b * C * plane;
+    const float* f2b = f2 + (size_t)b * C * plane;
+
+    float acc[4][9];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
+
+    // staging: float4 item i = tid + q NT -> (channel in chunk, halo row, column group); decoded on the fly (constant divisors) instead
+    // of held in 21 registers: the kernel has to stay under 96 VGPRs for two workgroups (18 waves) per CU.  A group of four pixels is
+    // inside the image or outside it as a whole (W % 4 == 0, tile origin a multiple of 32).
+    v4f r2[Q2], r1[Q1];                          // (native vectors: arrays of HIP's float4 struct are copied by memcpy and end up in scratch)
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int cb, int nc) {
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) {
+            const int i = tid + q * NT;
+            const int c = i / (F2H4 * (F2W4 / 4)), rem = i - c * (F2H4 * (F2W4 / 4));
+            const int ly = rem / (F2W4 / 4), lx = 4 * (rem - ly * (F2W4 / 4));
+            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+            const bool ok = c < nc && gy >= 0 && gy < H && gx >= 0 && gx < W;          // (c < nc <= CC also bounds i)
+            r2[q] = ok ? *reinterpret_cast<const v4f*>(f2b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
+        }
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            const int i = tid + q * NT;
+            const int c = i / (TH4 * (TW4 / 4)), rem = i - c * (TH4 * (TW4 / 4));
+            const int ly = rem / (TW4 / 4), lx = 4 * (rem - ly * (TW4 / 4));
+            const int gy = y0 + ly, gx = x0 + lx;
+            const bool ok = c < nc && gy < H && gx < W;
+            r1[q] = ok ? *reinterpret_cast<const v4f*>(f1b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
+        }
+    };
+    auto commit = [&]() {                        // item i lives at float4 slot i of its tile: both tiles are dense [c][row][col] arrays
+#pragma unroll
+        for (int q = 0; q < Q2; ++q)
+            if (tid + q * NT < CC * F2H4 * (F2W4 / 4)) *reinterpret_cast<v4f*>(&s2[4 * (tid + q * NT)]) = r2[q];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q)
+            if (tid + q * NT < CC * TH4 * (TW4 / 4)) *reinterpret_cast<v4f*>(&s1[4 * (tid + q * NT)]) = r1[q];
+    };
+
+    // [measured on one box, level-2 call: 72.5 us for the one-pixel-pair kernel, 39.1 us for this form (one workgroup of nine waves
+    //  per CU: 122 VGPRs); capped at 96 VGPRs for two workgroups per CU (no register prefetch, 60 bytes of scratch) it is SLOWER (49.6 vs
+    //  41.5 us on another box); the 36 FMAs as 16 v_pk_fma_f32 + 4 v_fma_f32: 39.1 us, no change -- the kernel is not VALU-bound,
+    //  560 workgroups on 256 CUs run in three rounds of ~13 us of latencies (first fetch, two barriers per chunk, store tail)]
+    fetch(c_begin, min(CC, c_end - c_begin));
+    for (int cb = c_begin; cb < c_end; cb += CC) {
+        const int nc = min(CC, c_end - cb);
+        __syncthreads();                         // previous chunk fully consumed
+        commit();
+        __syncthreads();
+        if (cb + CC < c_end) fetch(cb + CC, min(CC, c_end - cb - CC));      // in flight while this chunk is consumed
+        for (int c = 0; c < nc; ++c) {
+            const v4f a = *reinterpret_cast<const v4f*>(&s1[(c * TH4 + ty) * TW4 + 4 * tx]);
+            const float* row = &s2[(c * F2H4 + ty + dyi) * F2W4 + 4 * tx];
+            float r[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const v4f v = *reinterpret_cast<const v4f*>(row + 4 * q);
+                r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+            }
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int dx = 0; dx < 9; ++dx) acc[p][dx] = fmaf(av[p], r[p + dx], acc[p][dx]);
+        }
+    }
+    const int gy = y0 + ty, gx = x0 + 4 * tx;
+    if (gy < H && gx < W) {
+        const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
+        float* ob = (nslice == 1 ? out + ((size_t)b * otot + ooff + (size_t)dyi * 9) * plane
+                                 : part + (size_t)slice * B * 81 * plane + ((size_t)b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
+        const float sl = nslice == 1 ? slope : 1.0f;
+        auto act = [&](float v) { return v > 0.0f ? v : v * sl; };
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx)
+            *reinterpret_cast<v4f*>(ob + (size_t)dx * plane) = v4f{act(acc[0][dx] * sc), act(acc[1][dx] * sc), act(acc[2][dx] * sc), act(acc[3][dx] * sc)};
     }
 }
 
@@ -599,24 +708,42 @@ static void launch_head_up(const float* x, const float* w, const float* bias, fl
 
 extern "C" {
 
-size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
-    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+// which kernel, how many channel slices (small pyramid levels: too few tiles for 256 CUs), channels per slice -- ONE place, so that
+// the scratch a caller sizes with islam_corr81_scratch_bytes is the scratch the launch uses
+static void corr81_plan(int B, int C, int H, int W, bool* fwd4, int* nslice, int* cps) {
+    static const bool corr4 = [] { const char* e = std::getenv("ISLAM_CORR4"); return !(e && e[0] == '0'); }();   // 0: the one-pixel-pair kernel (A/B runs)
+    *fwd4 = corr4 && (W & 3) == 0 && H * W >= 1024;                      // small maps keep the 32 x 4 tile (more workgroups)
+    const int th = *fwd4 ? TH4 : TH;
+    const int tiles = ((W + TW - 1) / TW) * ((H + th - 1) / th) * B;
     const int chunks = (C + CC - 1) / CC;
-    int nslice = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
+    int ns = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
+    *cps = ((chunks + ns - 1) / ns) * CC;                                // channels per slice (whole chunks)
+    *nslice = (C + *cps - 1) / *cps;
+}
+
+size_t islam_corr81_scratch_bytes(int B, int C, int H, int W) {
+    bool fwd4;
+    int nslice, cps;
+    corr81_plan(B, C, H, W, &fwd4, &nslice, &cps);
     if (nslice <= 1) return 0;
     return (size_t)nslice * B * 81 * H * W * sizeof(float);
 }
 
 static int corr81_launch(const float* f1, const float* f2, float* out, int otot, int ooff, float slope, int B, int C, int H, int W, void* scratch,
                          void* stream) {
-    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
-    const int chunks = (C + CC - 1) / CC;
-    int nslice = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
-    if (nslice > 1 && scratch == nullptr) nslice = 1;                   // no scratch: single pass
-    const int cps = ((chunks + nslice - 1) / nslice) * CC;              // channels per slice (whole chunks)
-    nslice = (C + cps - 1) / cps;
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
-    hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
+    bool fwd4;
+    int nslice, cps;
+    corr81_plan(B, C, H, W, &fwd4, &nslice, &cps);
+    if (nslice > 1 && scratch == nullptr) { nslice = 1; cps = ((C + CC - 1) / CC) * CC; }      // no scratch: single pass
+    const bool al = ((reinterpret_cast<uintptr_t>(f1) | reinterpret_cast<uintptr_t>(f2) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(scratch)) & 15) == 0;
+    if (fwd4 && al) {
+        dim3 grid4((W + TW4 - 1) / TW4, (H + TH4 - 1) / TH4, B * nslice);
+        hipLaunchKernelGGL(corr81_fwd4_kernel, grid4, dim3(NT), 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
+    } else {
+        dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
+        hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
+    }
     if (nslice > 1) {
         const size_t n = (size_t)B * 81 * H * W;
         hipLaunchKernelGGL(corr81_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),

@@ -39,6 +39,24 @@ def test_corr81_forward_full_batch(cuda):
     torch.testing.assert_close(out[:, 40], (f1 * f2).mean(1), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('C,H,W', [(64, 56, 80), (96, 28, 40), (32, 112, 160)])
+def test_corr81_forward_at_the_batch_of_the_bench(cuda, C, H, W):
+    """B = 8: the slice plan (channel slices + reduction through the scratch buffer) depends on the number of tiles, i.e. on B and on
+    the kernel variant -- the scratch a caller sizes and the scratch the launch uses must follow the same plan."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    f1 = torch.randn(8, C, H, W, generator=g).to(cuda)
+    f2 = torch.randn(8, C, H, W, generator=g).to(cuda)
+    out = ops.corr81_forward(f1, f2)
+    for b in (0, 7):
+        ref = cwrap.corr81_fwd(f1[b:b + 1].cpu().numpy(), f2[b:b + 1].cpu().numpy())
+        np.testing.assert_allclose(out[b:b + 1].cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    buf = torch.full((8, 81 + 7, H, W), 3.0, device=cuda)
+    ops.corr81_act(f1, f2, buf, 4, 0.1)                          # into a channel slice, LeakyReLU applied
+    torch.testing.assert_close(buf[:, 4:85], torch.nn.functional.leaky_relu(out, 0.1), rtol=1e-6, atol=1e-7)
+    assert float((buf[:, :4] - 3.0).abs().max()) == 0.0 and float((buf[:, 85:] - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('C,H,W', [(8, 14, 20), (5, 9, 33), (32, 28, 40), (3, 8, 32)])
 def test_corr81_backward(cuda, C, H, W):
     from islam_amd import ops
