@@ -33,10 +33,27 @@ loop.reset()
 for k in range(warmup):
     loop.step(seq[k], next_sample=seq[k + 1])
 torch.cuda.synchronize()
+for k_ in loop.timing: loop.timing[k_] = 0.0
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for k in range(warmup, warmup + steps):
         loop.step(seq[k], next_sample=seq[k + 1])
     torch.cuda.synchronize()
+print('host time per stage and step (pipelined schedule, ms): ' + ', '.join('%s %.2f' % (k_, v_ / steps * 1e3) for k_, v_ in loop.timing.items()))
+# busy time per stream (the union of a stream's kernel intervals)
+import collections
+per = collections.defaultdict(list)
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CUDA:
+        per[e.thread].append((e.time_range.start, e.time_range.end))
+for sid, ivs in sorted(per.items(), key=lambda kv: -len(kv[1])):
+    ivs.sort()
+    tot, end = 0.0, None
+    for a, b in ivs:
+        if end is None or a > end:
+            tot += b - a; end = b
+        elif b > end:
+            tot += b - end; end = b
+    print('  stream %s: %d kernels per step, busy %.2f ms per step, kernel-time sum %.2f ms per step' % (sid, len(ivs) // steps, tot / steps / 1e3, sum(b - a for a, b in ivs) / steps / 1e3))
 iv = sorted((e.time_range.start, e.time_range.end) for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
 t0, t1 = iv[0][0], max(b for _, b in iv)
 pts = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
