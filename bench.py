@@ -59,6 +59,47 @@ def build_problem(device, n_frames=N_FRAMES):
     return prob, tr
 
 
+def reject_heavy_rate(ops, prob, prm, device, runs=12, sig=1.5, seed=6):
+    """The LM rate on a graph that makes LM REJECT trials and change its damping (the headline graph accepts
+    all ten trials and keeps its radius, so the fused kernel's speculation is always right there).  Same graph, dead-reckoning start
+    perturbed by N(0, sig) m per axis in translation and N(0, 0.2 sig) rad per axis in rotation (what tests/test_pvgo_gpu.py
+    ::test_fused_loop_equals_the_launch_per_stage_loop_on_reject_heavy_graphs perturbs with the oracle's Lie algebra; here with the
+    product's).  Every run starts from the same perturbed state; returns iters/s, trials, accepted steps, and the share of trials
+    whose speculation missed (rejects + radius changes = the launches behind them re-done)."""
+    from islam_amd import lietensor as pp
+    g = torch.Generator().manual_seed(seed)
+    N = prob['init_nodes'].shape[0]
+    dt_ = torch.randn(N, 3, generator=g, dtype=torch.float64) * sig
+    dr_ = torch.randn(N, 3, generator=g, dtype=torch.float64) * (0.2 * sig)
+    n0 = prob['init_nodes'].cpu()
+    n0 = torch.cat([n0[:, :3] + dt_, n0[:, 3:]], 1)
+    pert = pp.SE3(torch.cat([torch.zeros(N, 3, dtype=torch.float64), pp.so3(dr_).Exp().tensor()], 1))
+    start = (pert @ pp.SE3(n0)).tensor().to(device).contiguous()
+    ws = ops.pvgo_workspace(N, device)
+    states = [(start.clone(), prob['init_vels'].clone()) for _ in range(runs + 2)]
+    trials = steps = 0
+    trace = None
+    for i, (nodes, vels) in enumerate(states):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        res, tr_ = ops.pvgo_run_chain(nodes, vels, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'], prm, workspace=ws,
+                                      trace_cap=256 if i == 0 else 0)
+        if i == 0:
+            trace = np.asarray(tr_)[:res.trials]
+        if i >= 2:
+            trials += res.trials
+            steps += res.steps
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rej = int((trace[:, 2] == 0).sum()) if trace is not None and len(trace) else 0
+    damp_changes = int((np.abs(np.diff(trace[:, 1])) > 0).sum()) if trace is not None and len(trace) > 1 else 0
+    return {'value': trials / el, 'unit': 'LM iters/s', 'us_per_lm_iter': el / trials * 1e6, 'lm_iters_per_run': trials / runs,
+            'accepted_steps_per_run': steps / runs, 'rejected_trials_per_run': rej, 'damping_changes_per_run': damp_changes,
+            'what': 'same graph, start perturbed by N(0, %.1f m) / N(0, %.2f rad) per axis (seed %d): trials are rejected and the damping moves, '
+                    'so trial_elim_kernel mis-speculates and the host re-does the solve from the stored linearisation' % (sig, 0.2 * sig, seed)}
+
+
 def eliminate_l0_burst(ops, Hd, Ho, rhs, N, levels, device, launches=40):
     """Average period (us) of back-to-back launches of the level-0 up-sweep kernel (all segments; the launch
     islam_pvgo_solve_chain makes, through islam_pvgo_eliminate_level0), HIP events on the stream the kernel is launched on
@@ -461,6 +502,11 @@ def main():
             'us_per_lm_iter': elapsed / trials * 1e6,
             'roofline': roofline,
         }
+        if world == 1 and not force_sharded:
+            try:
+                out['reject_heavy'] = reject_heavy_rate(ops, prob, prm, device)
+            except Exception as e:
+                out['reject_heavy'] = {'error': repr(e)[:300]}
         if replicas is not None:
             out['independent_graphs'] = replicas
         if world > 1 or force_sharded:

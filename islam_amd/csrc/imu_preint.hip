@@ -15,7 +15,7 @@
 //
 // Kernels (data stays in HBM/L2 between them; sizes are tiny, the path is launch-latency bound):
 //   A  scan_kernel   one wave per frame: dr_j = Exp(gyro_j dt_j), doubling scan in LDS -> incre_r
-//   B  chain_kernel  one lane: R0_{i+1} = R0_i * incre_r_i[F]   (strictly sequential, like the reference)
+//   B  chain_rot_kernel  four lanes (one quaternion component each): R0_{i+1} = R0_i * incre_r_i[F]   (strictly sequential, like the reference)
 //   C  frame_kernel  one lane per frame: a_j, cumsum of dv / dp / dt, rotate by R0_i
 //   D  (world mode, inside chain_kernel's second pass) p/v chain
 #include <hip/hip_runtime.h>
@@ -149,42 +149,75 @@ __global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, cons
 }
 
 // B: sequential rotation chain over frames.  R0[i] = rotation at the start of frame i, R0[nframes] = final.
-// The products must be taken strictly left to right (bit-exact contract), so one lane walks the chain; the other
-// lanes of the workgroup stream the per-frame increments into LDS ahead of it and the results back out, so the
-// walking lane never waits on HBM (5000 frames: 1.7 ms with per-step global loads -> ~0.1 ms).
+// The products must be taken strictly left to right (bit-exact contract: the reference chains `rot = rot * drot` frame by frame,
+// imu_integrator.py:151), so the chain itself is serial -- but a quaternion product is four independent sums of four products, and
+// in every one of them term k multiplies the SAME component of the running rotation (qmul: a.w, a.x, a.y, a.z in that order).  Four
+// lanes of a wavefront walk the chain together, one output component each: per frame a lane reads its four signed factors
+// +-b[sigma_c(k)] from a table the rest of the workgroup has staged in LDS (negation is exact, so a - x y == a + x (-y) bit for bit),
+// takes the running rotation's component k from the lane that holds it with a DPP quad broadcast (a VALU move, no LDS round trip),
+// and does 4 multiplies + 3 adds in the order qmul writes them.  One lane alone spent ~330 clocks per frame (28 dependent double
+// operations issued at wave rate + LDS round trips for operands and results: 0.78 ms for 5000 frames); the quad form ~70.
 constexpr int CHAIN_CHUNK = 512;
+constexpr int ROT_CHUNK = 256;        // frames per staged chunk of the rotation chain (16 factors per frame)
+
+// double <-> two dwords through a DPP quad permutation (ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6: lane i of a quad reads lane p_i)
+template <int CTRL> __device__ __forceinline__ double quad_perm_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);      // (every lane of a full quad has a source: `old` is never taken;
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);      //  passing the source itself saves the move that zeroes it)
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float quad_perm_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double quad_bcast(double v) { return quad_perm_d<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ float quad_bcast(float v) { return quad_perm_f<CTRL>(v); }
 
 template <class T>
 __global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
                                                          const T* __restrict__ init_rot, T* __restrict__ R0) {
-    __shared__ T dq[CHAIN_CHUNK][4];       // per-frame increment incre_r_i[F_i]
-    __shared__ T out[CHAIN_CHUNK][4];      // R0[i+1]
-    __shared__ int has[CHAIN_CHUNK];       // F_i > 0
-    __shared__ T carry[4];
+    // sb[j][c][k]: factor of term k of output component c (x, y, z, w) for frame j's increment b = incre_r_j[F_j]:
+    //   x: +b.x +b.w +b.z -b.y    y: +b.y -b.z +b.w +b.x    z: +b.z +b.y -b.x +b.w    w: +b.w -b.x -b.y -b.z      (qmul above)
+    __shared__ __attribute__((aligned(16))) T sb[ROT_CHUNK][4][4];
+    __shared__ T out[ROT_CHUNK + 1][4];  // R0[i+1]; row ROT_CHUNK: where the idle lanes of the walking wave store (no branch in the loop)
+    __shared__ int has[ROT_CHUNK];       // F_i > 0
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        Q<T> r = ldq(init_rot);
-        stq(r, carry);
-        stq(r, R0);
-    }
-    for (int base = 0; base < nframes; base += CHAIN_CHUNK) {
-        const int cnt = min(CHAIN_CHUNK, nframes - base);
+    // lane c < 4 of wave 0 carries component c of the running rotation (x, y, z, w)
+    T rc = tid < 4 ? init_rot[tid] : (T)0;
+    if (tid < 4) R0[tid] = rc;
+    for (int base = 0; base < nframes; base += ROT_CHUNK) {
+        const int cnt = min(ROT_CHUNK, nframes - base);
         __syncthreads();
         for (int j = tid; j < cnt; j += 256) {
             const int i = base + j;
             const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
             has[j] = F > 0;
             const T* src = ir + 4 * ((size_t)a + i + F);
-            dq[j][0] = src[0]; dq[j][1] = src[1]; dq[j][2] = src[2]; dq[j][3] = src[3];
+            const T bx = src[0], by = src[1], bz = src[2], bw = src[3];
+            T* t = &sb[j][0][0];
+            t[0] = bx;  t[1] = bw;   t[2] = bz;   t[3] = -by;
+            t[4] = by;  t[5] = -bz;  t[6] = bw;   t[7] = bx;
+            t[8] = bz;  t[9] = by;   t[10] = -bx; t[11] = bw;
+            t[12] = bw; t[13] = -bx; t[14] = -by; t[15] = -bz;
         }
         __syncthreads();
-        if (tid == 0) {
-            Q<T> r = ldq(carry);
+        if (tid < 64) {                    // (whole wave 0 executes the loop: DPP needs its quad's lanes active; lanes >= 4 carry zeros)
+            const int c = tid & 3;
+            T* op = tid < 4 ? &out[0][c] : &out[ROT_CHUNK][c];
+            const int ostep = tid < 4 ? 4 : 0;
+            T f0 = sb[0][c][0], f1 = sb[0][c][1], f2 = sb[0][c][2], f3 = sb[0][c][3];
+            int h = has[0];
             for (int j = 0; j < cnt; ++j) {
-                if (has[j]) r = qmul(r, ldq(dq[j]));
-                stq(r, out[j]);
+                const int jn = j + 1 < cnt ? j + 1 : j;                 // next frame's factors: requested before this frame's arithmetic
+                const T n0 = sb[jn][c][0], n1 = sb[jn][c][1], n2 = sb[jn][c][2], n3 = sb[jn][c][3];
+                const int hn = has[jn];
+                const T aw = quad_bcast<0xff>(rc), ax = quad_bcast<0x00>(rc), ay = quad_bcast<0x55>(rc), az = quad_bcast<0xaa>(rc);
+                const T o = aw * f0 + ax * f1 + ay * f2 + az * f3;      // = qmul(r, b) component c, same operations in the same order
+                rc = h ? o : rc;
+                *op = rc;
+                op += ostep;
+                f0 = n0; f1 = n1; f2 = n2; f3 = n3; h = hn;
             }
-            stq(r, carry);
         }
         __syncthreads();
         for (int j = tid; j < cnt * 4; j += 256) R0[4 * (size_t)(base + 1) + j] = (&out[0][0])[j];
@@ -253,7 +286,7 @@ __global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, cons
         stq(qmul(ai, b), out_rot + 4 * (size_t)i);
         return;
     }
-    // world mode: sequential p/v chain (one lane), per-frame terms staged through LDS by the whole workgroup
+    // world mode: sequential p/v chain (three lanes, one per coordinate), per-frame terms staged through LDS by the whole workgroup
     __shared__ T sl[CHAIN_CHUNK][7];
     __shared__ T so[CHAIN_CHUNK][6];
     __shared__ int sF[CHAIN_CHUNK];
@@ -273,21 +306,29 @@ __global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, cons
         for (int j = tid; j < cnt; j += blockDim.x) sF[j] = (int)(seg[base + j + 1] - seg[base + j]);
         for (int j = tid; j < cnt * 7; j += blockDim.x) (&sl[0][0])[j] = loc[7 * (size_t)base + j];
         __syncthreads();
-        if (tid == 0) {
-            T p[3] = {carry[0], carry[1], carry[2]}, v[3] = {carry[3], carry[4], carry[5]}, sp[3] = {carry[6], carry[7], carry[8]};
+        if (tid < 3) {
+            // the three coordinates are independent chains: lane c walks coordinate c (one lane doing all three spent 12 dependent
+            // double operations + LDS round trips per frame: 0.46-0.9 ms for 5000 frames), the next frame's terms requested
+            // before this frame's arithmetic
+            const int c = tid;
+            T p = carry[c], v = carry[3 + c], sp = carry[6 + c];
+            T a = sl[0][c], b = sl[0][3 + c], t = sl[0][6];
+            int F = sF[0];
             for (int j = 0; j < cnt; ++j) {
-                T sv[3];
-                if (sF[j] == 0) {                           // imu_integrator.py:134-140: vel zeroed, pos / rot held
-                    sv[0] = sv[1] = sv[2] = 0;
+                const int jn = j + 1 < cnt ? j + 1 : j;
+                const T an = sl[jn][c], bn = sl[jn][3 + c], tn = sl[jn][6];
+                const int Fn = sF[jn];
+                T sv;
+                if (F == 0) {                               // imu_integrator.py:134-140: vel zeroed, pos / rot held
+                    sv = 0;
                 } else {
-                    for (int c = 0; c < 3; ++c) {
-                        sv[c] = v[c] + sl[j][c];
-                        sp[c] = p[c] + sl[j][3 + c] + v[c] * sl[j][6];
-                    }
+                    sv = v + a;
+                    sp = p + b + v * t;
                 }
-                for (int c = 0; c < 3; ++c) { so[j][c] = sp[c]; so[j][3 + c] = sv[c]; p[c] = sp[c]; v[c] = sv[c]; }
+                so[j][c] = sp; so[j][3 + c] = sv; p = sp; v = sv;
+                a = an; b = bn; t = tn; F = Fn;
             }
-            for (int c = 0; c < 3; ++c) { carry[c] = p[c]; carry[3 + c] = v[c]; carry[6 + c] = sp[c]; }
+            carry[c] = p; carry[3 + c] = v; carry[6 + c] = sp;
         }
         __syncthreads();
         for (int j = tid; j < cnt * 3; j += blockDim.x) {
