@@ -96,8 +96,9 @@ def reject_heavy_rate(ops, prob, prm, device, runs=12, sig=1.5, seed=6):
     damp_changes = int((np.abs(np.diff(trace[:, 1])) > 0).sum()) if trace is not None and len(trace) > 1 else 0
     return {'value': trials / el, 'unit': 'LM iters/s', 'us_per_lm_iter': el / trials * 1e6, 'lm_iters_per_run': trials / runs,
             'accepted_steps_per_run': steps / runs, 'rejected_trials_per_run': rej, 'damping_changes_per_run': damp_changes,
-            'what': 'same graph, start perturbed by N(0, %.1f m) / N(0, %.2f rad) per axis (seed %d): trials are rejected and the damping moves, '
-                    'so trial_elim_kernel mis-speculates and the host re-does the solve from the stored linearisation' % (sig, 0.2 * sig, seed)}
+            'what': 'same graph, start perturbed by N(0, %.1f m) / N(0, %.2f rad) per axis (seed %d): the trust region moves (and, for other '
+                    'seeds, trials are rejected), so trial_elim_kernel mis-speculates the damping and the host re-does the level-0 '
+                    'elimination from the stored linearisation -- the counts are those of one run' % (sig, 0.2 * sig, seed)}
 
 
 def eliminate_l0_burst(ops, Hd, Ho, rhs, N, levels, device, launches=40):
@@ -378,6 +379,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # ---- a second strong-scaling point on a graph LARGE enough for sharding to pay: the 5000-frame
+    # graph of the headline is one 57 us chain of dependent launches per LM iteration -- two latency-bound all-reduces per trial cost
+    # about as much -- while at N = 300 007 one iteration is 1.3 ms of work on one GPU.  Same code path as the headline at every world
+    # size (fused single-GPU loop at world 1, islam_pvgo_run_chain_sharded otherwise); ISLAM_BENCH_LARGE_N=0 skips it.
+    large = None
+    big_n = int(os.environ.get('ISLAM_BENCH_LARGE_N', '300007'))
+    if big_n > 0:
+        try:
+            t_b = time.perf_counter()
+            prob_b, _ = build_problem(device, big_n)
+            build_s = time.perf_counter() - t_b
+            runs_b = 3
+            if world == 1 and not force_sharded:
+                ws_b = ops.pvgo_workspace(big_n, device)
+                st_b = [(prob_b['init_nodes'].clone(), prob_b['init_vels'].clone()) for _ in range(runs_b + 1)]
+
+                def step_b(i):
+                    r, _ = ops.pvgo_run_chain(st_b[i][0], st_b[i][1], prob_b['vo'], prob_b['drots'], prob_b['dtrans'], prob_b['dvels'], prob_b['dts'],
+                                              prm, workspace=ws_b)
+                    return r.trials
+            else:
+                def step_b(i):
+                    _, _, r, _ = dist_pvgo.run_chain_sharded(comm, prob_b['init_nodes'], prob_b['init_vels'], prob_b['vo'], prob_b['drots'],
+                                                             prob_b['dtrans'], prob_b['dvels'], prob_b['dts'], LOSS_WEIGHT, radius=1e4)
+                    return r.trials
+            step_b(0)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t_b = time.perf_counter()
+            tr_b = sum(step_b(1 + i) for i in range(runs_b))
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            el_b = time.perf_counter() - t_b
+            if dist is not None:
+                tb_ = torch.tensor([el_b], dtype=torch.float64, device=device)
+                dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+                el_b = tb_.item()
+            large = {'N': big_n, 'value': tr_b / el_b, 'unit': 'LM iters/s', 'us_per_lm_iter': el_b / tr_b * 1e6, 'n_gpus': world, 'scaling': 'strong',
+                     'runs': runs_b, 'lm_iters_per_run': tr_b / runs_b, 'problem_build_s': build_s,
+                     'what': 'the same chain graph at N = %d nodes, one graph over %d GPU(s): the size at which sharding can pay' % (big_n, world)}
+            del prob_b
+        except Exception as e:           # the headline metric must still be reported
+            large = {'error': repr(e)[:300]}
+
     # ---- N > 1 only: the same graph solved independently on every GPU (one trajectory per GPU, SURVEY 8(e) row 4: no
     # data-path collective), reported NEXT to the headline sharded-graph figure, never instead of it
     replicas = None
@@ -507,6 +554,8 @@ def main():
                 out['reject_heavy'] = reject_heavy_rate(ops, prob, prm, device)
             except Exception as e:
                 out['reject_heavy'] = {'error': repr(e)[:300]}
+        if large is not None:
+            out['large_graph'] = large
         if replicas is not None:
             out['independent_graphs'] = replicas
         if world > 1 or force_sharded:

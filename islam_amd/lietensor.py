@@ -30,6 +30,63 @@ se3_type = LieType('se3', 6, 6, False)
 
 
 # ------------------------------------------------------------------------------------------ plain math
+# Host fast path.  The bilevel loop keeps its O(batch) pose algebra on the host in float64 (TartanVO(host_glue=True),
+# BilevelLoop): ~200 group operations per batch on (8, 7) tensors, each of them a handful of torch CPU ops at 5-10 us of
+# dispatch apiece -- 4 ms of a 12 ms step went into them (scripts/vio_hostprof.py).  The group primitives below are only ever
+# called inside the autograd.Functions of this file (no graph is recorded through them), so for small host tensors they
+# compute on numpy views instead: the same formulas, the same IEEE operations, ~1 us per operation.
+_NP_MAX = 4096
+
+
+def _host(*ts):
+    for t in ts:
+        if t.is_cuda or t.numel() > _NP_MAX or t.dtype not in (torch.float64, torch.float32):
+            return False
+    return True
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def _qmul_np(a, b):
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    o = np.empty(np.broadcast_shapes(a.shape, b.shape), dtype=np.result_type(a, b))
+    o[..., 0] = aw * bx + ax * bw + ay * bz - az * by
+    o[..., 1] = aw * by - ax * bz + ay * bw + az * bx
+    o[..., 2] = aw * bz + ax * by - ay * bx + az * bw
+    o[..., 3] = aw * bw - ax * bx - ay * by - az * bz
+    return o
+
+
+def _cross_np(a, b):
+    o = np.empty(np.broadcast_shapes(a.shape, b.shape), dtype=np.result_type(a, b))
+    o[..., 0] = a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1]
+    o[..., 1] = a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2]
+    o[..., 2] = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    return o
+
+
+def _qact_np(q, p):
+    u, w = q[..., :3], q[..., 3:]
+    uv = 2.0 * _cross_np(u, p)
+    return p + w * uv + _cross_np(u, uv)
+
+
+def _qmat_np(q):
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def _skew_np(v):
+    z = np.zeros_like(v[..., 0])
+    return np.stack([np.stack([z, -v[..., 2], v[..., 1]], -1), np.stack([v[..., 2], z, -v[..., 0]], -1),
+                     np.stack([-v[..., 1], v[..., 0], z], -1)], -2)
+
+
 def _skew(v):
     z = torch.zeros_like(v[..., 0])
     return torch.stack([torch.stack([z, -v[..., 2], v[..., 1]], -1), torch.stack([v[..., 2], z, -v[..., 0]], -1),
@@ -37,6 +94,8 @@ def _skew(v):
 
 
 def _qmul(a, b):
+    if _host(a, b):
+        return torch.from_numpy(_qmul_np(_np(a), _np(b)))
     ax, ay, az, aw = a.unbind(-1)
     bx, by, bz, bw = b.unbind(-1)
     return torch.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
@@ -48,12 +107,16 @@ def _qinv(q):
 
 
 def _qact(q, p):
+    if _host(q, p) and q.dtype == p.dtype:
+        return torch.from_numpy(_qact_np(_np(q), _np(p)))
     u, w = q[..., :3], q[..., 3:]
     uv = 2.0 * torch.linalg.cross(u.expand(torch.broadcast_shapes(u.shape, p.shape)), p.expand(torch.broadcast_shapes(u.shape, p.shape)), dim=-1)
     return p + w * uv + torch.linalg.cross(u.expand(uv.shape), uv, dim=-1)
 
 
 def _qmat(q):
+    if _host(q):
+        return torch.from_numpy(_qmat_np(_np(q)))
     x, y, z, w = q.unbind(-1)
     return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
                         torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
@@ -125,16 +188,30 @@ def _se3_Jl_inv(xi):
 
 
 def _se3_adj(X):
+    if _host(X):
+        x = _np(X)
+        R = _qmat_np(x[..., 3:])
+        top = np.concatenate([R, _skew_np(x[..., :3]) @ R], -1)
+        return torch.from_numpy(np.concatenate([top, np.concatenate([np.zeros_like(R), R], -1)], -2))
     R = _qmat(X[..., 3:])
     Z = torch.zeros_like(R)
     return torch.cat([torch.cat([R, _skew(X[..., :3]) @ R], -1), torch.cat([Z, R], -1)], -2)
 
 
 def _se3_mul(X, Y):
+    if _host(X, Y) and X.dtype == Y.dtype:
+        x, y = _np(X), _np(Y)
+        t = x[..., :3] + _qact_np(x[..., 3:], y[..., :3])
+        q = _qmul_np(x[..., 3:], y[..., 3:])
+        return torch.from_numpy(np.concatenate([t, q], -1))
     return torch.cat([X[..., :3] + _qact(X[..., 3:], Y[..., :3]), _qmul(X[..., 3:], Y[..., 3:])], -1)
 
 
 def _se3_inv(X):
+    if _host(X):
+        x = _np(X)
+        qi = np.concatenate([-x[..., 3:6], x[..., 6:7]], -1)
+        return torch.from_numpy(np.concatenate([-_qact_np(qi, x[..., :3]), qi], -1))
     qi = _qinv(X[..., 3:])
     return torch.cat([-_qact(qi, X[..., :3]), qi], -1)
 
@@ -153,6 +230,8 @@ def _unbroadcast(g, shape):
 
 
 def _row(g, M):      # row-vector times matrix, batched
+    if _host(g, M) and g.dtype == M.dtype:
+        return torch.from_numpy(np.einsum('...i,...ij->...j', _np(g), _np(M)))
     return (g.unsqueeze(-2) @ M).squeeze(-2)
 
 
@@ -322,16 +401,35 @@ class LieTensor(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        # the Lie type of the first LieTensor among the arguments (one level into lists / tuples: torch.cat / stack); the generic
+        # pytree walk is kept for anything nested deeper -- it cost ~25 us per call, on ~60 calls per bilevel step
         ltype = None
-        for a in tree_flatten((args, kwargs))[0]:
+        for a in args:
             if isinstance(a, LieTensor):
                 ltype = getattr(a, 'ltype', None)
                 break
+            if isinstance(a, (list, tuple)):
+                for b in a:
+                    if isinstance(b, LieTensor):
+                        ltype = getattr(b, 'ltype', None)
+                        break
+                if ltype is not None:
+                    break
+        if ltype is None and kwargs:
+            for a in tree_flatten(kwargs)[0]:
+                if isinstance(a, LieTensor):
+                    ltype = getattr(a, 'ltype', None)
+                    break
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         name = getattr(func, '__name__', '')
-        if ltype is None or name not in _KEEP:
-            return tree_map(_plain, out) if name not in _KEEP else out
+        keep = name in _KEEP
+        if isinstance(out, torch.Tensor):                    # the common case: one tensor out
+            if keep and ltype is not None and out.dim() >= 1 and out.shape[-1] == ltype.dim and out.dtype.is_floating_point:
+                return LieTensor(out, ltype)
+            return _plain(out)
+        if ltype is None or not keep:
+            return tree_map(_plain, out) if not keep else out
 
         def wrap(o):
             if isinstance(o, torch.Tensor) and o.dim() >= 1 and o.shape[-1] == ltype.dim and o.dtype.is_floating_point:

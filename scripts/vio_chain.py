@@ -17,7 +17,7 @@ vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord
 with torch.no_grad():
     vo.vonet.stereoNet.conv_c13.weight.zero_(); vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
 steps, warmup = 48, 6
-tr = synthetic.car_trajectory((3 * (steps + warmup) + 8) * batch + 1, seed=3)
+tr = synthetic.car_trajectory((7 * (steps + warmup) + 8) * batch + 1, seed=3)
 imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], np.zeros(3), np.zeros(3), tr['init'], tr['gravity'], tr['rgb2imu_sync'],
                 device=str(device), denoise_model_name=None, denoise_accel=True, denoise_gyro=False)
 loop = BilevelLoop(vo, imu, pp.identity_SE3(), tr['init'], batch_size=batch, device=str(device))
@@ -55,9 +55,24 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): vo.vonet.frozen_forward(*imgs)
 torch.cuda.synchronize()
 print('%-46s %.2f ms per batch' % ('frozen replay alone, back to back:', (time.perf_counter() - t0) / steps * 1e3), flush=True)
-# the main chain alone: cached frozen outputs
+# sensitivities: the pipelined step with parts of the work removed
 cached = tuple(t.clone() for t in vo.vonet.frozen_forward(*imgs))
 torch.cuda.synchronize()
+k0 = 2 * (steps + warmup)
+orig_run_frozen = vo.vonet._run_frozen
+def without(name):
+    def rf(nm, master, dtype, x, quarter=False):
+        if nm == name:
+            return ((cached[0],), None) if nm == 'flow' else (cached[1], None)
+        return orig_run_frozen(nm, master, dtype, x, quarter=quarter)
+    return rf
+for name in ('flow', 'stereo'):
+    vo.vonet._run_frozen = without(name)
+    vo.vonet.reset_graphs()
+    run('pipelined, %s net replaced by a cached result:' % name, k0); k0 += steps + warmup
+vo.vonet._run_frozen = orig_run_frozen
+vo.vonet.reset_graphs()
+# the main chain alone: cached frozen outputs
 vo.vonet.frozen_forward = lambda *a: cached
 vo.vonet._frozen_graphed = lambda imgs_: cached
-run('main chain alone (frozen outputs cached):', 2 * (steps + warmup))
+run('main chain alone (frozen outputs cached):', k0); k0 += steps + warmup

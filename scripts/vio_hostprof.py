@@ -29,6 +29,12 @@ for k in range(2):
 seq = []
 for k in range(steps + warmup + 2):
     smp = dict(samples[k % 2]); smp['link'] = samples[k % 2]['link'] + k * batch; seq.append(smp)
+if os.environ.get('CACHE_FROZEN') == '1':          # the main chain alone: the frozen nets' replay replaced by cached outputs
+    imgs = [samples[0][k] for k in ('img0', 'img1', 'img0_norm', 'img0_r_norm')]
+    cached = tuple(t.clone() for t in vo.vonet.frozen_forward(*imgs))
+    torch.cuda.synchronize()
+    vo.vonet.frozen_forward = lambda *a: cached
+    vo.vonet._frozen_graphed = lambda imgs_: cached
 loop.reset()
 for k in range(warmup):
     loop.step(seq[k], next_sample=seq[k + 1])
