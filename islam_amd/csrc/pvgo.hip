@@ -2292,6 +2292,190 @@ __global__ __launch_bounds__(LB_THREADS) void trial_lin_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Small graphs: the WHOLE LM loop of run_pvgo in ONE launch of ONE workgroup.
+// The reference optimises a window of batch_size + 1 = 9 nodes per training step (train.py:253-263, run_kitti.sh:8): one
+// block-tridiagonal segment (bt_top_kernel with a single level) and one block of links (trial_lin_kernel).  Launched per stage that is
+// two dependent launches and one host round trip per LM trial -- ~40 us per trial on an idle GPU, and 3-4x that inside the bilevel
+// step, where every one of those launches waits for a CU slot beside the frozen nets' convolution kernels of the next batch
+// (scripts/vio_chain.py: the PVGO stage took 0.7 ms alone and 3.0 ms in the pipelined step).  Here the host launches once and polls
+// once: the loop of islam_pvgo_run_chain's launch-per-stage branch -- damped solve, trial step, TrustRegion.update, accept / reject,
+// StopOnPlateau, the linearisation at an accepted trial point, the re-linearisation after a failed solve -- runs on the device with
+// the same device functions in the same order (same numbers: tests/test_pvgo_gpu.py compares both loops), workgroup barriers where
+// the launch-per-stage loop has kernel boundaries.  The linearisation at the trial point is built only once the trial is accepted.
+struct SmallArgs {
+    double *nodes, *vels;                               // the iterate (in / out)
+    const double *poses, *drots, *dtrans, *dvels, *dts;
+    int N;
+    double *nodes_t, *vels_t, *dx;
+    double *LIN[2], *HD[2], *HO[2], *RH[2];              // linearisation buffers; [0] holds the linearisation of the initial iterate
+    double* loss_part;
+    double* st;
+    int* flags;
+    TRParams tr;
+    LinWeights W;
+    LevelDst dst;                                       // factor storage of the single level
+    double* report;                                     // pinned host block: [0] loss [2] damping [10] status [11] trials [13] steps [15] marker
+    double* trace;                                      // pinned host rows (trial loss, damping, accepted) or nullptr
+    int trace_cap;
+    double marker;
+};
+
+__global__ __launch_bounds__(LB_THREADS) void small_lm_kernel(SmallArgs a) {
+    __shared__ double sl[64][LB_REC];
+    __shared__ double s_sq;
+    __shared__ int s_verdict;
+    extern __shared__ __attribute__((aligned(16))) double small_dyn[];      // lb_out of nodes_build_copy | the solve's column copies
+    double* lb_out = small_dyn;
+    double* lds_solve = small_dyn + LB_DYN_BYTES / (int)sizeof(double);
+    const int N = a.N, M = N - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int L = lane - 1;                                      // link of this lane (block 0 of linbuild / trial_lin)
+    const bool valid = L >= 0 && L < M && lane <= LB_NODES;
+    const ReprojDev rp{};
+    int pb = 0, trials = 0, status = ISLAM_OK;
+    double *cur_n = a.nodes, *cur_v = a.vels, *tri_n = a.nodes_t, *tri_v = a.vels_t;
+    for (;;) {
+        // ---- damped solve on buffer pb (bt_top_kernel with one level: the diagonal is damped in place, cumulatively over retries)
+        if (wave == 0) {
+            LevelSrc src{};
+            src.level0 = 1; src.Hd = a.HD[pb]; src.Ho = a.HO[pb]; src.rhs0 = a.RH[pb]; src.state = a.st; src.damping_override = 0.0;
+            eliminate_segment(src, a.dst, N, N, 0, a.flags, lane, lds_solve);
+            double xn[9], xL[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
+            backsub_segment(a.dst.fac, a.dst.inv, a.dx, 0, N, lane, xn, xL);
+        }
+        __syncthreads();                                         // dx is visible to the workgroup
+        // ---- the trial point, its residuals (wave 0) and the trust-region term of the old linearisation (wave 1): trial_lin_kernel
+        SE3<double> Xi{}, Xj{};
+        V3<double> vi{}, vj{};
+        LinkRes r{};
+        double dt = 0.0, qd = 0.0;
+        if (wave == 0) {
+            double sq = 0.0;
+            if (valid) {
+                const double* di = a.dx + (size_t)L * 9;
+                const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+                const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+                Xi = se3_mul(se3_exp(dri, dpi), se3_load(cur_n + 7 * L));                      // LieTensor.add_
+                Xj = se3_mul(se3_exp(drj, dpj), se3_load(cur_n + 7 * (L + 1)));
+                vi = ld3(cur_v + 3 * L) + dvi;
+                vj = ld3(cur_v + 3 * (L + 1)) + dvj;
+                dt = a.dts[L];
+                r = link_residuals(Xi, Xj, vi, vj, se3_load(a.poses + 7 * L), ld4(a.drots + 4 * L), ld3(a.dtrans + 3 * L),
+                                   ld3(a.dvels + 3 * L), dt);
+                sq = dot(r.erho, r.erho) + dot(r.ephi, r.ephi) + dot(r.rv, r.rv) + dot(r.er, r.er) + dot(r.rt, r.rt);
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) s_sq = sq;
+        } else if (wave == 1) {
+            if (valid) {
+                const double* lin = a.LIN[pb];
+                const double* di = a.dx + (size_t)L * 9;
+                const V3<double> dri = ld3(di), dpi = ld3(di + 3), dvi = ld3(di + 6);
+                const V3<double> drj = ld3(di + 9), dpj = ld3(di + 12), dvj = ld3(di + 15);
+                const double dtl = a.dts[L];
+                double rec[LIN_C];
+#pragma unroll
+                for (int c = 0; c < LIN_C; ++c) rec[c] = lin[(size_t)c * M + L];
+                const M3<double> G = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
+                const V3<double> ddr = drj - dri, ddp = dpj - dpi;
+                const V3<double> j0 = G * ddr + C * ddp, j1 = G * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
+                const V3<double> R0{rec[0], rec[1], rec[2]}, R1{rec[3], rec[4], rec[5]}, R2{rec[36], rec[37], rec[38]},
+                    R3{rec[24], rec[25], rec[26]}, R4{rec[39], rec[40], rec[41]};
+                qd = dot(j0, 2.0 * R0 + j0) + dot(j1, 2.0 * R1 + j1) + dot(j2, 2.0 * R2 + j2) + dot(j3, 2.0 * R3 + j3) +
+                     dot(j4, 2.0 * R4 + j4);
+            }
+            qd = wave_sum(qd);
+        }
+        __syncthreads();
+        if (wave == 0 && valid) {                                // the trial iterate
+            se3_store(Xi, tri_n + 7 * L);
+            tri_v[3 * L] = vi.x; tri_v[3 * L + 1] = vi.y; tri_v[3 * L + 2] = vi.z;
+            if (L == M - 1) {
+                se3_store(Xj, tri_n + 7 * (L + 1));
+                tri_v[3 * L + 3] = vj.x; tri_v[3 * L + 4] = vj.y; tri_v[3 * L + 5] = vj.z;
+            }
+        }
+        if (wave == 1 && lane == 0) {                            // the LM decision (one lane, as in the deciding workgroup of trial_lin_kernel)
+            const bool failed = a.flags[0] != 0;
+            a.flags[0] = 0;
+            const int v = lm_control(s_sq, qd, a.st, failed, a.tr, nullptr, (double)(trials + 1));
+            if (a.trace && trials < a.trace_cap && v < 3) {
+                __hip_atomic_store(&a.trace[3 * trials], a.st[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a.trace[3 * trials + 1], a.st[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a.trace[3 * trials + 2], v == 1 ? 0.0 : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            s_verdict = v;
+        }
+        __syncthreads();
+        const int verdict = s_verdict;
+        ++trials;
+        if (verdict == 0) {
+            // accepted, continue: the linearisation at the trial point into the other buffer (trial_lin_kernel's second half), then swap
+            if (wave == 0 && valid) {
+                M3<double> G, C, B;
+                link_jacobians(r, G, C, B);
+                link_emit(r, G, C, B, dt, L, M, true, a.W, a.LIN[1 - pb], sl[lane], nullptr, rp, Xi);
+            }
+            __syncthreads();
+            nodes_build_copy(sl, lb_out, 0, N, a.W, a.HD[1 - pb], a.HO[1 - pb], a.RH[1 - pb]);
+            __syncthreads();
+            pb = 1 - pb;
+            double* t;
+            t = cur_n; cur_n = tri_n; tri_n = t;
+            t = cur_v; cur_v = tri_v; tri_v = t;
+            continue;
+        }
+        if (verdict == 1) continue;                              // rejected: same iterate, same (cumulatively damped) linearisation
+        if (verdict == 2) {                                      // accepted, StopOnPlateau says stop
+            double* t;
+            t = cur_n; cur_n = tri_n; tri_n = t;
+            t = cur_v; cur_v = tri_v; tri_v = t;
+            break;
+        }
+        status = ISLAM_ENOTPD;                                   // "Linear solver failed. Breaking optimization step..."
+        if (verdict == 4) break;
+        // PyPose keeps looping through the scheduler: same iterate, new linearisation (linbuild_kernel's body)
+        if (wave == 0) {
+            double sq = 0.0;
+            if (valid) {
+                const SE3<double> Yi = se3_load(cur_n + 7 * L), Yj = se3_load(cur_n + 7 * (L + 1));
+                const double dtl = a.dts[L];
+                const LinkRes rr = link_residuals(Yi, Yj, ld3(cur_v + 3 * L), ld3(cur_v + 3 * (L + 1)), se3_load(a.poses + 7 * L),
+                                                  ld4(a.drots + 4 * L), ld3(a.dtrans + 3 * L), ld3(a.dvels + 3 * L), dtl);
+                M3<double> G, C, B;
+                link_jacobians(rr, G, C, B);
+                sq = dot(rr.erho, rr.erho) + dot(rr.ephi, rr.ephi) + dot(rr.rv, rr.rv) + dot(rr.er, rr.er) + dot(rr.rt, rr.rt);
+                link_emit(rr, G, C, B, dtl, L, M, true, a.W, a.LIN[pb], sl[lane], nullptr, rp, Yi);
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) a.loss_part[0] = sq;
+        }
+        __syncthreads();
+        nodes_build_copy(sl, lb_out, 0, N, a.W, a.HD[pb], a.HO[pb], a.RH[pb]);
+        __syncthreads();
+    }
+    // ---- the result goes back into the caller's arrays; one record for the host
+    __syncthreads();
+    if (cur_n != a.nodes) {
+        for (int e = threadIdx.x; e < 7 * N; e += LB_THREADS) a.nodes[e] = cur_n[e];
+        for (int e = threadIdx.x; e < 3 * N; e += LB_THREADS) a.vels[e] = cur_v[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&a.report[0], a.st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.report[2], a.st[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.report[10], (double)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.report[11], (double)trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.report[13], a.st[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the copy above has left the CU before the host is told (it may launch readers next)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&a.report[15], a.marker, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The LM loop's steady state in ONE launch: trial step + loss / trust-region partial sums of trial t, the linearisation at the
 // trial point, AND the level-0 elimination of the next solve straight out of LDS.
 //
@@ -3932,6 +4116,57 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     }
     enqueue_linbuild(A.cur_n, A.cur_v, A.pb, false);
     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
+    // ---- small graphs (one segment, one block of links: the reference's own per-batch window of 9 nodes): the whole loop in ONE launch
+    const bool no_small = [] { const char* e = std::getenv("ISLAM_PVGO_NO_SMALL"); return e && e[0] == '1'; }();      // (read per call: A/B tests)
+    // (one wave eliminates the window's nodes one after the other, ~2 us each: beyond a couple of dozen nodes the level tree of the
+    // launch-per-stage loop is faster -- N = 65 takes 190 us per run there)
+    constexpr int SMALL_MAX_N = 16;
+    if (!no_small && !reproj && N <= SMALL_MAX_N) {
+        constexpr int SMALL_LDS = LB_DYN_BYTES + LDS_PER_WAVE * (int)sizeof(double);
+        static bool sm_attr_set[64] = {};
+        int dev_i = 0;
+        ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+        if (dev_i >= 0 && dev_i < 64 && !sm_attr_set[dev_i]) {
+            ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)small_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS));
+            sm_attr_set[dev_i] = true;
+        }
+        static thread_local double* host_trace = nullptr;       // pinned rows for the optional trace (3 per trial)
+        constexpr int TRACE_ROWS = 1024;
+        double* trace_dev = nullptr;
+        if (trace && trace_cap > 0) {
+            if (!host_trace) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_trace, 3 * TRACE_ROWS * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));
+            ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&trace_dev, host_trace, 0));
+        }
+        SmallArgs sa{};
+        sa.nodes = nodes; sa.vels = vels; sa.poses = poses; sa.drots = drots; sa.dtrans = dtrans; sa.dvels = dvels; sa.dts = dts; sa.N = N;
+        sa.nodes_t = w.nodes_t; sa.vels_t = w.vels_t; sa.dx = w.dx;
+        for (int i = 0; i < 2; ++i) { sa.LIN[i] = LIN[i]; sa.HD[i] = HD[i]; sa.HO[i] = HO[i]; sa.RH[i] = RH[i]; }
+        sa.loss_part = w.loss_part; sa.st = w.state; sa.flags = w.flags; sa.tr = tr; sa.W = W;
+        sa.dst = level_dst(w.lv[0], w.dx);
+        sa.report = report; sa.trace = trace_dev; sa.trace_cap = std::min(trace_cap, TRACE_ROWS); sa.marker = 7.0;
+        hipLaunchKernelGGL(small_lm_kernel, dim3(1), dim3(LB_THREADS), SMALL_LDS, s, sa);
+        ISLAM_LAUNCH_CHECK();
+        {
+            unsigned long spins = 0;
+            while (hs_all[15] != sa.marker) {
+                if (++spins > 400000000ul) {
+                    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                    if (hs_all[15] != sa.marker) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: no status from the device (small-graph loop)");
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        result->loss = hs_all[0];
+        result->damping = hs_all[2];
+        result->status = (int)hs_all[10];
+        result->trials = (int)hs_all[11];
+        result->steps = (int)hs_all[13];
+        if (trace && trace_cap > 0) {
+            const int nt = std::min(result->trials, sa.trace_cap);
+            for (int i = 0; i < 3 * nt; ++i) trace[i] = host_trace[i];
+        }
+        return ISLAM_OK;
+    }
     int rc = enqueue_iter(A, 1.0, epoch);
     if (rc != ISLAM_OK) return rc;
     for (;;) {

@@ -57,8 +57,9 @@ __device__ __forceinline__ double speculated_damping(const double* __restrict__ 
 // pp.optim.LM accept/reject + ppost.TrustRegion.update on the summed partials (one lane)
 // failed: a solver error was flagged for the solve whose trial this is.  d_spec >= 0: the solve of the next step is already running
 // with this damping; an accepted trial whose TrustRegion.update yields another damping closes the gate (verdict 5).
-__device__ inline void lm_control(double s, double q, double* __restrict__ st, bool failed, const TRParams& tr,
-                                  double* __restrict__ report, double seq, double d_spec = -1.0) {
+// Returns the verdict (= report[12]); report may be nullptr (small_lm_kernel keeps the whole loop on the device).
+__device__ inline int lm_control(double s, double q, double* __restrict__ st, bool failed, const TRParams& tr,
+                                 double* __restrict__ report, double seq, double d_spec = -1.0) {
     double rep[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) rep[i] = 0.0;
@@ -105,6 +106,7 @@ __device__ inline void lm_control(double s, double q, double* __restrict__ st, b
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // payload written through before the sequence number
         __hip_atomic_store(&report[15], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    return (int)rep[12];
 }
 
 // ---- gated stage entry points (defined in pvgo.hip) --------------------------------------------------------------------------
