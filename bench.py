@@ -143,16 +143,19 @@ def trial_elim_burst(ops, prob, prm, N, device, launches=40):
 
 
 def committed_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_r03.json), valid only for the kernel source
-    they were taken on: the file records sha256(pvgo.hip)[:16]; a different source -> no traffic figure (never a stale one)."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (the latest profiles/traffic_r*.json), valid only for the kernel
+    source they were taken on: the file records sha256(pvgo.hip)[:16]; a different source -> no traffic figure (never a stale one)."""
+    import glob
     import hashlib
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_r03.json')
-    if not os.path.exists(tpath):
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic_r[0-9]*.json')))
+    if not fs:
         return None
+    tpath = fs[-1]
     t = json.load(open(tpath))
+    t['file'] = os.path.relpath(tpath, ROOT)
     sha = hashlib.sha256(open(os.path.join(ROOT, 'islam_amd', 'csrc', 'pvgo.hip'), 'rb').read()).hexdigest()[:16]
     if t.get('pvgo_hip_sha16') != sha:
-        return {'stale': True, 'note': 'profiles/traffic_r03.json was taken on pvgo.hip %s, this is %s: dropped' % (t.get('pvgo_hip_sha16'), sha)}
+        return {'stale': True, 'note': '%s was taken on pvgo.hip %s, this is %s: dropped' % (t['file'], t.get('pvgo_hip_sha16'), sha)}
     return t
 
 
@@ -258,20 +261,87 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
 
     el_seq, tm = run(False)
     el, _ = run(True)      # the frozen flow / disparity forward of batch k+1 overlaps the IMU / PVGO / backward of batch k
-    return {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo',
-            'nets': 'stereo net: bf16 NHWC execution copy -- every stride-1 3x3 convolution and the hourglass 1x1 convolutions on the HIP '
-                    'implicit-GEMM kernel (BatchNorm statistics in the epilogue, BatchNorm + ReLU on load; pooling / up-sample+add / SPP '
-                    'kernels), the decoder\'s transposed convolutions on the same kernel, the four stride-2 convolutions on MIOpen / CK; '
-                    'flow net: HIP implicit-GEMM 3x3 convolutions (bf16 operands, fp32 accumulate; DenseNet blocks on the channels-last kernel '
-                    'through a bf16 mirror of the fp32 buffer), pyramid levels 1-2 as one fused three-layer launch each, flow head + '
-                    'up-sampled features of a level as one convolution of the mirror, stride-2 layers of levels 3-6 on MIOpen; pose head '
-                    'fp32 (trainable, MIOpen with a pinned solution set; forward / backward as HIP graphs)',
-            'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
-            'ms_per_batch': el / steps * 1e3,
-            'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
-            'sequential_frames_per_s': steps * batch / el_seq, 'sequential_ms_per_batch': el_seq / steps * 1e3,
-            'sequential_stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
-            'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic'}
+    out = {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo',
+           'nets': 'stereo net: bf16 NHWC execution copy -- every stride-1 3x3 / 1x1 convolution on the HIP implicit-GEMM kernel (BatchNorm '
+                   'statistics in the epilogue, BatchNorm + ReLU on load; pooling / up-sample+add / SPP kernels), the 35 hourglass Residual modules '
+                   'as ONE launch each (islam_hg_residual_nhwc_bf16: intermediates in LDS), the decoder\'s transposed convolutions on the convolution '
+                   'kernel, the four stride-2 convolutions on MIOpen / CK; flow net: no MIOpen kernel -- HIP implicit-GEMM 3x3 convolutions (bf16 '
+                   'operands, fp32 accumulate; DenseNet blocks / context network on the channels-last kernel through a bf16 mirror), pyramid levels 1-2 '
+                   'as one fused three-layer launch each, stride-2 layers of levels 3-6 on islam_conv3x3_mfma, flow head + up-sampled features of a '
+                   'level as one convolution of the mirror, 81-channel correlation at four pixels per lane; pose head fp32 (trainable, MIOpen with a '
+                   'pinned solution set; forward / backward as HIP graphs); PVGO of the 9-node window: the whole LM loop in one launch (small_lm_kernel)',
+           'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
+           'ms_per_batch': el / steps * 1e3,
+           'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
+           'sequential_frames_per_s': steps * batch / el_seq, 'sequential_ms_per_batch': el_seq / steps * 1e3,
+           'sequential_stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
+           'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic'}
+    # roofline of the front end with EXECUTED matrix-core work (the reference-equivalent 466.4 GFLOP per frame above counts the
+    # full-resolution tail the quarter-resolution evaluation skips) and the shader clock the chip sustains under this load: both from
+    # the committed hardware-counter pass over the frozen forward (scripts/frozen_pmc.sh -> profiles/r04/frozen_exec_summary_*.json)
+    ex = committed_exec_summary()
+    if ex:
+        g = ex['executed_gflop_per_frame']
+        clk = ex.get('shader_clock_ghz_time_weighted') or 2.4
+        rate = g * 1e-3 * steps * batch / el
+        out['roofline'] = {'bound': 'mfma', 'executed_gflop_per_frame': g, 'achieved': rate, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': rate / 2500.0,
+                           'shader_clock_ghz': clk, 'peak_at_clock': 2500.0 * clk / 2.4, 'frac_at_clock': rate / (2500.0 * clk / 2.4),
+                           'frozen_kernel_ms_per_batch': ex.get('kernel_ms_per_forward'),
+                           'source': ex.get('source'),
+                           'note': 'frames/s x executed bf16 matrix-core flops of the frozen nets per frame (SQ_VALU_MFMA_BUSY_CYCLES x 1024); the pose '
+                                   'head (fp32, 1.9 GFLOP per frame) and everything that is not a matrix instruction is not counted'}
+    return out
+
+
+def committed_exec_summary():
+    """profiles/r04/frozen_exec_summary_*.json (latest): executed matrix-core GFLOP per frame and the shader clock of the frozen forward,
+    from rocprofv3 PMC passes on the GPU box; None if no summary is committed."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04', 'frozen_exec_summary_*.json')))
+    if not fs:
+        return None
+    try:
+        d = json.load(open(fs[-1]))
+        d['source'] = os.path.relpath(fs[-1], ROOT)
+        return d
+    except Exception:
+        return None
+
+
+def front_end_kernel_rooflines(device):
+    """HBM rooflines of the two bandwidth-bound front-end kernels north_star names (81-channel correlation, warp + mask) at the PWC
+    level where they move the most bytes (level 2: C = 32, 112 x 160, B = 8): a burst between one event pair on the launch stream,
+    algorithmic bytes of SURVEY 8(d) (4 B H W (2 C + 81) and 4 B H W (2 C + 2))."""
+    from islam_amd import ops
+    B, C, H, W = 8, 32, 112, 160
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.randn(B, C, H, W, generator=g).to(device)
+    f2 = torch.randn(B, C, H, W, generator=g).to(device)
+    # a smooth field of a few pixels (what an optical-flow estimate looks like), not per-pixel noise: neighbouring lanes gather neighbouring texels
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    flow = torch.stack([0.6 * torch.sin(yy / 17.0) + 0.3 * torch.cos(xx / 23.0), 0.5 * torch.cos(yy / 29.0 + xx / 31.0)], 0)
+    flow = (flow[None].repeat(B, 1, 1, 1) + 0.02 * torch.randn(B, 2, H, W, generator=g)).contiguous().to(device)
+    buf = torch.empty(B, 81 + 8, H, W, device=device)
+
+    def burst(fn, n=40):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+    out = {}
+    us = burst(lambda: ops.corr81_act(f1, f2, buf, 8, 0.1))
+    by = 4.0 * B * H * W * (2 * C + 81)
+    out['corr81_fwd_level2'] = {'us': us, 'bytes': by, 'GB/s': by / us / 1e3, 'frac': by / us / 1e3 / HBM_PEAK_GBS, 'timing': 'burst of launches, one event pair'}
+    us = burst(lambda: ops.warp_mask(f2, flow, 5.0))
+    by = 4.0 * B * H * W * (2 * C + 2)
+    out['warp_mask_level2'] = {'us': us, 'bytes': by, 'GB/s': by / us / 1e3, 'frac': by / us / 1e3 / HBM_PEAK_GBS, 'timing': 'burst of launches, one event pair'}
+    return out
 
 
 def main():
@@ -527,7 +597,7 @@ def main():
         iter_bytes = 5000 * N                                           # ~5.0 KB per node per LM iteration
         roofline = {'bound': 'hbm', 'kernel': dom_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                    'traffic_source': (None if traffic is None else 'profiles/traffic_r03.json (rocprofv3 PMC passes, separate FETCH_SIZE / WRITE_SIZE '
+                    'traffic_source': (None if traffic is None else '%s (rocprofv3 PMC passes,' % tfile.get('file') + ' separate FETCH_SIZE / WRITE_SIZE '
                                        'runs of this command; valid for pvgo.hip sha256[:16] = %s)' % tfile.get('pvgo_hip_sha16')) if not (tfile or {}).get('stale')
                                       else tfile['note'],
                     'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': dom_s * 1e6,
@@ -565,6 +635,10 @@ def main():
                 out['stereo_vio'] = vio_frames_per_sec(device)
             except Exception as e:           # the headline metric must still be reported
                 out['stereo_vio'] = {'error': repr(e)[:300]}
+            try:
+                out['front_end_per_launch'] = front_end_kernel_rooflines(device)
+            except Exception as e:
+                out['front_end_per_launch'] = {'error': repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             host = {k: v.cpu().numpy() for k, v in (('init_nodes', prob['init_nodes']), ('init_vels', prob['init_vels']),
                                                      ('vo_motions', prob['vo']), ('imu_drots', prob['drots']),

@@ -2570,7 +2570,20 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
             int spins = 0;
             while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)a.nwg) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 22)) { atomicOr(a.flags, 2); break; }     // never observed; a logic error must not hang the GPU
+                if (++spins > (1 << 22)) {
+                    // Never observed; a logic error must not hang the GPU.  The partial sums are incomplete, so this is NOT a trial
+                    // outcome: close the run-ahead gate (everything queued behind becomes a no-op), leave the ticket alone (stragglers
+                    // of this launch still count into it; control_init_kernel clears it for the next run) and hand the host verdict 9,
+                    // which fails the run with ISLAM_EHIP.
+                    atomicOr(a.flags, 8);
+                    a.st[14] = -1.0;
+                    if (a.report) {
+                        __hip_atomic_store(&a.report[12], 9.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&a.report[15], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return;
+                }
             }
         }
         asm volatile("" ::: "memory");
@@ -3888,6 +3901,20 @@ int islam_pvgo_run_chain(double* nodes, double* vels, const double* poses, const
                                        workspace_bytes, result, trace, trace_cap, stream);
 }
 
+}  // extern "C"
+
+// error path of the run: an epoch no enqueued kernel carries turns everything still queued into no-ops
+__global__ void close_gate_kernel(double* __restrict__ st) {
+    if (threadIdx.x == 0) st[14] = -1.0;
+}
+
+static int run_chain_impl(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
+                          const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                          const islam_pvgo_reproj* reproj, const ReprojDev& rp, Workspace& w, hipStream_t s,
+                          islam_pvgo_result* result, double* trace, int trace_cap);
+
+extern "C" {
+
 int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
                                 const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
                                 const islam_pvgo_reproj* reproj, void* workspace, size_t workspace_bytes,
@@ -3904,6 +3931,24 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
                     islam_pvgo_workspace_bytes(N));
     Workspace w = carve((void*)align_up((size_t)workspace), N);
     hipStream_t s = as_stream(stream);
+    const int rc = run_chain_impl(nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, reproj, rp, w, s, result, trace, trace_cap);
+    if (rc != ISLAM_OK) {
+        // A failed enqueue or status wait leaves epoch-gated kernels of the run-ahead chain queued: they would still write the pinned
+        // status block and the workspace the NEXT call reuses.  Close the gate and drain the stream before handing the error up (the
+        // message of the original failure is kept) -- the same rule as the sharded loop (pvgo_dist.hip).
+        hipLaunchKernelGGL(close_gate_kernel, dim3(1), dim3(64), 0, s, w.state);
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+
+}  // extern "C"
+
+static int run_chain_impl(double* nodes, double* vels, const double* poses, const double* drots, const double* dtrans,
+                          const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                          const islam_pvgo_reproj* reproj, const ReprojDev& rp, Workspace& w, hipStream_t s,
+                          islam_pvgo_result* result, double* trace, int trace_cap) {
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     const int M = N - 1;
     // status blocks in pinned, device-visible host memory: the deciding wave of trial_lin_kernel writes one per trial
@@ -4077,6 +4122,7 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
             }
             ++trials;
             const int verdict = (int)hs[12];
+            if (verdict == 9) return fail(ISLAM_EHIP, "islam_pvgo_run_chain: the deciding workgroup of trial %d gave up waiting for the level's workgroups", trials);
             damping = hs[2];
             loss = hs[0];
             steps = (int)hs[13];
@@ -4234,6 +4280,8 @@ int islam_pvgo_run_chain_reproj(double* nodes, double* vels, const double* poses
     result->damping = damping;
     return ISLAM_OK;
 }
+
+extern "C" {
 
 // Measurement hook (bench.py's roofline leg): the LM loop's dominant launch, trial_elim_kernel, exactly as islam_pvgo_run_chain
 // launches it in its steady state -- after one linearisation and one damped solve of the given problem (so that `dx` and the old

@@ -14,4 +14,6 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/fpmc_$TAG/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/fpmc_$TAG/write -o f -- $CMD > $OUT/write.log 2>&1
 python3 $GRAFT_REPO_ROOT/scripts/frozen_pmc_summary.py /tmp/fpmc_$TAG > $OUT/summary.txt 2>&1
+cp /tmp/fpmc_$TAG/exec_summary.json $OUT/ 2>/dev/null
+for p in mfma fetch write; do f=$(find /tmp/fpmc_$TAG/$p -name '*counter_collection.csv' | head -1); [ -n "$f" ] && gzip -c $f > $OUT/${p}_counter_collection.csv.gz; done
 cat $OUT/summary.txt

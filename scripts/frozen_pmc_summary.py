@@ -58,6 +58,39 @@ for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['ns']):
     print('%-58s %5d %9.1f %7.1f%% %8.2f %7.1f%% %10.1f %8.2f' % (k[:58], g['n'], us, util_pk, clk, util_clk, mb, tbs))
     if 'conv' in k or 'pyr_level' in k or 'hg_residual' in k:
         tot['busy'] += g['busy']; tot['ns'] += g['ns']; tot['gui'] += g['gui']
+# everything ONE forward launches (hand-written and library kernels alike): the pass records `reps` forwards, the first of which also
+# carries weight packing and MIOpen's set-up; the steady-state forward is the period of the kernel-name sequence at the end of the trace
+import json
+reps = float(os.environ.get('FWD_REPS', '4'))
+seq = [mf[k] for k in sorted(mf, key=lambda i: int(i))]
+names = [d['name'] for d in seq]
+period = None
+for K in range(50, len(names) // 2 + 1):
+    if names[-K:] == names[-2 * K:-K]:
+        period = K
+        break
+last = seq[-period:] if period else seq
+all_busy = sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for d in last)
+all_ns = sum(d['ns'] for d in last)
+all_gui = sum(d.get('GRBM_GUI_ACTIVE', 0.0) for d in last)
+# the clock: GRBM_GUI_ACTIVE also counts the cycles around a dispatch, so short kernels read far too high; kernels of >= 50 us only
+long_ = [d for d in last if d['ns'] >= 50000]
+clk_gui = sum(d.get('GRBM_GUI_ACTIVE', 0.0) for d in long_)
+clk_ns = sum(d['ns'] for d in long_)
+summary = {
+    'what': 'scripts/frozen_pmc.sh: the last of %d eager forwards of the frozen stereo + flow nets at B=8, 448x640 (%s kernel launches)' % (int(reps), period),
+    'mfma_busy_cycles_per_forward': all_busy,
+    # one busy cycle of a SIMD's matrix pipe = 1024 bf16 flops (v_mfma_f32_32x32x16_bf16: 32768 flops in 32 cycles; 16x16x32: 16384 in 16);
+    # the counter is the sum over the chip's 1024 SIMDs
+    'executed_gflop_per_forward': all_busy * 1024 / 1e9,
+    'executed_gflop_per_frame': all_busy * 1024 / 1e9 / 8.0,
+    'kernel_ms_per_forward': all_ns / 1e6,
+    'shader_clock_ghz_time_weighted': clk_gui / XCDS / clk_ns if clk_ns else None,
+    'shader_clock_note': 'GRBM_GUI_ACTIVE / 8 XCDs / duration over the kernels of >= 50 us (%.0f %% of the kernel time); kernels run one at a time under the counter pass' % (100.0 * clk_ns / max(all_ns, 1)),
+}
+print(json.dumps(summary))
+with open(os.path.join(root, 'exec_summary.json'), 'w') as f:
+    json.dump(summary, f, indent=1)
 if tot['ns']:
     print('matrix-core kernels together (time-weighted): MFMA busy %.1f %% of the 2.4 GHz peak, %.1f %% at the measured clock (%.2f GHz)'
           % (100 * tot['busy'] / (tot['ns'] * 2.4 * 1024), 100 * tot['busy'] / (tot['gui'] / XCDS * 1024), tot['gui'] / XCDS / tot['ns']))

@@ -5,6 +5,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export ISLAM_BENCH_LARGE_N=0      # the headline loop only: the N = 300 007 point would put its own (larger) grids into the per-kernel averages
 CMD="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-frontend"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 if [ -z "$TRACE_ONLY" ]; then
