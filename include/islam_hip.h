@@ -271,6 +271,15 @@ int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const in
                      const void* init_vel, double gravity, int motion_mode, void* out_pos, void* out_rot,
                      void* out_vel, void* scratch, int dtype, void* stream);
 
+/* Both call forms of IMUModule.integrate on one frame range from ONE pass (the reference's loop calls integrate twice per batch with
+ * the same range and init['rot']: train.py:200-215 -> imu_integrator.py:69-164): world_* get nframes + 1 rows (row 0 = the initial
+ * state), motion_* nframes rows (every frame from p = v = 0).  Bit-identical to islam_imu_preint(motion_mode = 0) followed by
+ * islam_imu_preint(motion_mode = 1); same scratch size. */
+int islam_imu_preint_both(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes, int64_t S,
+                          int max_frame_samples, const void* init_pos, const void* init_rot, const void* init_vel, double gravity,
+                          void* world_pos, void* world_rot, void* world_vel, void* motion_pos, void* motion_rot, void* motion_vel,
+                          void* scratch, int dtype, void* stream);
+
 /* Backward of islam_imu_preint w.r.t. the gyro and accelerometer samples: what PyPose's autograd returns through
  * pp.module.IMUPreintegrator when the denoiser runs with grad enabled (imu_integrator.py:107-113,146-153 with eval=False;
  * the IMU-target epoch of train.py:177-179,207-212 -- SURVEY F6).  fwd_scratch: the scratch buffer of the forward call on the

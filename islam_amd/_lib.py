@@ -87,6 +87,8 @@ SIGNATURES = {
     'islam_imu_scratch_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'islam_imu_preint': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double, c_int] +
                          [c_void_p] * 4 + [c_int, c_void_p]),
+    'islam_imu_preint_both': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int] + [c_void_p] * 3 + [c_double] + [c_void_p] * 7 +
+                              [c_int, c_void_p]),
     'islam_imu_preint_bwd_scratch_bytes': (c_size_t, [c_int]),
     'islam_imu_preint_bwd': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_double, c_int] + [c_void_p] * 7 + [c_int, c_void_p]),
     'islam_pvgo_default_params': (None, [ctypes.POINTER(PvgoParams)]),

@@ -114,12 +114,17 @@ class BilevelLoop:
         st, end = self.current_idx, self.current_idx + bs
         if hasattr(self.imu, 'train_denoiser'):
             self.imu.train_denoiser = self.train_imu_denoiser and target == 'imu' and self.imu_optimizer is not None
-        imu_trans, imu_rots, _, imu_vels = self.imu.integrate(st, end, self.init_state, motion_mode=False)
+        # train.py:231-247 calls integrate twice on the same range (world rows, then motion rows); IMUModule.integrate_both produces
+        # the pair from one pass over the samples (same values bit for bit), any other integrator object gets the two calls
+        if hasattr(self.imu, 'integrate_both'):
+            (imu_trans, imu_rots, _, imu_vels), (imu_dtrans, imu_drots, _, imu_dvels) = self.imu.integrate_both(st, end, self.init_state)
+        else:
+            imu_trans, imu_rots, _, imu_vels = self.imu.integrate(st, end, self.init_state, motion_mode=False)
+            imu_dtrans, imu_drots, _, imu_dvels = self.imu.integrate(st, end, self.init_state, motion_mode=True)
         imu_poses = pp.SE3(torch.cat((imu_trans, imu_rots.tensor()), axis=1))
         self.imu_poses.extend(imu_poses[1:].detach().numpy())
         with torch.no_grad():
             self.imu_motions.extend(pose2motion_pypose(pp.SE3(imu_poses.detach().tensor())).numpy())    # train.py:240-242
-        imu_dtrans, imu_drots, _, imu_dvels = self.imu.integrate(st, end, self.init_state, motion_mode=True)
         sync(); t2 = time.perf_counter()
 
         links = sample['link'] - self.current_idx

@@ -157,8 +157,9 @@ __global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, cons
 // takes the running rotation's component k from the lane that holds it with a DPP quad broadcast (a VALU move, no LDS round trip),
 // and does 4 multiplies + 3 adds in the order qmul writes them.  One lane alone spent ~330 clocks per frame (28 dependent double
 // operations issued at wave rate + LDS round trips for operands and results: 0.78 ms for 5000 frames); the quad form ~70.
-constexpr int CHAIN_CHUNK = 512;
-constexpr int ROT_CHUNK = 256;        // frames per staged chunk of the rotation chain (16 factors per frame)
+constexpr int CHAIN_CHUNK = 256;      // frames per staged chunk of the p / v chain (7 terms per frame), two buffers
+constexpr int ROT_CHUNK = 128;        // frames per staged chunk of the rotation chain (16 factors per frame), two buffers
+static_assert(CHAIN_CHUNK % 64 == 0 && ROT_CHUNK % 64 == 0, "a chunk is whole wavefronts of frames (ballot masks) and an even number of register blocks");
 
 // double <-> two dwords through a DPP quad permutation (ctrl = p0 | p1 << 2 | p2 << 4 | p3 << 6: lane i of a quad reads lane p_i)
 template <int CTRL> __device__ __forceinline__ double quad_perm_d(double v) {
@@ -173,55 +174,135 @@ template <int CTRL> __device__ __forceinline__ float quad_perm_f(float v) {
 template <int CTRL> __device__ __forceinline__ double quad_bcast(double v) { return quad_perm_d<CTRL>(v); }
 template <int CTRL> __device__ __forceinline__ float quad_bcast(float v) { return quad_perm_f<CTRL>(v); }
 
+// One frame of the rotation chain on the four-lane form: the lane's component of qmul(r, b) from its four signed factors.
+// double: each product is ONE v_fmac_f64 whose first operand is a DPP row broadcast of the component it needs (gfx90a+ "DP ALU" DPP:
+// row_newbcast only; v_mul_f64 / v_add_f64 are VOP3 and take no DPP operand, the VOP2 v_fmac_f64 does) onto an accumulator preset
+// to -0.0: fma(a, f, -0.0) IS round(a f), sign of a zero product included (-0 + x == x for every x) -- instead of two 32-bit DPP
+// moves in front of every multiply on the chain.  The builtin has no 64-bit form, hence the assembler text; the four presets come
+// first, which also gives the DPP reads their two wait states after the VALU write of r (the hazard recogniser does not look
+// into inline assembly).  The sums are taken in the order qmul writes them.
+__device__ __forceinline__ double rot_step(double rc, double f0, double f1, double f2, double f3) {
+    double m0, m1, m2, m3;
+    const double nz = -0.0;
+    asm volatile(
+        "v_mov_b64 %0, %9\n\tv_mov_b64 %1, %9\n\tv_mov_b64 %2, %9\n\tv_mov_b64 %3, %9\n\t"
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf"
+        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+        : "v"(rc), "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(nz));
+    return m0 + m1 + m2 + m3;
+}
+__device__ __forceinline__ float rot_step(float rc, float f0, float f1, float f2, float f3) {
+    const float aw = quad_bcast<0xff>(rc), ax = quad_bcast<0x00>(rc), ay = quad_bcast<0x55>(rc), az = quad_bcast<0xaa>(rc);
+    return aw * f0 + ax * f1 + ay * f2 + az * f3;
+}
+
+constexpr int ROT_U = 8;              // frames per register block of the walk: one LDS round trip per block instead of per frame
+
 template <class T>
 __global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
-                                                         const T* __restrict__ init_rot, T* __restrict__ R0) {
-    // sb[j][c][k]: factor of term k of output component c (x, y, z, w) for frame j's increment b = incre_r_j[F_j]:
-    //   x: +b.x +b.w +b.z -b.y    y: +b.y -b.z +b.w +b.x    z: +b.z +b.y -b.x +b.w    w: +b.w -b.x -b.y -b.z      (qmul above)
-    __shared__ __attribute__((aligned(16))) T sb[ROT_CHUNK][4][4];
-    __shared__ T out[ROT_CHUNK + 1][4];  // R0[i+1]; row ROT_CHUNK: where the idle lanes of the walking wave store (no branch in the loop)
-    __shared__ int has[ROT_CHUNK];       // F_i > 0
+                                                         const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy) {
+    // sb[.][j][c][k]: factor of term k of output component c (x, y, z, w) for frame j's increment b = incre_r_j[F_j], in the order
+    // qmul multiplies the running rotation's components w, x, y, z:
+    //   x: a.w b.x + a.x b.w + a.y b.z - a.z b.y    y: a.w b.y - a.x b.z + a.y b.w + a.z b.x
+    //   z: a.w b.z + a.x b.y - a.y b.x + a.z b.w    w: a.w b.w - a.x b.x - a.y b.y - a.z b.z
+    // Two buffers: while wave 0 walks chunk k, waves 1-3 stage chunk k + 1 (two dependent global round trips per frame: offsets,
+    // then the increment) and copy chunk k - 1 out -- the walk is all that is left on the kernel's critical path.
+    // (rows past a chunk's last frame are read by the walk's look-ahead and never used)
+    __shared__ __attribute__((aligned(16))) T sb[2][ROT_CHUNK + 3 * ROT_U][4][4];
+    __shared__ __attribute__((aligned(16))) T out[2][ROT_CHUNK + 2 * ROT_U][4];      // R0[base + 1 + j]
+    __shared__ unsigned long long hasm[2][ROT_CHUNK / 64 + 1];                        // bit j: F_j > 0 (frames past the chunk: 0)
     const int tid = threadIdx.x;
+    const int nchunk = (nframes + ROT_CHUNK - 1) / ROT_CHUNK;
     // lane c < 4 of wave 0 carries component c of the running rotation (x, y, z, w)
     T rc = tid < 4 ? init_rot[tid] : (T)0;
-    if (tid < 4) R0[tid] = rc;
-    for (int base = 0; base < nframes; base += ROT_CHUNK) {
-        const int cnt = min(ROT_CHUNK, nframes - base);
-        __syncthreads();
-        for (int j = tid; j < cnt; j += 256) {
-            const int i = base + j;
-            const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
-            has[j] = F > 0;
-            const T* src = ir + 4 * ((size_t)a + i + F);
-            const T bx = src[0], by = src[1], bz = src[2], bw = src[3];
-            T* t = &sb[j][0][0];
-            t[0] = bx;  t[1] = bw;   t[2] = bz;   t[3] = -by;
-            t[4] = by;  t[5] = -bz;  t[6] = bw;   t[7] = bx;
-            t[8] = bz;  t[9] = by;   t[10] = -bx; t[11] = bw;
-            t[12] = bw; t[13] = -bx; t[14] = -by; t[15] = -bz;
+    if (tid < 4) { R0[tid] = rc; if (rot_copy) rot_copy[tid] = rc; }
+    if (tid < 2) hasm[tid][ROT_CHUNK / 64] = 0;
+    auto stage = [&](int k, int t, int nt) {                 // threads t = 0 .. nt - 1 (whole wavefronts) fill buffer k & 1 with chunk k
+        const int base = k * ROT_CHUNK, cnt = min(ROT_CHUNK, nframes - base), b = k & 1;
+        for (int j = t; j < ROT_CHUNK; j += nt) {
+            bool h = false;
+            if (j < cnt) {
+                const int i = base + j;
+                const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
+                h = F > 0;
+                const T* src = ir + 4 * ((size_t)a + i + F);
+                const T bx = src[0], by = src[1], bz = src[2], bw = src[3];
+                T* o = &sb[b][j][0][0];
+                o[0] = bx;  o[1] = bw;   o[2] = bz;   o[3] = -by;
+                o[4] = by;  o[5] = -bz;  o[6] = bw;   o[7] = bx;
+                o[8] = bz;  o[9] = by;   o[10] = -bx; o[11] = bw;
+                o[12] = bw; o[13] = -bx; o[14] = -by; o[15] = -bz;
+            }
+            const unsigned long long m = __ballot(h);
+            if ((t & 63) == 0) hasm[b][j >> 6] = m;
         }
-        __syncthreads();
-        if (tid < 64) {                    // (whole wave 0 executes the loop: DPP needs its quad's lanes active; lanes >= 4 carry zeros)
-            const int c = tid & 3;
-            T* op = tid < 4 ? &out[0][c] : &out[ROT_CHUNK][c];
-            const int ostep = tid < 4 ? 4 : 0;
-            T f0 = sb[0][c][0], f1 = sb[0][c][1], f2 = sb[0][c][2], f3 = sb[0][c][3];
-            int h = has[0];
-            for (int j = 0; j < cnt; ++j) {
-                const int jn = j + 1 < cnt ? j + 1 : j;                 // next frame's factors: requested before this frame's arithmetic
-                const T n0 = sb[jn][c][0], n1 = sb[jn][c][1], n2 = sb[jn][c][2], n3 = sb[jn][c][3];
-                const int hn = has[jn];
-                const T aw = quad_bcast<0xff>(rc), ax = quad_bcast<0x00>(rc), ay = quad_bcast<0x55>(rc), az = quad_bcast<0xaa>(rc);
-                const T o = aw * f0 + ax * f1 + ay * f2 + az * f3;      // = qmul(r, b) component c, same operations in the same order
-                rc = h ? o : rc;
-                *op = rc;
-                op += ostep;
-                f0 = n0; f1 = n1; f2 = n2; f3 = n3; h = hn;
+    };
+    auto copy_out = [&](int k, int t, int nt) {
+        const int base = k * ROT_CHUNK, cnt = min(ROT_CHUNK, nframes - base);
+        const T* o = &out[k & 1][0][0];
+        for (int j = t; j < cnt * 4; j += nt) {
+            const T v = o[j];
+            R0[4 * (size_t)(base + 1) + j] = v;
+            if (rot_copy) rot_copy[4 * (size_t)(base + 1) + j] = v;
+        }
+    };
+    stage(0, tid, 256);
+    __syncthreads();
+    for (int k = 0; k < nchunk; ++k) {
+        if (tid >= 64) {
+            if (k + 1 < nchunk) stage(k + 1, tid - 64, 192);
+            if (k > 0) copy_out(k - 1, tid - 64, 192);
+        } else if (tid < 4) {
+            // Blocks of ROT_U frames: the block's factors sit in registers (requested one block ahead, 16-byte LDS reads at
+            // immediate offsets), so the walk itself is 4 multiplies + 3 adds + one LDS store per frame and its dependency chain
+            // (multiply -> three adds) is all that is left of a frame.  A frame without IMU samples keeps the rotation
+            // (imu_integrator.py:134-140): a uniform branch on the chunk's bit mask, no select on the chain.
+            const int cnt = min(ROT_CHUNK, nframes - k * ROT_CHUNK);
+            const T* fb = &sb[k & 1][0][tid][0];
+            T* ob = &out[k & 1][0][tid];
+            const unsigned char* hb = reinterpret_cast<const unsigned char*>(&hasm[k & 1][0]);
+            T fa[ROT_U][4], fn[ROT_U][4];
+            auto load = [&](T (&f)[ROT_U][4], int& hv, int blk) {       // (the block's mask byte travels with its factors: one block ahead)
+#pragma unroll
+                for (int u = 0; u < ROT_U; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f[u][q] = fb[(size_t)(blk * ROT_U + u) * 16 + q];
+                hv = hb[blk];
+            };
+            auto walk = [&](const T (&f)[ROT_U][4], int hv, int blk) {
+                const unsigned bits = __builtin_amdgcn_readfirstlane(hv);
+                T* o = ob + (size_t)blk * ROT_U * 4;
+                if (__builtin_expect(bits == 0xffu, 1)) {       // every frame of the block has samples: no branch per frame
+#pragma unroll
+                    for (int u = 0; u < ROT_U; ++u) {
+                        rc = rot_step(rc, f[u][0], f[u][1], f[u][2], f[u][3]);      // = qmul(r, b) component c
+                        o[u * 4] = rc;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < ROT_U; ++u) {
+                        if (bits & (1u << u)) rc = rot_step(rc, f[u][0], f[u][1], f[u][2], f[u][3]);
+                        o[u * 4] = rc;
+                    }
+                }
+            };
+            asm volatile("s_nop 4" ::: "memory");              // (EXEC was narrowed to four lanes just above: DPP wait states)
+            const int nblk = (cnt + ROT_U - 1) / ROT_U;
+            int ha, hn;
+            load(fa, ha, 0);
+            for (int blk = 0; blk < nblk; blk += 2) {
+                load(fn, hn, blk + 1);
+                walk(fa, ha, blk);
+                load(fa, ha, blk + 2);
+                walk(fn, hn, blk + 1);
             }
         }
         __syncthreads();
-        for (int j = tid; j < cnt * 4; j += 256) R0[4 * (size_t)(base + 1) + j] = (&out[0][0])[j];
     }
+    copy_out(nchunk - 1, tid, 256);
 }
 
 // C: per frame (one lane each): local integration, rotated into the frame's start orientation.
@@ -286,74 +367,124 @@ __global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, cons
         stq(qmul(ai, b), out_rot + 4 * (size_t)i);
         return;
     }
-    // world mode: sequential p/v chain (three lanes, one per coordinate), per-frame terms staged through LDS by the whole workgroup
-    __shared__ T sl[CHAIN_CHUNK][7];
-    __shared__ T so[CHAIN_CHUNK][6];
-    __shared__ int sF[CHAIN_CHUNK];
-    __shared__ T carry[9];                 // p (3), v (3), held position sp (3)
+    // world mode: sequential p/v chain (three lanes of wave 0, one per coordinate).  Two LDS buffers: while wave 0 walks chunk k,
+    // waves 1-3 stage the per-frame terms of chunk k + 1 (all of a thread's global loads issued before the first LDS store: one
+    // memory round trip per chunk instead of ten) and copy chunk k - 1 out.  (The rotations of the world rows are written by
+    // chain_rot_kernel.)
+    __shared__ __attribute__((aligned(16))) T sl[2][CHAIN_CHUNK + 3 * ROT_U][7];      // (rows past a chunk's last frame: look-ahead only)
+    __shared__ __attribute__((aligned(16))) T so[2][CHAIN_CHUNK + 2 * ROT_U][6];
+    __shared__ unsigned long long hasm[2][CHAIN_CHUNK / 64 + 1];                       // bit j: F_j > 0
     const int tid = threadIdx.x;
     if (blockIdx.x != 0) return;
-    if (tid == 0) {
-        for (int c = 0; c < 3; ++c) {
-            carry[c] = init_pos[c]; carry[3 + c] = init_vel[c]; carry[6 + c] = init_pos[c];
-            out_pos[c] = init_pos[c]; out_vel[c] = init_vel[c];
+    const int nchunk = (nframes + CHAIN_CHUNK - 1) / CHAIN_CHUNK;
+    if (tid < 3) { out_pos[tid] = init_pos[tid]; out_vel[tid] = init_vel[tid]; }
+    if (tid < 2) hasm[tid][CHAIN_CHUNK / 64] = 0;
+    constexpr int SL_ITEMS = (CHAIN_CHUNK * 7 + 191) / 192;          // loc values per staging thread (192 threads in the loop)
+    auto stage = [&](int k, int t, int nt) {
+        const int base = k * CHAIN_CHUNK, cnt = min(CHAIN_CHUNK, nframes - base), b = k & 1;
+        T r[SL_ITEMS];
+        const T* src = loc + 7 * (size_t)base;
+#pragma unroll
+        for (int i = 0; i < SL_ITEMS; ++i) { const int e = t + i * nt; r[i] = e < cnt * 7 ? src[e] : (T)0; }
+        for (int j = t; j < CHAIN_CHUNK; j += nt) {
+            const bool h = j < cnt && seg[base + j + 1] > seg[base + j];
+            const unsigned long long m = __ballot(h);
+            if ((t & 63) == 0) hasm[b][j >> 6] = m;
         }
-        stq(ldq(R0), out_rot);
-    }
-    for (int base = 0; base < nframes; base += CHAIN_CHUNK) {
-        const int cnt = min(CHAIN_CHUNK, nframes - base);
-        __syncthreads();
-        for (int j = tid; j < cnt; j += blockDim.x) sF[j] = (int)(seg[base + j + 1] - seg[base + j]);
-        for (int j = tid; j < cnt * 7; j += blockDim.x) (&sl[0][0])[j] = loc[7 * (size_t)base + j];
-        __syncthreads();
-        if (tid < 3) {
-            // the three coordinates are independent chains: lane c walks coordinate c (one lane doing all three spent 12 dependent
-            // double operations + LDS round trips per frame: 0.46-0.9 ms for 5000 frames), the next frame's terms requested
-            // before this frame's arithmetic
-            const int c = tid;
-            T p = carry[c], v = carry[3 + c], sp = carry[6 + c];
-            T a = sl[0][c], b = sl[0][3 + c], t = sl[0][6];
-            int F = sF[0];
-            for (int j = 0; j < cnt; ++j) {
-                const int jn = j + 1 < cnt ? j + 1 : j;
-                const T an = sl[jn][c], bn = sl[jn][3 + c], tn = sl[jn][6];
-                const int Fn = sF[jn];
-                T sv;
-                if (F == 0) {                               // imu_integrator.py:134-140: vel zeroed, pos / rot held
-                    sv = 0;
-                } else {
-                    sv = v + a;
-                    sp = p + b + v * t;
-                }
-                so[j][c] = sp; so[j][3 + c] = sv; p = sp; v = sv;
-                a = an; b = bn; t = tn; F = Fn;
-            }
-            carry[c] = p; carry[3 + c] = v; carry[6 + c] = sp;
-        }
-        __syncthreads();
-        for (int j = tid; j < cnt * 3; j += blockDim.x) {
+        T* dst = &sl[b][0][0];
+#pragma unroll
+        for (int i = 0; i < SL_ITEMS; ++i) { const int e = t + i * nt; if (e < cnt * 7) dst[e] = r[i]; }
+    };
+    auto copy_out = [&](int k, int t, int nt) {
+        const int base = k * CHAIN_CHUNK, cnt = min(CHAIN_CHUNK, nframes - base);
+        for (int j = t; j < cnt * 3; j += nt) {
             const int f = j / 3, c = j - 3 * f;
-            out_pos[3 * (size_t)(base + 1) + j] = so[f][c];
-            out_vel[3 * (size_t)(base + 1) + j] = so[f][3 + c];
+            out_pos[3 * (size_t)(base + 1) + j] = so[k & 1][f][c];
+            out_vel[3 * (size_t)(base + 1) + j] = so[k & 1][f][3 + c];
         }
-        for (int j = tid; j < cnt * 4; j += blockDim.x) out_rot[4 * (size_t)(base + 1) + j] = R0[4 * (size_t)(base + 1) + j];
+    };
+    if (tid < 192) stage(0, tid, 192);                   // (the prologue uses the loop's 192-thread mapping: whole wavefronts)
+    __syncthreads();
+    T p = 0, v = 0, sp = 0;
+    if (tid < 3) { p = init_pos[tid]; v = init_vel[tid]; sp = p; }
+    for (int k = 0; k < nchunk; ++k) {
+        if (tid >= 64) {
+            if (k + 1 < nchunk) stage(k + 1, tid - 64, 192);
+            if (k > 0) copy_out(k - 1, tid - 64, 192);
+        } else if (tid < 3) {
+            // the three coordinates are independent chains: lane c walks coordinate c.  Blocks of ROT_U frames with the block's terms
+            // in registers, requested one block ahead (a frame-by-frame walk waits for an LDS round trip per frame); a frame without
+            // samples (imu_integrator.py:134-140: vel zeroed, pos / rot held) is a uniform branch on the chunk's bit mask
+            const int c = tid, b = k & 1;
+            const int cnt = min(CHAIN_CHUNK, nframes - k * CHAIN_CHUNK);
+            const unsigned char* hb = reinterpret_cast<const unsigned char*>(&hasm[b][0]);
+            T fa[ROT_U][3], fn[ROT_U][3];
+            auto load = [&](T (&f)[ROT_U][3], int& hv, int blk) {
+#pragma unroll
+                for (int u = 0; u < ROT_U; ++u) {
+                    const T* r = &sl[b][blk * ROT_U + u][0];
+                    f[u][0] = r[c]; f[u][1] = r[3 + c]; f[u][2] = r[6];
+                }
+                hv = hb[blk];
+            };
+            auto walk = [&](const T (&f)[ROT_U][3], int hv, int blk) {
+                const unsigned bits = __builtin_amdgcn_readfirstlane(hv);
+                T* o = &so[b][blk * ROT_U][c];
+                if (__builtin_expect(bits == 0xffu, 1)) {       // every frame of the block has samples: no branch per frame
+#pragma unroll
+                    for (int u = 0; u < ROT_U; ++u) {
+                        const T sv = v + f[u][0];
+                        sp = p + f[u][1] + v * f[u][2];
+                        o[u * 6] = sp; o[u * 6 + 3] = sv; p = sp; v = sv;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < ROT_U; ++u) {
+                        T sv = 0;
+                        if (bits & (1u << u)) {
+                            asm volatile("" ::: "memory");      // (keeps the branch: as selects, two v_cndmask sit on the p chain of every frame)
+                            sv = v + f[u][0];
+                            sp = p + f[u][1] + v * f[u][2];
+                        }
+                        o[u * 6] = sp; o[u * 6 + 3] = sv; p = sp; v = sv;
+                    }
+                }
+            };
+            const int nblk = (cnt + ROT_U - 1) / ROT_U;
+            int ha, hn;
+            load(fa, ha, 0);
+            for (int blk = 0; blk < nblk; blk += 2) {
+                load(fn, hn, blk + 1);
+                walk(fa, ha, blk);
+                load(fa, ha, blk + 2);
+                walk(fn, hn, blk + 1);
+            }
+            // (only the LAST chunk has blocks past its frames -- a full chunk is an even number of blocks -- so the velocity those
+            // zero is never carried on)
+        }
+        __syncthreads();
     }
+    copy_out(nchunk - 1, tid, 256);
 }
 
 template <class T>
 int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframes, int64_t S, const T* ip, const T* ir0,
-        const T* iv, double gravity, int motion_mode, T* opos, T* orot, T* ovel, void* scratch, int maxF, hipStream_t s) {
+        const T* iv, double gravity, int motion_mode, T* opos, T* orot, T* ovel, void* scratch, int maxF, hipStream_t s,
+        T* mpos = nullptr, T* mrot = nullptr, T* mvel = nullptr) {
     T* ir = reinterpret_cast<T*>(scratch);                 // 4 * (S + nframes)
     T* R0 = ir + 4 * ((size_t)S + nframes);                // 4 * (nframes + 1)
     T* loc = R0 + 4 * ((size_t)nframes + 1);               // 7 * nframes
     const size_t lds = 2 * 4 * (size_t)(maxF + 1) * sizeof(T);
     if (lds > 64 * 1024) return fail(ISLAM_EARG, "islam_imu_preint: %d IMU samples in one frame interval exceed the LDS scan buffer", maxF);
     hipLaunchKernelGGL(scan_kernel<T>, dim3(nframes), dim3(64), lds, s, dt, gyro, seg, ir);
-    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, ir, ir0, R0);
+    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, ir, ir0, R0, motion_mode != 1 ? orot : (T*)nullptr);
     hipLaunchKernelGGL(frame_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, dt, acc, seg, nframes, ir, R0, (T)gravity, loc);
-    if (motion_mode)
-        hipLaunchKernelGGL(finish_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 1, opos, orot, ovel);
-    else
+    // motion_mode 2: both sets of outputs from ONE scan / rotation chain / frame pass (opos / orot / ovel: world rows, then the
+    // motion rows in mpos / mrot / mvel) -- the two modes differ in the last kernel only
+    if (motion_mode != 0)
+        hipLaunchKernelGGL(finish_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 1,
+                           motion_mode == 2 ? mpos : opos, motion_mode == 2 ? mrot : orot, motion_mode == 2 ? mvel : ovel);
+    if (motion_mode != 1)
         hipLaunchKernelGGL(finish_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, R0, loc, ip, iv, 0, opos, orot, ovel);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
@@ -545,6 +676,30 @@ int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const in
                           (const float*)init_rot, (const float*)init_vel, gravity, flag, (float*)out_pos, (float*)out_rot,
                           (float*)out_vel, scratch, maxF, s);
     return fail(ISLAM_EARG, "islam_imu_preint: dtype %d", dtype);
+}
+
+// Both call forms of IMUModule.integrate on the same frame range (the reference's loop calls it twice per batch, train.py:200-215:
+// world rows for the trajectory, motion rows for the PVGO factors) from ONE pass: the sample scan, the rotation chain and the
+// frame sums are the same in both modes (imu_integrator.py:116-158 with the same init['rot']), only the last step differs.
+// world_*: nframes + 1 rows (row 0 = the initial state); motion_*: nframes rows (p0 = v0 = 0).  Bit-identical to the two
+// islam_imu_preint calls.
+int islam_imu_preint_both(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes, int64_t S,
+                          int max_frame_samples, const void* init_pos, const void* init_rot, const void* init_vel, double gravity,
+                          void* world_pos, void* world_rot, void* world_vel, void* motion_pos, void* motion_rot, void* motion_vel,
+                          void* scratch, int dtype, void* stream) {
+    if (nframes < 1 || S < 0) return fail(ISLAM_EARG, "islam_imu_preint_both: nframes=%d S=%lld", nframes, (long long)S);
+    const int maxF = max_frame_samples;
+    if (maxF < 0 || maxF > S) return fail(ISLAM_EARG, "islam_imu_preint_both: max frame samples %d out of range", maxF);
+    hipStream_t s = as_stream(stream);
+    if (dtype == ISLAM_F64)
+        return run<double>((const double*)dt, (const double*)gyro, (const double*)acc, seg, nframes, S, (const double*)init_pos,
+                           (const double*)init_rot, (const double*)init_vel, gravity, 2, (double*)world_pos, (double*)world_rot,
+                           (double*)world_vel, scratch, maxF, s, (double*)motion_pos, (double*)motion_rot, (double*)motion_vel);
+    if (dtype == ISLAM_F32)
+        return run<float>((const float*)dt, (const float*)gyro, (const float*)acc, seg, nframes, S, (const float*)init_pos,
+                          (const float*)init_rot, (const float*)init_vel, gravity, 2, (float*)world_pos, (float*)world_rot,
+                          (float*)world_vel, scratch, maxF, s, (float*)motion_pos, (float*)motion_rot, (float*)motion_vel);
+    return fail(ISLAM_EARG, "islam_imu_preint_both: dtype %d", dtype);
 }
 
 }  // extern "C"

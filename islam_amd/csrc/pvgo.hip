@@ -4169,12 +4169,12 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
     constexpr int SMALL_MAX_N = 16;
     if (!no_small && !reproj && N <= SMALL_MAX_N) {
         constexpr int SMALL_LDS = LB_DYN_BYTES + LDS_PER_WAVE * (int)sizeof(double);
-        static bool sm_attr_set[64] = {};
+        static bool small_attr_set[64] = {};
         int dev_i = 0;
         ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
-        if (dev_i >= 0 && dev_i < 64 && !sm_attr_set[dev_i]) {
+        if (dev_i >= 0 && dev_i < 64 && !small_attr_set[dev_i]) {
             ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)small_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS));
-            sm_attr_set[dev_i] = true;
+            small_attr_set[dev_i] = true;
         }
         static thread_local double* host_trace = nullptr;       // pinned rows for the optional trace (3 per trial)
         constexpr int TRACE_ROWS = 1024;

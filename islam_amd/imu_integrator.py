@@ -55,10 +55,8 @@ class IMUModule:
         # (islam_imu_preint_bwd), so run_pvgo(target='imu') back-propagates into its parameters.  Default: reference behaviour.
         self.train_denoiser = False
 
-    def integrate(self, st, end, init=None, motion_mode=False):
-        """imu_integrator.py:69-164.  world mode: (end-st+1) rows incl. the initial state; motion mode: (end-st) rows.
-        Host traffic per call: one H2D of the 10 initial-state values, one of the frame offsets, one D2H of the packed
-        result (the reference: 3 D2H copies per frame)."""
+    def _corrected(self, st, end):
+        """The stream slice of frames [st, end] after the static-bias / denoiser correction (imu_integrator.py:94-113)."""
         b0 = int(self.rgb2imu_sync[st])
         b1 = int(self.rgb2imu_sync[end]) + 1
         dts = self.dts[b0:b1, 0]                    # contiguous views of the stream; only written to through new tensors
@@ -76,6 +74,45 @@ class IMUModule:
                 accels = d_acc.to(self.dtype)
             if self.denoise_gyro:
                 gyros = d_gyro.to(self.dtype)
+        return b0, dts, gyros, accels
+
+    def integrate_both(self, st, end, init=None):
+        """``integrate(st, end, init, motion_mode=False)`` and ``integrate(st, end, init, motion_mode=True)`` -- the pair the
+        reference's loop asks for on every batch (train.py:200-215) -- from ONE pass over the samples (islam_imu_preint_both: the
+        scan, the rotation chain and the frame sums are common to the two modes) and one device->host copy.  Returns the two
+        result tuples, bit-identical to the two calls.  Forward values only: with ``train_denoiser`` the two differentiable calls
+        are made instead."""
+        if self.train_denoiser and self.use_denoise_model:
+            return self.integrate(st, end, init, motion_mode=False), self.integrate(st, end, init, motion_mode=True)
+        b0, dts, gyros, accels = self._corrected(st, end)
+        np_dt = {torch.float32: np.float32, torch.float64: np.float64}[self.dtype]
+        i10 = np.zeros(10, dtype=np_dt)
+        i10[6] = 1.0
+        if init is not None:                        # prase_init: the motion rows ignore pos / vel (the kernel starts them from zero)
+            i10[3:7] = np.asarray(init['rot'], dtype=np_dt)
+            i10[0:3] = np.asarray(init['pos'], dtype=np_dt)
+            i10[7:10] = np.asarray(init['vel'], dtype=np_dt)
+        i10 = torch.from_numpy(i10).to(self.device)
+        seg_host = np.ascontiguousarray(self.rgb2imu_sync[st:end + 1] - b0, dtype=np.int64)
+        seg = torch.from_numpy(seg_host).to(self.device)
+        with torch.no_grad():
+            world, motion, packed = ops.imu_preint_both(dts.contiguous(), gyros.detach().contiguous(), accels.detach().contiguous(), seg,
+                                                        seg_host, i10[0:3], i10[3:7], i10[7:10], self.gravity)
+        host = packed.cpu()
+        n = len(seg_host) - 1
+        res, o = [], 0
+        for rows in (n + 1, n):
+            pos = host[o:o + rows * 3].view(rows, 3); o += rows * 3
+            rot = host[o:o + rows * 4].view(rows, 4); o += rows * 4
+            vel = host[o:o + rows * 3].view(rows, 3); o += rows * 3
+            res.append((pos.contiguous(), pp.SO3(rot.contiguous()), [], vel.contiguous()))
+        return res[0], res[1]
+
+    def integrate(self, st, end, init=None, motion_mode=False):
+        """imu_integrator.py:69-164.  world mode: (end-st+1) rows incl. the initial state; motion mode: (end-st) rows.
+        Host traffic per call: one H2D of the 10 initial-state values, one of the frame offsets, one D2H of the packed
+        result (the reference: 3 D2H copies per frame)."""
+        b0, dts, gyros, accels = self._corrected(st, end)
         # prase_init (imu_integrator.py:11-28) packed into one transfer: [pos(3) | rot(4) | vel(3)]
         np_dt = {torch.float32: np.float32, torch.float64: np.float64}[self.dtype]
         i10 = np.zeros(10, dtype=np_dt)

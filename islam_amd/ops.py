@@ -586,6 +586,30 @@ def _imu_preint_raw(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, 
     return pos, rot, vel, scratch
 
 
+def imu_preint_both(dt, gyro, acc, seg, seg_host, init_pos, init_rot, init_vel, gravity):
+    """World-mode and motion-mode outputs of one frame range from ONE pass (islam_imu_preint_both): ((pos, rot, vel) with
+    nframes + 1 rows, (pos, rot, vel) with nframes rows), bit-identical to two imu_preint calls.  Forward values only."""
+    require_cuda(dt, gyro, acc, seg)
+    dtype = dt.dtype
+    code = {torch.float32: 0, torch.float64: 1}[dtype]
+    dev = dt.device
+    nframes = int(seg_host.shape[0]) - 1
+    S = int(dt.shape[0])
+    maxF = int(np.max(np.diff(seg_host))) if nframes > 0 else 0
+    # one allocation for the six outputs: [world pos | rot | vel | motion pos | rot | vel], 10 columns per row
+    out = torch.empty((2 * nframes + 1) * 10, dtype=dtype, device=dev)
+    w, m = nframes + 1, nframes
+    views, o = [], 0
+    for rows, cols in ((w, 3), (w, 4), (w, 3), (m, 3), (m, 4), (m, 3)):
+        views.append(out[o:o + rows * cols].view(rows, cols))
+        o += rows * cols
+    nbytes = lib().islam_imu_scratch_bytes(S, nframes, code)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().islam_imu_preint_both(ptr(dt), ptr(gyro), ptr(acc), ptr(seg), nframes, S, maxF, ptr(init_pos), ptr(init_rot),
+                                      ptr(init_vel), c_double(gravity), *[ptr(v) for v in views], ptr(scratch), code, stream_ptr(dev)))
+    return tuple(views[:3]), tuple(views[3:]), out
+
+
 class _ImuPreint(torch.autograd.Function):
     """islam_imu_preint with islam_imu_preint_bwd: gradients w.r.t. the gyro / accelerometer samples (the denoiser's outputs
     in the IMU-target epoch).  The gradient of the quaternion output is read in PyPose's convention (left tangent, padded)."""

@@ -19,6 +19,14 @@ for motion in (False, True):
     for _ in range(20): fn()
     b.record(); torch.cuda.synchronize()
     print('imu_preint 5000 frames, %s mode: %.1f us per call' % ('motion' if motion else 'world', a.elapsed_time(b) / 20 * 1e3))
+fn = lambda: ops.imu_preint_both(dt, gyro, acc, seg_d, seg_h, ip, ir, iv, tr['gravity'])
+for _ in range(3): fn()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(20): fn()
+b.record(); torch.cuda.synchronize()
+print('imu_preint_both 5000 frames (world + motion rows from one pass): %.1f us per call' % (a.elapsed_time(b) / 20 * 1e3))
 from torch.profiler import profile, ProfilerActivity
 import collections
 for motion in (False, True):

@@ -96,3 +96,63 @@ def test_gap_to_torch_op_arithmetic(cuda, tag, dtype, bound):
                 worst[k] = max(worst.get(k, 0.0), ulp)
     print('islam_imu_preint vs torch-op arithmetic (%s): max ulp pos %.3g rot %.3g vel %.3g' % (tag, worst['pos'], worst['rot'], worst['vel']))
     assert max(worst.values()) <= bound, worst
+
+
+def _ragged_stream(nframes, seed, p_empty=0.2):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(1, 6, nframes)
+    counts[rng.random(nframes) < p_empty] = 0
+    for i, c in ((0, 0), (7, 0), (8, 3), (255, 0), (256, 2), (257, 0), (511, 0), (512, 0)):      # block / chunk borders
+        if i < nframes:
+            counts[i] = c
+    seg = np.concatenate([[0], np.cumsum(counts)])
+    S = int(seg[-1])
+    dt = rng.uniform(0.004, 0.012, S)
+    gyro = rng.normal(0, 0.5, (S, 3))
+    acc = rng.normal(0, 1.0, (S, 3)) + np.array([0, 0, 9.81])
+    init = dict(pos=np.array([1.0, 2.0, 3.0]), rot=np.array([0.1, -0.2, 0.3, 0.9273618495495703]), vel=np.array([5.0, 0.1, -0.2]))
+    return dt, gyro, acc, seg, init
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('motion', [False, True])
+def test_empty_intervals_across_the_chain_blocks(cuda, dtype, motion):
+    """The frame chains walk register blocks of 8 frames inside LDS chunks of 256 / 512: frames without samples (rotation and position
+    held, velocity zeroed: imu_integrator.py:134-140) at block and chunk borders, a last chunk that ends inside a block."""
+    dt, gyro, acc, seg, init = _ragged_stream(1301, 5)
+    ref = cwrap.imu_integrate(dt, gyro, acc, seg, init['pos'], init['rot'], init['vel'], 9.81007, motion, dtype)
+    out = _run(cuda, dt, gyro, acc, seg, init, 9.81007, motion, dtype)
+    for o, r, name in zip(out, ref, ('pos', 'rot', 'vel')):
+        np.testing.assert_array_equal(o, r, err_msg=name)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_both_modes_from_one_pass(cuda, dtype):
+    """islam_imu_preint_both == islam_imu_preint(world) + islam_imu_preint(motion), bit for bit (and the oracle)."""
+    from islam_amd import ops
+    dt, gyro, acc, seg, init = _ragged_stream(700, 11)
+    td = {np.float64: torch.float64, np.float32: torch.float32}[dtype]
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=dtype), dtype=td, device=cuda)
+    seg = np.ascontiguousarray(seg, dtype=np.int64)
+    world, motion, _ = ops.imu_preint_both(t(dt), t(gyro), t(acc), torch.tensor(seg, device=cuda), seg, t(init['pos']), t(init['rot']),
+                                           t(init['vel']), 9.81007)
+    for got, mm in ((world, False), (motion, True)):
+        ref = cwrap.imu_integrate(dt, gyro, acc, seg, init['pos'], init['rot'], init['vel'], 9.81007, mm, dtype)
+        sep = _run(cuda, dt, gyro, acc, seg, init, 9.81007, mm, dtype)
+        for g, s, r in zip(got, sep, ref):
+            np.testing.assert_array_equal(g.cpu().numpy(), s)
+            np.testing.assert_array_equal(s, r)
+
+
+def test_imu_module_integrate_both_matches_two_calls(cuda):
+    from islam_amd.imu_integrator import IMUModule
+    tr = synthetic.car_trajectory(41, seed=3)
+    imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], init=tr['init'], gravity=tr['gravity'], rgb2imu_sync=tr['rgb2imu_sync'],
+                    device='cuda:0', denoise_accel=False, denoise_gyro=False, dtype=torch.float64)
+    st, end = 8, 16
+    init = dict(pos=tr['init']['pos'], rot=tr['init']['rot'], vel=tr['init']['vel'])
+    w, m = imu.integrate_both(st, end, init)
+    for got, mm in ((w, False), (m, True)):
+        ref = imu.integrate(st, end, init, motion_mode=mm)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1].tensor(), ref[1].tensor()) and torch.equal(got[3], ref[3])
+        assert got[2] == [] and got[0].device.type == 'cpu'
