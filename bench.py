@@ -288,8 +288,12 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                            'shader_clock_ghz': clk, 'peak_at_clock': 2500.0 * clk / 2.4, 'frac_at_clock': rate / (2500.0 * clk / 2.4),
                            'frozen_kernel_ms_per_batch': ex.get('kernel_ms_per_forward'),
                            'source': ex.get('source'),
-                           'note': 'frames/s x executed bf16 matrix-core flops of the frozen nets per frame (SQ_VALU_MFMA_BUSY_CYCLES x 1024); the pose '
-                                   'head (fp32, 1.9 GFLOP per frame) and everything that is not a matrix instruction is not counted'}
+                           'note': 'frames/s x the matrix-pipe work the frozen nets EXECUTE per frame: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 '
+                                   'SIMDs, one eager forward at B=8 under rocprofv3 --pmc) x 1024 bf16 flop per busy cycle / 8 frames.  It counts what '
+                                   'the pipe did -- tile and channel padding included, the skipped full-resolution tail excluded -- which is why it '
+                                   'differs from the reference-equivalent gflop_per_frame above; the trainable pose head (fp32, MIOpen) is not in it.  '
+                                   'shader_clock_ghz: GRBM_GUI_ACTIVE / 8 XCDs / duration over the kernels of >= 50 us of that pass (one kernel at a '
+                                   'time; the pipelined step runs two streams and may clock lower)'}
     return out
 
 

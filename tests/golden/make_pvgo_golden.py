@@ -2,6 +2,18 @@
 
   python tests/golden/make_pvgo_golden.py            # needs `import pypose` to succeed (build container only)
 
+ONE COMMAND on a machine with network access and a checkout of sair-lab/iSLAM at /root/reference (CPU only, ~2 minutes):
+
+  pip install "pypose>=0.6.0,<0.7" "torch>=2.0" && python tests/golden/make_pvgo_golden.py \
+      && python -m pytest tests/test_pypose_pin_cpu.py -q        # then commit tests/golden/{pvgo_*,imu_*,lieops}.npz
+
+PyPose version: the reference pins none (environment.yml lists no pypose; its README installs the current release of autumn
+2024).  The API it calls -- pp.optim.LM(reject=...), pp.optim.strategy.TrustRegion, pp.optim.scheduler.StopOnPlateau,
+pp.optim.solver.Cholesky, pp.module.IMUPreintegrator(prop_cov=False), pp.reprojerr, LieTensor.Jinvp / add_ / cumprod -- is the
+0.6 line (0.6.0 ... 0.6.8), which is also the line oracle/pvgo.py and oracle/imu.py restate; 0.7 is excluded because it has not
+been read against the oracle.  Every fixture records pypose.__version__ and torch.__version__ (keys `pypose_version`,
+`torch_version`), and the consumers print them, so a pin always says what it was taken on.
+
 Writes tests/golden/pvgo_*.npz, imu_*.npz, lieops.npz.  The consumers (tests/test_pypose_pin_cpu.py for the oracle,
 tests/test_pypose_pin_gpu.py for the HIP path) use them when present and XFAIL with reason "parity unpinned" when absent.
 
