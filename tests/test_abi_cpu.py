@@ -121,7 +121,7 @@ def test_product_fails_loudly_without_gpu():
         IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')
 
 
-@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json', 'bench_r03_final.json'])
+@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json', 'bench_r03_final.json', 'bench_r04_final.json'])
 def test_committed_bench_line_follows_the_contract(name):
     """profiles/bench_rNN_final.json is the last `python bench.py` line of a round measured on the MI355X: one JSON object with
     the driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline; from round 2 on
@@ -147,6 +147,20 @@ def test_committed_bench_line_follows_the_contract(name):
         assert d['roofline']['traffic'] is None or 'pvgo.hip sha256' in d['roofline']['traffic_source']
         dense = d['cpu_baseline']['dense_pypose_style']
         assert {'f32', 'f64'} <= set(dense) and dense['cores'] >= 1 and dense['f32']['fit_exponent'] > 1
+    if 'r04' in name:                 # round 4: front-end roofline with executed matrix-core work, correlation / warp per launch, reject-heavy and large graph
+        it = d['roofline']['iteration']
+        assert abs(it['us'] - d['us_per_lm_iter']) < 1e-9 and it['bytes'] == 5000 * 5001
+        assert {'bt_eliminate_tw_kernel_L0', 'bt_downsweep_kernel', 'trial_elim_kernel'} <= set(d['roofline']['per_launch'])
+        assert d['roofline']['traffic'] is None or 'pvgo.hip sha256' in d['roofline']['traffic_source']
+        fr = d['stereo_vio']['roofline']
+        assert fr['bound'] == 'mfma' and abs(fr['frac'] - fr['achieved'] / fr['peak']) < 1e-9 and 0 < fr['frac'] < fr['frac_at_clock'] < 1
+        assert abs(fr['achieved'] - fr['executed_gflop_per_frame'] * 1e-3 * d['stereo_vio']['value']) < 1e-6 * fr['achieved']
+        for k in ('corr81_fwd_level2', 'warp_mask_level2'):
+            e = d['front_end_per_launch'][k]
+            assert abs(e['frac'] - e['bytes'] / (e['us'] * 1e-6) / 1e9 / 8000.0) < 1e-9 and 0 < e['frac'] < 1
+        assert d['reject_heavy']['value'] > 0 and d['reject_heavy']['damping_changes_per_run'] + d['reject_heavy']['rejected_trials_per_run'] > 0
+        assert d['large_graph']['N'] == 300007 and d['large_graph']['scaling'] == 'strong' and d['large_graph']['value'] > 0
+        assert 'MIOpen stride-2 flow' not in d['stereo_vio']['nets'] and 'islam_hg_residual_nhwc_bf16' in d['stereo_vio']['nets']
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
