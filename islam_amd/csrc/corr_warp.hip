@@ -155,38 +155,49 @@ constexpr int Q1 = (CC * TH4 * (TW4 / 4) + NT - 1) / NT;       // float4 items o
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Persistent form: the launch has one workgroup per CU (122 VGPRs x 9 waves: a CU holds one), workgroup i walks the logical tiles
+// i', i' + G', ... of ITS XCD's contiguous range (workgroup i runs on XCD i % 8: the 32 tiles the CUs of an XCD work on at a time are
+// neighbours -- 6 tile rows of one image -- so their halos come out of that XCD's L2 instead of being fetched once per XCD), and the
+// first chunk of the NEXT tile is requested before the 81 result planes of the current one are stored.  As independent workgroups
+// the level-2 call (560 tiles on 256 CUs) ran in three rounds of ~13 us of latencies each (first fetch, two barriers per chunk,
+// store tail): 39 us.
 __global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           float* __restrict__ out, float* __restrict__ part, int B, int C,
-                                                          int H, int W, int nslice, int cps, int otot, int ooff, float slope) {
+                                                          int H, int W, int nslice, int cps, int otot, int ooff, float slope,
+                                                          int ntx, int nty, int ntiles) {
     __shared__ __attribute__((aligned(16))) float s1[CC * TH4 * TW4];
     __shared__ __attribute__((aligned(16))) float s2[CC * F2H4 * F2W4];
     const int tid = threadIdx.x, lane = tid & 63, dyi = tid >> 6;        // 9 waves = 9 vertical displacements
     const int tx = lane & 7, ty = lane >> 3;                              // pixels 4 tx ... 4 tx + 3 of tile row ty
-    const int b = blockIdx.z / nslice, slice = blockIdx.z - b * nslice;
-    const int c_begin = slice * cps, c_end = min(C, c_begin + cps);
-    const int x0 = blockIdx.x * TW4, y0 = blockIdx.y * TH4;
     const size_t plane = (size_t)H * W;
-    const float* f1b = f1 + (size_t)b * C * plane;
-    const float* f2b = f2 + (size_t)b * C * plane;
-
-    float acc[4][9];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
+    // XCD x owns the logical tiles [x Q, (x + 1) Q); its workgroups (blockIdx.x >> 3 = 0 .. G8 - 1) take every G8-th of them
+    const int Q = (ntiles + 7) / 8, G8 = (gridDim.x + 7) / 8, xcd = blockIdx.x & 7;
+    const int t_end = min(ntiles, (xcd + 1) * Q);
+    struct Tile { int x0, y0, c_begin, c_end, b, slice; };
+    auto tile_of = [&](int t) {
+        Tile T;
+        const int tx_ = t % ntx, r = t / ntx;
+        const int ty_ = r % nty, z = r / nty;                              // z = b * nslice + slice
+        T.b = z / nslice; T.slice = z - T.b * nslice;
+        T.x0 = tx_ * TW4; T.y0 = ty_ * TH4;
+        T.c_begin = T.slice * cps; T.c_end = min(C, T.c_begin + cps);
+        return T;
+    };
 
     // staging: float4 item i = tid + q NT -> (channel in chunk, halo row, column group); decoded on the fly (constant divisors) instead
-    // of held in 21 registers: the kernel has to stay under 96 VGPRs for two workgroups (18 waves) per CU.  A group of four pixels is
-    // inside the image or outside it as a whole (W % 4 == 0, tile origin a multiple of 32).
+    // of held in 21 registers.  A group of four pixels is inside the image or outside it as a whole (W % 4 == 0, tile origin a
+    // multiple of 32).
     v4f r2[Q2], r1[Q1];                          // (native vectors: arrays of HIP's float4 struct are copied by memcpy and end up in scratch)
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](int cb, int nc) {
+    auto fetch = [&](const Tile& T, int cb, int nc) {
+        const float* f1b = f1 + (size_t)T.b * C * plane;
+        const float* f2b = f2 + (size_t)T.b * C * plane;
 #pragma unroll
         for (int q = 0; q < Q2; ++q) {
             const int i = tid + q * NT;
             const int c = i / (F2H4 * (F2W4 / 4)), rem = i - c * (F2H4 * (F2W4 / 4));
             const int ly = rem / (F2W4 / 4), lx = 4 * (rem - ly * (F2W4 / 4));
-            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+            const int gy = T.y0 - 4 + ly, gx = T.x0 - 4 + lx;
             const bool ok = c < nc && gy >= 0 && gy < H && gx >= 0 && gx < W;          // (c < nc <= CC also bounds i)
             r2[q] = ok ? *reinterpret_cast<const v4f*>(f2b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
         }
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict
             const int i = tid + q * NT;
             const int c = i / (TH4 * (TW4 / 4)), rem = i - c * (TH4 * (TW4 / 4));
             const int ly = rem / (TW4 / 4), lx = 4 * (rem - ly * (TW4 / 4));
-            const int gy = y0 + ly, gx = x0 + lx;
+            const int gy = T.y0 + ly, gx = T.x0 + lx;
             const bool ok = c < nc && gy < H && gx < W;
             r1[q] = ok ? *reinterpret_cast<const v4f*>(f1b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
         }
@@ -209,43 +220,60 @@ __global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict
             if (tid + q * NT < CC * TH4 * (TW4 / 4)) *reinterpret_cast<v4f*>(&s1[4 * (tid + q * NT)]) = r1[q];
     };
 
-    // [measured on one box, level-2 call: 72.5 us for the one-pixel-pair kernel, 39.1 us for this form (one workgroup of nine waves
-    //  per CU: 122 VGPRs); capped at 96 VGPRs for two workgroups per CU (no register prefetch, 60 bytes of scratch) it is SLOWER (49.6 vs
-    //  41.5 us on another box); the 36 FMAs as 16 v_pk_fma_f32 + 4 v_fma_f32: 39.1 us, no change -- the kernel is not VALU-bound,
-    //  560 workgroups on 256 CUs run in three rounds of ~13 us of latencies (first fetch, two barriers per chunk, store tail)]
-    fetch(c_begin, min(CC, c_end - c_begin));
-    for (int cb = c_begin; cb < c_end; cb += CC) {
-        const int nc = min(CC, c_end - cb);
-        __syncthreads();                         // previous chunk fully consumed
-        commit();
-        __syncthreads();
-        if (cb + CC < c_end) fetch(cb + CC, min(CC, c_end - cb - CC));      // in flight while this chunk is consumed
-        for (int c = 0; c < nc; ++c) {
-            const v4f a = *reinterpret_cast<const v4f*>(&s1[(c * TH4 + ty) * TW4 + 4 * tx]);
-            const float* row = &s2[(c * F2H4 + ty + dyi) * F2W4 + 4 * tx];
-            float r[12];
+    // [measured on one box, level-2 call, as independent workgroups: 72.5 us for the one-pixel-pair kernel, 39.1 us for this lane
+    //  layout; capped at 96 VGPRs for two workgroups per CU (no register prefetch, 60 bytes of scratch) it is SLOWER (49.6 vs 41.5 us
+    //  on another box); the 36 FMAs as 16 v_pk_fma_f32 + 4 v_fma_f32: 39.1 us, no change -- the kernel is not VALU-bound]
+    int t = xcd * Q + (blockIdx.x >> 3);
+    if (t >= t_end) return;
+    Tile T = tile_of(t);
+    fetch(T, T.c_begin, min(CC, T.c_end - T.c_begin));
+    for (;;) {
+        const int tn = t + G8;
+        const bool more = tn < t_end;
+        Tile Tn = T;
+        if (more) Tn = tile_of(tn);
+        float acc[4][9];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const v4f v = *reinterpret_cast<const v4f*>(row + 4 * q);
-                r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
+        for (int cb = T.c_begin; cb < T.c_end; cb += CC) {
+            const int nc = min(CC, T.c_end - cb);
+            __syncthreads();                         // previous chunk fully consumed
+            commit();
+            __syncthreads();
+            if (cb + CC < T.c_end) fetch(T, cb + CC, min(CC, T.c_end - cb - CC));      // in flight while this chunk is consumed
+            else if (more) fetch(Tn, Tn.c_begin, min(CC, Tn.c_end - Tn.c_begin));      // ... and across the tile boundary
+            for (int c = 0; c < nc; ++c) {
+                const v4f a = *reinterpret_cast<const v4f*>(&s1[(c * TH4 + ty) * TW4 + 4 * tx]);
+                const float* row = &s2[(c * F2H4 + ty + dyi) * F2W4 + 4 * tx];
+                float r[12];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const v4f v = *reinterpret_cast<const v4f*>(row + 4 * q);
+                    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+                }
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int dx = 0; dx < 9; ++dx) acc[p][dx] = fmaf(av[p], r[p + dx], acc[p][dx]);
             }
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int dx = 0; dx < 9; ++dx) acc[p][dx] = fmaf(av[p], r[p + dx], acc[p][dx]);
         }
-    }
-    const int gy = y0 + ty, gx = x0 + 4 * tx;
-    if (gy < H && gx < W) {
-        const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
-        float* ob = (nslice == 1 ? out + ((size_t)b * otot + ooff + (size_t)dyi * 9) * plane
-                                 : part + (size_t)slice * B * 81 * plane + ((size_t)b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
-        const float sl = nslice == 1 ? slope : 1.0f;
-        auto act = [&](float v) { return v > 0.0f ? v : v * sl; };
+        const int gy = T.y0 + ty, gx = T.x0 + 4 * tx;
+        if (gy < H && gx < W) {
+            const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
+            float* ob = (nslice == 1 ? out + ((size_t)T.b * otot + ooff + (size_t)dyi * 9) * plane
+                                     : part + (size_t)T.slice * B * 81 * plane + ((size_t)T.b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
+            const float sl = nslice == 1 ? slope : 1.0f;
+            auto act = [&](float v) { return v > 0.0f ? v : v * sl; };
 #pragma unroll
-        for (int dx = 0; dx < 9; ++dx)
-            *reinterpret_cast<v4f*>(ob + (size_t)dx * plane) = v4f{act(acc[0][dx] * sc), act(acc[1][dx] * sc), act(acc[2][dx] * sc), act(acc[3][dx] * sc)};
+            for (int dx = 0; dx < 9; ++dx)
+                *reinterpret_cast<v4f*>(ob + (size_t)dx * plane) = v4f{act(acc[0][dx] * sc), act(acc[1][dx] * sc), act(acc[2][dx] * sc), act(acc[3][dx] * sc)};
+        }
+        if (!more) break;
+        t = tn;
+        T = Tn;
     }
 }
 
@@ -738,8 +766,18 @@ static int corr81_launch(const float* f1, const float* f2, float* out, int otot,
     const bool al = ((reinterpret_cast<uintptr_t>(f1) | reinterpret_cast<uintptr_t>(f2) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(scratch)) & 15) == 0;
     if (fwd4 && al) {
-        dim3 grid4((W + TW4 - 1) / TW4, (H + TH4 - 1) / TH4, B * nslice);
-        hipLaunchKernelGGL(corr81_fwd4_kernel, grid4, dim3(NT), 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
+        // one workgroup per CU (a multiple of 8, so that every XCD gets the same number), each walking its share of the tiles
+        const int ntx = (W + TW4 - 1) / TW4, nty = (H + TH4 - 1) / TH4, ntiles = ntx * nty * B * nslice;
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+            const char* e = std::getenv("ISLAM_CORR4_WGS");              // (A/B runs: workgroups of the launch)
+            if (e && std::atoi(e) > 0) n = std::atoi(e);
+            return n / 8 * 8;
+        }();
+        const int grid4 = std::max(8, std::min(cus, (ntiles + 7) / 8 * 8));
+        hipLaunchKernelGGL(corr81_fwd4_kernel, dim3(grid4), dim3(NT), 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps,
+                           otot, ooff, slope, ntx, nty, ntiles);
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
         hipLaunchKernelGGL(corr81_fwd_kernel, grid, block, 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps, otot, ooff, slope);
