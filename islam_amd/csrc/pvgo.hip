@@ -976,6 +976,100 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   nbar       (HELP) barriers every wave of the workgroup executes = node steps of the forward sweep
 //   L0         1 / 0: the level is known at compile time (level-0 instantiation: no composition loads, fewer registers); -1: runtime
 //   PF / nbst  (HELP, upper levels) the next node's columns come composed from the helper: nbst[2][H_NB], buffer t & 1 for step t
+// ---- the pivot phase of a node step and the lane map that goes with it.
+// ISLAM_PVGO_DPP_PIVOTS (default 1): the multiplier of a row update, element (r, i) of the node's S block, reaches the 28 columns
+// through the DP ALU's only DPP form -- `v_fmac_f64_dpp D, D, -f row_newbcast:i`, i.e. m[r] += bcast_i(m[r]) * (-f), ONE instruction
+// instead of two v_readlane_b32 + v_fma_f64 (the same operation: a (-f) == (-a) f exactly) -- and the pivot itself through one
+// v_mov_b64_dpp.  row_newbcast broadcasts inside a row of 16 lanes, so the nine S columns are held by lanes 16 k + 0..8 of EVERY row
+// k (the copies are loaded, damped and updated by the same instructions: they ride along for free) and the 19 other columns
+// (U 9..17, spike 18..26, right-hand side 27) by lanes 16 k + 9..15 of rows 0, 1, 2.  The pivot phase of a node step, measured in
+// isolation (scripts/probes/pivot_dpp.hip): 948 -> 700 clocks, same bits.  A DPP read needs two wait states after the VALU write of
+// its source, which the assembler text cannot leave to the hazard recogniser: s_nop in front of the pivot broadcasts (the row
+// updates of a pivot read registers written by the previous pivot's updates, at least the reciprocal's Newton steps earlier).
+#ifndef ISLAM_PVGO_DPP_PIVOTS
+#define ISLAM_PVGO_DPP_PIVOTS 1
+#endif
+__device__ __forceinline__ int pivot_col_of(int lane) {
+#if ISLAM_PVGO_DPP_PIVOTS
+    const int k = lane >> 4, j = lane & 15;
+    if (j < 9) return j;
+    const int o = 7 * k + (j - 9);
+    return o < 19 ? 9 + o : 28;                      // 28: no column (like lanes 28..63 of the identity map)
+#else
+    return lane;
+#endif
+}
+__device__ __forceinline__ bool pivot_col_primary(int lane) {
+#if ISLAM_PVGO_DPP_PIVOTS
+    return (lane & 15) < 9 ? lane < 16 : true;
+#else
+    return true;
+#endif
+}
+#if ISLAM_PVGO_DPP_PIVOTS == 1
+template <int I> __device__ __forceinline__ double pivot_bcast(double v) {
+    double o;
+    if constexpr (I == 0) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 1) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 2) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 3) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 4) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 5) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 6) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 7) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    if constexpr (I == 8) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:8 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    return o;
+}
+// all row updates of pivot I in ONE assembler block: m[r] += bcast_I(m[r]) * nf for r = I + 1 .. 8.  One block, so that whatever the
+// register allocator puts in front of it (copies out of AGPRs under a VGPR cap, PHI copies at the loop head) is followed by the
+// block's own two wait states before the first DPP read
+template <int I> __device__ __forceinline__ void pivot_updates(double (&m)[9], double nf) {
+    if constexpr (I == 0) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 1) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 2) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 3) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 4) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf" : "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 5) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(m[6]), "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 6) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "+v"(m[7]), "+v"(m[8]) : "v"(nf));
+    if constexpr (I == 7) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf" : "+v"(m[8]) : "v"(nf));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void pivot_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pivot_static_for<I + 1, N>(f);
+    }
+}
+#endif
+// LDL^T pivots of the node's 9x9 S block applied to the lane's column; ipv[i] = 1 / pivot i (every lane), bad |= a non-positive pivot
+__device__ __forceinline__ void pivot_phase(double (&mcol)[9], double (&ipv)[9], int& bad) {
+#if ISLAM_PVGO_DPP_PIVOTS == 1
+    // (nothing that writes a column register may be scheduled into the phase: the assembler text hides its DPP reads from the
+    // hazard recogniser, and the wait states in pivot_bcast only cover what was issued before it)
+    __builtin_amdgcn_sched_barrier(0);
+    pivot_static_for<0, 9>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const double piv = pivot_bcast<i>(mcol[i]);
+        bad |= !(piv > 0.0);                     // off the critical path; a non-positive pivot only poisons this solve
+        const double ip = rcp_nr(piv);
+        ipv[i] = ip;
+        const double nf = -(mcol[i] * ip);
+        if constexpr (i < 8) pivot_updates<i>(mcol, nf);
+    });
+#else
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double piv = bcast(mcol[i], i);
+        bad |= !(piv > 0.0);                     // off the critical path; a non-positive pivot only poisons this solve
+        const double ip = rcp_nr(piv);
+        ipv[i] = ip;
+        const double f = mcol[i] * ip;
+#pragma unroll
+        for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
+    }
+#endif
+}
+
 template <bool REV, bool HELP = false, int L0 = -1, bool PF = false>
 __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const LevelDst& dst, int n, int p, int first, int count,
                                               bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
@@ -993,6 +1087,10 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     const long long t_entry = wall_clock64();
 #endif
     const Damp damping = make_damp(src);
+    // which of the 28 columns this lane holds (pivot_col_of: with the DP-ALU DPP pivots the nine S columns are replicated in every
+    // row of 16 lanes); prim: the lane that stores the column (a replica computes along and stores nothing)
+    const int col = pivot_col_of(lane);
+    const bool prim = pivot_col_primary(lane);
     const int tr = lane % 9, tg = lane / 9;
     const bool t_on = tg < 7;
     const bool t_third = t_on && (tg + 14) < 19;
@@ -1002,10 +1100,10 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     const bool acc_on = !HELP && has_spike && lane < 54;
     // a lane that takes no Schur-update column (U lanes, lanes without a column, the spike lanes of a sweep without an outer
     // separator) reads the column of zeros behind Tn: the next node's columns are a plain nb - tcol on every lane
-    const bool use_tn = lane < 9 || lane == 27 || (has_spike && lane >= 18 && lane < 27);
-    const int tn_off = (!use_tn ? 19 : lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
+    const bool use_tn = col < 9 || col == 27 || (has_spike && col >= 18 && col < 27);
+    const int tn_off = (!use_tn ? 19 : col < 9 ? col : (col >= 18 && col < 27) ? col - 9 : 18) * XS;
     if (lane < XS) Tn[19 * XS + lane] = 0.0;
-    const LaneSrc LS = REV ? lane_source_rev<L0 == 2>(src, lane) : lane_source<L0 == 2>(src, lane);
+    const LaneSrc LS = REV ? lane_source_rev<L0 == 2>(src, col) : lane_source<L0 == 2>(src, col);
     const bool level0 = src.level0 != 0;
     auto clampi = [&](int k) { return min(max(k, 0), n - 1); };
     double mcol[9], nb[9];
@@ -1013,7 +1111,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     issue_cols(LS, level0, first, REV ? first <= 0 : (first + 1) >= n, (first + 1) >= src.Pprev, raw);
     double spike[9];
     {
-        const int jj = (lane >= 18 && lane < 27) ? lane - 18 : 0;
+        const int jj = (col >= 18 && col < 27) ? col - 18 : 0;
         if (!REV) {         // coupling (left separator rows, first cols), transposed
             const int cl = has_spike ? first : 1;
             const double* O = src.level0 ? (src.Ho + (size_t)(cl - 1) * 81) : (src.fill + (size_t)cl * 81);
@@ -1036,9 +1134,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
     if (prb) islam_probe_buf[pbase] = t_entry;
 #endif
     PROBE_WALL(prb, pbase + 1);
-    if (REV) combine_cols_rev(LS, src, first, lane, damping, raw, mcol);
-    else combine_cols(LS, src, first, n, lane, damping, raw, mcol);
-    if (lane >= 18 && lane < 27) {
+    if (REV) combine_cols_rev(LS, src, first, col, damping, raw, mcol);
+    else combine_cols(LS, src, first, n, col, damping, raw, mcol);
+    if (col >= 18 && col < 27) {
 #pragma unroll
         for (int r = 0; r < 9; ++r) mcol[r] = has_spike ? spike[r] : 0.0;
     }
@@ -1052,16 +1150,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
         if constexpr (!PF) { const int kn = clampi(nxt); issue_cols(LS, level0, kn, REV ? kn <= 0 : (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
         __builtin_amdgcn_sched_barrier(0);
         double ipv[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const double piv = bcast(mcol[i], i);
-            bad |= !(piv > 0.0);                 // off the critical path; a non-positive pivot only poisons this solve
-            const double ip = rcp_nr(piv);
-            ipv[i] = ip;
-            const double f = mcol[i] * ip;
-#pragma unroll
-            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
-        }
+        pivot_phase(mcol, ipv, bad);
         PROBE_WALL(prb, pbase + 3 + 5 * t);
         if constexpr (HELP) {
             // the eliminated node goes to the stage of its parity: all 28 columns (the helper streams them out as the factor),
@@ -1069,17 +1158,17 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
             double* st = lds + (t & 1) * H_STAGE;
             Xa = st + 9 * XS;
             Xb = st + H_FST;
-            if (lane < 28) {
-                double* fc = st + lane * XS;
+            if (prim && col < 28) {
+                double* fc = st + col * XS;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) fc[r] = mcol[r];
             }
-            if (lane >= 9 && lane < 28) {
-                double* xb = Xb + (lane - 9) * XS;
+            if (prim && col >= 9 && col < 28) {
+                double* xb = Xb + (col - 9) * XS;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) xb[r] = mcol[r] * ipv[r];
             }
-            if (lane < 9) {
+            if (lane < 9) {                      // (lanes 0-8 hold the S columns 0-8 in either lane map)
                 double mine = 0.0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r)
@@ -1087,9 +1176,9 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
                 st[H_FST + H_XB + lane] = mine;
             }
         } else {
-            if (lane >= 9 && lane < 28) {
-                double* xa = Xa + (lane - 9) * XS;
-                double* xb = Xb + (lane - 9) * XS;
+            if (prim && col >= 9 && col < 28) {
+                double* xa = Xa + (col - 9) * XS;
+                double* xb = Xb + (col - 9) * XS;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
             }
@@ -1121,13 +1210,13 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
         // the next node's own columns; wave B never forms the middle node's (wave A does: its diagonal is damped once)
         const bool want_next = REV ? !last : (nxt >= 0 && nxt < n && (!last || last_next >= 0));
         if (want_next) {
-            if constexpr (PF) ldcol(nbst + (t & 1) * H_NB + min(lane, 28) * XS, nb);      // composed by the helper before this step's barrier
-            else if (REV) combine_cols_rev(LS, src, nxt, lane, damping, raw, nb);
-            else combine_cols(LS, src, nxt, n, lane, damping, raw, nb);
+            if constexpr (PF) ldcol(nbst + (t & 1) * H_NB + min(col, 28) * XS, nb);       // composed by the helper before this step's barrier
+            else if (REV) combine_cols_rev(LS, src, nxt, col, damping, raw, nb);
+            else combine_cols(LS, src, nxt, n, col, damping, raw, nb);
         }
         if constexpr (!HELP) {
-            if (lane < 28) {
-                double* f = dst.fac + (size_t)c * FAC + lane * 9;
+            if (prim && col < 28) {
+                double* f = dst.fac + (size_t)c * FAC + col * 9;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);
             }
@@ -1150,12 +1239,12 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
                 // (HELP: barrier t above is the rendezvous -- the reverse sweep finished its last step before it)
                 if constexpr (!HELP) __syncthreads();
                 double tb[9];
-                const int off = (lane < 9 ? lane : lane < 18 ? lane : 18) * XS;       // U lane 9+cu reads column 9+cu
+                const int off = (col < 9 ? col : col < 18 ? col : 18) * XS;           // U column 9+cu reads column 9+cu
                 ldcol(TnB + off, tb);
-                if (lane < 9 || lane == 27) {
+                if (col < 9 || col == 27) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) mcol[r] -= tb[r];
-                } else if (lane >= 9 && lane < 18) {
+                } else if (col >= 9 && col < 18) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) mcol[r] = has_right ? -tb[r] : 0.0;
                 }
@@ -1174,7 +1263,7 @@ __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const Leve
 #pragma unroll
                     for (int r = 0; r < 9; ++r) dst.Dsep[(size_t)p * 81 + r * 9 + lane] = nb[r];
                 }
-                if (lane == 27) {
+                if (col == 27 && prim) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
                 }
