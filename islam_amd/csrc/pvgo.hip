@@ -1041,6 +1041,10 @@ __device__ __forceinline__ void pivot_static_for(F&& f) {
     }
 }
 #endif
+// (v_rcp_f64_dpp ASSEMBLES for gfx950 but does not work: scripts/probes/pivot_dpp.hip gets inf from it on every lane -- the DPP operand of
+// a double-precision VOP1 instruction is not honoured; only the VOP2 v_fmac_f64 and v_mov_b64 forms are used here.  Also measured and
+// dropped: the multiplier as (m r1)(1 + e1) beside the second Newton residual, one operation less on the dependent chain -- 55.9 / 56.3 /
+// 56.8 against 55.5 / 55.4 us per LM iteration in alternating runs of two builds on one box.)
 // LDL^T pivots of the node's 9x9 S block applied to the lane's column; ipv[i] = 1 / pivot i (every lane), bad |= a non-positive pivot
 __device__ __forceinline__ void pivot_phase(double (&mcol)[9], double (&ipv)[9], int& bad) {
 #if ISLAM_PVGO_DPP_PIVOTS == 1

@@ -92,6 +92,17 @@ __global__ __launch_bounds__(64) void pivots(const double* __restrict__ in, doub
     if (blockIdx.x == 0) for (int r = 0; r < 9; ++r) out[lane * 9 + r] = acc[r];
 }
 
+template <int I> __device__ __forceinline__ void rcp_dpp(double m, double& r0, double& piv) {
+    asm volatile("s_nop 1\n\tv_rcp_f64_dpp %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=&v"(r0), "=&v"(piv) : "v"(m));
+}
+__global__ void rcp_test(const double* in, double* out) {
+    const int lane = threadIdx.x;
+    double m = in[lane % 28 * 9] + 1.0 + lane;
+    double r0, piv;
+    rcp_dpp<3>(m, r0, piv);
+    double ref = __builtin_amdgcn_rcp(piv);
+    out[lane * 3] = r0; out[lane * 3 + 1] = ref; out[lane * 3 + 2] = piv;
+}
 int main() {
     // a 28-column augmented block: S = SPD 9x9 (columns 0..8), 19 more columns
     std::vector<double> h(28 * 9);
@@ -99,6 +110,9 @@ int main() {
     double *din, *dout; long long* dclk;
     hipMalloc(&din, h.size() * 8); hipMalloc(&dout, 64 * 9 * 8); hipMalloc(&dclk, 1024 * 8);
     hipMemcpy(din, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    { double* o3; hipMalloc(&o3, 64 * 3 * 8); hipLaunchKernelGGL(rcp_test, dim3(1), dim3(64), 0, 0, din, o3); hipDeviceSynchronize();
+      std::vector<double> h3(192); hipMemcpy(h3.data(), o3, 192 * 8, hipMemcpyDeviceToHost); int nb = 0; for (int l = 0; l < 64; ++l) nb += memcmp(&h3[l * 3], &h3[l * 3 + 1], 8) != 0;
+      printf("v_rcp_f64_dpp vs v_rcp_f64 of the broadcast: %d of 64 lanes differ (lane 5: %.17g vs %.17g, piv %.17g)\n", nb, h3[15], h3[16], h3[17]); }
     const int reps = 2000;
     std::vector<double> oa(64 * 9), ob(64 * 9);
     for (int blocks : {1, 1024}) {
