@@ -752,230 +752,6 @@ __device__ __forceinline__ void backsub_run(const double* __restrict__ fac, cons
 // LDS per wave: Xa = [U- | F- | y-] (rows of L^-1 [U F^T g]), Xb = D^-1 Xa, Tn = Xa^T D^-1 Xa entries for the next node
 constexpr int LDS_PER_WAVE = 3 * 19 * XS + XS;       // Xa | Xb | Tn (19 columns each) + one column of zeros behind Tn (twisted_sweep)
 
-__device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
-                                                  int lane, double* __restrict__ lds) {
-    double* Xa = lds;
-    double* Xb = lds + 19 * XS;
-    double* Tn = lds + 2 * 19 * XS;
-    const int stride = m + 1;
-    const int c0 = p * stride;
-    const int cnt = min(m, n - c0);
-    const bool has_left = p > 0;
-    const int sR = c0 + m;
-    const bool has_right = sR < n;
-    const Damp damping = make_damp(src);
-
-    // Schur-update work split, fixed per lane: entries (r, cb) = X[:,r] . D^-1 X[:,cb] for cb = g, g+7, g+14
-    const int tr = lane % 9, tg = lane / 9;                         // lanes 0..62 (g <= 6); lane 63 idles
-    const bool t_on = tg < 7;
-    const bool t_third = t_on && (tg + 14) < 19;
-    int pa, pb;                                                     // left-separator accumulation F-^T D^-1 [F- | y-]
-    pair_of(lane, pa, pb);
-    if (lane >= 45) { pa = lane - 45; pb = 9; }
-    const bool acc_on = has_left && lane < 54;
-    // role of this lane when the next node's columns are formed: S columns and g take (next - update), U columns take
-    // the next node's coupling unchanged, spike columns take -(update) (0 without a left separator)
-    const bool use_nb = lane < 18 || lane == 27;
-    const bool use_tn = lane < 9 || lane == 27 || (has_left && lane >= 18 && lane < 27);
-    const int tn_off = (lane < 9 ? lane : (lane >= 18 && lane < 27) ? lane - 9 : 18) * XS;
-
-    const LaneSrc LS = lane_source(src, lane);
-    const bool level0 = src.level0 != 0;
-    double mcol[9], nb[9];
-    RawCols raw;
-    issue_cols(LS, level0, c0, (c0 + 1) >= n, (c0 + 1) >= src.Pprev, raw);
-    // spike F^T: coupling (left separator rows, c0 cols) transposed; requested together with the first node's columns
-    // (every lane loads from a valid address, lanes outside 18..26 / segments without a left separator discard it)
-    double spike[9];
-    {
-        const int jj = (lane >= 18 && lane < 27) ? lane - 18 : 0;
-        const int cl = has_left ? c0 : 1;
-        const double* O = src.level0 ? (src.Ho + (size_t)(cl - 1) * 81) : (src.fill + (size_t)cl * 81);
-#pragma unroll
-        for (int r = 0; r < 9; ++r) spike[r] = O[jj * 9 + r];
-    }
-    combine_cols(LS, src, c0, n, lane, damping, raw, mcol);
-    if (lane >= 18 && lane < 27) {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) mcol[r] = has_left ? spike[r] : 0.0;
-    }
-    double accL = 0.0;
-    int bad = 0;
-
-    PROBE(0);
-    for (int t = 0; t < cnt; ++t) {
-        const int c = c0 + t;
-        const bool last = (t == cnt - 1);
-        PROBE(8 * t + 1);
-        // prefetch: the columns of node c+1 are requested now and first touched after the whole elimination and Schur
-        // update of node c (~1 us later).  Unconditional (index clamped) so that every path through the loop body issues
-        // the same memory operations and the compiler can place an exact, late s_waitcnt.
-        { const int kn = min(c + 1, n - 1); issue_cols(LS, level0, kn, (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- LDL^T elimination of the 9 unknowns of node c, applied to all 28 columns
-        double ipv[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const double piv = bcast(mcol[i], i);
-            bad |= !(piv > 0.0);                 // off the critical path; a non-positive pivot only poisons this solve
-            const double ip = rcp_nr(piv);
-            ipv[i] = ip;
-            const double f = mcol[i] * ip;
-#pragma unroll
-            for (int r = i + 1; r < 9; ++r) mcol[r] = fma(-bcast(mcol[r], i), f, mcol[r]);
-        }
-        PROBE(8 * t + 2);
-        if (lane >= 9 && lane < 28) {
-            double* xa = Xa + (lane - 9) * XS;
-            double* xb = Xb + (lane - 9) * XS;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
-        }
-        lds_sync();
-        PROBE(8 * t + 3);
-        // ---- Schur update: T = X^T D^-1 X, entries (r, cb), r < 9 (U- columns), cb < 19
-        if (t_on) {
-            double ca[9], cbv[9];
-            ldcol(Xa + tr * XS, ca);
-            ldcol(Xb + tg * XS, cbv);
-            Tn[tg * XS + tr] = dot9r(ca, cbv);
-            ldcol(Xb + (tg + 7) * XS, cbv);
-            Tn[(tg + 7) * XS + tr] = dot9r(ca, cbv);
-            if (t_third) {
-                ldcol(Xb + (tg + 14) * XS, cbv);
-                Tn[(tg + 14) * XS + tr] = dot9r(ca, cbv);
-            }
-        }
-        if (acc_on) {
-            double ca[9], cbv[9];
-            ldcol(Xa + (9 + pa) * XS, ca);
-            ldcol(Xb + (9 + pb) * XS, cbv);
-            accL += dot9r(ca, cbv);
-        }
-        lds_sync();
-        PROBE(8 * t + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < n) combine_cols(LS, src, c + 1, n, lane, damping, raw, nb);
-        // the factor goes out only now: vmcnt retires in order, so stores issued before the combine above would have to
-        // COMPLETE (write acknowledged, ~0.3 us) before the prefetched columns could be touched
-        if (lane < 28) {
-            double* f = dst.fac + (size_t)c * FAC + lane * 9;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);   // streamed out: not left dirty in the L2s for the end-of-kernel write-back
-        }
-        if (lane == 0) {
-            double* iv = dst.inv + (size_t)c * 9;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
-        }
-        PROBE(8 * t + 5);
-        if (!last) {
-            // next node's columns, branch-free: (own column of the next node) - (Schur update column), per-lane role
-            double tcol[9];
-            ldcol(Tn + tn_off, tcol);
-#pragma unroll
-            for (int r = 0; r < 9; ++r) mcol[r] = (use_nb ? nb[r] : 0.0) - (use_tn ? tcol[r] : 0.0);
-        } else if (has_right) {
-            // contributions to the right separator (reduced node p) and the separator's own blocks
-            for (int e = lane; e < 81; e += 64) {
-                const int r = e / 9, cc = e - r * 9;
-                dst.cR[(size_t)p * 81 + e] = Tn[cc * XS + r];
-                dst.fill[(size_t)p * 81 + e] = has_left ? -Tn[(9 + r) * XS + cc] : 0.0;   // rows: left sep, cols: right sep
-            }
-            if (lane < 9) {
-                dst.cgR[(size_t)p * 9 + lane] = Tn[18 * XS + lane];
-#pragma unroll
-                for (int r = 0; r < 9; ++r) dst.Dsep[(size_t)p * 81 + r * 9 + lane] = nb[r];
-            }
-            if (lane == 27) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
-            }
-        }
-        lds_sync();
-    }
-    if (has_left) {
-        if (lane < 45) {
-            dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
-            dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
-        } else if (lane < 54) {
-            dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
-        }
-    }
-    PROBE(100);
-    if (bad && lane == 0) atomicOr(flags, 1);
-}
-
-// ------------------------------------------------------------------------------------------
-// Twisted (two-sided) elimination of a segment by TWO wavefronts.  Wave A sweeps the interior nodes left -> right exactly
-// like eliminate_segment (spike = coupling to the left separator), wave B sweeps right -> left over the mirrored chain
-// (its "next node" is c-1, its spike is the coupling to the RIGHT separator); they meet at the middle node c0+h, which A
-// eliminates last with the Schur contributions of both sides: a segment of cnt interior nodes costs h+1 = cnt/2+1
-// dependent node steps instead of cnt.  The products handed to the next level (cL, cR, fill, cgL, cgR, Dsep, rsep) and
-// the factor layout per node are those of eliminate_segment; a B-side node's U~ couples to the node on its LEFT and its
-// F~ to the right separator (backsub_twisted).  Segments with fewer than 3 interior nodes run one-sided on wave A.
-template <bool ZG = false>
-__device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) {
-    LaneSrc L = lane_source<ZG>(s, lane);
-    if (L.isU) {                                    // U' column cu of node k = coupling (k rows, k-1 col cu) = row cu of the
-        const int cu = lane - 9;                    // block that couples k-1 -> k
-        L.A = (s.level0 ? s.Ho - 81 : s.fill) + cu * 9;
-        L.sa = 1;
-    }
-    return L;
-}
-
-__device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, const Damp& damping,
-                                                 const RawCols& raw, double (&m)[9]) {
-    if (s.level0) {
-        double dg = 0.0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            double v = raw.a[r];
-            if (r == lane) { v = damp_apply(damping, v); dg = v; }
-            m[r] = v;
-        }
-        if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) m[r] = raw.a[r] - raw.b[r] - raw.c[r];
-    }
-}
-
-constexpr int TW_ACC = 9 * 10;                                  // wave B's accumulation onto the right separator: [a][b], b = 9: g
-constexpr int LDS_TWISTED = 2 * LDS_PER_WAVE + TW_ACC + 2;      // doubles per workgroup
-
-// Helper wavefronts (HELP = true, bt_eliminate_tw_kernel: four wavefronts per segment).  Of the ~4400 clocks of a node step only
-// the pivots, the Schur update and the formation of the next node's columns lie on the k -> k+1 dependency; the factor / reciprocal
-// stores (address arithmetic + 18 store instructions per lane) and the accumulation onto the outer separator (two more column
-// reads + a 9-term dot product) do not.  Each sweeping wave therefore leaves the eliminated node -- all 28 columns, the D^-1-scaled
-// copies and the reciprocal pivots -- in an LDS stage (two stages, alternating with the node's parity) and a helper wave picks it
-// up one node step later: it streams the factor out with lane-contiguous 512-byte stores and keeps the separator accumulation.
-// One s_barrier per node step (all four waves execute the same number of barriers: the forward sweep's step count) hands a stage
-// over; the barrier after step h-1 is also where the forward sweep folds the reverse sweep's side in.
-constexpr int H_FST = 28 * XS;                                  // eliminated columns [L^T | U~ | F~ | y~]
-constexpr int H_XB = 19 * XS;                                   // D^-1 [U~ | F~ | y~]
-constexpr int H_STAGE = H_FST + H_XB + 10;                      // + reciprocal pivots (9, padded)
-constexpr int H_SWEEP = 2 * H_STAGE + 20 * XS;                  // two stages + Tn + one column of zeros
-constexpr int LDS_TW4 = 2 * H_SWEEP + TW_ACC + 2;               // doubles per workgroup
-// PF (upper levels: bt_eliminate_tw_kernel<0>): the helper also FETCHES AND COMPOSES the next node's columns (27 global loads with
-// their address arithmetic and the a - b - c per lane -- a sixth of the sweeping wave's instructions, and the sweep is bound by
-// instruction issue) and leaves them in LDS, two buffers per sweep by step parity, 29 columns each (28 + one that reads 0.0).
-constexpr int H_NB = 29 * XS;
-constexpr int LDS_TW4_PF = LDS_TW4 + 4 * H_NB + 2;
-
-// workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: global prefetches and stores stay in flight)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// One directed sweep.  REV = false: nodes first, first+1, ...; REV = true: first, first-1, ...
-//   count      nodes eliminated by this wave
-//   has_spike  an outer separator exists (left for forward, right for reverse)
-//   merge_t    (forward only) after node step merge_t the next node is the MIDDLE node: wait for wave B and fold its
-//              contributions in (-1: one-sided)
-//   last_next  (forward only) node whose columns follow the last eliminated node (the right separator), -1: none
-//   nbar       (HELP) barriers every wave of the workgroup executes = node steps of the forward sweep
-//   L0         1 / 0: the level is known at compile time (level-0 instantiation: no composition loads, fewer registers); -1: runtime
-//   PF / nbst  (HELP, upper levels) the next node's columns come composed from the helper: nbst[2][H_NB], buffer t & 1 for step t
 // ---- the pivot phase of a node step and the lane map that goes with it.
 // ISLAM_PVGO_DPP_PIVOTS (default 1): the multiplier of a row update, element (r, i) of the node's S block, reaches the 28 columns
 // through the DP ALU's only DPP form -- `v_fmac_f64_dpp D, D, -f row_newbcast:i`, i.e. m[r] += bcast_i(m[r]) * (-f), ONE instruction
@@ -1074,6 +850,223 @@ __device__ __forceinline__ void pivot_phase(double (&mcol)[9], double (&ipv)[9],
 #endif
 }
 
+__device__ __forceinline__ void eliminate_segment(const LevelSrc& src, const LevelDst& dst, int n, int m, int p, int* flags,
+                                                  int lane, double* __restrict__ lds) {
+    double* Xa = lds;
+    double* Xb = lds + 19 * XS;
+    double* Tn = lds + 2 * 19 * XS;
+    const int stride = m + 1;
+    const int c0 = p * stride;
+    const int cnt = min(m, n - c0);
+    const bool has_left = p > 0;
+    const int sR = c0 + m;
+    const bool has_right = sR < n;
+    const Damp damping = make_damp(src);
+    const int col = pivot_col_of(lane);                              // the column this lane holds / whether it is the lane that stores it
+    const bool prim = pivot_col_primary(lane);                      // (see pivot_col_of)
+
+    // Schur-update work split, fixed per lane: entries (r, cb) = X[:,r] . D^-1 X[:,cb] for cb = g, g+7, g+14
+    const int tr = lane % 9, tg = lane / 9;                         // lanes 0..62 (g <= 6); lane 63 idles
+    const bool t_on = tg < 7;
+    const bool t_third = t_on && (tg + 14) < 19;
+    int pa, pb;                                                     // left-separator accumulation F-^T D^-1 [F- | y-]
+    pair_of(lane, pa, pb);
+    if (lane >= 45) { pa = lane - 45; pb = 9; }
+    const bool acc_on = has_left && lane < 54;
+    // role of this lane when the next node's columns are formed: S columns and g take (next - update), U columns take
+    // the next node's coupling unchanged, spike columns take -(update) (0 without a left separator)
+    const bool use_nb = col < 18 || col == 27;
+    const bool use_tn = col < 9 || col == 27 || (has_left && col >= 18 && col < 27);
+    const int tn_off = (col < 9 ? col : (col >= 18 && col < 27) ? col - 9 : 18) * XS;
+
+    const LaneSrc LS = lane_source(src, col);
+    const bool level0 = src.level0 != 0;
+    double mcol[9], nb[9];
+    RawCols raw;
+    issue_cols(LS, level0, c0, (c0 + 1) >= n, (c0 + 1) >= src.Pprev, raw);
+    // spike F^T: coupling (left separator rows, c0 cols) transposed; requested together with the first node's columns
+    // (every lane loads from a valid address, lanes outside 18..26 / segments without a left separator discard it)
+    double spike[9];
+    {
+        const int jj = (col >= 18 && col < 27) ? col - 18 : 0;
+        const int cl = has_left ? c0 : 1;
+        const double* O = src.level0 ? (src.Ho + (size_t)(cl - 1) * 81) : (src.fill + (size_t)cl * 81);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) spike[r] = O[jj * 9 + r];
+    }
+    combine_cols(LS, src, c0, n, col, damping, raw, mcol);
+    if (col >= 18 && col < 27) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) mcol[r] = has_left ? spike[r] : 0.0;
+    }
+    double accL = 0.0;
+    int bad = 0;
+
+    PROBE(0);
+    for (int t = 0; t < cnt; ++t) {
+        const int c = c0 + t;
+        const bool last = (t == cnt - 1);
+        PROBE(8 * t + 1);
+        // prefetch: the columns of node c+1 are requested now and first touched after the whole elimination and Schur
+        // update of node c (~1 us later).  Unconditional (index clamped) so that every path through the loop body issues
+        // the same memory operations and the compiler can place an exact, late s_waitcnt.
+        { const int kn = min(c + 1, n - 1); issue_cols(LS, level0, kn, (kn + 1) >= n, (kn + 1) >= src.Pprev, raw); }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LDL^T elimination of the 9 unknowns of node c, applied to all 28 columns
+        double ipv[9];
+        pivot_phase(mcol, ipv, bad);
+        PROBE(8 * t + 2);
+        if (prim && col >= 9 && col < 28) {
+            double* xa = Xa + (col - 9) * XS;
+            double* xb = Xb + (col - 9) * XS;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { xa[r] = mcol[r]; xb[r] = mcol[r] * ipv[r]; }
+        }
+        lds_sync();
+        PROBE(8 * t + 3);
+        // ---- Schur update: T = X^T D^-1 X, entries (r, cb), r < 9 (U- columns), cb < 19
+        if (t_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + tr * XS, ca);
+            ldcol(Xb + tg * XS, cbv);
+            Tn[tg * XS + tr] = dot9r(ca, cbv);
+            ldcol(Xb + (tg + 7) * XS, cbv);
+            Tn[(tg + 7) * XS + tr] = dot9r(ca, cbv);
+            if (t_third) {
+                ldcol(Xb + (tg + 14) * XS, cbv);
+                Tn[(tg + 14) * XS + tr] = dot9r(ca, cbv);
+            }
+        }
+        if (acc_on) {
+            double ca[9], cbv[9];
+            ldcol(Xa + (9 + pa) * XS, ca);
+            ldcol(Xb + (9 + pb) * XS, cbv);
+            accL += dot9r(ca, cbv);
+        }
+        lds_sync();
+        PROBE(8 * t + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < n) combine_cols(LS, src, c + 1, n, col, damping, raw, nb);
+        // the factor goes out only now: vmcnt retires in order, so stores issued before the combine above would have to
+        // COMPLETE (write acknowledged, ~0.3 us) before the prefetched columns could be touched
+        if (prim && col < 28) {
+            double* f = dst.fac + (size_t)c * FAC + col * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(mcol[r], &f[r]);   // streamed out: not left dirty in the L2s for the end-of-kernel write-back
+        }
+        if (lane == 0) {
+            double* iv = dst.inv + (size_t)c * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) iv[r] = ipv[r];
+        }
+        PROBE(8 * t + 5);
+        if (!last) {
+            // next node's columns, branch-free: (own column of the next node) - (Schur update column), per-lane role
+            double tcol[9];
+            ldcol(Tn + tn_off, tcol);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) mcol[r] = (use_nb ? nb[r] : 0.0) - (use_tn ? tcol[r] : 0.0);
+        } else if (has_right) {
+            // contributions to the right separator (reduced node p) and the separator's own blocks
+            for (int e = lane; e < 81; e += 64) {
+                const int r = e / 9, cc = e - r * 9;
+                dst.cR[(size_t)p * 81 + e] = Tn[cc * XS + r];
+                dst.fill[(size_t)p * 81 + e] = has_left ? -Tn[(9 + r) * XS + cc] : 0.0;   // rows: left sep, cols: right sep
+            }
+            if (lane < 9) {
+                dst.cgR[(size_t)p * 9 + lane] = Tn[18 * XS + lane];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst.Dsep[(size_t)p * 81 + r * 9 + lane] = nb[r];
+            }
+            if (col == 27 && prim) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst.rsep[(size_t)p * 9 + r] = nb[r];
+            }
+        }
+        lds_sync();
+    }
+    if (has_left) {
+        if (lane < 45) {
+            dst.cL[(size_t)p * 81 + pa * 9 + pb] = accL;
+            dst.cL[(size_t)p * 81 + pb * 9 + pa] = accL;
+        } else if (lane < 54) {
+            dst.cgL[(size_t)p * 9 + (lane - 45)] = accL;
+        }
+    }
+    PROBE(100);
+    if (bad && lane == 0) atomicOr(flags, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Twisted (two-sided) elimination of a segment by TWO wavefronts.  Wave A sweeps the interior nodes left -> right exactly
+// like eliminate_segment (spike = coupling to the left separator), wave B sweeps right -> left over the mirrored chain
+// (its "next node" is c-1, its spike is the coupling to the RIGHT separator); they meet at the middle node c0+h, which A
+// eliminates last with the Schur contributions of both sides: a segment of cnt interior nodes costs h+1 = cnt/2+1
+// dependent node steps instead of cnt.  The products handed to the next level (cL, cR, fill, cgL, cgR, Dsep, rsep) and
+// the factor layout per node are those of eliminate_segment; a B-side node's U~ couples to the node on its LEFT and its
+// F~ to the right separator (backsub_twisted).  Segments with fewer than 3 interior nodes run one-sided on wave A.
+template <bool ZG = false>
+__device__ __forceinline__ LaneSrc lane_source_rev(const LevelSrc& s, int lane) {
+    LaneSrc L = lane_source<ZG>(s, lane);
+    if (L.isU) {                                    // U' column cu of node k = coupling (k rows, k-1 col cu) = row cu of the
+        const int cu = lane - 9;                    // block that couples k-1 -> k
+        L.A = (s.level0 ? s.Ho - 81 : s.fill) + cu * 9;
+        L.sa = 1;
+    }
+    return L;
+}
+
+__device__ __forceinline__ void combine_cols_rev(const LaneSrc& L, const LevelSrc& s, int k, int lane, const Damp& damping,
+                                                 const RawCols& raw, double (&m)[9]) {
+    if (s.level0) {
+        double dg = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = raw.a[r];
+            if (r == lane) { v = damp_apply(damping, v); dg = v; }
+            m[r] = v;
+        }
+        if (lane < 9 && damping.wb) s.Hd[(size_t)k * 81 + lane * 10] = dg;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) m[r] = raw.a[r] - raw.b[r] - raw.c[r];
+    }
+}
+
+constexpr int TW_ACC = 9 * 10;                                  // wave B's accumulation onto the right separator: [a][b], b = 9: g
+constexpr int LDS_TWISTED = 2 * LDS_PER_WAVE + TW_ACC + 2;      // doubles per workgroup
+
+// Helper wavefronts (HELP = true, bt_eliminate_tw_kernel: four wavefronts per segment).  Of the ~4400 clocks of a node step only
+// the pivots, the Schur update and the formation of the next node's columns lie on the k -> k+1 dependency; the factor / reciprocal
+// stores (address arithmetic + 18 store instructions per lane) and the accumulation onto the outer separator (two more column
+// reads + a 9-term dot product) do not.  Each sweeping wave therefore leaves the eliminated node -- all 28 columns, the D^-1-scaled
+// copies and the reciprocal pivots -- in an LDS stage (two stages, alternating with the node's parity) and a helper wave picks it
+// up one node step later: it streams the factor out with lane-contiguous 512-byte stores and keeps the separator accumulation.
+// One s_barrier per node step (all four waves execute the same number of barriers: the forward sweep's step count) hands a stage
+// over; the barrier after step h-1 is also where the forward sweep folds the reverse sweep's side in.
+constexpr int H_FST = 28 * XS;                                  // eliminated columns [L^T | U~ | F~ | y~]
+constexpr int H_XB = 19 * XS;                                   // D^-1 [U~ | F~ | y~]
+constexpr int H_STAGE = H_FST + H_XB + 10;                      // + reciprocal pivots (9, padded)
+constexpr int H_SWEEP = 2 * H_STAGE + 20 * XS;                  // two stages + Tn + one column of zeros
+constexpr int LDS_TW4 = 2 * H_SWEEP + TW_ACC + 2;               // doubles per workgroup
+// PF (upper levels: bt_eliminate_tw_kernel<0>): the helper also FETCHES AND COMPOSES the next node's columns (27 global loads with
+// their address arithmetic and the a - b - c per lane -- a sixth of the sweeping wave's instructions, and the sweep is bound by
+// instruction issue) and leaves them in LDS, two buffers per sweep by step parity, 29 columns each (28 + one that reads 0.0).
+constexpr int H_NB = 29 * XS;
+constexpr int LDS_TW4_PF = LDS_TW4 + 4 * H_NB + 2;
+
+// workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: global prefetches and stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One directed sweep.  REV = false: nodes first, first+1, ...; REV = true: first, first-1, ...
+//   count      nodes eliminated by this wave
+//   has_spike  an outer separator exists (left for forward, right for reverse)
+//   merge_t    (forward only) after node step merge_t the next node is the MIDDLE node: wait for wave B and fold its
+//              contributions in (-1: one-sided)
+//   last_next  (forward only) node whose columns follow the last eliminated node (the right separator), -1: none
+//   nbar       (HELP) barriers every wave of the workgroup executes = node steps of the forward sweep
+//   L0         1 / 0: the level is known at compile time (level-0 instantiation: no composition loads, fewer registers); -1: runtime
+//   PF / nbst  (HELP, upper levels) the next node's columns come composed from the helper: nbst[2][H_NB], buffer t & 1 for step t
 template <bool REV, bool HELP = false, int L0 = -1, bool PF = false>
 __device__ __forceinline__ void twisted_sweep(const LevelSrc& src_in, const LevelDst& dst, int n, int p, int first, int count,
                                               bool has_spike, int merge_t, int last_next, bool has_right, int* flags, int lane,
