@@ -175,6 +175,14 @@ int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout);
 size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout);
 int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
                          uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
+/* `convbn` in training mode up to the BatchNorm's [scale | shift] (Network/PSM/submodule.py:10-13): islam_conv_nhwc_bf16 with `stats`
+ * followed by islam_bn_finalize in two launches instead of three, bit for bit the same results (y raw convolution output, scale_shift
+ * 2*Cout floats, running statistics updated like nn.BatchNorm2d; count = B*H*W).  counter: one int of device memory that is zero
+ * before the call and is left zero; calls that may run concurrently on different streams must not share it. */
+int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, uint16_t* y, float* stats, int B, int Cin,
+                            int H, int W, int Cout, int ksize, int in_relu, const float* weight, const float* bias, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, double momentum, double eps, float* scale_shift,
+                            int* counter, void* stream);
 /* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),
  * :237-292 the blocks) on the channels-last kernel.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) MIRROR of the block's
  * concatenation buffer; the result goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what correlation /

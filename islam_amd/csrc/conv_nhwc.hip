@@ -404,6 +404,75 @@ __global__ __launch_bounds__(256) void partial_fold_kernel(const float* __restri
     }
 }
 
+// partial_fold_kernel and conv_mfma.hip's bn_finalize_kernel in ONE launch (islam_conv_nhwc_bf16_bn): every workgroup folds its
+// share of the per-tile partial sums as partial_fold_kernel does (write-through stores), takes a ticket, and the workgroup that
+// draws the last one turns the folded [RED_BLOCKS][2][C] sums into the BatchNorm's [scale | shift] and running statistics with
+// bn_finalize_kernel's arithmetic in its order (1024 threads = 1024 / C slices of the folded blocks, slices combined in slice
+// order): the same bits as the two launches, one ~4.5 us launch less behind each of the stereo net's ~45 convbn layers -- they
+// sit on the critical path of the frozen nets' graph replay.  counter: one zero-initialised int, left at zero.
+constexpr int FF_THREADS = 1024;
+__device__ __forceinline__ float ldc_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(FF_THREADS) void fold_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ folded,
+                                                                   double count, const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   long long* __restrict__ num_batches, double momentum, double eps,
+                                                                   float* __restrict__ scale_shift, int* __restrict__ counter) {
+    __shared__ double ls[FF_THREADS], lq[FF_THREADS];
+    __shared__ int s_last;
+    const int j = blockIdx.x, C2 = 2 * C;
+    for (int c = threadIdx.x; c < C2; c += FF_THREADS) {
+        float s = 0.0f;
+        for (int bI = j; bI < nblk; bI += RED_BLOCKS) s += partial[(size_t)bI * C2 + c];
+        __hip_atomic_store(&folded[(size_t)j * C2 + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: bn_finalize_kernel over folded[RED_BLOCKS][2][C], read past this XCD's L2
+    const int nsl = FF_THREADS / C, c = threadIdx.x % C, sl = threadIdx.x / C;
+    double s = 0.0, q = 0.0;
+    if (sl < nsl) {
+        const int per = (RED_BLOCKS + nsl - 1) / nsl, b0 = sl * per, b1 = min(RED_BLOCKS, b0 + per);
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            const float s0 = ldc_f32(&folded[((size_t)b * 2) * C + c]), q0 = ldc_f32(&folded[((size_t)b * 2 + 1) * C + c]);
+            const float s1 = ldc_f32(&folded[((size_t)b * 2 + 2) * C + c]), q1 = ldc_f32(&folded[((size_t)b * 2 + 3) * C + c]);
+            const float s2 = ldc_f32(&folded[((size_t)b * 2 + 4) * C + c]), q2 = ldc_f32(&folded[((size_t)b * 2 + 5) * C + c]);
+            const float s3 = ldc_f32(&folded[((size_t)b * 2 + 6) * C + c]), q3 = ldc_f32(&folded[((size_t)b * 2 + 7) * C + c]);
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; b < b1; ++b) {
+            s += (double)ldc_f32(&folded[((size_t)b * 2) * C + c]);
+            q += (double)ldc_f32(&folded[((size_t)b * 2 + 1) * C + c]);
+        }
+    }
+    ls[threadIdx.x] = s;
+    lq[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        s = 0.0;
+        q = 0.0;
+        for (int k = 0; k < nsl; ++k) { s += ls[k * C + c]; q += lq[k * C + c]; }
+        const double mean = s / count;
+        const double var = fmax(q / count - mean * mean, 0.0);
+        const double sc = (double)weight[c] / sqrt(var + eps);
+        scale_shift[c] = (float)sc;
+        scale_shift[C + c] = (float)((double)bias[c] - mean * sc);
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (num_batches) *num_batches += 1;
+        *counter = 0;
+    }
+}
+
 template <int TN, int KS, int ROWS, int KC, bool FLOW = false>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
@@ -483,6 +552,38 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
                            stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
     }
+    return ISLAM_OK;
+}
+
+
+// convbn in training mode (Network/PSM/submodule.py:10-13: Conv2d(bias=False) + BatchNorm2d) up to the BatchNorm's [scale | shift]:
+// islam_conv_nhwc_bf16 with `stats` followed by islam_bn_finalize, as TWO launches instead of three (fold_finalize_kernel).  Same
+// results bit for bit.  counter: one int in device memory, zero before the call and after it (not shared with a call that may run
+// concurrently on another stream).  count = B H W; C = Cout <= 256.
+int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, uint16_t* y, float* stats, int B, int Cin,
+                            int H, int W, int Cout, int ksize, int in_relu, const float* weight, const float* bias, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, double momentum, double eps, float* scale_shift,
+                            int* counter, void* stream) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7) || Cout > 256)
+        return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_bn: bad shape (Cin=%d, Cout=%d: multiples of 8, Cout <= 256)", Cin, Cout);
+    if (ksize != 1 && ksize != 3) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_bn: kernel size %d (1 or 3)", ksize);
+    if (!stats || !weight || !bias || !scale_shift || !counter) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_bn: null argument");
+    if ((size_t)B * H * W * std::max(Cin, Cout) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_bn: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = Cout > 32;
+    const int ir = in_relu ? 1 : 0;
+    int rc;
+    if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
+                              : launch<32, 3, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
+    else rc = wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
+                   : launch<32, 1, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
+    if (rc != ISLAM_OK) return rc;
+    const int nblk = tiles_of(B, H, W, tile_h(Cout));
+    hipLaunchKernelGGL(fold_finalize_kernel, dim3(RED_BLOCKS), dim3(FF_THREADS), 0, s, stats, nblk, Cout,
+                       stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout, (double)B * H * W, weight, bias, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, scale_shift, counter);
+    ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
 

@@ -383,6 +383,10 @@ FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '1') == '1'
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 # hourglass Residual modules as one launch each (0: three convolution launches, for A/B runs); only for maps of at most
 # ISLAM_HG_FUSED_MAX_PIXELS pixels per image
+# 1: the convolution's batch statistics folded AND finalized by one launch (islam_conv_nhwc_bf16_bn, same bits) instead of partial_fold +
+# bn_finalize.  Measured on the stereo net's graph replay in alternating runs: 6.80 / 6.80 ms with it, 6.76 / 6.75 ms without -- the 45 saved
+# launches are not on the replay's critical path and the ticketed 256 x 1024-thread launch costs what the two small ones do: default off.
+BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
 HG_FUSED_MAX_PIXELS = int(_os.environ.get('ISLAM_HG_FUSED_MAX_PIXELS', str(1 << 30)))
 
@@ -435,9 +439,13 @@ def _cbn(convbn, x, relu=False, res=None, defer=False):
     plain_bn = type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32
     xin = x.raw if isinstance(x, _Pending) else x
     if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin):
-        y, folded = ops.conv_nhwc(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0],
-                                  in_affine=x.affine if isinstance(x, _Pending) else None, stats=True)
-        affine = ops.bn_finalize(folded, bn, y.shape[0] * y.shape[2] * y.shape[3])
+        if BN_FOLD_FINALIZE:          # statistics folded and finalized by ONE launch behind the convolution (islam_conv_nhwc_bf16_bn)
+            y, affine = ops.conv_nhwc_bn(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0], bn,
+                                         in_affine=x.affine if isinstance(x, _Pending) else None)
+        else:
+            y, folded = ops.conv_nhwc(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0],
+                                      in_affine=x.affine if isinstance(x, _Pending) else None, stats=True)
+            affine = ops.bn_finalize(folded, bn, y.shape[0] * y.shape[2] * y.shape[3])
         if defer and relu and res is None:
             return _Pending(y, affine)
         if res is not None and not res.is_contiguous(memory_format=torch.channels_last):

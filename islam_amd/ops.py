@@ -287,6 +287,39 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
     return y
 
 
+_BN_COUNTERS = {}
+
+
+def _bn_counter(device):
+    """A zero-initialised int32 slot for islam_conv_nhwc_bf16_bn's ticket (one ring of 256 per device: two launches that could run at
+    the same time -- two streams, two nodes of a captured graph -- never share a slot; the kernel leaves its slot at zero)."""
+    key = (device.type, device.index)
+    hit = _BN_COUNTERS.get(key)
+    if hit is None:
+        hit = _BN_COUNTERS[key] = [torch.zeros(256 * 32, dtype=torch.int32, device=device), 0]      # one 128-byte line per slot
+    hit[1] = (hit[1] + 1) % 256
+    return hit[0][hit[1] * 32:]
+
+
+def conv_nhwc_bn(x, packed, cout, ksize, bn, in_affine=None, in_relu=False):
+    """conv_nhwc(..., stats=True) followed by bn_finalize as two launches instead of three (islam_conv_nhwc_bf16_bn): returns
+    (raw output, [scale | shift] of the train-mode BatchNorm ``bn``, whose running statistics are updated).  Same bits."""
+    require_cuda(x, packed)
+    B, Cin, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and bn.num_features == cout
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    st = torch.empty(lib().islam_conv_nhwc_stats_floats(B, H, W, cout), dtype=torch.float32, device=x.device)
+    out = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    check(lib().islam_conv_nhwc_bf16_bn(ptr(x), ptr(packed), ptr(in_affine), ptr(y), ptr(st), B, Cin, H, W, int(cout), int(ksize),
+                                        int(bool(in_relu)), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean) if track else None,
+                                        ptr(bn.running_var) if track else None, ptr(bn.num_batches_tracked) if track else None,
+                                        c_double(mom), c_double(float(bn.eps)), ptr(out), ptr(_bn_counter(x.device)),
+                                        stream_ptr(x.device)))
+    return y, out
+
+
 def pack_hg_residual(w1, w2, w3):
     """Weights of one hourglass Residual (hourglass.py:28-40: conv1 (h,Cin,1,1), conv2 (h,h,3,3), conv3 (Cout,h,1,1)) as the MFMA A
     fragments islam_hg_residual_nhwc_bf16 loads (1 KiB each: 64 lanes x 8 bf16), in the order its waves consume them

@@ -274,3 +274,33 @@ def test_statistics_of_layers_with_several_channel_blocks(cuda, B, Cin, H, W, Co
     np.testing.assert_allclose(s[1].cpu().numpy(), (yd ** 2).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5)
     y2, f2 = ops.conv_nhwc(x, wp, Cout, 3, stats=True)
     assert torch.equal(f, f2) and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,k', [(16, 32, 224, 320, 32, 3), (2, 64, 40, 72, 64, 3), (2, 128, 24, 40, 128, 3), (1, 64, 17, 50, 128, 1),
+                                               (3, 32, 7, 5, 32, 3), (1, 48, 19, 35, 40, 3)])
+def test_convolution_with_fold_and_finalize_in_one_launch(cuda, B, Cin, H, W, Cout, k):
+    """islam_conv_nhwc_bf16_bn == islam_conv_nhwc_bf16(stats) + islam_bn_finalize, bit for bit: raw output, [scale | shift], running
+    statistics, batch counter; twice in a row (the ticket counter must come back to zero) and with the producer's affine on load."""
+    from islam_amd import ops
+    x, w = _mk(B, Cin, H, W, Cout, k, seed=B + Cin + k)
+    wp = ops.pack_conv_nhwc_weight(w)
+    g = torch.Generator().manual_seed(5)
+    aff = torch.cat((torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.1)).to(cuda)
+
+    def bn():
+        m = torch.nn.BatchNorm2d(Cout).to(cuda).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        return m
+    for in_affine in (None, aff):
+        a, b = bn(), bn()
+        b.load_state_dict(a.state_dict())
+        for _ in range(2):
+            y0, folded = ops.conv_nhwc(x, wp, Cout, k, in_affine=in_affine, stats=True)
+            s0 = ops.bn_finalize(folded, a, B * H * W)
+            y1, s1 = ops.conv_nhwc_bn(x, wp, Cout, k, b, in_affine=in_affine)
+            assert torch.equal(y0, y1) and torch.equal(s0, s1)
+            assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+            assert int(a.num_batches_tracked) == int(b.num_batches_tracked)
+    assert all(int(t[0].abs().sum()) == 0 for t in ops._BN_COUNTERS.values())
