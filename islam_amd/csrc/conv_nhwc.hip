@@ -106,7 +106,7 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; int tc; };
 
 template <int TN, int KS, int ROWS, int KC, bool FLOW>
-__global__ __launch_bounds__(THREADS) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
+__global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
                                                              float* __restrict__ partial, int Cin, int CinP, int H, int W, int Cout,
@@ -514,7 +514,23 @@ size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
     return (size_t)ksize * ksize * CoutP * CinP;
 }
 
-static int tile_h(int Cout) { return Cout > 32 ? 8 : 16; }
+// The 64-channel-block 3x3 kernel with FOUR pixel rows per wave and 16-channel chunks (conv_nhwc_kernel<64, 3, 4, 16>): tile 32 x 16,
+// 0.5 instead of 0.83 LDS operand reads per MFMA, the same MFMAs per barrier pair, 47 KB of LDS and 244 VGPRs (two workgroups per
+// CU as before).  Measured (B = 16, scripts/conv_nhwc_bench.py, alternating runs): 352->128 @224x320 1000 -> 910 us (1.02 PFLOP/s),
+// 128->128 @112x160 110 -> 111 us, 64->128 the same, 64->64 39 -> 44 us: it pays where the chunk loop dominates the workgroup's life,
+// so it serves the layers with at least 256 input channels (ISLAM_CONV_R4=0: never, =1: every 3x3 layer with more than 32 outputs).
+// ... AND enough 32 x 16 tiles to fill the chip twice: on the flow net's DenseNet layers (up to 565 input channels, but maps of
+// 112 x 160 and smaller at B = 8) the larger tile costs parallelism -- flow forward 3.21 -> 3.50 ms with the rule on channels alone.
+static bool conv_r4(int Cin, int Cout, int ksize, int B, int H, int W) {
+    static const int mode = [] { const char* e = std::getenv("ISLAM_CONV_R4"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    if (ksize != 3 || Cout <= 32 || mode == 0) return false;
+    if (mode == 1) return true;
+    const long long work = (long long)((W + 31) / 32) * ((H + 15) / 16) * B * ((Cout + 63) / 64);
+    return Cin >= 256 && work >= 1024;
+}
+static int tile_h(int Cout, int Cin = 0, int ksize = 0, int B = 0, int H = 0, int W = 0) {
+    return Cout > 32 ? (conv_r4(Cin, Cout, ksize, B, H, W) ? 16 : 8) : 16;
+}
 static int tiles_of(int B, int H, int W, int th) { return ((W + TW - 1) / TW) * ((H + th - 1) / th) * B; }
 // rows of the per-workgroup partial sums a caller must provide room for (the smallest tile any kernel variant uses for this Cout)
 int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout) { return tiles_of(B, H, W, Cout > 32 ? 8 : 16); }
@@ -542,12 +558,14 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 #define ISLAM_CONV_LAUNCH(TN_, KS_, ROWS_)                                                                                              \
     (kc16 ? launch<TN_, KS_, ROWS_, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s) \
           : launch<TN_, KS_, ROWS_, 32>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s))
-    if (ksize == 3) rc = wide ? ISLAM_CONV_LAUNCH(64, 3, 2) : ISLAM_CONV_LAUNCH(32, 3, 4);
+    if (conv_r4(Cin, Cout, ksize, B, H, W))
+        rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
+    else if (ksize == 3) rc = wide ? ISLAM_CONV_LAUNCH(64, 3, 2) : ISLAM_CONV_LAUNCH(32, 3, 4);
     else rc = wide ? ISLAM_CONV_LAUNCH(64, 1, 2) : ISLAM_CONV_LAUNCH(32, 1, 4);
 #undef ISLAM_CONV_LAUNCH
     if (rc != ISLAM_OK) return rc;
     if (stats) {
-        const int nblk = tiles_of(B, H, W, tile_h(Cout));                   // workgroups along x of the launch above
+        const int nblk = tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));      // workgroups along x of the launch above
         hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout,
                            stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
@@ -574,12 +592,13 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
     const bool wide = Cout > 32;
     const int ir = in_relu ? 1 : 0;
     int rc;
-    if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
-                              : launch<32, 3, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
+    if (conv_r4(Cin, Cout, ksize, B, H, W)) rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
+    else if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
+                                   : launch<32, 3, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else rc = wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
                    : launch<32, 1, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     if (rc != ISLAM_OK) return rc;
-    const int nblk = tiles_of(B, H, W, tile_h(Cout));
+    const int nblk = tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
     hipLaunchKernelGGL(fold_finalize_kernel, dim3(RED_BLOCKS), dim3(FF_THREADS), 0, s, stats, nblk, Cout,
                        stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout, (double)B * H * W, weight, bias, running_mean,
                        running_var, num_batches_tracked, momentum, eps, scale_shift, counter);
@@ -635,6 +654,8 @@ int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const u
     const int d = dilation;
     const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W, 0};
     hipStream_t s = (hipStream_t)stream;
+    if (conv_r4(Cin, Cout, 3, B * d * d, H / d, W / d))
+        return launch<64, 3, 4, 16, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl);
     return Cout > 32 ? launch<64, 3, 2, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl)
                      : launch<32, 3, 4, 32, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl);
 }
