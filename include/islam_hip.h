@@ -175,6 +175,12 @@ int islam_conv_nhwc_stat_blocks(int B, int H, int W, int Cout);
 size_t islam_conv_nhwc_stats_floats(int B, int H, int W, int Cout);
 int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
                          uint16_t* y, float* stats, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
+/* islam_conv_nhwc_bf16 (no residual, no statistics) with the result written into channels [yoff, yoff + Cout) of a (B,H,W,ytot) bf16
+ * tensor: straight into a concatenation under construction (Network/StereoNet7.py:103-105) instead of a dense tensor torch.cat copies.
+ * ytot, yoff: multiples of 8.  `relu` as in islam_conv_nhwc_bf16. */
+int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, uint16_t* y, int ytot,
+                              int yoff, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
+
 /* `convbn` in training mode up to the BatchNorm's [scale | shift] (Network/PSM/submodule.py:10-13): islam_conv_nhwc_bf16 with `stats`
  * followed by islam_bn_finalize in two launches instead of three, bit for bit the same results (y raw convolution output, scale_shift
  * 2*Cout floats, running statistics updated like nn.BatchNorm2d; count = B*H*W).  counter: one int of device memory that is zero

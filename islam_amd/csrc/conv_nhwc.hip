@@ -574,6 +574,29 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 }
 
 
+// islam_conv_nhwc_bf16 with the result written into channels [yoff, yoff + Cout) of a (B,H,W,ytot) bf16 tensor -- straight into a
+// concatenation under construction (Network/StereoNet7.py:103-105: torch.cat((left features, right features, half-resolution image))
+// in front of conv_c0) instead of a dense tensor that torch.cat then copies.  No residual, no statistics.
+int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, uint16_t* y, int ytot,
+                              int yoff, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream) {
+    const int in_relu = (relu >> 1) & 1;
+    relu &= 1;
+    if (B < 1 || H < 1 || W < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+    if (ksize != 1 && ksize != 3) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: kernel size %d (1 or 3)", ksize);
+    if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + Cout > ytot) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: output slice %d+%d of %d", yoff, Cout, ytot);
+    if ((size_t)B * H * W * std::max(Cin, ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 1, W, 0};
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = Cout > 32;
+    if (conv_r4(Cin, Cout, ksize, B, H, W)) return launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
+    if (ksize == 3) return wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl)
+                                : launch<32, 3, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
+    return wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl)
+                : launch<32, 1, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
+}
+
 // convbn in training mode (Network/PSM/submodule.py:10-13: Conv2d(bias=False) + BatchNorm2d) up to the BatchNorm's [scale | shift]:
 // islam_conv_nhwc_bf16 with `stats` followed by islam_bn_finalize, as TWO launches instead of three (fold_finalize_kernel).  Same
 // results bit for bit.  counter: one int in device memory, zero before the call and after it (not shared with a call that may run

@@ -387,6 +387,8 @@ HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 # bn_finalize.  Measured on the stereo net's graph replay in alternating runs: 6.80 / 6.80 ms with it, 6.76 / 6.75 ms without -- the 45 saved
 # launches are not on the replay's critical path and the ticketed 256 x 1024-thread launch costs what the two small ones do: default off.
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
+# the feature extractor's last convolution writes conv_c0's input in place (left images first in the batch); 0: dense features + two copies
+STEREO_DIRECT_CAT = os.environ.get('ISLAM_STEREO_DIRECT_CAT', '1') != '0'
 HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
 HG_FUSED_MAX_PIXELS = int(_os.environ.get('ISLAM_HG_FUSED_MAX_PIXELS', str(1 << 30)))
 
@@ -525,7 +527,10 @@ class feature_extraction(nn.Module):
         mods += [_PSMBlock(planes, planes, 1, None) for _ in range(1, blocks)]
         return nn.Sequential(*mods)
 
-    def forward(self, x):
+    def forward(self, x, into=None):
+        """into: callable (images, channels, h, w, dtype, device) -> None | (buffer, [(first image, images, channel offset), ...]):
+        when it returns a buffer, the result is written into those channel slices of it (batch ranges of the result, in order)
+        and the buffer is returned instead of the feature tensor -- StereoNet7 assembles conv_c0's input this way."""
         f = x
         for i in (0, 2, 4):                                  # firstconv = (convbn, ReLU) x 3; the middle one's BatchNorm + ReLU
             f = _cbn(self.firstconv[i], f, relu=True, defer=(i == 2))      # is applied by the third convolution's load
@@ -558,6 +563,12 @@ class feature_extraction(nn.Module):
         if isinstance(y, _Pending) and last.bias is None and _hip_conv_ok(last, y.raw, fused_1x1=True):
             # BatchNorm + ReLU of the 352 -> 128 convolution applied while the 1x1 convolution stages its input: no apply pass over the
             # 128-channel half-resolution tensor (94 us) and no MIOpen / CK launch (94 us) -- one launch of the channels-last kernel
+            dest = into(y.raw.shape[0], last.out_channels, y.raw.shape[2], y.raw.shape[3], y.raw.dtype, y.raw.device) if into else None
+            if dest is not None:
+                buf, parts = dest
+                for b0, nb, off in parts:                     # (a batch range of a channels-last tensor is itself dense channels-last)
+                    ops.conv_nhwc_into(y.raw[b0:b0 + nb], _packed_nhwc(last), last.out_channels, 1, buf, off, in_affine=y.affine)
+                return buf
             return ops.conv_nhwc(y.raw, _packed_nhwc(last), last.out_channels, 1, in_affine=y.affine)
         return last(y.materialize() if isinstance(y, _Pending) else y)
 
@@ -710,21 +721,42 @@ class StereoNet7(nn.Module):
         collapses to a 2x2 stride-2 convolution at half resolution -- the same arithmetic for the pixels that are used."""
         assert x.shape[1] % 2 == 0
         B, C2, H, W = x.shape
-        f2 = self.feature_extraction(x.reshape(B * 2, C2 // 2, H, W))         # left/right stacked along the batch
+        c0 = self.conv_c0
+        cin = (c0.in_channels + 7) // 8 * 8
+        direct = {}
+
+        def into(n, cf, h, w, dtype, device):
+            # conv_c0's input is torch.cat((left features, right features, half-resolution image)) (StereoNet7.py:103-105).  With the
+            # left images first and the right images behind them in the batch, the feature extractor's last convolution writes the two
+            # halves of its result straight into their channel slices of that (padded) buffer: no dense feature tensor, no copies of it
+            if not (STEREO_DIRECT_CAT and HIP_CONV_LEVEL >= 1 and n == 2 * B and dtype == torch.bfloat16 and c0.weight.dtype == torch.bfloat16
+                    and cf % 8 == 0 and 2 * cf + C2 == c0.in_channels):
+                return None
+            direct['buf'] = torch.empty((B, cin, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+            return direct['buf'], [(0, B, 0), (B, B, cf)]
+        stacked = STEREO_DIRECT_CAT and x.dtype == torch.bfloat16
+        xs = torch.cat((x[:, :C2 // 2], x[:, C2 // 2:]), 0) if stacked else x.reshape(B * 2, C2 // 2, H, W)
+        f2 = self.feature_extraction(xs, into=into if stacked else None)      # left / right images stacked along the batch
         half = F.interpolate(x, scale_factor=0.5, mode='bilinear')
         act = self.actfun
         pool = ops.maxpool2                                                   # F.max_pool2d(t, kernel_size=2); HIP kernel for bf16 channels-last
         relu_pool = (lambda t: ops.maxpool2(t, relu=True)) if act is F.relu else (lambda t: pool(act(t)))      # pool(relu(t)) in one pass
-        c0 = self.conv_c0
-        cf = f2.shape[1]
-        if HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f2, cf) and c0.weight.dtype == torch.bfloat16 and cf % 8 == 0:
+        if 'buf' in direct:
+            buf = direct['buf']
+            cf = (c0.in_channels - C2) // 2
+        else:
+            if stacked:                                      # (the direct path did not apply: back to the reference's interleaved order)
+                f2 = torch.stack((f2[:B], f2[B:]), 1).reshape(B * 2, f2.shape[1], f2.shape[2], f2.shape[3])
+            cf = f2.shape[1]
+            buf = None
+        if buf is not None or (HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(f2, cf) and c0.weight.dtype == torch.bfloat16 and cf % 8 == 0):
             # 134 = 128 + 6 input channels: the concatenation is built with 136 channels (two zero ones) so that conv_c0 runs on
             # islam_conv_nhwc_bf16 -- MIOpen's bf16 kernel for this shape truncates its output (scripts/calib/bf16_rounding_probe.py)
             # and this is the first layer of the un-normalised hourglass path, where that loss of magnitude is never renormalised
-            cin = (c0.in_channels + 7) // 8 * 8
-            buf = torch.empty((B, cin, f2.shape[2], f2.shape[3]), dtype=f2.dtype, device=f2.device, memory_format=torch.channels_last)
-            buf[:, :cf].copy_(f2[0::2])                      # f.reshape(B, 2*cf, h, w) of the reference: [left | right] features per
-            buf[:, cf:2 * cf].copy_(f2[1::2])                # image, written straight into the padded buffer (one copy, not two)
+            if buf is None:
+                buf = torch.empty((B, cin, f2.shape[2], f2.shape[3]), dtype=f2.dtype, device=f2.device, memory_format=torch.channels_last)
+                buf[:, :cf].copy_(f2[0::2])                  # f.reshape(B, 2*cf, h, w) of the reference: [left | right] features per
+                buf[:, cf:2 * cf].copy_(f2[1::2])            # image, written straight into the padded buffer (one copy, not two)
             buf[:, 2 * cf:c0.in_channels].copy_(half)
             buf[:, c0.in_channels:].zero_()
             bkey = (c0.bias._version, c0.bias.data_ptr())

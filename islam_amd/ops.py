@@ -287,6 +287,19 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
     return y
 
 
+def conv_nhwc_into(x, packed, cout, ksize, out, yoff, in_affine=None, bias=None, relu=False, in_relu=False):
+    """conv_nhwc with the result written into out[:, yoff:yoff+cout] of a larger channels-last bf16 tensor (a concatenation under
+    construction; islam_conv_nhwc_bf16_into).  Returns ``out``."""
+    require_cuda(x, packed, out)
+    B, Cin, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last) and out.shape[0] == B
+    assert tuple(out.shape[2:]) == (H, W)
+    check(lib().islam_conv_nhwc_bf16_into(ptr(x), ptr(packed), ptr(in_affine), ptr(bias), ptr(out), int(out.shape[1]), int(yoff), B, Cin, H, W,
+                                          int(cout), int(ksize), int(bool(relu)) | (2 if in_relu else 0), stream_ptr(x.device)))
+    return out
+
+
 _BN_COUNTERS = {}
 
 

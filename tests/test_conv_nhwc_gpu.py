@@ -304,3 +304,24 @@ def test_convolution_with_fold_and_finalize_in_one_launch(cuda, B, Cin, H, W, Co
             assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
             assert int(a.num_batches_tracked) == int(b.num_batches_tracked)
     assert all(int(t[0].abs().sum()) == 0 for t in ops._BN_COUNTERS.values())
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,k,ytot,yoff', [(2, 128, 24, 40, 64, 1, 136, 64), (3, 32, 17, 33, 32, 3, 72, 8), (1, 64, 40, 72, 128, 3, 128, 0)])
+def test_convolution_into_a_channel_slice(cuda, B, Cin, H, W, Cout, k, ytot, yoff):
+    """islam_conv_nhwc_bf16_into: the dense result, bit for bit, in channels [yoff, yoff + Cout) of a larger tensor whose other channels
+    stay untouched; batch ranges of the input go to the same destination rows (how StereoNet7 assembles conv_c0's input)."""
+    from islam_amd import ops
+    x, w = _mk(B, Cin, H, W, Cout, k, seed=ytot)
+    wp = ops.pack_conv_nhwc_weight(w)
+    aff = torch.cat((torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1)).to(cuda)
+    want = ops.conv_nhwc(x, wp, Cout, k, in_affine=aff)
+    out = torch.full((B, ytot, H, W), 7.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
+    ops.conv_nhwc_into(x, wp, Cout, k, out, yoff, in_affine=aff)
+    assert torch.equal(out[:, yoff:yoff + Cout], want)
+    keep = torch.ones(ytot, dtype=torch.bool)
+    keep[yoff:yoff + Cout] = False
+    assert bool((out[:, keep.to(cuda)] == 7.0).all())
+    if B > 1:                                   # a batch range of the input into the rows of a smaller destination
+        out1 = torch.zeros((1, ytot, H, W), dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
+        ops.conv_nhwc_into(x[1:2], wp, Cout, k, out1, yoff, in_affine=aff)
+        assert torch.equal(out1[:, yoff:yoff + Cout], want[1:2])

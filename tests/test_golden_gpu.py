@@ -133,11 +133,14 @@ def test_flow_net_matrix_core_path_matches_reference(cuda):
     assert max(errs) > 1e-5                  # it IS the reduced-precision path (the fp32 path sits at ~1e-6)
 
 
-def test_stereo_net_bf16_execution_copy_matches_reference(cuda):
+@pytest.mark.parametrize('direct_cat', [True, False])
+def test_stereo_net_bf16_execution_copy_matches_reference(cuda, monkeypatch, direct_cat):
     """The frozen stereo net as the bench runs it: bf16 channels-last execution copy in train mode, BatchNorm on
     islam_bn_train_nhwc_bf16 (batch statistics + running-stat update), islam_resize_bilinear_nhwc_bf16,
-    islam_bias_act_add_nhwc_bf16 -- against the reference's fp32 train-mode forward."""
+    islam_bias_act_add_nhwc_bf16 -- against the reference's fp32 train-mode forward.  direct_cat: the feature extractor writes
+    conv_c0's input in place (left images first in the batch: the default) / dense features in the reference's interleaved order."""
     from islam_amd import nets
+    monkeypatch.setattr(nets, 'STEREO_DIRECT_CAT', direct_cat)
     ref = _g('stereo')
     vn = nets.VONet(fix_parts=('flow', 'stereo'))
     fill_state_dict(vn.stereoNet)
