@@ -526,7 +526,8 @@ static bool conv_r4(int Cin, int Cout, int ksize, int B, int H, int W) {
     if (ksize != 3 || Cout <= 32 || mode == 0) return false;
     if (mode == 1) return true;
     const long long work = (long long)((W + 31) / 32) * ((H + 15) / 16) * B * ((Cout + 63) / 64);
-    return Cin >= 256 && work >= 1024;
+    static const long long min_work = [] { const char* e = std::getenv("ISLAM_CONV_R4_WORK"); return e ? std::atoll(e) : 1024ll; }();      // (A/B runs)
+    return Cin >= 256 && work >= min_work;
 }
 static int tile_h(int Cout, int Cin = 0, int ksize = 0, int B = 0, int H = 0, int W = 0) {
     return Cout > 32 ? (conv_r4(Cin, Cout, ksize, B, H, W) ? 16 : 8) : 16;
