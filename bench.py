@@ -473,6 +473,12 @@ def main():
                     r, _ = ops.pvgo_run_chain(st_b[i][0], st_b[i][1], prob_b['vo'], prob_b['drots'], prob_b['dtrans'], prob_b['dvels'], prob_b['dts'],
                                               prm, workspace=ws_b)
                     return r.trials
+            elif os.environ.get('ISLAM_SHARDED_PYTHON') == '1':       # (the gloo self-test of the plumbing: Python stage loop)
+                solver_b = dist_pvgo.ShardedChainPVGO(prob_b['init_nodes'], prob_b['init_vels'], prob_b['vo'], prob_b['drots'], prob_b['dtrans'],
+                                                      prob_b['dvels'], prob_b['dts'], LOSS_WEIGHT, radius=1e4, group=None)
+
+                def step_b(i):
+                    return solver_b.run()['trials']
             else:
                 def step_b(i):
                     _, _, r, _ = dist_pvgo.run_chain_sharded(comm, prob_b['init_nodes'], prob_b['init_vels'], prob_b['vo'], prob_b['drots'],
