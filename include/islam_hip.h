@@ -127,6 +127,12 @@ int islam_resize_bilinear_add_nhwc_bf16_into(const uint16_t* x, const uint16_t* 
 /* MaxPool2d(2, 2) / F.max_pool2d(kernel_size=2) of a channels-last bf16 tensor (hourglass.py:52, StereoNet7.py:117-125), relu != 0:
  * of relu(x) (the two commute); (B,H,W,C) -> (B,H/2,W/2,C), C a multiple of 8. */
 int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int relu, void* stream);
+
+/* F.interpolate(x, scale_factor=0.5, mode='bilinear') of a channels-last bf16 image with C <= 8 (even) channels -- the half-resolution
+ * stereo pair of Network/StereoNet7.py:101 -- written with 8 - C zero channels behind it into channels [yoff, yoff + 8) of a
+ * (B,H/2,W/2,ytot) bf16 tensor (the padded tail of conv_c0's concatenated input): one launch instead of ATen's up-sampling kernel, a
+ * slice copy and a zero fill; the same values as ATen bit for bit.  H, W even; ytot, yoff multiples of 8. */
+int islam_half_image_into_nhwc_bf16(const uint16_t* x, uint16_t* y, int ytot, int yoff, int B, int C, int H, int W, void* stream);
 /* AvgPool2d((k,k), stride=(k,k)) of a channels-last bf16 tensor (the SPP branches, submodule.py:103-122): fp32 accumulation, one
  * rounding; (B,H,W,C) -> (B,H/k,W/k,C). */
 int islam_avgpool_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int k, void* stream);

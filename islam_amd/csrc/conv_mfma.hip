@@ -452,6 +452,40 @@ extern "C" int islam_maxpool2_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, i
     return ISLAM_OK;
 }
 
+// F.interpolate(x, scale_factor=0.5, mode='bilinear') of a channels-last bf16 image with C <= 8 channels (Network/StereoNet7.py:101: the
+// half-resolution stereo pair that joins the features in front of conv_c0), written into channels [yoff, yoff + 8) of a (B,H/2,W/2,ytot)
+// bf16 tensor: the C values and 8 - C zeros as ONE 16-byte store per pixel (the padded tail of the concatenation buffer).  With
+// align_corners = False and scale 1/2 the source coordinate of output pixel o is 2 o + 1/2: the mean of a 2 x 2 block, evaluated as
+// ATen does (0.5 (0.5 a + 0.5 b) + 0.5 (0.5 c + 0.5 d) in fp32, one rounding to bf16).  H, W even; C even.
+__global__ __launch_bounds__(256) void half_image_into_kernel(const unsigned* __restrict__ x, uint4* __restrict__ y, int C2, int Hi, int Wi,
+                                                              int ytot8, int yoff8, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int Wo = Wi / 2, Ho = Hi / 2;
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), b = (int)(i / ((long long)Wo * Ho));
+    const unsigned* p00 = x + (((size_t)b * Hi + 2 * oy) * Wi + 2 * ox) * C2;
+    const unsigned* p10 = p00 + (size_t)Wi * C2;
+    unsigned o[4] = {0u, 0u, 0u, 0u};
+    for (int c = 0; c < C2; ++c) {
+        const unsigned a = p00[c], bq = p00[C2 + c], cq = p10[c], d = p10[C2 + c];
+        const float lo = 0.5f * (0.5f * bf16_lo(a) + 0.5f * bf16_lo(bq)) + 0.5f * (0.5f * bf16_lo(cq) + 0.5f * bf16_lo(d));
+        const float hi = 0.5f * (0.5f * bf16_hi(a) + 0.5f * bf16_hi(bq)) + 0.5f * (0.5f * bf16_hi(cq) + 0.5f * bf16_hi(d));
+        o[c] = pack_bf16(lo, hi);
+    }
+    y[(size_t)i * ytot8 + yoff8] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int islam_half_image_into_nhwc_bf16(const uint16_t* x, uint16_t* y, int ytot, int yoff, int B, int C, int H, int W, void* stream) {
+    if (B < 1 || C < 2 || C > 8 || (C & 1) || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(ISLAM_EARG, "islam_half_image_into_nhwc_bf16: bad shape (C=%d even and <= 8, %dx%d even)", C, H, W);
+    if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + 8 > ytot) return fail(ISLAM_EARG, "islam_half_image_into_nhwc_bf16: output slot %d+8 of %d", yoff, ytot);
+    const long long total = (long long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(half_image_into_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(x), reinterpret_cast<uint4*>(y), C / 2, H, W, ytot / 8, yoff / 8, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 // AvgPool2d((k,k), stride=(k,k)) of a channels-last bf16 tensor (the SPP branches, submodule.py:103-122); (B,H,W,C) -> (B,H/k,W/k,C)
 extern "C" int islam_avgpool_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C, int H, int W, int k, void* stream) {
     if (B < 1 || C < 8 || (C & 7) || k < 1 || H < k || W < k) return fail(ISLAM_EARG, "islam_avgpool_nhwc_bf16: bad shape (C=%d, %dx%d, k=%d)", C, H, W, k);

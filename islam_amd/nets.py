@@ -737,7 +737,7 @@ class StereoNet7(nn.Module):
         stacked = STEREO_DIRECT_CAT and x.dtype == torch.bfloat16
         xs = torch.cat((x[:, :C2 // 2], x[:, C2 // 2:]), 0) if stacked else x.reshape(B * 2, C2 // 2, H, W)
         f2 = self.feature_extraction(xs, into=into if stacked else None)      # left / right images stacked along the batch
-        half = F.interpolate(x, scale_factor=0.5, mode='bilinear')
+        half = None
         act = self.actfun
         pool = ops.maxpool2                                                   # F.max_pool2d(t, kernel_size=2); HIP kernel for bf16 channels-last
         relu_pool = (lambda t: ops.maxpool2(t, relu=True)) if act is F.relu else (lambda t: pool(act(t)))      # pool(relu(t)) in one pass
@@ -757,8 +757,12 @@ class StereoNet7(nn.Module):
                 buf = torch.empty((B, cin, f2.shape[2], f2.shape[3]), dtype=f2.dtype, device=f2.device, memory_format=torch.channels_last)
                 buf[:, :cf].copy_(f2[0::2])                  # f.reshape(B, 2*cf, h, w) of the reference: [left | right] features per
                 buf[:, cf:2 * cf].copy_(f2[1::2])            # image, written straight into the padded buffer (one copy, not two)
-            buf[:, 2 * cf:c0.in_channels].copy_(half)
-            buf[:, c0.in_channels:].zero_()
+            if (STEREO_DIRECT_CAT and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and C2 <= 8 and C2 % 2 == 0
+                    and H % 2 == 0 and W % 2 == 0 and (2 * cf) % 8 == 0 and cin == 2 * cf + 8 and buf.shape[2:] == (H // 2, W // 2)):
+                ops.half_image_into(x, buf, 2 * cf)          # the half-resolution pair + the zero channels, one launch
+            else:
+                buf[:, 2 * cf:c0.in_channels].copy_(F.interpolate(x, scale_factor=0.5, mode='bilinear'))
+                buf[:, c0.in_channels:].zero_()
             bkey = (c0.bias._version, c0.bias.data_ptr())
             b32 = self.__dict__.get('_c0_b32')
             if b32 is None or b32[0] != bkey:
@@ -766,7 +770,7 @@ class StereoNet7(nn.Module):
             x0 = ops.conv_nhwc(buf, _packed_nhwc(c0, cin), c0.out_channels, 3, bias=b32[1])
         else:
             f = f2.reshape(B, cf * 2, f2.shape[2], f2.shape[3])
-            x0 = c0(torch.cat((f, half), 1))
+            x0 = c0(torch.cat((f, F.interpolate(x, scale_factor=0.5, mode='bilinear')), 1))
         cat0 = self.conv_c1(x0)                                               # 1/2, 64
         cat1 = self.conv_c2_SSP(pool(self.conv_c2(cat0)))                     # 1/4, 128
         cat2 = pool(self.conv_c3(cat1))                                       # 1/8, 192

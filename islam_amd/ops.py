@@ -509,6 +509,18 @@ def resize_bilinear_add(x, add, align_corners=False, out=None, coff=0):
     return y
 
 
+def half_image_into(x, out, yoff):
+    """F.interpolate(x, scale_factor=0.5, mode='bilinear') of a channels-last bf16 image with at most 8 channels, written (zero padded to
+    8 channels) into out[:, yoff:yoff+8] of a larger channels-last bf16 tensor (islam_half_image_into_nhwc_bf16).  Returns ``out``."""
+    require_cuda(x, out)
+    B, C, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
+    assert tuple(out.shape[2:]) == (H // 2, W // 2) and out.shape[0] == B
+    check(lib().islam_half_image_into_nhwc_bf16(ptr(x), ptr(out), int(out.shape[1]), int(yoff), B, C, H, W, stream_ptr(x.device)))
+    return out
+
+
 def maxpool2(x, relu=False):
     """F.max_pool2d([relu](x), 2): islam_maxpool2_nhwc_bf16 for channels-last bf16 inference tensors, torch otherwise."""
     if fusable_nhwc_bf16(x, x.shape[1]) and x.shape[2] >= 2 and x.shape[3] >= 2:

@@ -46,3 +46,17 @@ def test_upsample_add_equals_the_two_ops(cuda, shape):
     assert torch.equal(y, two)                                   # same roundings: bf16 after the interpolation, bf16 after the add
     ref = u.float() + F.interpolate(low.float(), scale_factor=2, mode='bilinear', align_corners=False)
     assert float((y.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 6, 64, 96), (1, 6, 448, 640), (3, 8, 10, 6), (1, 2, 2, 2)])
+def test_half_resolution_image_into_the_concatenation(cuda, B, C, H, W):
+    """islam_half_image_into_nhwc_bf16 == F.interpolate(x, scale_factor=0.5, mode='bilinear') bit for bit, zero padded to 8 channels, in its
+    slot of a larger channels-last tensor whose other channels stay untouched (Network/StereoNet7.py:101-105)."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 3).to(cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = torch.full((B, 24, H // 2, W // 2), 5.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=torch.channels_last)
+    ops.half_image_into(x, out, 8)
+    want = F.interpolate(x, scale_factor=0.5, mode='bilinear')
+    assert torch.equal(out[:, 8:8 + C], want)
+    assert bool((out[:, 8 + C:16] == 0).all()) and bool((out[:, :8] == 5.0).all()) and bool((out[:, 16:] == 5.0).all())
