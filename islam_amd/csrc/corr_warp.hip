@@ -744,7 +744,13 @@ static void corr81_plan(int B, int C, int H, int W, bool* fwd4, int* nslice, int
     const int th = *fwd4 ? TH4 : TH;
     const int tiles = ((W + TW - 1) / TW) * ((H + th - 1) / th) * B;
     const int chunks = (C + CC - 1) / CC;
-    int ns = std::min(chunks, std::max(1, 1024 / std::max(tiles, 1)));
+    // workgroups wanted before the channels are split into slices (partial sums + a reduce pass: 4 x the output traffic of the level-3
+    // call).  The four-pixel kernel holds one workgroup per CU: past ~256 of them slicing only adds traffic -- B = 8, level 3 (C 64, 56 x 80)
+    // 39.3 -> 22.5 us, level 4 (C 96, 28 x 40) 29.1 -> 21.4 us with 256 instead of 1024; the small-map kernel keeps 1024 (16.3 -> 18.6 us
+    // at 128).  ISLAM_CORR_SLICE_TARGET overrides both (A/B runs).
+    static const int forced = [] { const char* e = std::getenv("ISLAM_CORR_SLICE_TARGET"); return e && std::atoi(e) > 0 ? std::atoi(e) : 0; }();
+    const int target = forced ? forced : (*fwd4 ? 256 : 1024);
+    int ns = std::min(chunks, std::max(1, target / std::max(tiles, 1)));
     *cps = ((chunks + ns - 1) / ns) * CC;                                // channels per slice (whole chunks)
     *nslice = (C + *cps - 1) / *cps;
 }
