@@ -92,6 +92,12 @@ size_t islam_pyramid_packed_elems(int Cin, int Cout);
 int islam_flow_pyramid_level(const float* x, const uint16_t* wA, const float* bA, const uint16_t* wB, const float* bB, const uint16_t* wC,
                              const float* bC, float* y, int B, int Cin, int H, int W, int C, float slope, void* stream);
 
+/* Level 1 of the pyramid on the two frames of a pair tensor x (B, 6, H, W) fp32 = [frame 1 | frame 2] along the channels -- the input
+ * PWCDCNet.forward splits (Network/PWC/PWCNet.py:224-226): y (2 B, 16, H/2, W/2), first frames first, as islam_flow_pyramid_level
+ * gives for torch.cat((x[:, :3], x[:, 3:]), 0), without that copy. */
+int islam_flow_pyramid_level_pair(const float* x, const uint16_t* wA, const float* bA, const uint16_t* wB, const float* bB, const uint16_t* wC,
+                                  const float* bC, float* y, int B, int H, int W, float slope, void* stream);
+
 /* 3x3 convolution (+ bias + LeakyReLU) of the frozen flow network on the matrix cores (implicit GEMM, bf16 operands,
  * fp32 accumulate).  Replaces cuDNN under Network/PWC/PWCNet.py:16-20 `conv()` (Conv2d k=3, padding = dilation, then
  * LeakyReLU(0.1)) for inference:  y[b, coff+n, ho, wo] = act(bias[n] + sum w[n,c,r,s] x[b, c, ho*stride + (r-1)*dil,

@@ -53,6 +53,7 @@ SIGNATURES = {
     'islam_flow_head_up_f32': (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     'islam_pyramid_packed_elems': (c_size_t, [c_int, c_int]),
     'islam_flow_pyramid_level': (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
+    'islam_flow_pyramid_level_pair': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_float, c_void_p]),
     'islam_conv3x3_packed_elems': (c_size_t, [c_int, c_int]),
     'islam_conv3x3_mfma': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_float, c_void_p]),
     'islam_resize_bilinear_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

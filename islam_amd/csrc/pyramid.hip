@@ -101,7 +101,7 @@ __global__ __launch_bounds__(THREADS) void pyr_level_kernel(const float* __restr
                                                             const float* __restrict__ bA, const unsigned short* __restrict__ wB,
                                                             const float* __restrict__ bB, const unsigned short* __restrict__ wC,
                                                             const float* __restrict__ bC, float* __restrict__ y, int H, int W, int Ho, int Wo,
-                                                            float slope, int tiles_x, int tiles_per_img) {
+                                                            float slope, int tiles_x, int tiles_per_img, int bh, long long s_img, long long s_half) {
     constexpr int R1 = TH + 4, W1 = TW + 4, R2 = TH + 2, W2 = TW + 2, R0 = 2 * R1 + 1, W0 = 2 * W1 + 1;
     constexpr int NSA = k_steps<SC>(), NSB = k_steps<C>(), MB = C / 16, NW = THREADS / 64;
     constexpr int T0 = ((R0 * W0 * SC > R2 * W2 * C ? R0 * W0 * SC : R2 * W2 * C) + 7) / 8 * 8;
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(THREADS) void pyr_level_kernel(const float* __restr
     // ---- source patch: thread = (channel pair, pixel), consecutive threads along x; eight requests in flight per thread
     {
         constexpr int NPIX = R0 * W0, ITEMS = NPIX * (SC / 2), UN = 8;
-        const float* xb = x + (size_t)b * CIN * H * W;
+        // image b of the launch = image b % bh of half b / bh of the source (islam_flow_pyramid_level_pair: the two frames of a (B, 2 CIN, H, W)
+        // pair tensor as a batch of 2 B images, no concatenated copy); plain form: bh = B, s_half = 0
+        const float* xb = x + (size_t)(b % bh) * s_img + (size_t)(b / bh) * s_half;
         for (int i0 = threadIdx.x; i0 < ITEMS; i0 += THREADS * UN) {
             float v0[UN], v1[UN];
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(THREADS) void pyr_level_kernel(const float* __restr
 
 template <int CIN, int SC, int C, int TH, int TW, int THREADS>
 int launch_level(const float* x, const unsigned short* wA, const float* bA, const unsigned short* wB, const float* bB, const unsigned short* wC,
-                 const float* bC, float* y, int B, int H, int W, float slope, hipStream_t s) {
+                 const float* bC, float* y, int B, int H, int W, float slope, hipStream_t s, bool pair = false) {
     constexpr int R1 = TH + 4, W1 = TW + 4, R2 = TH + 2, W2 = TW + 2, R0 = 2 * R1 + 1, W0 = 2 * W1 + 1;
     constexpr int T0 = ((R0 * W0 * SC > R2 * W2 * C ? R0 * W0 * SC : R2 * W2 * C) + 7) / 8 * 8;
     constexpr size_t lds = ((size_t)T0 + (size_t)R1 * W1 * C) * sizeof(unsigned short);
@@ -196,7 +198,8 @@ int launch_level(const float* x, const unsigned short* wA, const float* bA, cons
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL((pyr_level_kernel<CIN, SC, C, TH, TW, THREADS>), dim3((unsigned)(tiles_x * tiles_y * B)), dim3(THREADS), lds, s, x, wA, bA, wB, bB,
-                       wC, bC, y, H, W, Ho, Wo, slope, tiles_x, tiles_x * tiles_y);
+                       wC, bC, y, H, W, Ho, Wo, slope, tiles_x, tiles_x * tiles_y, pair ? B / 2 : B, (long long)(pair ? 2 : 1) * CIN * H * W,
+                       pair ? (long long)CIN * H * W : 0ll);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -234,6 +237,16 @@ int islam_flow_pyramid_level(const float* x, const uint16_t* wA, const float* bA
         return launch_level<16, 16, 32, 8, 16, 256>(x, wA, bA, wB, bB, wC, bC, y, B, H, W, slope, s);
     }
     return fail(ISLAM_EARG, "islam_flow_pyramid_level: (Cin, C) = (%d, %d); built for PWC-Net's levels 1 and 2: (3, 16), (16, 32)", Cin, C);
+}
+
+// Level 1 on the two frames of a pair tensor: x (B, 6, H, W) fp32 = [frame 1 | frame 2] along the channels (what PWCDCNet.forward is
+// called with, PWCNet.py:224-226); the result is (2 B, 16, H/2, W/2) with the B first-frame images first -- the batch
+// torch.cat((x[:, :3], x[:, 3:]), 0) would give, without that copy.
+int islam_flow_pyramid_level_pair(const float* x, const uint16_t* wA, const float* bA, const uint16_t* wB, const float* bB, const uint16_t* wC,
+                                  const float* bC, float* y, int B, int H, int W, float slope, void* stream) {
+    if (B < 1 || H < 2 || W < 2) return fail(ISLAM_EARG, "islam_flow_pyramid_level_pair: bad shape B=%d H=%d W=%d", B, H, W);
+    if ((size_t)B * 2 * 16 * H * W >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_flow_pyramid_level_pair: tensor too large for 32-bit offsets");
+    return launch_level<3, 4, 16, 16, 32, 256>(x, wA, bA, wB, bB, wC, bC, y, 2 * B, H, W, slope, as_stream(stream), true);
 }
 
 }  // extern "C"

@@ -186,7 +186,7 @@ class PWCDCNet(nn.Module):
             off -= w
         return buf, None
 
-    def _pyramid_level(self, l, f):
+    def _pyramid_level(self, l, f, pair=False):
         """conv{l}a (stride 2), conv{l}aa, conv{l}b (PWCNet.py:78-83, :240-243) on islam_flow_pyramid_level; weights re-packed when the
         fp32 masters change (ISLAM_FLOW_PYR=0: layer by layer)."""
         convs = [getattr(self, 'conv%d%s' % (l, s))[0] for s in ('a', 'aa', 'b')]
@@ -195,6 +195,8 @@ class PWCDCNet(nn.Module):
         hit = cache.get(l)
         if hit is None or hit[0] != key:
             hit = cache[l] = (key, [ops.pack_pyramid_weight(c.weight) for c in convs], [c.bias.detach().float().contiguous() for c in convs])
+        if pair:                                              # f = the (B, 6, H, W) frame pair: both frames as one batch, no concatenated copy
+            return ops.flow_pyramid_level_pair(f, hit[1], hit[2], 0.1)
         return ops.flow_pyramid_level(f, hit[1], hit[2], 0.1)
 
     def _head_up(self, l, x, up, up_out=None, up_coff=0):
@@ -278,10 +280,11 @@ class PWCDCNet(nn.Module):
         _c(), concatenations through channel slices.  fp32 activations; bf16-rounded operands inside the convolutions."""
         B = x.shape[0]
         x = x.float()
-        f, feats = torch.cat((x[:, 0:3], x[:, 3:6]), 0).contiguous(), []
+        pair = FLOW_PYR and x.is_cuda and x.shape[1] == 6 and x.is_contiguous()      # level 1 reads the two frames where they lie
+        f, feats = (x if pair else torch.cat((x[:, 0:3], x[:, 3:6]), 0).contiguous()), []
         for l in range(1, 7):
             if FLOW_PYR and l <= 2 and f.is_cuda:                # levels 1, 2: the three layers in one launch, intermediates in LDS
-                f = self._pyramid_level(l, f)
+                f = self._pyramid_level(l, f, pair=pair and l == 1)
             else:
                 for s in (('a', 'aa', 'b') if l < 6 else ('aa', 'a', 'b')):
                     f = self._c('conv%d%s' % (l, s), f)

@@ -217,6 +217,18 @@ def flow_pyramid_level(x, packed, biases, slope=0.1):
     return y
 
 
+def flow_pyramid_level_pair(x, packed, biases, slope=0.1):
+    """flow_pyramid_level (level 1: 3 -> 16 channels) on the two frames of a pair tensor x (B, 6, H, W) fp32: the result for
+    torch.cat((x[:, :3], x[:, 3:]), 0) -- (2 B, 16, H/2, W/2), first frames first -- without that copy."""
+    require_cuda(x, *packed)
+    B, C6, H, W = x.shape
+    assert C6 == 6 and x.dtype == torch.float32 and x.is_contiguous() and len(packed) == 3 and int(biases[0].numel()) == 16
+    y = torch.empty((2 * B, 16, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib().islam_flow_pyramid_level_pair(ptr(x), ptr(packed[0]), ptr(biases[0]), ptr(packed[1]), ptr(biases[1]), ptr(packed[2]),
+                                              ptr(biases[2]), ptr(y), B, H, W, float(slope), stream_ptr(x.device)))
+    return y
+
+
 def pack_conv3x3_weight(w):
     """(Cout, Cin, 3, 3) fp32 -> bf16 [9][CoutP][CinP] (tap-major, zero padded), the layout islam_conv3x3_mfma stages.
     The kernel walks the input channels in chunks of 16; when Cin > 16 is not a multiple of 16 its last chunk reads the LAST

@@ -421,6 +421,11 @@ def test_fused_pyramid_level(cuda, Cin, C, B, H, W):
     assert float(err.max()) <= 2e-2 * scale, float(err.max()) / scale
     assert float((err > 1e-4 * scale).double().mean()) < 0.02, float((err > 1e-4 * scale).double().mean())
     assert torch.equal(got, ops.flow_pyramid_level(x, [ops.pack_pyramid_weight(w) for w in ws], bs, 0.1))
+    if Cin == 3:              # the pair form: both frames of a (B, 6, H, W) tensor as one batch, first frames first, bit for bit
+        x2 = torch.randn(B, 3, H, W, generator=g).to(cuda)
+        packed = [ops.pack_pyramid_weight(w) for w in ws]
+        pair = ops.flow_pyramid_level_pair(torch.cat((x, x2), 1).contiguous(), packed, bs, 0.1)
+        assert torch.equal(pair, ops.flow_pyramid_level(torch.cat((x, x2), 0).contiguous(), packed, bs, 0.1))
 
 
 @pytest.mark.parametrize('B,C,H,W,up', [(2, 529, 7, 10, True), (1, 149, 9, 67, True), (1, 33, 1, 1, True), (2, 565, 14, 20, False), (1, 5, 33, 130, False),
