@@ -193,6 +193,16 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, uint16_t* y, int ytot,
                               int yoff, int B, int Cin, int H, int W, int Cout, int ksize, int relu, void* stream);
 
+/* Conv2d(Cin, Cout, k, stride = 2, padding = k / 2) on the same kernel: layer2's stride-2 3x3 convbn and its stride-2 1x1 downsample
+ * (Network/PSM/submodule.py:24-26, 76-85) and the 2x2 stride-2 form of StereoNet7's last transposed convolution at the pixels VONet keeps
+ * (Network/StereoNet7.py:88-90, Network/VONet.py:33-34).  x (B,Hi,Wi,Cin) -> y (B,Ho,Wo,Cout), Ho <= (Hi + 2 (k/2) - k) / 2 + 1 (fewer rows /
+ * columns may be asked for); k = 1, 2, 3; the other arguments as islam_conv_nhwc_bf16, `stats` sized by islam_conv_nhwc_s2_stats_floats
+ * (its last 256*2*Cout floats are the folded sums). */
+size_t islam_conv_nhwc_s2_stats_floats(int B, int Ho, int Wo, int Cout);
+int islam_conv_nhwc_bf16_s2(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
+                            uint16_t* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int relu,
+                            void* stream);
+
 /* `convbn` in training mode up to the BatchNorm's [scale | shift] (Network/PSM/submodule.py:10-13): islam_conv_nhwc_bf16 with `stats`
  * followed by islam_bn_finalize in two launches instead of three, bit for bit the same results (y raw convolution output, scale_shift
  * 2*Cout floats, running statistics updated like nn.BatchNorm2d; count = B*H*W).  counter: one int of device memory that is zero

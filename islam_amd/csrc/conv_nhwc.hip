@@ -103,9 +103,9 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // convolutions, one per output parity class (a, c), each with its own taps K[r][s] = W[:, :, 3 - 2r - a, 3 - 2s - c].  The kernel runs
 // on B * 4 "images" (d = 2 decodes the class like a dilation sub-grid): the INPUT is the dense image with its origin shifted by
 // (a, c), the OUTPUT is the sub-grid (a::2, c::2) of the (2H, 2W) result, the weights are the class's slice of the packed array.
-struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; int tc; };
+struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; int tc; int Hi, Wi; };      // (Hi, Wi: the input's size when it differs from the output's -- stride 2)
 
-template <int TN, int KS, int ROWS, int KC, bool FLOW>
+template <int TN, int KS, int ROWS, int KC, bool FLOW, int S = 1>
 __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
@@ -113,11 +113,14 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
                                                              int CoutP, int relu, int tiles_x, int tiles, int in_relu, Slices sl, int nimg,
                                                              int nblk_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    constexpr int TH = 4 * ROWS, P = KS / 2, IH = TH + 2 * P, IW = TW + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
+    // (S = 2: Conv2d(stride = 2, padding = KS / 2) -- Network/PSM/submodule.py:76-85 layer2's first block and its 1x1 downsample, the
+    //  quarter-resolution tail of StereoNet7: output pixel (y, x) reads input rows 2 y - P ... 2 y - P + KS - 1; the halo tile covers
+    //  (TH - 1) S + 1 + 2 P rows, the B operand of output column li is input column li S + tap)
+    constexpr int TH = 4 * ROWS, P = KS / 2, IH = (TH - 1) * S + 1 + 2 * P, IW = (TW - 1) * S + 1 + 2 * P, NPIX = IH * IW, TAPS = KS * KS;
     constexpr int PS = KC + 8, OPP = KC / 8;                 // LDS row stride (elements), 16-byte octets per pixel / weight row
     constexpr int NIN = (NPIX * (KC / 8) + THREADS - 1) / THREADS;       // 16-byte items of the halo tile per thread
     constexpr int NWT = (TAPS * TN * (KC / 8) + THREADS - 1) / THREADS;  // 16-byte items of the weight taps per thread
-    constexpr int NT = TN / 32, NR = ROWS + KS - 1;
+    constexpr int NT = TN / 32, NR = (ROWS - 1) * S + KS;
     unsigned short* lin = lds;                               // [IH][IW][PS]
     unsigned short* lw = lds + (size_t)NPIX * PS;            // [TAPS][TN][PS]
     constexpr int DUMMY = (NPIX + TAPS * TN) * PS;           // 16 bytes of scratch behind both tiles
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
     const int dd = sl.d * sl.d, bb = b / dd, sga = (b - bb * dd) / sl.d, sgc = b - bb * dd - sga * sl.d;
     const size_t img0 = ((size_t)(bb * H * sl.d + sga)) * sl.Wf + sgc;          // first pixel of the image, in full-resolution pixels
     const bool tcm = sl.tc != 0;                             // transposed convolution: dense input image, output on a sub-grid
-    const int idil = tcm ? 1 : sl.d, iWf = tcm ? W : sl.Wf, oWf = tcm ? 2 * W : sl.Wf;
+    const int Hin = S > 1 ? sl.Hi : H, Win = S > 1 ? sl.Wi : W;                 // (S > 1: dense input of its own size, d = 1, tc = 0)
+    const int idil = tcm ? 1 : sl.d, iWf = S > 1 ? Win : (tcm ? W : sl.Wf), oWf = tcm ? 2 * W : sl.Wf;
     const int oy = tcm ? sga : 0, ox = tcm ? sgc : 0;        // origin shift of the 2x2 patch of parity class (sga, sgc)
-    const size_t in_img0 = tcm ? (size_t)bb * H * W : img0;
+    const size_t in_img0 = S > 1 ? (size_t)bb * Hin * Win : (tcm ? (size_t)bb * H * W : img0);
     const size_t out_img0 = tcm ? ((size_t)(bb * 2 * H + sga)) * (2 * W) + sgc : img0;
     if (tcm) wp += (size_t)(sga * 2 + sgc) * TAPS * CoutP * CinP;
     const unsigned short* xb = x + in_img0 * sl.xs + sl.xoff;
@@ -171,9 +175,9 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
         if (it < NPIX * (KC / 8)) {
             const int pix = it / OPP;
             const int yy = pix / IW, xx = pix - yy * IW;
-            const int gy = ho0 - P + oy + yy, gx = wo0 - P + ox + xx;
+            const int gy = ho0 * S - P + oy + yy, gx = wo0 * S - P + ox + xx;
             loff[k] = pix * PS + coct;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[k] = (gy * iWf + gx) * idil * sl.xs + coct;
+            if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) goff[k] = (gy * iWf + gx) * idil * sl.xs + coct;
         }
     });
     int woff[NWT], wlds[NWT];
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
     };
 
     const int kg = lane >> 5, li = lane & 31;
-    const unsigned short* bbase = lin + ((size_t)(ROWS * wave) * IW + li) * PS + 8 * kg;
+    const unsigned short* bbase = lin + ((size_t)(ROWS * wave * S) * IW + li * S) * PS + 8 * kg;
     const unsigned short* abase = lw + (size_t)li * PS + 8 * kg;
     fetch(0);
     CPROBE(1);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
                     for (int a = 0; a < NT; ++a)
 #pragma unroll
                         for (int p = 0; p < ROWS; ++p)
-                            acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[p + r], acc[a][p], 0, 0, 0);
+                            acc[a][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[p * S + r], acc[a][p], 0, 0, 0);
                 }
             }
         CPROBE(cpi); ++cpi;
@@ -473,13 +477,13 @@ __global__ __launch_bounds__(FF_THREADS) void fold_finalize_kernel(const float* 
     }
 }
 
-template <int TN, int KS, int ROWS, int KC, bool FLOW = false>
+template <int TN, int KS, int ROWS, int KC, bool FLOW = false, int S = 1>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
-           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0, 0}) {
+           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0, 0, 0, 0}) {
     if (sl.xs == 0) { sl.xs = Cin; sl.ys = Cout; }           // dense tensors
     if (sl.Wf == 0) sl.Wf = W;
-    constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = (TH + 2 * P) * (TW + 2 * P), TAPS = KS * KS, PS = KC + 8;
+    constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = ((TH - 1) * S + 1 + 2 * P) * ((TW - 1) * S + 1 + 2 * P), TAPS = KS * KS, PS = KC + 8;
     const size_t conv_lds = ((size_t)NPIX * PS + (size_t)TAPS * TN * PS + 8) * sizeof(unsigned short);
     const size_t epi_lds = std::max((size_t)TW * TH * (TN + 8) * sizeof(unsigned short), (size_t)THREADS * 17 * sizeof(float));
     const size_t lds = std::max(conv_lds, epi_lds);
@@ -487,13 +491,13 @@ int launch(const unsigned short* x, const unsigned short* wp, const float* in_af
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[dev] = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int nblk_n = (Cout + TN - 1) / TN, nwork = tiles_x * tiles_y * B * nblk_n;      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
     dim3 grid(nblk_n > 1 ? 8 * ((nwork + 7) / 8) : nwork);
-    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP,
+    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP,
                        H, W, Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu, sl, B, nblk_n);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
@@ -588,7 +592,7 @@ int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const 
     if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + Cout > ytot) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: output slice %d+%d of %d", yoff, Cout, ytot);
     if ((size_t)B * H * W * std::max(Cin, ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_into: tensor too large for 32-bit offsets");
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
-    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 1, W, 0};
+    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 1, W, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const bool wide = Cout > 32;
     if (conv_r4(Cin, Cout, ksize, B, H, W)) return launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
@@ -596,6 +600,54 @@ int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const 
                                 : launch<32, 3, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
     return wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl)
                 : launch<32, 1, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
+}
+
+// Conv2d(Cin, Cout, k, stride = 2, padding = k / 2) on the same kernel (template parameter S = 2): the feature extractor's layer2 opens
+// with a stride-2 3x3 convbn and a stride-2 1x1 downsample convbn (Network/PSM/submodule.py:76-85 `_make_layer(BasicBlock, 64, 16, 2, ...)`,
+// :24-26), and the quarter-resolution tail of StereoNet7 is a 2x2 stride-2 convolution (islam_amd/nets.py::_deconv_c11_quarter).
+// x (B,Hi,Wi,Cin) -> y (B,Ho,Wo,Cout) with Ho <= (Hi + 2 (k/2) - k) / 2 + 1 (fewer rows / columns may be asked for); in_affine / bias / res
+// / stats / relu as in islam_conv_nhwc_bf16.  k = 1, 2, 3.
+int islam_conv_nhwc_bf16_s2(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, const float* bias, const uint16_t* res,
+                            uint16_t* y, float* stats, int B, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int relu,
+                            void* stream) {
+    const int in_relu = (relu >> 1) & 1;
+    relu &= 1;
+    if (B < 1 || Hi < 1 || Wi < 1 || Cin < 8 || (Cin & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2: bad shape (Cin=%d, Cout=%d must be multiples of 8)", Cin, Cout);
+    if (ksize < 1 || ksize > 3) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2: kernel size %d (1, 2 or 3)", ksize);
+    const int P = ksize / 2, Hmax = (Hi + 2 * P - ksize) / 2 + 1, Wmax = (Wi + 2 * P - ksize) / 2 + 1;
+    if (Ho < 1 || Wo < 1 || Ho > Hmax || Wo > Wmax) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2: output %dx%d of at most %dx%d", Ho, Wo, Hmax, Wmax);
+    if (stats && (bias || res || relu)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2: statistics go with the raw output (no bias / residual / ReLU)");
+    if ((size_t)B * Hi * Wi * std::max(Cin, Cout) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{Cin, 0, Cout, 0, nullptr, 0, 0, 0.0f, 1, Wo, 0, Hi, Wi};
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = Cout > 32;
+    int rc, th;
+    if (ksize == 3) { th = wide ? 4 : 8;
+        rc = wide ? launch<64, 3, 1, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl)
+                  : launch<32, 3, 2, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl);
+    } else if (ksize == 2) { th = 8;
+        rc = wide ? launch<64, 2, 2, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl)
+                  : launch<32, 2, 2, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl);
+    } else { th = 8;
+        rc = wide ? launch<64, 1, 2, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl)
+                  : launch<32, 1, 2, 16, false, 2>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu, in_relu, s, sl);
+    }
+    if (rc != ISLAM_OK) return rc;
+    if (stats) {
+        // (the stride-2 variants use tiles of 4 or 8 rows: islam_conv_nhwc_stats_floats(B, Ho, Wo, Cout) sizes `stats` for 8-row tiles when
+        //  Cout > 32 and 16-row tiles otherwise -- the caller sizes it with islam_conv_nhwc_s2_stats_floats)
+        const int nblk = tiles_of(B, Ho, Wo, th);
+        hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout, stats + (size_t)tiles_of(B, Ho, Wo, 4) * 2 * Cout);
+        ISLAM_LAUNCH_CHECK();
+    }
+    return ISLAM_OK;
+}
+
+// floats of `stats` for islam_conv_nhwc_bf16_s2 (per-tile partial sums for the smallest tile any of its variants uses + the folded block)
+size_t islam_conv_nhwc_s2_stats_floats(int B, int Ho, int Wo, int Cout) {
+    return (size_t)tiles_of(B, Ho, Wo, 4) * 2 * Cout + (size_t)RED_BLOCKS * 2 * Cout;
 }
 
 // convbn in training mode (Network/PSM/submodule.py:10-13: Conv2d(bias=False) + BatchNorm2d) up to the BatchNorm's [scale | shift]:
@@ -649,7 +701,7 @@ int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, cons
     if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + Cout > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16: output slice %d+%d of %d", yoff, Cout, ytot);
     if ((size_t)B * 4 * H * W * std::max(Cin, ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16: tensor too large for 32-bit offsets");
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
-    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 2, W, 1};
+    const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 2, W, 1, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     return Cout > 32 ? launch<64, 2, 2, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl)
                      : launch<32, 2, 4, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl);
@@ -676,7 +728,7 @@ int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const u
     if ((size_t)B * H * W * std::max(std::max(xtot, mtot), ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_flow: tensor too large for 32-bit offsets");
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     const int d = dilation;
-    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W, 0};
+    const Slices sl{xtot, xoff, ymir ? mtot : Cout, ymir ? moff : 0, y32, ytot, coff, slope, d, W, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     if (conv_r4(Cin, Cout, 3, B * d * d, H / d, W / d))
         return launch<64, 3, 4, 16, true>(x, wpacked, nullptr, bias, nullptr, ymir, nullptr, B * d * d, Cin, CinP, H / d, W / d, Cout, CoutP, 0, 0, s, sl);

@@ -390,23 +390,27 @@ HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 # bn_finalize.  Measured on the stereo net's graph replay in alternating runs: 6.80 / 6.80 ms with it, 6.76 / 6.75 ms without -- the 45 saved
 # launches are not on the replay's critical path and the ticketed 256 x 1024-thread launch costs what the two small ones do: default off.
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
+# stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
+HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
 # the feature extractor's last convolution writes conv_c0's input in place (left images first in the batch); 0: dense features + two copies
 STEREO_DIRECT_CAT = os.environ.get('ISLAM_STEREO_DIRECT_CAT', '1') != '0'
 HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
 HG_FUSED_MAX_PIXELS = int(_os.environ.get('ISLAM_HG_FUSED_MAX_PIXELS', str(1 << 30)))
 
 
-def _hip_conv_ok(conv, x, fused_1x1=False):
+def _hip_conv_ok(conv, x, fused_1x1=False, strided=False):
+    """strided: the caller can also run Conv2d(stride = 2) on the channels-last kernel (islam_conv_nhwc_bf16_s2)."""
     if HIP_CONV_LEVEL < 1 or not isinstance(conv, nn.Conv2d) or not isinstance(x, torch.Tensor):
         return False
     k = conv.kernel_size[0]
-    if conv.kernel_size != (k, k) or k not in (1, 3) or conv.stride != (1, 1) or conv.padding != (k // 2, k // 2) \
-            or conv.dilation != (1, 1) or conv.groups != 1 or conv.in_channels % 8 or conv.out_channels % 8:
+    s2 = conv.stride == (2, 2)
+    if conv.kernel_size != (k, k) or k not in (1, 3) or not (conv.stride == (1, 1) or (s2 and strided and HIP_CONV_S2)) \
+            or conv.padding != (k // 2, k // 2) or conv.dilation != (1, 1) or conv.groups != 1 or conv.in_channels % 8 or conv.out_channels % 8:
         return False
     if not ops.fusable_nhwc_bf16(x, conv.in_channels) or conv.weight.dtype != torch.bfloat16:
         return False
     if k == 1:
-        return HIP_CONV_LEVEL >= 2 and fused_1x1
+        return HIP_CONV_LEVEL >= 2 and (fused_1x1 or s2)
     return max(conv.in_channels, conv.out_channels) <= HIP_CONV_MAX_C
 
 
@@ -443,8 +447,12 @@ def _cbn(convbn, x, relu=False, res=None, defer=False):
     conv, bn = convbn[0], convbn[1]
     plain_bn = type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32
     xin = x.raw if isinstance(x, _Pending) else x
-    if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin):
-        if BN_FOLD_FINALIZE:          # statistics folded and finalized by ONE launch behind the convolution (islam_conv_nhwc_bf16_bn)
+    if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin, strided=True):
+        if conv.stride == (2, 2):     # layer2's first block (submodule.py:76-85): stride-2 3x3 convbn and its stride-2 1x1 downsample
+            y, folded = ops.conv_nhwc_s2(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0],
+                                         in_affine=x.affine if isinstance(x, _Pending) else None, stats=True)
+            affine = ops.bn_finalize(folded, bn, y.shape[0] * y.shape[2] * y.shape[3])
+        elif BN_FOLD_FINALIZE:          # statistics folded and finalized by ONE launch behind the convolution (islam_conv_nhwc_bf16_bn)
             y, affine = ops.conv_nhwc_bn(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0], bn,
                                          in_affine=x.affine if isinstance(x, _Pending) else None)
         else:
@@ -786,7 +794,7 @@ class StereoNet7(nn.Module):
         x = self.conv_c9(self._deconv_act(self.deconv_c9, x), cat_with=cat1)
         x = self.conv_c10(self._deconv_act(self.deconv_c10, x), cat_with=cat0)
         if quarter:
-            x = act(self._deconv_c11_quarter(x))
+            x = self._deconv_c11_quarter(x, act)
         else:
             x = act(self.deconv_c11(x))
         return self.conv_c13(act(self.conv_c12(x))), None
@@ -815,8 +823,8 @@ class StereoNet7(nn.Module):
         y = act(dc(x))
         return y if skip is None else torch.cat((y, skip), 1)
 
-    def _deconv_c11_quarter(self, x):
-        """deconv_c11(x)[..., ::4, ::4].  ConvTranspose2d(k=4, s=2, p=1): out[o, oy, ox] = b[o] + sum_i sum_ky,kx x[i, (oy+1-ky)/2,
+    def _deconv_c11_quarter(self, x, act=None):
+        """act(deconv_c11(x)[..., ::4, ::4]).  ConvTranspose2d(k=4, s=2, p=1): out[o, oy, ox] = b[o] + sum_i sum_ky,kx x[i, (oy+1-ky)/2,
         (ox+1-kx)/2] W[i, o, ky, kx] over the taps where the division is exact; for oy = 4y: ky = 1 -> row 2y, ky = 3 -> row 2y-1.
         That is a 2x2 convolution with stride 2 and one row / column of zero padding in front: K[o, i, a, b] = W[i, o, 3-2a, 3-2b]."""
         dc = self.deconv_c11
@@ -828,7 +836,16 @@ class StereoNet7(nn.Module):
                 K = K.contiguous(memory_format=torch.channels_last)
             hit = self.__dict__['_c11q'] = (key, K)
         h, w = x.shape[2] // 2, x.shape[3] // 2
-        return F.conv2d(x, hit[1], dc.bias, stride=2, padding=1)[:, :, :h, :w]
+        co, ci = hit[1].shape[0], hit[1].shape[1]
+        if (HIP_CONV_S2 and HIP_CONV_LEVEL >= 1 and act is F.relu and ops.fusable_nhwc_bf16(x, ci) and hit[1].dtype == torch.bfloat16
+                and ci % 8 == 0 and co % 8 == 0 and dc.bias is not None):
+            # the 2x2 stride-2 convolution, its bias, the ReLU and the crop to (h, w) in one launch of the channels-last kernel
+            pk = self.__dict__.get('_c11q_packed')
+            if pk is None or pk[0] != key:
+                pk = self.__dict__['_c11q_packed'] = (key, ops.pack_conv_nhwc_weight(hit[1]), dc.bias.detach().float().contiguous())
+            return ops.conv_nhwc_s2(x, pk[1], co, 2, bias=pk[2], relu=True, out_hw=(h, w))
+        y = F.conv2d(x, hit[1], dc.bias, stride=2, padding=1)[:, :, :h, :w]
+        return y if act is None else act(y)
 
 
 # ------------------------------------------------------------------------------------------ VOFlowRes

@@ -270,7 +270,7 @@ def pack_conv_nhwc_weight(w):
     """(Cout, Cin, k, k) -> bf16 [k*k][CoutP][CinP] (tap-major, zero padded; CoutP = Cout up to 64s, CinP = Cin up to 32s), the
     layout islam_conv_nhwc_bf16 stages."""
     Cout, Cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    assert w.shape[2] == w.shape[3] and k in (1, 3)
+    assert w.shape[2] == w.shape[3] and k in (1, 2, 3)
     CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 63) // 64 * 64
     p = torch.zeros((k * k, CoutP, CinP), dtype=torch.bfloat16, device=w.device)
     p[:, :Cout, :Cin] = w.detach().permute(2, 3, 0, 1).reshape(k * k, Cout, Cin).to(torch.bfloat16)
@@ -294,6 +294,27 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
         assert res.shape == y.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
     check(lib().islam_conv_nhwc_bf16(ptr(x), ptr(packed), ptr(in_affine), ptr(bias), ptr(res), ptr(y), ptr(st), B, Cin, H, W, int(cout),
                                      int(ksize), int(bool(relu)) | (2 if in_relu else 0), stream_ptr(x.device)))
+    if stats:
+        return y, st[st.numel() - 256 * 2 * cout:]
+    return y
+
+
+def conv_nhwc_s2(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False, in_relu=False, out_hw=None):
+    """conv_nhwc at stride 2 with padding ksize // 2 (islam_conv_nhwc_bf16_s2; ksize 1, 2 or 3).  out_hw: fewer output rows / columns than
+    the convolution has (the quarter-resolution tail keeps (H/2, W/2) of (H/2 + 1, W/2 + 1))."""
+    require_cuda(x, packed)
+    B, Cin, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    P = ksize // 2
+    Ho, Wo = ((H + 2 * P - ksize) // 2 + 1, (W + 2 * P - ksize) // 2 + 1) if out_hw is None else out_hw
+    y = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    st = None
+    if stats:
+        st = torch.empty(lib().islam_conv_nhwc_s2_stats_floats(B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.shape == y.shape and res.dtype == torch.bfloat16 and res.is_contiguous(memory_format=torch.channels_last)
+    check(lib().islam_conv_nhwc_bf16_s2(ptr(x), ptr(packed), ptr(in_affine), ptr(bias), ptr(res), ptr(y), ptr(st), B, Cin, H, W, int(cout), Ho, Wo,
+                                        int(ksize), int(bool(relu)) | (2 if in_relu else 0), stream_ptr(x.device)))
     if stats:
         return y, st[st.numel() - 256 * 2 * cout:]
     return y

@@ -325,3 +325,39 @@ def test_convolution_into_a_channel_slice(cuda, B, Cin, H, W, Cout, k, ytot, yof
         out1 = torch.zeros((1, ytot, H, W), dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
         ops.conv_nhwc_into(x[1:2], wp, Cout, k, out1, yoff, in_affine=aff)
         assert torch.equal(out1[:, yoff:yoff + Cout], want[1:2])
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout,k', [(2, 32, 64, 96, 64, 3), (1, 32, 33, 47, 64, 3), (2, 32, 64, 96, 64, 1), (1, 64, 37, 70, 32, 2), (2, 64, 16, 40, 128, 3),
+                                               (1, 40, 9, 9, 24, 3)])
+def test_stride_two_convolution(cuda, B, Cin, H, W, Cout, k):
+    """islam_conv_nhwc_bf16_s2 against torch.conv2d(stride = 2, padding = k // 2) on the same bf16 operands: round-to-nearest output,
+    the producer's affine + ReLU on load with zero padding of the NORMALISED input, batch statistics of the bf16-rounded output, bias +
+    ReLU epilogue, and an output window smaller than the convolution's (the quarter-resolution tail)."""
+    from islam_amd import ops
+    x, w = _mk(B, Cin, H, W, Cout, k, seed=H + k)
+    wp = ops.pack_conv_nhwc_weight(w)
+    P = k // 2
+    ref = F.conv2d(x.float(), w.float(), None, 2, P)
+    y = ops.conv_nhwc_s2(x, wp, Cout, k)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=CL)
+    scale = float(ref.abs().max())
+    err = (y.float() - ref).abs()
+    assert float((err - 0.5 * torch.pow(2.0, torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)).max()) <= 1e-5 * scale
+    # affine + ReLU on load, statistics
+    g = torch.Generator().manual_seed(7)
+    aff = torch.cat((torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.1)).to(cuda)
+    xn = F.relu((x.float() * aff[:Cin].view(1, -1, 1, 1) + aff[Cin:].view(1, -1, 1, 1)).to(torch.bfloat16)).float()
+    ref2 = F.conv2d(xn, w.float(), None, 2, P)
+    y2, folded = ops.conv_nhwc_s2(x, wp, Cout, k, in_affine=aff, stats=True)
+    assert float((y2.float() - ref2).abs().max()) <= 1.0e-2 * float(ref2.abs().max())
+    tot = folded.view(256, 2, Cout).double().sum(0)
+    yb = y2.float().double()
+    np.testing.assert_allclose(tot[0].cpu().numpy(), yb.sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=1e-3 * float(yb.abs().max()))
+    np.testing.assert_allclose(tot[1].cpu().numpy(), (yb * yb).sum((0, 2, 3)).cpu().numpy(), rtol=1e-4)
+    # bias + ReLU, cropped output window
+    bias = torch.randn(Cout, generator=g).to(cuda)
+    ho, wo = ref.shape[2] - 1, ref.shape[3] - 1
+    if ho >= 1 and wo >= 1:
+        y3 = ops.conv_nhwc_s2(x, wp, Cout, k, bias=bias, relu=True, out_hw=(ho, wo))
+        ref3 = F.relu((ref + bias.view(1, -1, 1, 1)).to(torch.bfloat16).float())[:, :, :ho, :wo]
+        assert y3.shape == ref3.shape and float((y3.float() - ref3).abs().max()) <= 1.0e-2 * max(float(ref3.abs().max()), 1.0)
