@@ -2628,6 +2628,15 @@ struct FusedArgs {
     int* eflag_prev;                              // ... of the level-0 elimination of the solve whose trial is evaluated here
     const double* loss_part0;                     // first trial of a run only: the partial sums of the initial loss (linbuild_kernel) --
     int nlb0;                                     // the deciding wave does control_begin_kernel's job on the way (one launch less per run)
+    // ---- one rank of the sharded loop (run_chain_sharded_fused; all zero on a single GPU except Ms = N - 1)
+    int Ms;                                       // row stride of lin / lin_o (links of the WHOLE chain)
+    int shard;                                    // 1: no deciding workgroup -- the sums leave in part[0 .. 2 nwg), part[2 nwg] = failed-pivot
+                                                  //    word of the solve whose trial this is; the decision follows the all-reduce
+    int seg_lo;                                   // first level-0 segment of the rank; P = the rank's segment count; N = one past the rank's
+                                                  //    right outer separator (the link beyond it belongs to the next rank)
+    int own_left;                                 // the rank has a left outer separator: its first workgroup owns the link that leaves it,
+    double* share;                                //    steps it, and writes that link's UNCLAMPED, undamped part of its block + rhs here (90)
+    int open_right;                               // node N - 1 is shared with the next rank: its diagonal is clamped after the all-reduce
 };
 
 __device__ __forceinline__ M3<double> m3_zero() { return M3<double>{0, 0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -2646,7 +2655,8 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     double* rhs_l = lds + FZ_OFF_RHS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int N = a.N, M = N - 1;
-    if (blockIdx.x == gridDim.x - 1) {
+    const size_t Ms = (size_t)a.Ms;
+    if (!a.shard && blockIdx.x == gridDim.x - 1) {
         // the deciding workgroup (see trial_lin_kernel): sums the partials in index order, LM decision, validates the speculation
         if (wave != 0 || gate_closed(gate)) return;
         const bool first = a.dx == nullptr;
@@ -2707,8 +2717,9 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     const double d_spec = first ? a.st[2] : speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
     // the level's segments are dealt out evenly: workgroup wg takes segments [wg P / nwg, (wg+1) P / nwg) -- three or four of them
     // on the 5000-frame graph, so that all 256 CUs share the level's pivots
-    const int seg0 = (int)(((long long)wg * a.P) / a.nwg), seg1 = (int)(((long long)(wg + 1) * a.P) / a.nwg);
+    const int seg0 = a.seg_lo + (int)(((long long)wg * a.P) / a.nwg), seg1 = a.seg_lo + (int)(((long long)(wg + 1) * a.P) / a.nwg);
     const int m = a.m, stride = m + 1, G = (seg1 - seg0) * stride;
+    const bool ownl = a.own_left && wg == 0;                     // (sharded: the link cb-1 -> cb has no other owner on this rank)
     const int cb = seg0 * stride;                                // first node of the stretch; links cb-1 .. cb+G-1, nodes cb-1 .. cb+G
     [[maybe_unused]] const bool fpr = lane == 0 && (wg == 1 || wg == a.nwg / 2);     // probe build only
     [[maybe_unused]] const int fpo = 600 + (wg == 1 ? 0 : 100) + 12 * wave;
@@ -2730,7 +2741,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
             double* o = xt + lane * FZ_XT;
             se3_store(X, o);
             o[7] = v.x; o[8] = v.y; o[9] = v.z;
-            if (lane >= 1 && lane <= G) {                            // the stretch's own nodes
+            if ((lane >= 1 || ownl) && lane <= G) {                  // the stretch's own nodes
                 se3_store(X, a.nodes_t + 7 * k);
                 a.vels_t[3 * k] = v.x; a.vels_t[3 * k + 1] = v.y; a.vels_t[3 * k + 2] = v.z;
             }
@@ -2742,7 +2753,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     {
         const int L = cb - 1 + lane;
         const bool valid = lane <= G && L >= 0 && L < M;
-        const bool owns = valid && lane >= 1;                        // links cb .. cb+G-1 belong to this stretch
+        const bool owns = valid && (lane >= 1 || ownl);              // links cb .. cb+G-1 belong to this stretch
         const double* xi = xt + lane * FZ_XT;
         const double* xj = xi + FZ_XT;
         if (wave == 0 && valid) {
@@ -2756,13 +2767,13 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
             const M3<double> C = Ji * (skew(pre.t) * R - se3_Q(erho, ephi) * Gm);
             if (owns) {
                 double* lo = a.lin_o + L;
-                lo[0] = erho.x; lo[(size_t)M] = erho.y; lo[(size_t)2 * M] = erho.z;
-                lo[(size_t)3 * M] = ephi.x; lo[(size_t)4 * M] = ephi.y; lo[(size_t)5 * M] = ephi.z;
+                lo[0] = erho.x; lo[Ms] = erho.y; lo[2 * Ms] = erho.z;
+                lo[3 * Ms] = ephi.x; lo[4 * Ms] = ephi.y; lo[5 * Ms] = ephi.z;
                 double rec[18];
                 m3_store(Gm, rec);
                 m3_store(C, rec + 9);
 #pragma unroll
-                for (int c = 0; c < 18; ++c) lo[(size_t)(6 + c) * M] = rec[c];
+                for (int c = 0; c < 18; ++c) lo[(size_t)(6 + c) * Ms] = rec[c];
             }
             const M3<double> Gt = transpose(Gm), Ct = transpose(C);
             const M3<double> GtG = Gt * Gm;
@@ -2784,13 +2795,13 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
             const M3<double> B = so3_Jl_inv(er) * qmat(rpre);
             if (owns) {
                 double* lo = a.lin_o + L;
-                lo[(size_t)24 * M] = er.x; lo[(size_t)25 * M] = er.y; lo[(size_t)26 * M] = er.z;
+                lo[24 * Ms] = er.x; lo[25 * Ms] = er.y; lo[26 * Ms] = er.z;
                 double rec[9];
                 m3_store(B, rec);
 #pragma unroll
-                for (int c = 0; c < 9; ++c) lo[(size_t)(27 + c) * M] = rec[c];
-                lo[(size_t)36 * M] = rv.x; lo[(size_t)37 * M] = rv.y; lo[(size_t)38 * M] = rv.z;
-                lo[(size_t)39 * M] = rt.x; lo[(size_t)40 * M] = rt.y; lo[(size_t)41 * M] = rt.z;
+                for (int c = 0; c < 9; ++c) lo[(size_t)(27 + c) * Ms] = rec[c];
+                lo[36 * Ms] = rv.x; lo[37 * Ms] = rv.y; lo[38 * Ms] = rv.z;
+                lo[39 * Ms] = rt.x; lo[40 * Ms] = rt.y; lo[41 * Ms] = rt.z;
             }
             const M3<double> Bt = transpose(B);
             double* o = si + lane * FZ_RI;
@@ -2809,7 +2820,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                 const double dtl = a.dts[L];
                 double rec[LIN_C];
 #pragma unroll
-                for (int c = 0; c < LIN_C; ++c) rec[c] = a.lin[(size_t)c * M + L];
+                for (int c = 0; c < LIN_C; ++c) rec[c] = a.lin[(size_t)c * Ms + L];
                 const M3<double> Gm = m3_load(rec + 6), C = m3_load(rec + 15), B = m3_load(rec + 27);
                 const V3<double> ddr = drj - dri, ddp = dpj - dpi;
                 const V3<double> j0 = Gm * ddr + C * ddp, j1 = Gm * ddp, j2 = dvi - dvj, j3 = B * ddp, j4 = ddr - dtl * dvi;
@@ -2856,7 +2867,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                     if (hn) { const double d = i1[21]; hvv += w1 + w3 * d * d; }
                     blk = hvv * I;
                 } else if (br + bc == 2) { blk = (hn ? w3 * i1[21] : 0.0) * I; }
-                if (br == bc) {                                          // A.diagonal().clamp_(min, max)
+                if (br == bc && !(a.open_right && k == N - 1)) {         // A.diagonal().clamp_(min, max)
                     blk.a00 = fmin(fmax(blk.a00, a.W.vmin), a.W.vmax);
                     blk.a11 = fmin(fmax(blk.a11, a.W.vmin), a.W.vmax);
                     blk.a22 = fmin(fmax(blk.a22, a.W.vmin), a.W.vmax);
@@ -2899,6 +2910,31 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                 bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
             }
         }
+        // sharded: what the link cb-1 -> cb adds to the block and the right-hand side of node cb-1, the PREVIOUS rank's right outer
+        // separator (the `hn` terms above with link slot 0).  Unclamped and undamped: the block is a sum over two ranks
+        // (shard_pack_kernel adds this part to the separator's row of the exchange buffer, shard_decide_kernel clamps the sum).
+        if (ownl && threadIdx.x < 10) {
+            const int ty = threadIdx.x;
+            const double* v1 = sv;
+            const double* i1 = si;
+            const double d = i1[21];
+            if (ty < 9) {
+                const int br = ty / 3, bc = ty - br * 3;
+                M3<double> blk = m3_zero();
+                if (br == 0 && bc == 0) blk = blk + m3_load(v1);
+                else if (br + bc == 1) { blk = blk + m3_load(v1 + 9); if (br == 1) blk = transpose(blk); }
+                else if (br == 1 && bc == 1) blk = blk + (m3_load(v1 + 18) + m3_load(i1));
+                else if (br == 2 && bc == 2) blk = (w1 + w3 * d * d) * I;
+                else if (br + bc == 2) blk = (w3 * d) * I;
+                put33(a.share + br * 27 + bc * 3, blk);
+            } else {
+                const V3<double> gr = V3<double>{0, 0, 0} - (ld3(v1 + 27) + ld3(i1 + 9)), gp = V3<double>{0, 0, 0} - (ld3(v1 + 30) + ld3(i1 + 12));
+                const V3<double> gv = V3<double>{0, 0, 0} + w1 * ld3(i1 + 15) - (w3 * d) * ld3(i1 + 18);
+                double* bb = a.share + 81;
+                bb[0] = -gr.x; bb[1] = -gr.y; bb[2] = -gr.z; bb[3] = -gp.x; bb[4] = -gp.y; bb[5] = -gp.z;
+                bb[6] = -gv.x; bb[7] = -gv.y; bb[8] = -gv.z;
+            }
+        }
     }
     lds_barrier();
     PROBE_WALL(fpr, fpo + 3);
@@ -2929,12 +2965,20 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
             // sums: write-through stores + completion wait instead of a release fence, then the ticket (fire and forget)
             const int L = cb - 1 + lane;
             double sq = 0.0;
-            if (lane >= 1 && lane <= G && L < M) {
+            if ((lane >= 1 || ownl) && lane <= G && L < M) {
                 const double* o = si + lane * FZ_RI;
                 sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
             }
             sq = wave_sum(sq);
-            if (lane == 0) {
+            if (lane == 0 && a.shard) {              // the sums and the decision come after the all-reduce (shard_pack / shard_decide)
+                a.part[2 * wg] = sq;
+                a.part[2 * wg + 1] = s_sum[1];
+                if (wg == 0) {
+                    a.part[2 * a.nwg] = (!first && (a.flags[0] != 0 || *a.eflag_prev != 0)) ? 1.0 : 0.0;
+                    a.flags[0] = 0;
+                    *a.eflag_prev = 0;
+                }
+            } else if (lane == 0) {
                 st_coherent(&a.part[2 * wg], sq);
                 st_coherent(&a.part[2 * wg + 1], s_sum[1]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3841,6 +3885,291 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
     return ISLAM_OK;
 }
 
+// ---- the sharded loop on the fused kernel -----------------------------------------------------------
+// One trial of a rank = trial_elim_kernel over the rank's own level-0 segments (trial step, linearisation at the trial point,
+// level-0 elimination under the speculated damping) -> levels 1 .. xl -> shard_pack_kernel -> ONE all-reduce of
+//   [ interface blocks of the NEXT solve (351 per segment of the exchange level) | sum r^2 | sum JD.(2R+JD) | failed pivots |
+//     per cut: the two ranks' parts of the cut node's raw diagonal (9 + 9) ]
+// -> shard_decide_kernel (LM decision of THIS trial, replicated on every rank; validates the speculation; clamps the cut nodes'
+// diagonals) -> levels above xl + root + local back-substitution (bt_downsweep_kernel) -> dx of the next trial.
+//
+// What makes one collective enough: a rank never needs anything of a node it does not hold.  Its stretch ends AT its right outer
+// separator (node sR): the link sR -> sR+1 belongs to the next rank, which holds both of its nodes (it back-substitutes its left
+// outer separator itself, from the replicated top of the tree) and hands the link's part of node sR's block and right-hand side
+// up in the exchange buffer, next to the Schur parts it has always handed up (OuterFix).  No halo rows, no second all-reduce.
+// PyPose clamps the diagonal of A before damping it (A.diagonal().clamp_): the cut nodes' diagonals are sums over two ranks, so
+// both raw parts travel in the message and every rank applies the clamp to the sum (a no-op unless an entry leaves
+// [vmin, vmax] -- then the damped difference is added to the row of the exchange buffer).
+struct PackArgs {
+    OuterFix f;                   // Schur parts of the left outer separator (n may be 0)
+    int has_left, has_right;
+    const double* share;          // trial_elim_kernel's FusedArgs::share of the linearisation being solved
+    const double* Hd_right;       // block of the rank's right outer separator in that linearisation (undamped)
+    const double* st; TRParams tr;
+    int damp_mode;                // 0: speculated_damping(st) once; 1: the list of the current linearisation; 2: st[2] once (first solve)
+    const double* part; int nwg;  // trial sums (nullptr: a solve without a trial -- the scalars stay zero)
+    double* msg; int nmsg, rank;
+};
+__device__ __forceinline__ double shard_damp(const double* st, const TRParams& tr, int mode, double v) {
+    if (mode == 1) {
+        const int n = (int)st[8] + 1;
+        for (int i = 0; i < n; ++i) v = v + v * st[STATE_HIST + i];
+        return v;
+    }
+    const double d = mode == 0 ? speculated_damping(st, tr) : st[2];
+    return v + v * d;
+}
+__global__ __launch_bounds__(128) void shard_pack_kernel(PackArgs a, Gate gate) {
+    if (gate_closed(gate)) return;
+    const int t = threadIdx.x;
+    for (int i = t; i < a.nmsg; i += 128) a.msg[i] = 0.0;
+    __syncthreads();
+    if (t < 90 && a.has_left) {
+        double v = 0.0;
+        for (int i = 0; i < a.f.n; ++i) v += t < 81 ? a.f.cL[i][t] : a.f.cgL[i][t - 81];
+        double sh = a.share[t];
+        if (t < 81 && t % 10 == 0) {
+            a.msg[3 + 18 * (a.rank - 1) + 9 + t / 10] = sh;
+            sh = shard_damp(a.st, a.tr, a.damp_mode, sh);
+        }
+        if (t < 81) a.f.Dsep[t] = sh - v; else a.f.rsep[t - 81] = sh - v;
+    }
+    if (t >= 96 && t < 105 && a.has_right) a.msg[3 + 18 * a.rank + (t - 96)] = a.Hd_right[(t - 96) * 10];
+    if (t >= 64 && a.part) {                                      // wave 1: the rank's sums, in index order
+        const int lane = t - 64;
+        double ssum = 0.0, qsum = 0.0;
+        for (int i = lane; i < a.nwg; i += 64) { ssum += a.part[2 * i]; qsum += a.part[2 * i + 1]; }
+        ssum = wave_sum(ssum);
+        qsum = wave_sum(qsum);
+        if (lane == 0) { a.msg[0] = ssum; a.msg[1] = qsum; a.msg[2] = a.part[2 * a.nwg]; }
+    }
+}
+
+// mode 0: a trial (LM decision; d_spec = the damping the solve that is already eliminated used); 1: a solve without a trial
+// (only the clamp); 2: the first linearisation (its loss opens the run)
+struct DecideArgs {
+    const double* msg; double* ex_Dsep; double* st; TRParams tr; double* report; double seq; int mode, damp_mode, world, Pxl;
+    double vmin, vmax;
+};
+__global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gate) {
+    if (gate_closed(gate)) return;
+    const int t = threadIdx.x;
+    const double d_spec = a.mode == 0 ? speculated_damping(a.st, a.tr) : -1.0;
+    for (int i = t; i < 9 * (a.world - 1); i += 64) {
+        const int b = i / 9, j = i - 9 * b;
+        const double da = a.msg[3 + 18 * b + j], db = a.msg[3 + 18 * b + 9 + j], tot = da + db;
+        const double cl = fmin(fmax(tot, a.vmin), a.vmax);
+        if (cl != tot) {
+            const int slot = (int)((long long)(b + 1) * a.Pxl / a.world) - 1;          // last exchange-level segment of rank b
+            a.ex_Dsep[(size_t)slot * 81 + j * 10] += shard_damp(a.st, a.tr, a.damp_mode, cl) -
+                                                     (shard_damp(a.st, a.tr, a.damp_mode, da) + shard_damp(a.st, a.tr, a.damp_mode, db));
+        }
+    }
+    __syncthreads();
+    if (t != 0) return;
+    if (a.mode == 2) { a.st[0] = a.msg[0]; a.st[1] = a.msg[0]; a.st[8] = 0.0; a.st[11] = 1.0; a.st[12] = 0.0; a.st[13] = 0.0; }
+    else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], a.st, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec);
+}
+
+__global__ void shard_close_gate_kernel(double* __restrict__ st) {
+    if (threadIdx.x == 0) st[14] = -1.0;
+}
+
+size_t shard_fused_scratch_doubles(int N, int world) {
+    const size_t n = (size_t)N + 2, ex = 351 * (n / 5 + 2) + 3 + 18 * (size_t)world;
+    auto a256 = [](size_t k) { return align_up(k * sizeof(double)) / sizeof(double); };
+    return 2 * a256(ex) + 2 * a256(96) + 64;
+}
+
+int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
+                            const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                            void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
+                            long long* exchanged_bytes, hipStream_t s, int* taken, const double** out_nodes, const double** out_vels,
+                            int* own0, int* own1) {
+    *taken = 0;
+    static const bool off = [] { const char* e = std::getenv("ISLAM_SHARD_FUSED"); return e && e[0] == '0'; }();
+    SolvePlan sp;
+    const int nl = shard_plan(N, prm->seg_len, sp);
+    ShardRanges R;
+    if (off || nl < 2 || shard_ranges(sp, world, rank, R) != 0) return ISLAM_OK;
+    static const int fz_spare = [] { const char* e = std::getenv("ISLAM_FZ_SPARE"); return e ? std::atoi(e) : 16; }();
+    // (the same plans the single-GPU loop fuses, decided on numbers every rank shares: all ranks take the same path)
+    int max_nseg = 0;
+    for (int r = 0; r < world; ++r) {
+        ShardRanges Rr;
+        if (shard_ranges(sp, world, r, Rr) != 0) return ISLAM_OK;
+        max_nseg = std::max(max_nseg, Rr.nseg[0]);
+        if (Rr.nseg[0] < 1) return ISLAM_OK;
+    }
+    const int cus = std::max(device_cus() - fz_spare, 1);
+    if (!(N > 96 && sp.twisted && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM && prm->reject < STATE_DOUBLES - STATE_HIST - 1 &&
+          (max_nseg + std::min(max_nseg, cus) - 1) / std::min(max_nseg, cus) <= FZ_S))
+        return ISLAM_OK;
+    if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: workspace too small");
+    if (scratch_bytes < shard_fused_scratch_doubles(N, world) * sizeof(double)) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: scratch too small");
+    *taken = 1;
+    const int M = N - 1, xl = R.xl, Pxl = sp.lv[xl].P, m = sp.lv[0].m, stride = m + 1;
+    const int seg_lo = R.seg0[0], nseg = R.nseg[0], first_node = seg_lo * stride, sR = (seg_lo + nseg - 1) * stride + m;
+    const bool has_left = seg_lo > 0, has_right = sR < N - 1;
+    const int N_eff = has_right ? sR + 1 : N;
+    const int nwg = std::min(nseg, cus);
+    const int nmsg = 3 + 18 * (world - 1);
+    const size_t nex = 351 * (size_t)Pxl + nmsg;
+    Workspace w = carve((void*)align_up((size_t)workspace), N);
+    double* p = (double*)align_up((size_t)scratch);
+    auto take = [&](size_t k) { double* r = p; p += align_up(k * sizeof(double)) / sizeof(double); return r; };
+    double* ex_own = take(nex);
+    double* ex = world > 1 ? take(nex) : ex_own;
+    double* SH[2] = {take(96), take(96)};
+    {
+        static bool fz_attr_set[64] = {};
+        int dev_i = 0;
+        ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
+        if (dev_i >= 0 && dev_i < 64 && !fz_attr_set[dev_i]) {
+            ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_elim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES));
+            fz_attr_set[dev_i] = true;
+        }
+    }
+    static thread_local double* host_state = nullptr;
+    if (!host_state) ISLAM_HIP_CHECK(hipHostMalloc((void**)&host_state, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));
+    double* report = nullptr;
+    ISLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&report, host_state, 0));
+    volatile double* hs_all = host_state;
+    hs_all[15] = 0.0;
+    hs_all[31] = 0.0;
+    // product rows of other ranks' segments read as zero; the own rows of the exchange buffer are rewritten by every solve
+    ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * nex, s));
+    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
+    const TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
+                      prm->max_steps, prm->patience, prm->decreasing};
+    const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
+    double* LIN[2] = {w.lin, w.lin2};
+    double* HD[2] = {w.Hd, w.Hd2};
+    double* HO[2] = {w.Ho, w.Ho2};
+    double* RH[2] = {w.rhs, w.rhs2};
+    LevelBufs xb{};
+    products_view(ex_own, Pxl, xb);
+    auto level_out = [&](int l) {                              // products of level l: the exchange buffer at the exchange level
+        LevelBufs ob = w.lv[l];
+        if (l == xl) { ob.Dsep = xb.Dsep; ob.rsep = xb.rsep; ob.cL = xb.cL; ob.cR = xb.cR; ob.fill = xb.fill; ob.cgL = xb.cgL; ob.cgR = xb.cgR; }
+        return ob;
+    };
+    int* const eflag_none = w.flags + 6;
+    long long xbytes = 0;
+    // levels 1 .. xl, the pack, the all-reduce, the decision and the down-sweep behind an eliminated level 0 of buffer pb
+    auto enqueue_rest = [&](int pb, int mode, int damp_mode, bool with_trial, double seq, const Gate& gate) -> int {
+        for (int l = 1; l <= xl; ++l)
+            launch_tw(level_src_from(w.lv[l - 1], sp.lv[l - 1].P), level_dst(level_out(l), nullptr), sp.lv[l].n, sp.lv[l].m, w.flags, R.seg0[l],
+                      R.nseg[l], gate, s);
+        PackArgs pa{};
+        pa.f.n = xl;
+        for (int l = 0; l < xl; ++l) { pa.f.cL[l] = w.lv[l].cL + (size_t)R.seg0[l] * 81; pa.f.cgL[l] = w.lv[l].cgL + (size_t)R.seg0[l] * 9; }
+        if (has_left) { pa.f.Dsep = xb.Dsep + (size_t)(R.seg0[xl] - 1) * 81; pa.f.rsep = xb.rsep + (size_t)(R.seg0[xl] - 1) * 9; }
+        pa.has_left = has_left; pa.has_right = has_right; pa.share = SH[pb]; pa.Hd_right = HD[pb] + (size_t)(N_eff - 1) * 81;
+        pa.st = w.state; pa.tr = tr; pa.damp_mode = damp_mode; pa.part = with_trial ? w.part : (const double*)nullptr; pa.nwg = nwg;
+        pa.msg = ex_own + 351 * (size_t)Pxl; pa.nmsg = nmsg; pa.rank = rank;
+        hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(128), 0, s, pa, gate);
+        if (world > 1) {
+            const int r = red.fn(red.self, ex_own, ex, nex, s);
+            if (r != ISLAM_OK) return r;
+            xbytes += 8LL * (long long)nex;
+        }
+        DecideArgs da{};
+        da.msg = ex + 351 * (size_t)Pxl; da.ex_Dsep = ex; da.st = w.state; da.tr = tr; da.report = report + 16 * ((long long)seq & 1); da.seq = seq;
+        da.mode = mode; da.damp_mode = damp_mode; da.world = world; da.Pxl = Pxl; da.vmin = prm->vmin; da.vmax = prm->vmax;
+        hipLaunchKernelGGL(shard_decide_kernel, dim3(1), dim3(64), 0, s, da, gate);
+        ISLAM_LAUNCH_CHECK();
+        // (a trial that is not "accepted, continue, damping as speculated" bumps the epoch: the down-sweep turns into a no-op)
+        return shard_downsweep_gated(ex, N, prm->seg_len, world, rank, 0, workspace, workspace_bytes, w.dx, w.flags, gate, s);
+    };
+    struct IterCfg { int pb; double *cur_n, *cur_v, *tri_n, *tri_v; };
+    auto fused_args = [&](const IterCfg& c, bool first, double seq, int* eprev) {
+        FusedArgs fa{};
+        fa.nodes = c.cur_n; fa.vels = c.cur_v; fa.dx = first ? (const double*)nullptr : w.dx; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans;
+        fa.dvels = dvels; fa.dts = dts; fa.lin = first ? (const double*)nullptr : LIN[c.pb]; fa.N = N_eff; fa.nodes_t = c.tri_n; fa.vels_t = c.tri_v;
+        fa.part = w.part; fa.st = w.state; fa.flags = w.flags; fa.ticket = nullptr; fa.tr = tr; fa.report = nullptr; fa.seq = seq; fa.W = W;
+        const int ob = first ? c.pb : 1 - c.pb;
+        fa.lin_o = LIN[ob]; fa.Hd_o = HD[ob]; fa.Ho_o = HO[ob]; fa.rhs_o = RH[ob];
+        fa.dst = level_dst(level_out(0), w.dx);
+        fa.m = m; fa.P = nseg; fa.nwg = nwg;
+        fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
+        fa.eflag_prev = eprev;
+        fa.Ms = M; fa.shard = 1; fa.seg_lo = seg_lo; fa.own_left = has_left ? 1 : 0; fa.share = SH[ob]; fa.open_right = has_right ? 1 : 0;
+        return fa;
+    };
+    IterCfg A{0, nodes, vels, w.nodes_t, w.vels_t};
+    int steps = 0, trials = 0, status = ISLAM_OK;
+    double loss = 0.0, damping = 1.0 / prm->radius, epoch = 1.0;
+    auto run = [&]() -> int {
+        int rc;
+        {   // the first solve: linearisation at the initial iterate, its loss, elimination with the initial damping
+            const Gate gate{w.state, epoch};
+            const FusedArgs fa = fused_args(A, true, 0.0, eflag_none);
+            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
+            if ((rc = enqueue_rest(A.pb, 2, 2, true, 0.0, gate)) != ISLAM_OK) return rc;
+        }
+        bool prev_fused = true;
+        for (;;) {
+            const double seq = (double)(trials + 1);
+            const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
+            {
+                const Gate gate{w.state, epoch};
+                const FusedArgs fa = fused_args(A, false, seq, prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none);
+                hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
+                if ((rc = enqueue_rest(1 - A.pb, 0, 0, true, seq, gate)) != ISLAM_OK) return rc;
+            }
+            volatile double* hs = hs_all + 16 * ((long long)seq & 1);
+            {
+                unsigned long spins = 0;
+                while (hs[15] != seq) {
+                    if (++spins > 400000000ul) {
+                        ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+                        if (hs[15] != seq) return fail(ISLAM_EHIP, "islam_pvgo_run_chain_sharded: no status from the device (trial %d)", trials + 1);
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            ++trials;
+            const int verdict = (int)hs[12];
+            damping = hs[2];
+            loss = hs[0];
+            steps = (int)hs[13];
+            if (verdict == 0) { A = B; prev_fused = true; continue; }
+            epoch += 1.0;
+            if (verdict == 2) { A = B; break; }
+            if (verdict == 4) { status = ISLAM_ENOTPD; break; }
+            // the speculative elimination is void: the next solve runs on the launched level-0 kernel from the linearisation in global
+            // memory (undamped: the damping list of the state), with its own all-reduce of the interface blocks
+            ISLAM_HIP_CHECK(hipMemsetAsync(w.flags + 4 + (((long long)seq + 1) & 1), 0, sizeof(int), s));
+            if (verdict == 5) A = B;
+            if (verdict == 3) status = ISLAM_ENOTPD;
+            {
+                const Gate gate{w.state, epoch};
+                LevelSrc src{};
+                src.level0 = 1; src.Hd = HD[A.pb]; src.Ho = HO[A.pb]; src.rhs0 = RH[A.pb]; src.state = w.state; src.hist = 1;
+                launch_tw(src, level_dst(level_out(0), nullptr), N_eff, m, w.flags, seg_lo, nseg, gate, s);
+                if ((rc = enqueue_rest(A.pb, 1, 1, false, seq, gate)) != ISLAM_OK) return rc;
+            }
+            prev_fused = false;
+        }
+        return ISLAM_OK;
+    };
+    const int rc = run();
+    if (rc != ISLAM_OK) {
+        hipLaunchKernelGGL(shard_close_gate_kernel, dim3(1), dim3(64), 0, s, w.state);
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        return rc;
+    }
+    res->steps = steps; res->trials = trials; res->status = status; res->loss = loss; res->damping = damping;
+    if (exchanged_bytes) *exchanged_bytes = xbytes;
+    *out_nodes = A.cur_n; *out_vels = A.cur_v;
+    *own0 = has_left ? first_node : 0;
+    *own1 = N_eff;
+    return ISLAM_OK;
+}
+
 int trial_gated(const double* nodes, const double* vels, const double* dx, const double* poses, const double* drots,
                 const double* dtrans, const double* dvels, const double* dts, const double* lin, int lin_stride, int M,
                 double* nodes_t, double* vels_t, double* part, const double* red_lin, const double* red_trial,
@@ -4160,6 +4489,7 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
             fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
             fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
             fa.eflag_prev = eprev;
+            fa.Ms = M;
             if (begin_pending) { fa.loss_part0 = w.loss_part; fa.nlb0 = nlb; begin_pending = false; }
             hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
             LevelSrc none{};
@@ -4180,6 +4510,7 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
             fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
             fa.eflag = w.flags + 4 + 1;                          // solve 1
             fa.eflag_prev = eflag_none;
+            fa.Ms = M;
             hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
             LevelSrc none{};
             none.level0 = 1;
@@ -4411,6 +4742,7 @@ int islam_pvgo_trial_elim_burst(const double* nodes, const double* vels, const d
     fa.dst = level_dst(w.lv[0], w.dx);
     fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
     fa.eflag = w.flags + 4; fa.eflag_prev = w.flags + 6;
+    fa.Ms = N - 1;
     const Gate open{nullptr, 0.0};
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, open);
     hipEvent_t e0, e1;

@@ -257,6 +257,35 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
     volatile double* hs_all = host_state;
     hs_all[15] = 0.0;
     hs_all[31] = 0.0;
+    // ---- the loop on the fused trial + elimination kernel, one collective per trial (pvgo.hip: run_chain_sharded_fused); plans it
+    // does not cover and the reprojection factor take the launch-per-stage loop below
+    if (!reproj) {
+        ShardSum sum{[](void* self, const double* send, double* recv, size_t count, hipStream_t st) -> int {
+                         return static_cast<const Reducer*>(self)->sum_to(send, recv, count, st);
+                     },
+                     const_cast<Reducer*>(&red)};
+        int taken = 0, own0 = 0, own1 = 0;
+        const double *fin_n = nullptr, *fin_v = nullptr;
+        rc = run_chain_sharded_fused(sum, world, rank, nodes, vels, poses, drots, dtrans, dvels, dts, N, prm, workspace, workspace_bytes, scratch,
+                                     scratch_bytes, res, exchanged_bytes, s, &taken, &fin_n, &fin_v, &own0, &own1);
+        if (rc != ISLAM_OK) return rc;
+        if (taken) {
+            if (world == 1) {
+                if (fin_n != nodes) {
+                    ISLAM_HIP_CHECK(hipMemcpyAsync(nodes, fin_n, sizeof(double) * 7 * (size_t)N, hipMemcpyDeviceToDevice, s));
+                    ISLAM_HIP_CHECK(hipMemcpyAsync(vels, fin_v, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, s));
+                }
+            } else {
+                ISLAM_HIP_CHECK(hipMemsetAsync(full, 0, sizeof(double) * 10 * (size_t)N, s));
+                hipLaunchKernelGGL(scatter_full_kernel, dim3(((own1 - own0) * 10 + 255) / 256), dim3(256), 0, s, fin_n, fin_v, own0, own1, 0, full);
+                if ((rc = red.sum(full, 10 * (size_t)N, s)) != ISLAM_OK) return rc;
+                hipLaunchKernelGGL(unpack_full_kernel, dim3((N * 10 + 255) / 256), dim3(256), 0, s, full, N, nodes, vels);
+                ISLAM_LAUNCH_CHECK();
+            }
+            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+            return ISLAM_OK;
+        }
+    }
     hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(64), 0, s, state, prm->radius, prm->down);     // (no host->device copy: see pvgo.hip)
     ISLAM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(double), s));
     ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));     // product rows of other ranks' segments read as zero

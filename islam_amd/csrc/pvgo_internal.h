@@ -135,4 +135,18 @@ int trial_gated(const double* nodes, const double* vels, const double* dx, const
                 double* nodes_t, double* vels_t, double* part, const double* red_lin, const double* red_trial,
                 const islam_pvgo_reproj* reproj, int link0, Gate gate, hipStream_t s);
 
+
+// ---- the sharded loop on the fused trial + elimination kernel (defined in pvgo.hip; the collective comes from pvgo_dist.hip)
+// fn: recv = sum over the ranks of send (count doubles), enqueued on s
+struct ShardSum { int (*fn)(void* self, const double* send, double* recv, size_t count, hipStream_t s); void* self; };
+size_t shard_fused_scratch_doubles(int N, int world);
+// *taken = 0: the plan is not one the fused kernel covers (or ISLAM_SHARD_FUSED=0) and nothing was enqueued -- the caller runs the
+// launch-per-stage loop.  Otherwise the LM loop has run (the stream is NOT drained): *out_nodes / *out_vels = the arrays that hold
+// the accepted iterate (full-size, global rows; only rows [*own0, *own1) are this rank's to hand on).
+int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
+                            const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
+                            void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, islam_pvgo_result* res,
+                            long long* exchanged_bytes, hipStream_t s, int* taken, const double** out_nodes, const double** out_vels,
+                            int* own0, int* own1);
+
 }  // namespace islam
