@@ -431,7 +431,7 @@ def main():
                                                             prob['dtrans'], prob['dvels'], prob['dts'], LOSS_WEIGHT, radius=1e4)
                 sharded_info['exchange_bytes_per_lm_iter'] = xb / max(res.trials, 1)
                 return res.trials, res.steps
-            sharded_info['loop'] = 'islam_pvgo_run_chain_sharded (C, RCCL)'
+            sharded_info['loop'] = 'islam_pvgo_run_chain_sharded (C, RCCL): fused trial + level-0 elimination kernel, one all-reduce per LM trial'
 
     for _ in range(args.warmup):
         step()

@@ -454,8 +454,13 @@ int islam_pvgo_shard_downsweep(const double* exchange, int N, const int seg_len[
                                size_t workspace_bytes, double* dx, int* flags, void* stream);
 /* The whole sharded LM loop in the library, on RCCL (islam_amd/csrc/pvgo_dist.hip): every rank passes the SAME full-size
  * inputs (device, float64: nodes (N,7), vels (N,3) in/out -- the full solution on every rank --, poses (N-1,7), drots (N-1,4),
- * dtrans, dvels (N-1,3), dts (N-1)) and works on its stretch of the chain; per LM trial two all-reduces (the interface blocks:
- * 351 doubles per segment of the exchange level; [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]); accept /
+ * dtrans, dvels (N-1,3), dts (N-1)) and works on its stretch of the chain.  Graphs the fused trial + elimination kernel covers
+ * (those islam_pvgo_run_chain fuses, without the reprojection factor): ONE all-reduce per LM trial -- the interface blocks of the
+ * next solve (351 doubles per segment of the exchange level) + [sum r^2 | sum JD.(2R+JD) | failed | 18 doubles per cut: the two
+ * ranks' parts of the cut node's diagonal] -- with the trial step, the linearisation and the level-0 elimination in one launch
+ * under a speculated damping; a rejected or re-damped trial costs one more solve with its own all-reduce (ISLAM_SHARD_FUSED=0:
+ * off).  Otherwise per LM trial two all-reduces (the interface blocks;
+ * [sum r^2 | sum JD.(2R+JD) | failed | 10-double halo per rank]); accept /
  * reject, TrustRegion and StopOnPlateau replicated on the DEVICE (every rank decides on the same summed scalars), the host
  * runs one trial ahead and reads 128-byte verdicts from pinned memory -- no stream synchronisation inside the loop; the
  * collectives of a cancelled run-ahead trial still execute, identically on every rank.  reproj (may be NULL): the sparse

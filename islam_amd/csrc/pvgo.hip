@@ -1847,6 +1847,8 @@ struct SweepArgs {
     int root_twisted;         // the root is eliminated by both wavefronts of workgroup 0 (root_n <= BS_PAR_MAX)
     const double* outer_x;    // sharded solve: the solution at the rank's left cut node (9 doubles, a replicated level's x) ...
     int outer_flag;           // ... and the ready word of the segment that publishes it
+    const double* fwd_src;    // sharded fused loop: the verdict block the decision kernel in front of this launch left in device memory ...
+    double* fwd_dst;          // ... goes to the host's pinned slot from here (16 doubles, [15] = sequence number, last), whatever the gate says
 };
 
 #ifndef ISLAM_POLL_SLEEP
@@ -1875,6 +1877,13 @@ __device__ __forceinline__ void publish_ready(int* f, int serial, int lane) {
 // half of the level-0 segments started only when the first had finished: 17 -> 25 us)
 __global__ __launch_bounds__(128, 2) void bt_downsweep_kernel(SweepArgs a, int* flags, Gate gate) {
     __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED > LDS_INFLUENCE ? LDS_TWISTED : LDS_INFLUENCE];
+    if (a.fwd_src && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {
+        // (a one-workgroup decision kernel that waits for its own stores to host memory is 2 us longer -- on the critical path of
+        // every trial; here the round trip over PCIe hides behind the sweep, in a workgroup that starts by waiting anyway)
+        if (threadIdx.x < 15) __hip_atomic_store(&a.fwd_dst[threadIdx.x], a.fwd_src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(&a.fwd_dst[15], a.fwd_src[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (gate_closed(gate)) return;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x;
@@ -3278,7 +3287,7 @@ int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = fal
     return best.nl;
 }
 
-struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x, *gx; };     // gx: influence matrices handed down (levels >= 1)
+struct LevelBufs { double *fac, *inv, *Dsep, *rsep, *cL, *cR, *cgL, *cgR, *fill, *x, *gx; size_t prod_bytes; };     // gx: influence matrices handed down (levels >= 1); prod_bytes: Dsep .. cgR, contiguous
 
 struct Workspace {
     double *lin, *loss_part, *part, *Hd, *Ho, *rhs, *dx, *nodes_t, *vels_t, *state;
@@ -3332,6 +3341,7 @@ Workspace carve(void* base, int N) {
         b.fill = take((size_t)segs * 81);
         b.cgL = take((size_t)segs * 9);
         b.cgR = take((size_t)segs * 9);
+        b.prod_bytes = (size_t)(p - (char*)b.Dsep);
         b.gx = l >= 1 ? take((size_t)n * 171) : nullptr;
         n = segs;
     }
@@ -3825,6 +3835,8 @@ int shard_upsweep_gated(double* Hd, const double* Ho, const double* rhs, double 
 // (bt_downsweep_kernel) for the root and the whole back-substitution: the replicated levels in full, levels xl .. 0 over the
 // rank's own segments.  dx: LOCAL array, row 0 = global node `node0`; rows node0 .. the rank's right outer separator are
 // written (the left outer separator's row too when the rank has one).
+static int shard_downsweep_planned(const SolvePlan& sp, const ShardRanges& R, const Workspace& w, const double* exchange, int world, int node0,
+                                   double* dx, int* flags, Gate gate, hipStream_t s, const double* fwd_src = nullptr, double* fwd_dst = nullptr);
 int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], int world, int rank, int node0, void* workspace,
                           size_t workspace_bytes, double* dx, int* flags, Gate gate, hipStream_t s) {
     SolvePlan sp;
@@ -3833,6 +3845,12 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
     if (nl < 2 || shard_ranges(sp, world, rank, R) != 0) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: N=%d, world=%d, rank=%d", N, world, rank);
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_shard_downsweep: workspace too small");
     Workspace w = carve((void*)align_up((size_t)workspace), N);
+    return shard_downsweep_planned(sp, R, w, exchange, world, node0, dx, flags, gate, s);
+}
+// (the plan, the ranges and the carved workspace do not change within a run: the loop in the library computes them once)
+static int shard_downsweep_planned(const SolvePlan& sp, const ShardRanges& R, const Workspace& w, const double* exchange, int world, int node0,
+                                   double* dx, int* flags, Gate gate, hipStream_t s, const double* fwd_src, double* fwd_dst) {
+    const int nl = sp.nl;
     const int top = nl - 1, xl = R.xl;
     const bool tw = sp.twisted != 0;
     LevelBufs pb{};
@@ -3853,6 +3871,7 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
     a.nl = top;
     a.outer_x = nullptr;
     a.outer_flag = 0;
+    a.fwd_src = fwd_src; a.fwd_dst = fwd_dst;
     int flag = 1, blk = 8;
     for (int i = 0; i < a.nl; ++i) {
         const int l = top - 1 - i;
@@ -3879,6 +3898,19 @@ int shard_downsweep_gated(const double* exchange, int N, const int seg_len[2], i
     }
     if (xl + 1 == top && R.seg0[xl] > 0) { a.outer_x = x_of(top) + (size_t)(R.seg0[xl] - 1) * 9; a.outer_flag = 0; }
     a.first_block[a.nl] = blk;
+    if (world == 1 && tw && blk <= 2048 && merge_levels()) {        // (one rank: every level in full -- the pairing of enqueue_levels)
+        for (int i = a.nl - 1; i >= 1; i -= 2) {
+            SweepLevel &C = a.lv[i], &Pp = a.lv[i - 1];
+            const int lp = top - 1 - (i - 1);
+            if (C.m > BS_PAR_MAX || Pp.m > BS_PAR_MAX || w.lv[lp].gx == nullptr) continue;
+            C.merge = 1;
+            Pp.publish_g = 1;
+            Pp.skip_x = 1;
+            Pp.gx = w.lv[lp].gx;
+            Pp.gflag0 = flag;
+            flag += Pp.P;
+        }
+    }
     if ((size_t)flag * READY_STRIDE * sizeof(int) > w.ready_bytes) return fail(ISLAM_EARG, "pvgo: ready-flag buffer too small (%d words)", flag);
     hipLaunchKernelGGL(bt_downsweep_kernel, dim3(blk), dim3(128), 0, s, a, flags, gate);
     ISLAM_LAUNCH_CHECK();
@@ -3919,8 +3951,7 @@ __device__ __forceinline__ double shard_damp(const double* st, const TRParams& t
     const double d = mode == 0 ? speculated_damping(st, tr) : st[2];
     return v + v * d;
 }
-__global__ __launch_bounds__(128) void shard_pack_kernel(PackArgs a, Gate gate) {
-    if (gate_closed(gate)) return;
+__device__ __forceinline__ void shard_pack(const PackArgs& a) {
     const int t = threadIdx.x;
     for (int i = t; i < a.nmsg; i += 128) a.msg[i] = 0.0;
     __syncthreads();
@@ -3944,6 +3975,10 @@ __global__ __launch_bounds__(128) void shard_pack_kernel(PackArgs a, Gate gate) 
         if (lane == 0) { a.msg[0] = ssum; a.msg[1] = qsum; a.msg[2] = a.part[2 * a.nwg]; }
     }
 }
+__global__ __launch_bounds__(128) void shard_pack_kernel(PackArgs a, Gate gate) {
+    if (gate_closed(gate)) return;
+    shard_pack(a);
+}
 
 // mode 0: a trial (LM decision; d_spec = the damping the solve that is already eliminated used); 1: a solve without a trial
 // (only the clamp); 2: the first linearisation (its loss opens the run)
@@ -3951,11 +3986,10 @@ struct DecideArgs {
     const double* msg; double* ex_Dsep; double* st; TRParams tr; double* report; double seq; int mode, damp_mode, world, Pxl;
     double vmin, vmax;
 };
-__global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gate) {
-    if (gate_closed(gate)) return;
+__device__ __forceinline__ void shard_decide(const DecideArgs& a) {
     const int t = threadIdx.x;
     const double d_spec = a.mode == 0 ? speculated_damping(a.st, a.tr) : -1.0;
-    for (int i = t; i < 9 * (a.world - 1); i += 64) {
+    for (int i = t; i < 9 * (a.world - 1); i += (int)blockDim.x) {
         const int b = i / 9, j = i - 9 * b;
         const double da = a.msg[3 + 18 * b + j], db = a.msg[3 + 18 * b + 9 + j], tot = da + db;
         const double cl = fmin(fmax(tot, a.vmin), a.vmax);
@@ -3970,6 +4004,17 @@ __global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gat
     if (a.mode == 2) { a.st[0] = a.msg[0]; a.st[1] = a.msg[0]; a.st[8] = 0.0; a.st[11] = 1.0; a.st[12] = 0.0; a.st[13] = 0.0; }
     else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], a.st, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec);
 }
+__global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gate) {
+    if (gate_closed(gate)) return;
+    shard_decide(a);
+}
+// one rank: nothing to sum between the two
+__global__ __launch_bounds__(128) void shard_pack_decide_kernel(PackArgs p, DecideArgs d, Gate gate) {
+    if (gate_closed(gate)) return;
+    shard_pack(p);
+    __syncthreads();
+    shard_decide(d);
+}
 
 __global__ void shard_close_gate_kernel(double* __restrict__ st) {
     if (threadIdx.x == 0) st[14] = -1.0;
@@ -3978,7 +4023,7 @@ __global__ void shard_close_gate_kernel(double* __restrict__ st) {
 size_t shard_fused_scratch_doubles(int N, int world) {
     const size_t n = (size_t)N + 2, ex = 351 * (n / 5 + 2) + 3 + 18 * (size_t)world;
     auto a256 = [](size_t k) { return align_up(k * sizeof(double)) / sizeof(double); };
-    return 2 * a256(ex) + 2 * a256(96) + 64;
+    return 2 * a256(ex) + 2 * a256(96) + a256(32) + 64;
 }
 
 int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
@@ -4021,6 +4066,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     double* ex_own = take(nex);
     double* ex = world > 1 ? take(nex) : ex_own;
     double* SH[2] = {take(96), take(96)};
+    double* rep_dev = take(32);
     {
         static bool fz_attr_set[64] = {};
         int dev_i = 0;
@@ -4038,7 +4084,9 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     hs_all[15] = 0.0;
     hs_all[31] = 0.0;
     // product rows of other ranks' segments read as zero; the own rows of the exchange buffer are rewritten by every solve
-    ISLAM_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, s));
+    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+    if (world > 1)
+        for (int l = 0; l < sp.nl; ++l) ISLAM_HIP_CHECK(hipMemsetAsync(w.lv[l].Dsep, 0, w.lv[l].prod_bytes, s));
     ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * nex, s));
     hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
     const TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
@@ -4058,8 +4106,10 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     int* const eflag_none = w.flags + 6;
     long long xbytes = 0;
     // levels 1 .. xl, the pack, the all-reduce, the decision and the down-sweep behind an eliminated level 0 of buffer pb
-    auto enqueue_rest = [&](int pb, int mode, int damp_mode, bool with_trial, double seq, const Gate& gate) -> int {
-        for (int l = 1; l <= xl; ++l)
+    // decision_only: an accepted trial would be the last optimizer step (StopOnPlateau's step limit) -- no solve follows it, only the
+    // scalars of the message matter (the blocks in front of them are whatever the buffer holds, the same on every rank)
+    auto enqueue_rest = [&](int pb, int mode, int damp_mode, bool with_trial, double seq, const Gate& gate, bool decision_only = false) -> int {
+        for (int l = 1; l <= xl && !decision_only; ++l)
             launch_tw(level_src_from(w.lv[l - 1], sp.lv[l - 1].P), level_dst(level_out(l), nullptr), sp.lv[l].n, sp.lv[l].m, w.flags, R.seg0[l],
                       R.nseg[l], gate, s);
         PackArgs pa{};
@@ -4069,19 +4119,26 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
         pa.has_left = has_left; pa.has_right = has_right; pa.share = SH[pb]; pa.Hd_right = HD[pb] + (size_t)(N_eff - 1) * 81;
         pa.st = w.state; pa.tr = tr; pa.damp_mode = damp_mode; pa.part = with_trial ? w.part : (const double*)nullptr; pa.nwg = nwg;
         pa.msg = ex_own + 351 * (size_t)Pxl; pa.nmsg = nmsg; pa.rank = rank;
-        hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(128), 0, s, pa, gate);
+        // the verdict block: straight to the host's slot when no down-sweep follows, else to device memory -- the down-sweep forwards it
+        double* const host_slot = report + 16 * ((long long)seq & 1);
+        double* const dev_slot = rep_dev + 16 * ((long long)seq & 1);
+        const bool forward = mode == 0 && !decision_only;
+        DecideArgs da{};
+        da.msg = ex + 351 * (size_t)Pxl; da.ex_Dsep = ex; da.st = w.state; da.tr = tr; da.report = forward ? dev_slot : host_slot; da.seq = seq;
+        da.mode = mode; da.damp_mode = damp_mode; da.world = world; da.Pxl = Pxl; da.vmin = prm->vmin; da.vmax = prm->vmax;
         if (world > 1) {
+            hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(128), 0, s, pa, gate);
             const int r = red.fn(red.self, ex_own, ex, nex, s);
             if (r != ISLAM_OK) return r;
             xbytes += 8LL * (long long)nex;
+            hipLaunchKernelGGL(shard_decide_kernel, dim3(1), dim3(64), 0, s, da, gate);
+        } else {
+            hipLaunchKernelGGL(shard_pack_decide_kernel, dim3(1), dim3(128), 0, s, pa, da, gate);
         }
-        DecideArgs da{};
-        da.msg = ex + 351 * (size_t)Pxl; da.ex_Dsep = ex; da.st = w.state; da.tr = tr; da.report = report + 16 * ((long long)seq & 1); da.seq = seq;
-        da.mode = mode; da.damp_mode = damp_mode; da.world = world; da.Pxl = Pxl; da.vmin = prm->vmin; da.vmax = prm->vmax;
-        hipLaunchKernelGGL(shard_decide_kernel, dim3(1), dim3(64), 0, s, da, gate);
         ISLAM_LAUNCH_CHECK();
         // (a trial that is not "accepted, continue, damping as speculated" bumps the epoch: the down-sweep turns into a no-op)
-        return shard_downsweep_gated(ex, N, prm->seg_len, world, rank, 0, workspace, workspace_bytes, w.dx, w.flags, gate, s);
+        if (decision_only) return ISLAM_OK;
+        return shard_downsweep_planned(sp, R, w, ex, world, 0, w.dx, w.flags, gate, s, forward ? dev_slot : (const double*)nullptr, host_slot);
     };
     struct IterCfg { int pb; double *cur_n, *cur_v, *tri_n, *tri_v; };
     auto fused_args = [&](const IterCfg& c, bool first, double seq, int* eprev) {
@@ -4109,16 +4166,23 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
             hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
             if ((rc = enqueue_rest(A.pb, 2, 2, true, 0.0, gate)) != ISLAM_OK) return rc;
         }
-        bool prev_fused = true;
+        // trial `seq` of iteration c: trial_elim_kernel (cur + dx -> tri, linearisation at tri, level 0 of solve seq+1) and the rest of
+        // solve seq+1 around the all-reduce
+        // steps_before: optimizer steps finished when this trial is evaluated
+        auto enqueue_trial = [&](const IterCfg& c, double seq, double ep, bool prev_fused, int steps_before) -> int {
+            const Gate gate{w.state, ep};
+            const FusedArgs fa = fused_args(c, false, seq, prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none);
+            hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
+            return enqueue_rest(1 - c.pb, 0, 0, true, seq, gate, steps_before + 1 >= prm->max_steps);
+        };
+        if ((rc = enqueue_trial(A, 1.0, epoch, true, 0)) != ISLAM_OK) return rc;
         for (;;) {
             const double seq = (double)(trials + 1);
+            // run ahead (the verdict of a trial is written BEHIND the all-reduce, too late to launch the next trial on time): trial
+            // seq+1 under the assumption "accepted, continue, damping as speculated"; any other verdict bumps the device epoch and the
+            // chain -- its collective included, on unchanged buffers, the same on every rank -- runs as no-ops
             const IterCfg B{1 - A.pb, A.tri_n, A.tri_v, A.cur_n, A.cur_v};
-            {
-                const Gate gate{w.state, epoch};
-                const FusedArgs fa = fused_args(A, false, seq, prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none);
-                hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
-                if ((rc = enqueue_rest(1 - A.pb, 0, 0, true, seq, gate)) != ISLAM_OK) return rc;
-            }
+            if (steps + 1 < prm->max_steps && (rc = enqueue_trial(B, seq + 1.0, epoch, true, steps + 1)) != ISLAM_OK) return rc;
             volatile double* hs = hs_all + 16 * ((long long)seq & 1);
             {
                 unsigned long spins = 0;
@@ -4135,7 +4199,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
             damping = hs[2];
             loss = hs[0];
             steps = (int)hs[13];
-            if (verdict == 0) { A = B; prev_fused = true; continue; }
+            if (verdict == 0) { A = B; continue; }              // B's trial is the one in flight
             epoch += 1.0;
             if (verdict == 2) { A = B; break; }
             if (verdict == 4) { status = ISLAM_ENOTPD; break; }
@@ -4151,7 +4215,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
                 launch_tw(src, level_dst(level_out(0), nullptr), N_eff, m, w.flags, seg_lo, nseg, gate, s);
                 if ((rc = enqueue_rest(A.pb, 1, 1, false, seq, gate)) != ISLAM_OK) return rc;
             }
-            prev_fused = false;
+            if ((rc = enqueue_trial(A, seq + 1.0, epoch, false, steps)) != ISLAM_OK) return rc;
         }
         return ISLAM_OK;
     };

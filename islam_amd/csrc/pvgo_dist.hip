@@ -2,6 +2,10 @@
 //
 // No reference counterpart (the reference is single-GPU).  One process per GPU; every rank calls
 // islam_pvgo_run_chain_sharded with the SAME full-size inputs (the problem is 0.9 MB) and works on its own stretch of the chain.
+// Graphs the fused trial + elimination kernel covers (the plans islam_pvgo_run_chain fuses; no reprojection factor) run on
+// pvgo.hip's run_chain_sharded_fused: trial_elim_kernel over the rank's segments -> levels 1 .. xl -> ONE all-reduce per trial
+// [interface blocks of the next solve | sum r^2 | sum JD.(2R+JD) | failed pivots | the cut nodes' diagonal parts] -> decision ->
+// down-sweep; no halo rows (see the comment there).  Everything else takes the launch-per-stage loop of this file:
 // One LM trial = one gated chain of launches on the rank's stream:
 //   linbuild_kernel            linearise + normal equations of the local links (only after an accepted step)
 //   bt_eliminate_tw_kernel x   up-sweep of the local sub-tree, levels 0 .. xl                  (shard_upsweep_gated)
@@ -281,8 +285,9 @@ static int run_sharded(const Reducer& red, int world, int rank, double* nodes, d
                 if ((rc = red.sum(full, 10 * (size_t)N, s)) != ISLAM_OK) return rc;
                 hipLaunchKernelGGL(unpack_full_kernel, dim3((N * 10 + 255) / 256), dim3(256), 0, s, full, N, nodes, vels);
                 ISLAM_LAUNCH_CHECK();
+                ISLAM_HIP_CHECK(hipStreamSynchronize(s));       // (as the launch-per-stage loop below: the ranks leave together)
             }
-            ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+            // (one rank: stream-ordered like islam_pvgo_run_chain -- the result block comes from the pinned verdicts, nothing to wait for)
             return ISLAM_OK;
         }
     }

@@ -119,7 +119,9 @@ def test_ranks_as_threads_through_the_allreduce_callback(cuda, world, F):
         per_solve = (351 * 23 + 3 + 18 * (world - 1)) * 8
         solves, rest = divmod(outs[0][3], per_solve)
         trials = outs[0][2].trials
-        assert rest == 0 and solves == trials + 1                        # (no reject on this graph: no solve was redone)
+        # (no reject on this graph: no solve was redone; the host runs one trial ahead, so a stop may cancel one enqueued chain
+        # whose collective still ran)
+        assert rest == 0 and trials + 1 <= solves <= trials + 2
 
 
 def _noisy(F, seed, sig, cuda):
