@@ -3986,34 +3986,43 @@ struct DecideArgs {
     const double* msg; double* ex_Dsep; double* st; TRParams tr; double* report; double seq; int mode, damp_mode, world, Pxl;
     double vmin, vmax;
 };
-__device__ __forceinline__ void shard_decide(const DecideArgs& a) {
+// (the state block is staged through LDS: lm_control is a chain of ~40 dependent reads and writes of it -- 3 us of global-memory round
+// trips on one lane when it works on the device copy, and this kernel sits on the critical path of every trial)
+__device__ __forceinline__ void shard_decide(const DecideArgs& a, double* st_l) {
     const int t = threadIdx.x;
-    const double d_spec = a.mode == 0 ? speculated_damping(a.st, a.tr) : -1.0;
+    if (t < STATE_DOUBLES) st_l[t] = a.st[t];
+    __syncthreads();
+    const double d_spec = a.mode == 0 ? speculated_damping(st_l, a.tr) : -1.0;
     for (int i = t; i < 9 * (a.world - 1); i += (int)blockDim.x) {
         const int b = i / 9, j = i - 9 * b;
         const double da = a.msg[3 + 18 * b + j], db = a.msg[3 + 18 * b + 9 + j], tot = da + db;
         const double cl = fmin(fmax(tot, a.vmin), a.vmax);
         if (cl != tot) {
             const int slot = (int)((long long)(b + 1) * a.Pxl / a.world) - 1;          // last exchange-level segment of rank b
-            a.ex_Dsep[(size_t)slot * 81 + j * 10] += shard_damp(a.st, a.tr, a.damp_mode, cl) -
-                                                     (shard_damp(a.st, a.tr, a.damp_mode, da) + shard_damp(a.st, a.tr, a.damp_mode, db));
+            a.ex_Dsep[(size_t)slot * 81 + j * 10] += shard_damp(st_l, a.tr, a.damp_mode, cl) -
+                                                     (shard_damp(st_l, a.tr, a.damp_mode, da) + shard_damp(st_l, a.tr, a.damp_mode, db));
         }
     }
     __syncthreads();
-    if (t != 0) return;
-    if (a.mode == 2) { a.st[0] = a.msg[0]; a.st[1] = a.msg[0]; a.st[8] = 0.0; a.st[11] = 1.0; a.st[12] = 0.0; a.st[13] = 0.0; }
-    else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], a.st, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec);
+    if (t == 0) {
+        if (a.mode == 2) { st_l[0] = a.msg[0]; st_l[1] = a.msg[0]; st_l[8] = 0.0; st_l[11] = 1.0; st_l[12] = 0.0; st_l[13] = 0.0; }
+        else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], st_l, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec);
+    }
+    __syncthreads();
+    if (t < STATE_DOUBLES && a.mode != 1) a.st[t] = st_l[t];
 }
 __global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gate) {
+    __shared__ double st_l[STATE_DOUBLES];
     if (gate_closed(gate)) return;
-    shard_decide(a);
+    shard_decide(a, st_l);
 }
 // one rank: nothing to sum between the two
 __global__ __launch_bounds__(128) void shard_pack_decide_kernel(PackArgs p, DecideArgs d, Gate gate) {
+    __shared__ double st_l[STATE_DOUBLES];
     if (gate_closed(gate)) return;
     shard_pack(p);
     __syncthreads();
-    shard_decide(d);
+    shard_decide(d, st_l);
 }
 
 __global__ void shard_close_gate_kernel(double* __restrict__ st) {

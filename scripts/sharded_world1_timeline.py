@@ -3,7 +3,7 @@ scripts/sharded_world1_time.py:   python scripts/sharded_world1_timeline.py <ker
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-short = lambda n: n.split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '').replace('islam::', '')[:44]
+short = lambda n: n.replace('void ', '').replace('(anonymous namespace)::', '').replace('islam::', '').split('(')[0][:44]
 
 
 def last_run(marker):
@@ -28,7 +28,7 @@ for title, marker in (('single GPU', 'trial_elim_kernel'), ('sharded, world 1', 
     t0 = int(run[0]['Start_Timestamp'])
     print('== %s: %d launches, %.1f us from the first start to the last end' % (title, len(run), (int(run[-1]['End_Timestamp']) - t0) / 1e3))
     prev_end = t0
-    for r in run[:40]:
+    for r in run[:24]:
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         print('  +%7.1f us  gap %5.1f  dur %5.1f  %s' % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, short(r['Kernel_Name'])))
         prev_end = e
