@@ -122,6 +122,13 @@ int islam_resize_bilinear_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C
  * intermediate torch.cat and without copying the up-sampled tensor into the next concatenation. */
 int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                          int align_corners, int ytot, int yoff, void* stream);
+/* torch.cat((F.interpolate(torch.cat(pieces, 1), (Ho, Wo), mode='bilinear'), tail), 1) in one launch: the `bigger` feature extractor of
+ * StereoNet7 (Network/StereoNet7.py:36-46 -> Network/PSM/submodule.py:139-152 with the extra up-sampling and layer1's output joined).
+ * srcs / chans: HOST arrays of n <= 8 device pointers to channels-last bf16 pieces (B, Hi, Wi, chans[k]) / their channel counts
+ * (multiples of 8); tail (may be NULL with tailC = 0): (B, Ho, Wo, tailC); y: (B, Ho, Wo, sum(chans) + tailC).  Every sample is
+ * islam_resize_bilinear_nhwc_bf16's arithmetic; whole pixels are written contiguously. */
+int islam_upsample_cat_nhwc_bf16(const uint16_t* const* srcs, const int* chans, int n, const uint16_t* tail, int tailC, uint16_t* y,
+                                 int B, int Hi, int Wi, int Ho, int Wo, int align_corners, void* stream);
 /* y = add + resize(x) in one pass (hourglass.py:60-69 `up1 + up2(low3)`): the up-sampled value is rounded to bf16 before the add,
  * like the two separate ops.  add, y: (B,Ho,Wo,C). */
 int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,

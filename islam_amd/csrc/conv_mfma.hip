@@ -347,6 +347,62 @@ __global__ __launch_bounds__(256) void resize_bilinear_nhwc_bf16_kernel(const ui
     y[opix * yC8 + yoff8 + cg] = o;                     // channels [8*yoff8, 8*yoff8 + C) of a (B,Ho,Wo,8*yC8) tensor
 }
 
+// torch.cat((F.interpolate(torch.cat(pieces, 1), size), tail), 1) in ONE launch (Network/PSM/submodule.py:139-152 as StereoNet7's
+// `bigger` feature extractor uses it: the six pieces of the 320-channel pyramid feature up-sampled to the resolution of layer1's
+// output, which joins them as the last 32 channels).  Bilinear resizing is per channel, so every piece is sampled where it lies; a
+// thread produces one 16-byte channel group of one output pixel and consecutive threads write consecutive groups of the same pixel
+// -- whole 704-byte pixels leave the CU contiguously, where six launches wrote 64 .. 256-byte pieces 704 bytes apart (1.8 - 2.3 TB/s)
+// and a seventh copied the tail.  The arithmetic of a sample is resize_bilinear_nhwc_bf16_kernel's, bit for bit.
+struct UpCatArgs {
+    const uint4* src[8];          // pieces, (B, Hi, Wi, 8 c8[k]) channels-last bf16
+    int c8[8], first8[9];         // channel groups of piece k, first group of piece k in the output
+    int n;
+    const uint4* tail;            // (B, Ho, Wo, 8 tail8) or nullptr
+    int tail8;
+};
+__global__ __launch_bounds__(256) void upsample_cat_nhwc_bf16_kernel(UpCatArgs a, uint4* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
+                                                                     float sh, float sw, int align, long long total, int yC8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const Idx4 ix = split4(i, total, yC8, Wo, Ho);
+    const int cgo = ix.cg, ox = ix.ox, oy = ix.oy, b = ix.b;
+    if (cgo >= a.first8[a.n]) {                          // the tail: a copy
+        y[i] = a.tail[ix.pix * a.tail8 + (cgo - a.first8[a.n])];
+        return;
+    }
+    const uint4* sp = a.src[0];                          // (selects, not an index: the argument block stays in scalar registers)
+    int C8 = a.c8[0], f8 = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+        if (q < a.n && cgo >= a.first8[q]) { sp = a.src[q]; C8 = a.c8[q]; f8 = a.first8[q]; }
+    const int cg = cgo - f8;
+    float fy, fx;
+    if (align) {
+        fy = sh * oy;
+        fx = sw * ox;
+    } else {
+        fy = fmaxf(sh * (oy + 0.5f) - 0.5f, 0.0f);
+        fx = fmaxf(sw * (ox + 0.5f) - 0.5f, 0.0f);
+    }
+    const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const uint4* base = sp + (size_t)b * Hi * Wi * C8 + cg;
+    const uint4 p00 = base[((size_t)y0 * Wi + x0) * C8], p01 = base[((size_t)y0 * Wi + x1) * C8];
+    const uint4 p10 = base[((size_t)y1 * Wi + x0) * C8], p11 = base[((size_t)y1 * Wi + x1) * C8];
+    auto mix = [&](unsigned va, unsigned vb, unsigned vc, unsigned vd) {
+        const float lo = hy * (hx * bf16_lo(va) + lx * bf16_lo(vb)) + ly * (hx * bf16_lo(vc) + lx * bf16_lo(vd));
+        const float hi = hy * (hx * bf16_hi(va) + lx * bf16_hi(vb)) + ly * (hx * bf16_hi(vc) + lx * bf16_hi(vd));
+        return pack_bf16(lo, hi);
+    };
+    uint4 o;
+    o.x = mix(p00.x, p01.x, p10.x, p11.x);
+    o.y = mix(p00.y, p01.y, p10.y, p11.y);
+    o.z = mix(p00.z, p01.z, p10.z, p11.z);
+    o.w = mix(p00.w, p01.w, p10.w, p11.w);
+    y[i] = o;
+}
+
 // 2x2 / stride-2 max pooling (floor mode), optionally of relu(x): relu and max commute
 __global__ __launch_bounds__(256) void maxpool2_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8, int Hi, int Wi,
                                                                  int Ho, int Wo, int relu, long long total) {
@@ -423,6 +479,42 @@ static int resize_bilinear_launch(const uint16_t* x, const uint16_t* add, uint16
 extern "C" int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                                     int align_corners, int ytot, int yoff, void* stream) {
     return resize_bilinear_launch(x, nullptr, y, B, C, Hi, Wi, Ho, Wo, align_corners, ytot, yoff, stream);
+}
+
+// srcs / chans: host arrays of n <= 8 device pointers / channel counts (multiples of 8); tail may be NULL (tailC = 0).
+// y: (B, Ho, Wo, sum(chans) + tailC).
+extern "C" int islam_upsample_cat_nhwc_bf16(const uint16_t* const* srcs, const int* chans, int n, const uint16_t* tail, int tailC, uint16_t* y,
+                                            int B, int Hi, int Wi, int Ho, int Wo, int align_corners, void* stream) {
+    if (!srcs || !chans || !y || n < 1 || n > 8 || B < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || tailC < 0 || (tailC & 7) || (tailC > 0 && !tail))
+        return fail(ISLAM_EARG, "islam_upsample_cat_nhwc_bf16: bad argument (n=%d, tailC=%d, %dx%d -> %dx%d)", n, tailC, Hi, Wi, Ho, Wo);
+    UpCatArgs a{};
+    a.n = n;
+    int off = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!srcs[k] || chans[k] < 8 || (chans[k] & 7)) return fail(ISLAM_EARG, "islam_upsample_cat_nhwc_bf16: piece %d has %d channels", k, chans[k]);
+        a.src[k] = reinterpret_cast<const uint4*>(srcs[k]);
+        a.c8[k] = chans[k] / 8;
+        a.first8[k] = off;
+        off += chans[k] / 8;
+    }
+    for (int k = n; k <= 8; ++k) a.first8[k] = off;
+    a.first8[n] = off;
+    a.tail = reinterpret_cast<const uint4*>(tail);
+    a.tail8 = tailC / 8;
+    const int yC8 = off + tailC / 8;
+    float sh, sw;
+    if (align_corners) {
+        sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+        sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    } else {
+        sh = (float)Hi / (float)Ho;
+        sw = (float)Wi / (float)Wo;
+    }
+    const long long total = (long long)B * Ho * Wo * yC8;
+    hipLaunchKernelGGL(upsample_cat_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       reinterpret_cast<uint4*>(y), Hi, Wi, Ho, Wo, sh, sw, align_corners, total, yC8);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
 }
 
 // y = add + resize(x): the hourglass's `up1 + up2(low3)` (Network/PSM/hourglass.py:60-69) in one pass; add, y: (B,Ho,Wo,C)

@@ -392,6 +392,7 @@ HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
+UPSAMPLE_CAT = os.environ.get('ISLAM_UPSAMPLE_CAT', '1') != '0'     # the feature extractor's six up-samplings + concatenation as one launch
 # the feature extractor's last convolution writes conv_c0's input in place (left images first in the batch); 0: dense features + two copies
 STEREO_DIRECT_CAT = os.environ.get('ISLAM_STEREO_DIRECT_CAT', '1') != '0'
 HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
@@ -557,14 +558,20 @@ class feature_extraction(nn.Module):
             # bilinear resizing is per channel: up(cat(pieces)) = cat(up(piece)) -- every piece is up-sampled straight into its
             # channel slice of the 352-channel input of lastconv (no torch.cat of the pieces, no copy of the up-sampled 320
             # channels into the second torch.cat: ~2 GB of traffic per forward at B=8)
-            ctot = sum(t.shape[1] for t in pieces) + o0.shape[1]
-            feat = torch.empty((skip.shape[0], ctot, hw[0] * 2, hw[1] * 2), dtype=skip.dtype, device=skip.device,
-                               memory_format=torch.channels_last)
-            off = 0
-            for t in pieces:
-                ops.resize_bilinear_into(t, feat, off, align_corners=True)
-                off += t.shape[1]
-            feat[:, off:].copy_(o0)
+            if UPSAMPLE_CAT and all(tuple(t.shape[2:]) == tuple(hw) for t in pieces) and tuple(o0.shape[2:]) == (hw[0] * 2, hw[1] * 2) \
+                    and o0.is_contiguous(memory_format=torch.channels_last):
+                # ... and in ONE launch that writes whole 352-channel pixels, layer1's 32 channels included (six launches writing
+                # 64 .. 256-byte pieces 704 bytes apart + a copy: 0.40 ms; ISLAM_UPSAMPLE_CAT=0)
+                feat = ops.upsample_cat(pieces, (hw[0] * 2, hw[1] * 2), tail=o0, align_corners=True)
+            else:
+                ctot = sum(t.shape[1] for t in pieces) + o0.shape[1]
+                feat = torch.empty((skip.shape[0], ctot, hw[0] * 2, hw[1] * 2), dtype=skip.dtype, device=skip.device,
+                                   memory_format=torch.channels_last)
+                off = 0
+                for t in pieces:
+                    ops.resize_bilinear_into(t, feat, off, align_corners=True)
+                    off += t.shape[1]
+                feat[:, off:].copy_(o0)
         else:
             feat = torch.cat(pieces, 1)
             if self.bigger:

@@ -494,6 +494,32 @@ def resize_bilinear_into(x, out, coff, align_corners=False):
     return out
 
 
+def upsample_cat(pieces, size, tail=None, align_corners=False):
+    """torch.cat([F.interpolate(p, size, mode='bilinear') for p in pieces] + [tail], 1) for channels-last bf16 pieces of one shape
+    (B, C_k, Hi, Wi), C_k multiples of 8, at most 8 of them; tail: (B, C_t, *size) or None.  One launch
+    (islam_upsample_cat_nhwc_bf16); every value is the one resize_bilinear produces."""
+    import ctypes
+    B, _, Hi, Wi = pieces[0].shape
+    Ho, Wo = int(size[0]), int(size[1])
+    for t in pieces:
+        assert t.dtype == torch.bfloat16 and t.is_contiguous(memory_format=torch.channels_last) and t.shape[0] == B and tuple(t.shape[2:]) == (Hi, Wi)
+        assert t.shape[1] % 8 == 0
+    ct = 0
+    if tail is not None:
+        assert tail.dtype == torch.bfloat16 and tail.is_contiguous(memory_format=torch.channels_last) and tuple(tail.shape[2:]) == (Ho, Wo)
+        assert tail.shape[0] == B and tail.shape[1] % 8 == 0
+        ct = int(tail.shape[1])
+    n = len(pieces)
+    assert 1 <= n <= 8
+    out = torch.empty((B, sum(int(t.shape[1]) for t in pieces) + ct, Ho, Wo), dtype=torch.bfloat16, device=pieces[0].device,
+                      memory_format=torch.channels_last)
+    srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in pieces])
+    chans = (ctypes.c_int * n)(*[int(t.shape[1]) for t in pieces])
+    check(lib().islam_upsample_cat_nhwc_bf16(srcs, chans, n, ptr(tail) if tail is not None else None, ct, ptr(out), B, Hi, Wi, Ho, Wo,
+                                             int(bool(align_corners)), stream_ptr(out.device)))
+    return out
+
+
 def nchw_to_nhwc_mirror(src, soff, C, dst, doff):
     """fp32 NCHW channels [soff, soff+C) of ``src`` -> bf16 channels [doff, doff+C) of the channels-last tensor ``dst`` (a
     (B, Ctot, H, W) bf16 tensor in torch.channels_last memory format); the channels up to the next multiple of 8 are zeroed."""

@@ -60,3 +60,30 @@ def test_half_resolution_image_into_the_concatenation(cuda, B, C, H, W):
     want = F.interpolate(x, scale_factor=0.5, mode='bilinear')
     assert torch.equal(out[:, 8:8 + C], want)
     assert bool((out[:, 8 + C:16] == 0).all()) and bool((out[:, :8] == 5.0).all()) and bool((out[:, 16:] == 5.0).all())
+
+
+@pytest.mark.parametrize('B,chans,tail,hw,align', [(2, (64, 128, 32, 32, 32, 32), 32, (14, 20), True), (1, (8, 16), 0, (9, 7), False),
+                                                  (3, (24,), 8, (5, 11), True), (2, (32, 32, 32, 32, 32, 32, 32, 32), 16, (6, 6), False)])
+def test_upsample_and_concatenate_in_one_launch(cuda, B, chans, tail, hw, align):
+    """islam_upsample_cat_nhwc_bf16 == one islam_resize_bilinear_nhwc_bf16_into per piece + a copy of the tail (bit for bit): the
+    `bigger` feature extractor's 352-channel input of lastconv (islam_amd/nets.py: feature_extraction.forward; reference:
+    Network/StereoNet7.py:36-46, Network/PSM/submodule.py:139-152)."""
+    from islam_amd import ops
+    torch.manual_seed(3)
+    cl = lambda t: t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    pieces = [cl(torch.randn(B, c, *hw, device=cuda)) for c in chans]
+    size = (hw[0] * 2, hw[1] * 2)
+    t = cl(torch.randn(B, tail, *size, device=cuda)) if tail else None
+    got = ops.upsample_cat(pieces, size, tail=t, align_corners=align)
+    ref = torch.empty_like(got)
+    off = 0
+    for p in pieces:
+        ops.resize_bilinear_into(p, ref, off, align_corners=align)
+        off += p.shape[1]
+    if tail:
+        ref[:, off:].copy_(t)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, ref)
+    # ... and resize_bilinear itself is F.interpolate up to one bf16 rounding of the fp32 result
+    want = torch.cat([torch.nn.functional.interpolate(p.float(), size, mode='bilinear', align_corners=align) for p in pieces], 1)
+    assert (got[:, :off].float() - want).abs().max() <= 2 ** -7 * want.abs().max()
