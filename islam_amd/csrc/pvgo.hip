@@ -2726,15 +2726,9 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     const double d_spec = first ? a.st[2] : speculated_damping(a.st, a.tr);       // (read before this workgroup publishes: the decision comes later)
     // the level's segments are dealt out evenly: workgroup wg takes segments [wg P / nwg, (wg+1) P / nwg) -- three or four of them
     // on the 5000-frame graph, so that all 256 CUs share the level's pivots
-    // (levels with more than FZ_S segments per workgroup -- graphs beyond ~8000 frames per GPU: the workgroup takes its range in
-    // chunks of FZ_S consecutive segments, one after the other through the same LDS, and publishes the sums of all of them)
-    const int segA = a.seg_lo + (int)(((long long)wg * a.P) / a.nwg), segB = a.seg_lo + (int)(((long long)(wg + 1) * a.P) / a.nwg);
-    const int m = a.m, stride = m + 1;
-    double acc_s = 0.0, acc_q = 0.0;                             // (lane 0 of the publishing helper wave)
-    for (int seg0 = segA; seg0 < segB; seg0 += FZ_S) {
-    const int seg1 = min(seg0 + FZ_S, segB);
-    const int G = (seg1 - seg0) * stride;
-    const bool ownl = a.own_left && wg == 0 && seg0 == segA;     // (sharded: the link cb-1 -> cb has no other owner on this rank)
+    const int seg0 = a.seg_lo + (int)(((long long)wg * a.P) / a.nwg), seg1 = a.seg_lo + (int)(((long long)(wg + 1) * a.P) / a.nwg);
+    const int m = a.m, stride = m + 1, G = (seg1 - seg0) * stride;
+    const bool ownl = a.own_left && wg == 0;                     // (sharded: the link cb-1 -> cb has no other owner on this rank)
     const int cb = seg0 * stride;                                // first node of the stretch; links cb-1 .. cb+G-1, nodes cb-1 .. cb+G
     [[maybe_unused]] const bool fpr = lane == 0 && (wg == 1 || wg == a.nwg / 2);     // probe build only
     [[maybe_unused]] const int fpo = 600 + (wg == 1 ? 0 : 100) + 12 * wave;
@@ -2985,21 +2979,17 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                 sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
             }
             sq = wave_sum(sq);
-            acc_s += sq;
-            acc_q += s_sum[1];
-            if (seg1 < segB) {
-                // (more chunks follow: the sums are published with the last one)
-            } else if (lane == 0 && a.shard) {       // the sums and the decision come after the all-reduce (shard_pack / shard_decide)
-                a.part[2 * wg] = acc_s;
-                a.part[2 * wg + 1] = acc_q;
+            if (lane == 0 && a.shard) {              // the sums and the decision come after the all-reduce (shard_pack / shard_decide)
+                a.part[2 * wg] = sq;
+                a.part[2 * wg + 1] = s_sum[1];
                 if (wg == 0) {
                     a.part[2 * a.nwg] = (!first && (a.flags[0] != 0 || *a.eflag_prev != 0)) ? 1.0 : 0.0;
                     a.flags[0] = 0;
                     *a.eflag_prev = 0;
                 }
             } else if (lane == 0) {
-                st_coherent(&a.part[2 * wg], acc_s);
-                st_coherent(&a.part[2 * wg + 1], acc_q);
+                st_coherent(&a.part[2 * wg], sq);
+                st_coherent(&a.part[2 * wg + 1], s_sum[1]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3023,10 +3013,8 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         }
         twisted_helper<2>(a.dst, sg, nbar, lane);
     }
-    if (seg1 < segB) lds_barrier();                  // the next chunk's retraction writes where this chunk's links were read
     PROBE_WALL(fpr, fpo + 5);
     PROBE_WALL(threadIdx.x == 0 && blockIdx.x < 300, 0 + blockIdx.x);
-    }
 }
 
 // state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
@@ -3769,15 +3757,6 @@ static int reproj_dev_local(const islam_pvgo_reproj* r, int link0, ReprojDev& d)
     return ISLAM_OK;
 }
 
-// trial_elim_kernel on levels with more than FZ_S segments per workgroup: it loops over chunks of FZ_S segments.  Off unless
-// ISLAM_FZ_CHUNKS=1 (read per call: tests, A/B runs): one workgroup per CU walking its chunks one after the other is latency-bound
-// where the launched level-0 kernel keeps three workgroups per CU in flight -- measured per LM trial, launch-per-stage / chunked:
-// N = 9000 89 / 119 us, 20 010 135 / 179 us, 40 010 234 / 407 us, 100 002 438 / 742 us (scripts/chunk_time.py).
-static bool fz_chunks() {
-    const char* e = std::getenv("ISLAM_FZ_CHUNKS");
-    return e && e[0] == '1';
-}
-
 static int device_cus() {
     static int cus[64] = {};
     int dev_i = 0;
@@ -4078,7 +4057,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     }
     const int cus = std::max(device_cus() - fz_spare, 1);
     if (!(N > 96 && sp.twisted && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM && prm->reject < STATE_DOUBLES - STATE_HIST - 1 &&
-          ((max_nseg + std::min(max_nseg, cus) - 1) / std::min(max_nseg, cus) <= FZ_S || fz_chunks())))
+          (max_nseg + std::min(max_nseg, cus) - 1) / std::min(max_nseg, cus) <= FZ_S))
         return ISLAM_OK;
     if (workspace_bytes < islam_pvgo_workspace_bytes(N)) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: workspace too small");
     if (scratch_bytes < shard_fused_scratch_doubles(N, world) * sizeof(double)) return fail(ISLAM_EARG, "islam_pvgo_run_chain_sharded: scratch too small");
@@ -4539,8 +4518,7 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
     // are cheaper than the fused kernel's fixed cost and a rejected trial costs no mis-speculated chain.  Measured per run_pvgo, fused /
     // launch-per-stage: N = 9 (18 trials) 1059 / 723 us, N = 65 206 / 190 us, N = 129 203 / 236 us, N = 513 443 / 508 us.)
     const bool fused = !no_fuse && !reproj && N > 96 && sp.twisted && sp.nl >= 2 && sp.top == sp.nl - 1 && sp.lv[0].m <= FZ_MAXM &&
-                       prm->reject < STATE_DOUBLES - STATE_HIST - 1 &&
-                       ((sp.lv[0].P + fz_nwg - 1) / fz_nwg <= FZ_S || fz_chunks());
+                       prm->reject < STATE_DOUBLES - STATE_HIST - 1 && (sp.lv[0].P + fz_nwg - 1) / fz_nwg <= FZ_S;
     if (fused) {
         static bool fz_attr_set[64] = {};                        // per device: the attribute lives in the device's code object
         int dev_i = 0;
