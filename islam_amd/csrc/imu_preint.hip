@@ -346,8 +346,10 @@ __global__ __launch_bounds__(64) void frame_kernel(const T* __restrict__ dt, con
 }
 
 // D: outputs.  world mode: sequential p/v chain (row 0 = init).  motion mode: every frame starts from p = v = 0.
+// (launched with 64 or 256 threads; without the bound the compiler budgets registers for 1024-thread blocks -- 128 per lane -- and the
+// world-mode walk spilled 17 of them)
 template <class T>
-__global__ void finish_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
+__global__ __launch_bounds__(256) void finish_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
                               const T* __restrict__ loc, const T* __restrict__ init_pos, const T* __restrict__ init_vel,
                               int motion_mode, T* __restrict__ out_pos, T* __restrict__ out_rot, T* __restrict__ out_vel) {
     if (motion_mode) {
