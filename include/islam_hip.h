@@ -129,6 +129,11 @@ int islam_resize_bilinear_nhwc_bf16_into(const uint16_t* x, uint16_t* y, int B, 
  * islam_resize_bilinear_nhwc_bf16's arithmetic; whole pixels are written contiguously. */
 int islam_upsample_cat_nhwc_bf16(const uint16_t* const* srcs, const int* chans, int n, const uint16_t* tail, int tailC, uint16_t* y,
                                  int B, int Hi, int Wi, int Ho, int Wo, int align_corners, void* stream);
+/* The stereo pair as the feature extractor's batch (Network/StereoNet7.py:95-97 feeds left and right images through one
+ * feature_extraction): x (B, H, W, C2) channels-last bf16 with the left image in channels [0, C2/2) and the right one behind it;
+ * y (2B, H, W, 8): images [0, B) left, [B, 2B) right, channels [C2/2, 8) zero -- the input of the 3 -> 32 stride-2 first layer
+ * (Network/PSM/submodule.py:63) on islam_conv_nhwc_bf16_s2 with its weights zero-padded to 8 input channels. */
+int islam_stack_pair_pad8_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C2, int H, int W, void* stream);
 /* y = add + resize(x) in one pass (hourglass.py:60-69 `up1 + up2(low3)`): the up-sampled value is rounded to bf16 before the add,
  * like the two separate ops.  add, y: (B,Ho,Wo,C). */
 int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,

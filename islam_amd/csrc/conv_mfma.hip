@@ -403,6 +403,36 @@ __global__ __launch_bounds__(256) void upsample_cat_nhwc_bf16_kernel(UpCatArgs a
     y[i] = o;
 }
 
+// The stereo pair as the feature extractor's batch: x (B, H, W, 2c) channels-last bf16 holds the left image in channels [0, c) and the
+// right one in [c, 2c) (Network/StereoNet7.py:95-97 runs both through one feature extractor); y (2B, H, W, 8): image b = left image b,
+// image B + b = right image b, channels [c, 8) zero -- the 8-channel input islam_conv_nhwc_bf16_s2 stages for the 3 -> 32 first layer
+// (Network/PSM/submodule.py:63), written by one launch instead of torch.cat + MIOpen's own layout pass.  One 16-byte store per pixel.
+__global__ __launch_bounds__(256) void stack_pair_pad8_kernel(const unsigned short* __restrict__ x, uint4* __restrict__ y, int B, int c,
+                                                              long long HW, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long n = i / HW, p = i - n * HW;
+    const int side = n >= B ? 1 : 0;
+    const unsigned short* s = x + (((long long)(n - (side ? B : 0)) * HW + p) * 2 + side) * c;
+    unsigned short v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < c ? s[k] : (unsigned short)0;
+    uint4 o;
+    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+    o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+    y[i] = o;
+}
+
+extern "C" int islam_stack_pair_pad8_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C2, int H, int W, void* stream) {
+    if (!x || !y || B < 1 || C2 < 2 || (C2 & 1) || C2 > 16 || H < 1 || W < 1)
+        return fail(ISLAM_EARG, "islam_stack_pair_pad8_nhwc_bf16: bad argument (B=%d, C2=%d, %dx%d)", B, C2, H, W);
+    const long long HW = (long long)H * W, total = 2LL * B * HW;
+    hipLaunchKernelGGL(stack_pair_pad8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<uint4*>(y), B, C2 / 2, HW, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 // 2x2 / stride-2 max pooling (floor mode), optionally of relu(x): relu and max commute
 __global__ __launch_bounds__(256) void maxpool2_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8, int Hi, int Wi,
                                                                  int Ho, int Wo, int relu, long long total) {

@@ -392,6 +392,7 @@ HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
+HIP_FIRST_LAYER = os.environ.get('ISLAM_HIP_FIRST_LAYER', '1') != '0'   # the 3 -> 32 stride-2 first layer of the stereo net on the channels-last kernel
 UPSAMPLE_CAT = os.environ.get('ISLAM_UPSAMPLE_CAT', '1') != '0'     # the feature extractor's six up-samplings + concatenation as one launch
 # the feature extractor's last convolution writes conv_c0's input in place (left images first in the batch); 0: dense features + two copies
 STEREO_DIRECT_CAT = os.environ.get('ISLAM_STEREO_DIRECT_CAT', '1') != '0'
@@ -544,7 +545,24 @@ class feature_extraction(nn.Module):
         when it returns a buffer, the result is written into those channel slices of it (batch ranges of the result, in order)
         and the buffer is returned instead of the feature tensor -- StereoNet7 assembles conv_c0's input this way."""
         f = x
-        for i in (0, 2, 4):                                  # firstconv = (convbn, ReLU) x 3; the middle one's BatchNorm + ReLU
+        c0, bn0 = self.firstconv[0][0], self.firstconv[0][1]
+        if (x.shape[1] == 8 and c0.in_channels < 8 and HIP_CONV_S2 and HIP_CONV_LEVEL >= 1 and ops.fusable_nhwc_bf16(x, 8)
+                and c0.weight.dtype == torch.bfloat16 and c0.kernel_size == (3, 3) and c0.stride == (2, 2) and c0.padding == (1, 1)
+                and c0.bias is None and type(bn0) is nn.BatchNorm2d and bn0.training and bn0.weight.dtype == torch.float32):
+            # x = ops.stack_pair_pad8 of the stereo pair (StereoNet7.forward): the 3 -> 32 stride-2 first layer on the channels-last
+            # kernel with its weights zero-padded to 8 input channels, statistics from the epilogue, BatchNorm + ReLU applied by the second
+            # convolution's load (MIOpen: a layout pass, the convolution, a statistics pass and an apply pass)
+            key = (c0.weight._version, c0.weight.data_ptr())
+            hit = self.__dict__.get('_first8')
+            if hit is None or hit[0] != key:
+                hit = self.__dict__['_first8'] = (key, ops.pack_conv_nhwc_weight(F.pad(c0.weight.detach(), (0, 0, 0, 0, 0, 8 - c0.in_channels))))
+            y, folded = ops.conv_nhwc_s2(x, hit[1], c0.out_channels, 3, stats=True)
+            f = _Pending(y, ops.bn_finalize(folded, bn0, y.shape[0] * y.shape[2] * y.shape[3]))
+        else:
+            if x.shape[1] == 8 and c0.in_channels < 8:
+                f = x[:, :c0.in_channels].contiguous(memory_format=torch.channels_last)
+            f = _cbn(self.firstconv[0], f, relu=True)
+        for i in (2, 4):                                     # firstconv = (convbn, ReLU) x 3; the middle one's BatchNorm + ReLU
             f = _cbn(self.firstconv[i], f, relu=True, defer=(i == 2))      # is applied by the third convolution's load
         o0 = self.layer1(f)
         raw = self.layer2(o0)
@@ -753,7 +771,10 @@ class StereoNet7(nn.Module):
             direct['buf'] = torch.empty((B, cin, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
             return direct['buf'], [(0, B, 0), (B, B, cf)]
         stacked = STEREO_DIRECT_CAT and x.dtype == torch.bfloat16
-        xs = torch.cat((x[:, :C2 // 2], x[:, C2 // 2:]), 0) if stacked else x.reshape(B * 2, C2 // 2, H, W)
+        if stacked and HIP_FIRST_LAYER and HIP_CONV_S2 and C2 // 2 < 8 and x.is_contiguous(memory_format=torch.channels_last):
+            xs = ops.stack_pair_pad8(x)                      # [left images; right images], three channels padded to eight
+        else:
+            xs = torch.cat((x[:, :C2 // 2], x[:, C2 // 2:]), 0) if stacked else x.reshape(B * 2, C2 // 2, H, W)
         f2 = self.feature_extraction(xs, into=into if stacked else None)      # left / right images stacked along the batch
         half = None
         act = self.actfun

@@ -494,6 +494,16 @@ def resize_bilinear_into(x, out, coff, align_corners=False):
     return out
 
 
+def stack_pair_pad8(x):
+    """(B, 2c, H, W) channels-last bf16 stereo pair -> (2B, 8, H, W): left images, then right images, channels [c, 8) zero
+    (islam_stack_pair_pad8_nhwc_bf16)."""
+    B, C2, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and C2 % 2 == 0 and C2 <= 16
+    y = torch.empty((2 * B, 8, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib().islam_stack_pair_pad8_nhwc_bf16(ptr(x), ptr(y), B, C2, H, W, stream_ptr(x.device)))
+    return y
+
+
 def upsample_cat(pieces, size, tail=None, align_corners=False):
     """torch.cat([F.interpolate(p, size, mode='bilinear') for p in pieces] + [tail], 1) for channels-last bf16 pieces of one shape
     (B, C_k, Hi, Wi), C_k multiples of 8, at most 8 of them; tail: (B, C_t, *size) or None.  One launch

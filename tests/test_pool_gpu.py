@@ -87,3 +87,19 @@ def test_upsample_and_concatenate_in_one_launch(cuda, B, chans, tail, hw, align)
     # ... and resize_bilinear itself is F.interpolate up to one bf16 rounding of the fp32 result
     want = torch.cat([torch.nn.functional.interpolate(p.float(), size, mode='bilinear', align_corners=align) for p in pieces], 1)
     assert (got[:, :off].float() - want).abs().max() <= 2 ** -7 * want.abs().max()
+
+
+@pytest.mark.parametrize('B,C2,H,W', [(2, 6, 10, 14), (1, 2, 5, 3), (3, 16, 4, 6)])
+def test_stereo_pair_stacked_and_padded_to_eight_channels(cuda, B, C2, H, W):
+    """islam_stack_pair_pad8_nhwc_bf16: [left images; right images] of a channels-last pair with the channels zero-padded to eight -- the
+    input of the stereo net's first layer on the channels-last kernel (islam_amd/nets.py: StereoNet7.forward; reference:
+    Network/StereoNet7.py:95-97)."""
+    from islam_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(B, C2, H, W, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = ops.stack_pair_pad8(x)
+    c = C2 // 2
+    want = torch.zeros(2 * B, 8, H, W, dtype=torch.bfloat16, device=cuda)
+    want[:B, :c] = x[:, :c]
+    want[B:, :c] = x[:, c:]
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, want)
