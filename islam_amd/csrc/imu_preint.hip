@@ -116,7 +116,8 @@ template <class T> __device__ __forceinline__ void stq(Q<T> q, T* p) { p[0] = q.
 // A: per frame i, incre_r (F_i + 1 quaternions) -> ir[(seg[i] + i) .. ]   (frame i owns F_i + 1 slots)
 template <class T>
 __global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, const T* __restrict__ gyro,
-                                                   const int64_t* __restrict__ seg, T* __restrict__ ir) {
+                                                   const int64_t* __restrict__ seg, T* __restrict__ ir, int* __restrict__ zero_word) {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;       // chain_world_kernel's published-rows counter
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* buf0 = reinterpret_cast<T*>(smem_raw);
     const int i = blockIdx.x;
@@ -201,9 +202,29 @@ __device__ __forceinline__ float rot_step(float rc, float f0, float f1, float f2
 
 constexpr int ROT_U = 8;              // frames per register block of the walk: one LDS round trip per block instead of per frame
 
+// rows of R0 that every agent may read: published (release, agent scope) by the rotation chain's workgroup after each chunk it has
+// copied out, awaited (acquire) by the p / v chain's workgroup of chain_world_kernel
+__device__ __forceinline__ void publish_rows(int* ready, int rows) {
+    __threadfence();
+    __hip_atomic_store(ready, rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void await_rows(const int* ready, int rows) {
+    if ((threadIdx.x & 63) == 0)
+        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < rows) __builtin_amdgcn_s_sleep(4);
+    __threadfence();
+}
+
 template <class T>
-__global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
-                                                         const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy) {
+struct RotLds {
+    T sb[2][ROT_CHUNK + 3 * ROT_U][4][4];
+    T out[2][ROT_CHUNK + 2 * ROT_U][4];      // R0[base + 1 + j]
+    unsigned long long hasm[2][ROT_CHUNK / 64 + 1];                        // bit j: F_j > 0 (frames past the chunk: 0)
+};
+
+// ready != nullptr: the number of valid rows of R0 is published after every chunk (chain_world_kernel)
+template <class T>
+__device__ __forceinline__ void chain_rot_body(RotLds<T>& L, const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                               const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy, int* ready) {
     // sb[.][j][c][k]: factor of term k of output component c (x, y, z, w) for frame j's increment b = incre_r_j[F_j], in the order
     // qmul multiplies the running rotation's components w, x, y, z:
     //   x: a.w b.x + a.x b.w + a.y b.z - a.z b.y    y: a.w b.y - a.x b.z + a.y b.w + a.z b.x
@@ -211,9 +232,9 @@ __global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restric
     // Two buffers: while wave 0 walks chunk k, waves 1-3 stage chunk k + 1 (two dependent global round trips per frame: offsets,
     // then the increment) and copy chunk k - 1 out -- the walk is all that is left on the kernel's critical path.
     // (rows past a chunk's last frame are read by the walk's look-ahead and never used)
-    __shared__ __attribute__((aligned(16))) T sb[2][ROT_CHUNK + 3 * ROT_U][4][4];
-    __shared__ __attribute__((aligned(16))) T out[2][ROT_CHUNK + 2 * ROT_U][4];      // R0[base + 1 + j]
-    __shared__ unsigned long long hasm[2][ROT_CHUNK / 64 + 1];                        // bit j: F_j > 0 (frames past the chunk: 0)
+    auto& sb = L.sb;
+    auto& out = L.out;
+    auto& hasm = L.hasm;
     const int tid = threadIdx.x;
     const int nchunk = (nframes + ROT_CHUNK - 1) / ROT_CHUNK;
     // lane c < 4 of wave 0 carries component c of the running rotation (x, y, z, w)
@@ -301,19 +322,27 @@ __global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restric
             }
         }
         __syncthreads();
+        if (ready && tid == 0) publish_rows(ready, 1 + k * ROT_CHUNK);          // R0[0 .. k ROT_CHUNK] are in memory
     }
     copy_out(nchunk - 1, tid, 256);
+    if (ready) {
+        __syncthreads();
+        if (tid == 0) publish_rows(ready, nframes + 1);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void chain_rot_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                                         const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy) {
+    __shared__ __attribute__((aligned(16))) RotLds<T> L;
+    chain_rot_body<T>(L, seg, nframes, ir, init_rot, R0, rot_copy, nullptr);
 }
 
 // C: per frame (one lane each): local integration, rotated into the frame's start orientation.
 //    loc[i] = { R0_i incre_v[F] (3), R0_i incre_p[F] (3), incre_t (1) }
 template <class T>
-__global__ __launch_bounds__(64) void frame_kernel(const T* __restrict__ dt, const T* __restrict__ acc,
-                                                    const int64_t* __restrict__ seg, int nframes,
-                                                    const T* __restrict__ ir, const T* __restrict__ R0, T gravity,
-                                                    T* __restrict__ loc) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= nframes) return;
+__device__ __forceinline__ void frame_loc(int i, const T* __restrict__ dt, const T* __restrict__ acc, const int64_t* __restrict__ seg,
+                                          const T* __restrict__ ir, const T* __restrict__ R0, T gravity, T (&o)[7]) {
     const int a = (int)seg[i], F = (int)(seg[i + 1] - seg[i]);
     const Q<T> r0 = ldq(R0 + 4 * (size_t)i);
     const T* irf = ir + 4 * ((size_t)a + i);
@@ -341,49 +370,75 @@ __global__ __launch_bounds__(64) void frame_kernel(const T* __restrict__ dt, con
     T rv[3], rp[3];
     qact(r0, iv, rv);
     qact(r0, ip, rp);
-    T* o = loc + 7 * (size_t)i;
     o[0] = rv[0]; o[1] = rv[1]; o[2] = rv[2]; o[3] = rp[0]; o[4] = rp[1]; o[5] = rp[2]; o[6] = it;
 }
 
-// D: outputs.  world mode: sequential p/v chain (row 0 = init).  motion mode: every frame starts from p = v = 0.
-// (launched with 64 or 256 threads; without the bound the compiler budgets registers for 1024-thread blocks -- 128 per lane -- and the
-// world-mode walk spilled 17 of them)
 template <class T>
-__global__ __launch_bounds__(256) void finish_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
-                              const T* __restrict__ loc, const T* __restrict__ init_pos, const T* __restrict__ init_vel,
-                              int motion_mode, T* __restrict__ out_pos, T* __restrict__ out_rot, T* __restrict__ out_vel) {
-    if (motion_mode) {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= nframes) return;
-        const int F = (int)(seg[i + 1] - seg[i]);
-        const T* l = loc + 7 * (size_t)i;
-        const T zero = 0;
+__global__ __launch_bounds__(64) void frame_kernel(const T* __restrict__ dt, const T* __restrict__ acc,
+                                                    const int64_t* __restrict__ seg, int nframes,
+                                                    const T* __restrict__ ir, const T* __restrict__ R0, T gravity,
+                                                    T* __restrict__ loc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nframes) return;
+    T o[7];
+    frame_loc<T>(i, dt, acc, seg, ir, R0, gravity, o);
+    T* d = loc + 7 * (size_t)i;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            // predict with p0 = v0 = 0:  vel = 0 + R0 iv ; pos = (0 + R0 ip) + 0 * t
-            out_vel[3 * (size_t)i + c] = (F > 0) ? (zero + l[c]) : zero;
-            out_pos[3 * (size_t)i + c] = (F > 0) ? ((zero + l[3 + c]) + zero * l[6]) : zero;
-        }
-        Q<T> a = ldq(R0 + 4 * (size_t)i), b = ldq(R0 + 4 * (size_t)(i + 1));
-        Q<T> ai{-a.x, -a.y, -a.z, a.w};
-        stq(qmul(ai, b), out_rot + 4 * (size_t)i);
-        return;
-    }
+    for (int c = 0; c < 7; ++c) d[c] = o[c];
+}
+
+template <class T>
+struct ChainLds {
+    T sl[2][CHAIN_CHUNK + 3 * ROT_U][7];      // (rows past a chunk's last frame: look-ahead only)
+    T so[2][CHAIN_CHUNK + 2 * ROT_U][6];
+    unsigned long long hasm[2][CHAIN_CHUNK / 64 + 1];                       // bit j: F_j > 0
+};
+// what the p / v chain needs to compute its frame terms itself (chain_world_kernel); ready == nullptr: they are read from `loc`
+template <class T>
+struct FrameSrc { const int* ready; const T* dt; const T* acc; const T* ir; T gravity; T* loc_out; };
+
+template <class T>
+__device__ __forceinline__ void chain_pv_body(ChainLds<T>& L, const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
+                                              const T* __restrict__ loc, const T* __restrict__ init_pos, const T* __restrict__ init_vel,
+                                              T* __restrict__ out_pos, T* __restrict__ out_vel, const FrameSrc<T>& fr) {
     // world mode: sequential p/v chain (three lanes of wave 0, one per coordinate).  Two LDS buffers: while wave 0 walks chunk k,
     // waves 1-3 stage the per-frame terms of chunk k + 1 (all of a thread's global loads issued before the first LDS store: one
     // memory round trip per chunk instead of ten) and copy chunk k - 1 out.  (The rotations of the world rows are written by
     // chain_rot_kernel.)
-    __shared__ __attribute__((aligned(16))) T sl[2][CHAIN_CHUNK + 3 * ROT_U][7];      // (rows past a chunk's last frame: look-ahead only)
-    __shared__ __attribute__((aligned(16))) T so[2][CHAIN_CHUNK + 2 * ROT_U][6];
-    __shared__ unsigned long long hasm[2][CHAIN_CHUNK / 64 + 1];                       // bit j: F_j > 0
+    auto& sl = L.sl;
+    auto& so = L.so;
+    auto& hasm = L.hasm;
     const int tid = threadIdx.x;
-    if (blockIdx.x != 0) return;
     const int nchunk = (nframes + CHAIN_CHUNK - 1) / CHAIN_CHUNK;
     if (tid < 3) { out_pos[tid] = init_pos[tid]; out_vel[tid] = init_vel[tid]; }
     if (tid < 2) hasm[tid][CHAIN_CHUNK / 64] = 0;
     constexpr int SL_ITEMS = (CHAIN_CHUNK * 7 + 191) / 192;          // loc values per staging thread (192 threads in the loop)
     auto stage = [&](int k, int t, int nt) {
         const int base = k * CHAIN_CHUNK, cnt = min(CHAIN_CHUNK, nframes - base), b = k & 1;
+        if (fr.ready) {
+            // chain_world_kernel: the frame terms are computed HERE (frame_kernel's arithmetic, one frame per thread) as soon as the
+            // rotation chain's workgroup has published the chunk's rows of R0 -- the chain of this workgroup runs a chunk or two behind
+            // the other one instead of a whole kernel behind it
+            await_rows(fr.ready, base + cnt);
+            for (int j = t; j < CHAIN_CHUNK; j += nt) {
+                bool h = false;
+                if (j < cnt) {
+                    T o[7];
+                    frame_loc<T>(base + j, fr.dt, fr.acc, seg, fr.ir, R0, fr.gravity, o);
+                    h = seg[base + j + 1] > seg[base + j];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) sl[b][j][c] = o[c];
+                    if (fr.loc_out) {
+                        T* d = fr.loc_out + 7 * (size_t)(base + j);
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) d[c] = o[c];
+                    }
+                }
+                const unsigned long long m = __ballot(h);
+                if ((t & 63) == 0) hasm[b][j >> 6] = m;
+            }
+            return;
+        }
         T r[SL_ITEMS];
         const T* src = loc + 7 * (size_t)base;
 #pragma unroll
@@ -469,6 +524,55 @@ __global__ __launch_bounds__(256) void finish_kernel(const int64_t* __restrict__
     copy_out(nchunk - 1, tid, 256);
 }
 
+// D: outputs.  world mode: sequential p/v chain (row 0 = init).  motion mode: every frame starts from p = v = 0.
+// (launched with 64 or 256 threads; without the bound the compiler budgets registers for 1024-thread blocks -- 128 per lane -- and the
+// world-mode walk spilled 17 of them)
+template <class T>
+__global__ __launch_bounds__(256) void finish_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
+                              const T* __restrict__ loc, const T* __restrict__ init_pos, const T* __restrict__ init_vel,
+                              int motion_mode, T* __restrict__ out_pos, T* __restrict__ out_rot, T* __restrict__ out_vel) {
+    if (motion_mode) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= nframes) return;
+        const int F = (int)(seg[i + 1] - seg[i]);
+        const T* l = loc + 7 * (size_t)i;
+        const T zero = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // predict with p0 = v0 = 0:  vel = 0 + R0 iv ; pos = (0 + R0 ip) + 0 * t
+            out_vel[3 * (size_t)i + c] = (F > 0) ? (zero + l[c]) : zero;
+            out_pos[3 * (size_t)i + c] = (F > 0) ? ((zero + l[3 + c]) + zero * l[6]) : zero;
+        }
+        Q<T> a = ldq(R0 + 4 * (size_t)i), b = ldq(R0 + 4 * (size_t)(i + 1));
+        Q<T> ai{-a.x, -a.y, -a.z, a.w};
+        stq(qmul(ai, b), out_rot + 4 * (size_t)i);
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    __shared__ __attribute__((aligned(16))) ChainLds<T> L;
+    const FrameSrc<T> none{nullptr, nullptr, nullptr, nullptr, (T)0, nullptr};
+    chain_pv_body<T>(L, seg, nframes, R0, loc, init_pos, init_vel, out_pos, out_vel, none);
+}
+
+// World rows in ONE launch of two workgroups: workgroup 0 walks the rotation chain (chain_rot_kernel's body) and publishes the rows of
+// R0 chunk by chunk; workgroup 1 turns them into the frames' terms (frame_kernel's arithmetic) and walks the p / v chain
+// (finish_kernel's body) a chunk or two behind -- the two serial chains of a 5000-frame trajectory overlap (236 us + 165 us one
+// after the other before).  Both workgroups are resident by construction (a grid of two).
+template <class T>
+__global__ __launch_bounds__(256) void chain_world_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
+                                                           const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy,
+                                                           const T* __restrict__ dt, const T* __restrict__ acc, T gravity, T* __restrict__ loc_out,
+                                                           const T* __restrict__ init_pos, const T* __restrict__ init_vel,
+                                                           T* __restrict__ out_pos, T* __restrict__ out_vel, int* __restrict__ ready) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    if (blockIdx.x == 0) {
+        chain_rot_body<T>(*reinterpret_cast<RotLds<T>*>(dyn_lds), seg, nframes, ir, init_rot, R0, rot_copy, ready);
+    } else {
+        const FrameSrc<T> fr{ready, dt, acc, ir, gravity, loc_out};
+        chain_pv_body<T>(*reinterpret_cast<ChainLds<T>*>(dyn_lds), seg, nframes, R0, nullptr, init_pos, init_vel, out_pos, out_vel, fr);
+    }
+}
+
 template <class T>
 int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframes, int64_t S, const T* ip, const T* ir0,
         const T* iv, double gravity, int motion_mode, T* opos, T* orot, T* ovel, void* scratch, int maxF, hipStream_t s,
@@ -478,15 +582,27 @@ int run(const T* dt, const T* gyro, const T* acc, const int64_t* seg, int nframe
     T* loc = R0 + 4 * ((size_t)nframes + 1);               // 7 * nframes
     const size_t lds = 2 * 4 * (size_t)(maxF + 1) * sizeof(T);
     if (lds > 64 * 1024) return fail(ISLAM_EARG, "islam_imu_preint: %d IMU samples in one frame interval exceed the LDS scan buffer", maxF);
-    hipLaunchKernelGGL(scan_kernel<T>, dim3(nframes), dim3(64), lds, s, dt, gyro, seg, ir);
-    hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, ir, ir0, R0, motion_mode != 1 ? orot : (T*)nullptr);
-    hipLaunchKernelGGL(frame_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, dt, acc, seg, nframes, ir, R0, (T)gravity, loc);
+    // world rows: the two serial chains in one launch of two workgroups (chain_world_kernel); ISLAM_IMU_FUSED_WORLD=0: one after the
+    // other in three launches (A/B runs)
+    static const bool fused_world = [] { const char* e = std::getenv("ISLAM_IMU_FUSED_WORLD"); return !(e && e[0] == '0'); }();
+    int* ready = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(loc + 7 * (size_t)nframes), 8));      // (inside the 256 spare bytes)
+    const bool fw = fused_world && motion_mode != 1;
+    hipLaunchKernelGGL(scan_kernel<T>, dim3(nframes), dim3(64), lds, s, dt, gyro, seg, ir, fw ? ready : (int*)nullptr);
+    if (fw) {
+        constexpr size_t dyn = sizeof(RotLds<T>) > sizeof(ChainLds<T>) ? sizeof(RotLds<T>) : sizeof(ChainLds<T>);
+        static_assert(dyn <= 64 * 1024, "chain_world_kernel: LDS");
+        hipLaunchKernelGGL(chain_world_kernel<T>, dim3(2), dim3(256), dyn, s, seg, nframes, ir, ir0, R0, orot, dt, acc, (T)gravity,
+                           loc, ip, iv, opos, ovel, ready);      // (loc: the motion rows and the backward pass read it from the scratch)
+    } else {
+        hipLaunchKernelGGL(chain_rot_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, ir, ir0, R0, motion_mode != 1 ? orot : (T*)nullptr);
+        hipLaunchKernelGGL(frame_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, dt, acc, seg, nframes, ir, R0, (T)gravity, loc);
+    }
     // motion_mode 2: both sets of outputs from ONE scan / rotation chain / frame pass (opos / orot / ovel: world rows, then the
     // motion rows in mpos / mrot / mvel) -- the two modes differ in the last kernel only
     if (motion_mode != 0)
         hipLaunchKernelGGL(finish_kernel<T>, dim3((nframes + 63) / 64), dim3(64), 0, s, seg, nframes, R0, loc, ip, iv, 1,
                            motion_mode == 2 ? mpos : opos, motion_mode == 2 ? mrot : orot, motion_mode == 2 ? mvel : ovel);
-    if (motion_mode != 1)
+    if (motion_mode != 1 && !fw)
         hipLaunchKernelGGL(finish_kernel<T>, dim3(1), dim3(256), 0, s, seg, nframes, R0, loc, ip, iv, 0, opos, orot, ovel);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;

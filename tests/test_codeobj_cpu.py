@@ -54,7 +54,7 @@ def test_hot_kernels_do_not_spill():
     assert len(ks) > 50
     # family: (bytes of private memory, spilled VGPRs) it may have -- zero for the kernels the headline numbers rest on, the present
     # values for the ones that have carried a small private array or a few spills since earlier rounds (a bound, not a target)
-    hot = {'trial_elim_kernel': (0, 0), 'chain_rot_kernel': (0, 0), 'corr81_fwd4_kernel': (0, 0), 'conv_nhwc_kernel': (0, 0),
+    hot = {'trial_elim_kernel': (0, 0), 'chain_rot_kernel': (0, 0), 'chain_world_kernel': (0, 0), 'corr81_fwd4_kernel': (0, 0), 'conv_nhwc_kernel': (0, 0),
            'hg_residual': (0, 0), 'pyr_level_kernel': (0, 0), 'warp_mask_kernel': (0, 0),
            'bt_eliminate_tw_kernel': (68, 0), 'bt_downsweep_kernel': (24, 0), 'small_lm_kernel': (0, 30), 'finish_kernel': (0, 0),
            'conv3x3_mfma_kernel': (156, 78)}
