@@ -411,8 +411,9 @@ def main():
             return res.trials, res.steps
     else:
         # N > 1: ONE graph sharded over the ranks, the whole LM loop inside the library on RCCL (islam_pvgo_run_chain_sharded,
-        # csrc/pvgo_dist.hip): per LM trial one all-reduce of the interface blocks of the exchange level and one of the
-        # loss / trust-region scalars + halos.  ISLAM_SHARDED_PYTHON=1: the Python-driven stage loop (islam_amd/dist_pvgo.py).
+        # csrc/pvgo_dist.hip -> pvgo.hip: run_chain_sharded_fused): per LM trial ONE all-reduce -- the interface blocks of the next solve,
+        # the trial's loss / trust-region scalars and the cut nodes' diagonal parts.  ISLAM_SHARDED_PYTHON=1: the Python-driven stage
+        # loop (islam_amd/dist_pvgo.py: two all-reduces per trial).
         from islam_amd import dist_pvgo
         sharded_info = {}
         if os.environ.get('ISLAM_SHARDED_PYTHON') == '1':
@@ -454,7 +455,7 @@ def main():
         elapsed = t.item()
 
     # ---- a second strong-scaling point on a graph LARGE enough for sharding to pay: the 5000-frame
-    # graph of the headline is one 57 us chain of dependent launches per LM iteration -- two latency-bound all-reduces per trial cost
+    # graph of the headline is one 57 us chain of dependent launches per LM iteration -- a latency-bound all-reduce per trial costs
     # about as much -- while at N = 300 007 one iteration is 1.3 ms of work on one GPU.  Same code path as the headline at every world
     # size (fused single-GPU loop at world 1, islam_pvgo_run_chain_sharded otherwise); ISLAM_BENCH_LARGE_N=0 skips it.
     large = None
