@@ -2646,6 +2646,7 @@ struct FusedArgs {
     int own_left;                                 // the rank has a left outer separator: its first workgroup owns the link that leaves it,
     double* share;                                //    steps it, and writes that link's UNCLAMPED, undamped part of its block + rhs here (90)
     int open_right;                               // node N - 1 is shared with the next rank: its diagonal is clamped after the all-reduce
+    int trial_only;                               // the last optimizer step of a sharded run: only the trial iterate and the sums (no blocks, no elimination)
 };
 
 __device__ __forceinline__ M3<double> m3_zero() { return M3<double>{0, 0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -2844,6 +2845,29 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
     }
     lds_barrier();
     PROBE_WALL(fpr, fpo + 2);
+    if (a.trial_only) {
+        // (sharded loop: nothing follows an accepted trial of the last optimizer step -- the trial iterate is stored, the sums go to the
+        // all-reduce; no node blocks, no elimination)
+        if (wave == 2 * FZ_S + FZ_HELPERS - 1) {
+            const int L = cb - 1 + lane;
+            double sq = 0.0;
+            if ((lane >= 1 || ownl) && lane <= G && L < M) {
+                const double* o = si + lane * FZ_RI;
+                sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) {
+                a.part[2 * wg] = sq;
+                a.part[2 * wg + 1] = s_sum[1];
+                if (wg == 0) {
+                    a.part[2 * a.nwg] = (!first && (a.flags[0] != 0 || *a.eflag_prev != 0)) ? 1.0 : 0.0;
+                    a.flags[0] = 0;
+                    *a.eflag_prev = 0;
+                }
+            }
+        }
+        return;
+    }
     // (the two partial sums are published after the block build, by a helper wave: a wave that waits for its write-through stores
     // here arrives ~1 us late at the barrier behind the build and holds the whole workgroup -- measured: blocks 1.4 -> 0.6 us)
     // ---- C: node blocks.  Node i of the stretch (k = cb+i) takes link slots i (k-1) and i+1 (k); coupling i (k' = cb-1+i) is link slot i.
@@ -3984,6 +4008,7 @@ __global__ __launch_bounds__(128) void shard_pack_kernel(PackArgs a, Gate gate) 
 // (only the clamp); 2: the first linearisation (its loss opens the run)
 struct DecideArgs {
     const double* msg; double* ex_Dsep; double* st; TRParams tr; double* report; double seq; int mode, damp_mode, world, Pxl;
+    int plain_report;             // report is device memory the down-sweep forwards (lm_control)
     double vmin, vmax;
 };
 // (the state block is staged through LDS: lm_control is a chain of ~40 dependent reads and writes of it -- 3 us of global-memory round
@@ -4006,7 +4031,7 @@ __device__ __forceinline__ void shard_decide(const DecideArgs& a, double* st_l) 
     __syncthreads();
     if (t == 0) {
         if (a.mode == 2) { st_l[0] = a.msg[0]; st_l[1] = a.msg[0]; st_l[8] = 0.0; st_l[11] = 1.0; st_l[12] = 0.0; st_l[13] = 0.0; }
-        else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], st_l, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec);
+        else if (a.mode == 0) lm_control(a.msg[0], a.msg[1], st_l, a.msg[2] > 0.0, a.tr, a.report, a.seq, d_spec, a.plain_report != 0);
     }
     __syncthreads();
     if (t < STATE_DOUBLES && a.mode != 1) a.st[t] = st_l[t];
@@ -4016,13 +4041,29 @@ __global__ __launch_bounds__(64) void shard_decide_kernel(DecideArgs a, Gate gat
     if (gate_closed(gate)) return;
     shard_decide(a, st_l);
 }
-// one rank: nothing to sum between the two
+// one rank: nothing to sum between the two, no cut -- the rank's sums go from the partials to the decision through LDS (the round trip
+// of the three scalars through the message in global memory and two of the barriers cost ~1.5 us of a launch that every trial waits for)
 __global__ __launch_bounds__(128) void shard_pack_decide_kernel(PackArgs p, DecideArgs d, Gate gate) {
     __shared__ double st_l[STATE_DOUBLES];
+    __shared__ double m3[3];
     if (gate_closed(gate)) return;
-    shard_pack(p);
+    const int t = threadIdx.x;
+    if (t < STATE_DOUBLES) st_l[t] = d.st[t];
+    if (t >= 64) {
+        const int lane = t - 64;
+        double ssum = 0.0, qsum = 0.0;
+        for (int i = lane; i < p.nwg; i += 64) { ssum += p.part[2 * i]; qsum += p.part[2 * i + 1]; }
+        ssum = wave_sum(ssum);
+        qsum = wave_sum(qsum);
+        if (lane == 0) { m3[0] = ssum; m3[1] = qsum; m3[2] = p.part[2 * p.nwg]; }
+    }
     __syncthreads();
-    shard_decide(d, st_l);
+    if (t == 0) {
+        if (d.mode == 2) { st_l[0] = m3[0]; st_l[1] = m3[0]; st_l[8] = 0.0; st_l[11] = 1.0; st_l[12] = 0.0; st_l[13] = 0.0; }
+        else lm_control(m3[0], m3[1], st_l, m3[2] > 0.0, d.tr, d.report, d.seq, speculated_damping(st_l, d.tr), d.plain_report != 0);
+    }
+    __syncthreads();
+    if (t < STATE_DOUBLES) d.st[t] = st_l[t];
 }
 
 __global__ void shard_close_gate_kernel(double* __restrict__ st) {
@@ -4096,7 +4137,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     if (world > 1)
         for (int l = 0; l < sp.nl; ++l) ISLAM_HIP_CHECK(hipMemsetAsync(w.lv[l].Dsep, 0, w.lv[l].prod_bytes, s));
-    ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * nex, s));
+    if (world > 1) ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * nex, s));
     hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
     const TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
                       prm->max_steps, prm->patience, prm->decreasing};
@@ -4135,13 +4176,14 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
         DecideArgs da{};
         da.msg = ex + 351 * (size_t)Pxl; da.ex_Dsep = ex; da.st = w.state; da.tr = tr; da.report = forward ? dev_slot : host_slot; da.seq = seq;
         da.mode = mode; da.damp_mode = damp_mode; da.world = world; da.Pxl = Pxl; da.vmin = prm->vmin; da.vmax = prm->vmax;
+        da.plain_report = forward ? 1 : 0;
         if (world > 1) {
             hipLaunchKernelGGL(shard_pack_kernel, dim3(1), dim3(128), 0, s, pa, gate);
             const int r = red.fn(red.self, ex_own, ex, nex, s);
             if (r != ISLAM_OK) return r;
             xbytes += 8LL * (long long)nex;
             hipLaunchKernelGGL(shard_decide_kernel, dim3(1), dim3(64), 0, s, da, gate);
-        } else {
+        } else if (mode != 1) {          // (one rank, a solve without a trial: nothing to pack, nothing to decide)
             hipLaunchKernelGGL(shard_pack_decide_kernel, dim3(1), dim3(128), 0, s, pa, da, gate);
         }
         ISLAM_LAUNCH_CHECK();
@@ -4150,7 +4192,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
         return shard_downsweep_planned(sp, R, w, ex, world, 0, w.dx, w.flags, gate, s, forward ? dev_slot : (const double*)nullptr, host_slot);
     };
     struct IterCfg { int pb; double *cur_n, *cur_v, *tri_n, *tri_v; };
-    auto fused_args = [&](const IterCfg& c, bool first, double seq, int* eprev) {
+    auto fused_args = [&](const IterCfg& c, bool first, double seq, int* eprev, bool trial_only = false) {
         FusedArgs fa{};
         fa.nodes = c.cur_n; fa.vels = c.cur_v; fa.dx = first ? (const double*)nullptr : w.dx; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans;
         fa.dvels = dvels; fa.dts = dts; fa.lin = first ? (const double*)nullptr : LIN[c.pb]; fa.N = N_eff; fa.nodes_t = c.tri_n; fa.vels_t = c.tri_v;
@@ -4162,6 +4204,7 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
         fa.eflag = w.flags + 4 + (((long long)seq + 1) & 1);
         fa.eflag_prev = eprev;
         fa.Ms = M; fa.shard = 1; fa.seg_lo = seg_lo; fa.own_left = has_left ? 1 : 0; fa.share = SH[ob]; fa.open_right = has_right ? 1 : 0;
+        fa.trial_only = trial_only ? 1 : 0;
         return fa;
     };
     IterCfg A{0, nodes, vels, w.nodes_t, w.vels_t};
@@ -4180,9 +4223,10 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
         // steps_before: optimizer steps finished when this trial is evaluated
         auto enqueue_trial = [&](const IterCfg& c, double seq, double ep, bool prev_fused, int steps_before) -> int {
             const Gate gate{w.state, ep};
-            const FusedArgs fa = fused_args(c, false, seq, prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none);
+            const bool last = steps_before + 1 >= prm->max_steps;      // nothing can follow an accepted trial: decision only
+            const FusedArgs fa = fused_args(c, false, seq, prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none, last);
             hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(nwg)), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
-            return enqueue_rest(1 - c.pb, 0, 0, true, seq, gate, steps_before + 1 >= prm->max_steps);
+            return enqueue_rest(1 - c.pb, 0, 0, true, seq, gate, last);
         };
         if ((rc = enqueue_trial(A, 1.0, epoch, true, 0)) != ISLAM_OK) return rc;
         for (;;) {

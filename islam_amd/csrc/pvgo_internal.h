@@ -58,8 +58,10 @@ __device__ __forceinline__ double speculated_damping(const double* __restrict__ 
 // failed: a solver error was flagged for the solve whose trial this is.  d_spec >= 0: the solve of the next step is already running
 // with this damping; an accepted trial whose TrustRegion.update yields another damping closes the gate (verdict 5).
 // Returns the verdict (= report[12]); report may be nullptr (small_lm_kernel keeps the whole loop on the device).
+// plain_report: `report` is device memory that a LATER launch reads (the sharded loop's down-sweep forwards it to the host): plain
+// stores, no completion wait -- the system-scope write-through + wait costs the one-workgroup decision kernel ~1.5 us.
 __device__ inline int lm_control(double s, double q, double* __restrict__ st, bool failed, const TRParams& tr,
-                                 double* __restrict__ report, double seq, double d_spec = -1.0) {
+                                 double* __restrict__ report, double seq, double d_spec = -1.0, bool plain_report = false) {
     double rep[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) rep[i] = 0.0;
@@ -100,7 +102,11 @@ __device__ inline int lm_control(double s, double q, double* __restrict__ st, bo
         }
     }
     rep[13] = st[12];
-    if (report) {
+    if (report && plain_report) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) report[i] = rep[i];
+        report[15] = seq;
+    } else if (report) {
 #pragma unroll
         for (int i = 0; i < 15; ++i) __hip_atomic_store(&report[i], rep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // payload written through before the sequence number
