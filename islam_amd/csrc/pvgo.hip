@@ -3275,9 +3275,16 @@ int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = fal
     double best_cost = 1e300;
     best.nl = 0;
     best.twisted = 0;
-    for (int depth = 1; depth <= MAXL; ++depth) {
+    // (cand 1: graphs too long for MAXL twisted levels of equal length -- beyond ~130 000 nodes -- with the twisted maximum on every
+    //  level and whatever is left, a dozen nodes, as a one-sided root: at N = 300 007 segments of 8 on the one-sided kernels cost 8 node
+    //  steps each, segments of 7 on the twisted ones 4 -- 1.40 -> 1.1x ms per LM iteration)
+    for (int depth = 1; depth <= MAXL; ++depth)
+    for (int cand = 0; cand < 2; ++cand) {
         int m_auto = std::max(4, (int)std::ceil(std::pow((double)N, 1.0 / depth)) - 1);
-        if (twisted) {
+        if (cand == 1) {
+            if (!(twisted && depth == MAXL && m_auto > BS_PAR_MAX)) continue;
+            m_auto = BS_PAR_MAX;
+        } else if (twisted) {
             if (m_auto > BS_PAR_MAX && depth < MAXL) continue;          // a deeper tree reaches a length the twisted path handles
             if (m_auto % 2 == 0 && m_auto + 1 <= BS_PAR_MAX) ++m_auto;
         }
@@ -3304,7 +3311,9 @@ int plan_levels(int N, const int seg_len[2], SolvePlan& best, bool twisted = fal
         for (int l = 0; l < c.nl; ++l) {
             const bool root = l == c.nl - 1;
             const bool ltw = tw && (!root || c.lv[l].n <= BS_PAR_MAX);
-            cost += segment_steps(c.lv[l].m, ltw) * t_node + (l < c.top ? 2 * t_launch : 0.0);
+            // (a level of more segments than the chip holds at once runs in rounds: 256 CUs x 3 workgroups of the level kernels)
+            const double rounds = c.lv[l].P > 3072 ? c.lv[l].P / 768.0 : 1.0;
+            cost += rounds * segment_steps(c.lv[l].m, ltw) * t_node + (l < c.top ? 2 * t_launch : 0.0);
         }
         if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
     }

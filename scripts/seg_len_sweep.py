@@ -1,20 +1,23 @@
-"""LM iteration time of the N=5001 benchmark graph for pinned segment lengths of levels 0 / 1 (planner tuning)."""
+"""LM iteration time of islam_pvgo_run_chain at one size under forced level-0 / level-1 segment lengths (islam_pvgo_params.seg_len;
+(0, 0) = the planner's own choice).    python scripts/seg_len_sweep.py [N]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from islam_amd import ops
 import bench
+from islam_amd import ops
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300007
 dev = torch.device('cuda:0')
-prob, tr = bench.build_problem(dev, 5001)
-ws = ops.pvgo_workspace(5001, dev)
-for sl in ((0, 0), (5, 5), (7, 5), (7, 7), (5, 7), (7, 0), (5, 3), (3, 5), (7, 3)):
-    prm = ops.pvgo_default_params(bench.LOSS_WEIGHT, radius=1e4, seg_len=sl)
-    def run():
-        n, v = prob['init_nodes'].clone(), prob['init_vels'].clone()
-        res, _ = ops.pvgo_run_chain(n, v, prob['vo'], prob['drots'], prob['dtrans'], prob['dvels'], prob['dts'], prm, workspace=ws)
-        return res.trials
-    for _ in range(3): run()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); tr_ = 0
-    for _ in range(60): tr_ += run()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print('seg_len=%s: %.1f us per LM iteration' % (sl, dt / tr_ * 1e6), flush=True)
+prob, _ = bench.build_problem(dev, N - 1)
+args = [prob[k] for k in ('init_nodes', 'init_vels', 'vo', 'drots', 'dtrans', 'dvels', 'dts')]
+for seg in [(0, 0), (8, 8), (10, 10)]:
+    prm = ops.pvgo_default_params(bench.LOSS_WEIGHT, radius=1e4, seg_len=seg)
+    best, res = 1e9, None
+    for rep in range(4):
+        n, v = args[0].clone(), args[1].clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, _ = ops.pvgo_run_chain(n, v, *args[2:], prm)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / res.trials)
+    print('N = %d  seg_len = %-8s %8.1f us per LM trial (%d trials, status %d, loss %.9e)' % (n.shape[0], seg, best * 1e6, res.trials, res.status, res.loss), flush=True)
