@@ -2670,7 +2670,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
         // the deciding workgroup (see trial_lin_kernel): sums the partials in index order, LM decision, validates the speculation
         if (wave != 0 || gate_closed(gate)) return;
         const bool first = a.dx == nullptr;
-        const double d_spec = first ? -1.0 : speculated_damping(a.st, a.tr);
+        const double d_spec = (first || a.trial_only) ? -1.0 : speculated_damping(a.st, a.tr);      // (trial only: no solve is running ahead)
         __builtin_amdgcn_s_sleep(64);
         if (lane == 0) {
             int spins = 0;
@@ -2856,7 +2856,7 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                 sq = sv[lane * FZ_RV + 33] + o[22] + o[23] + o[24];
             }
             sq = wave_sum(sq);
-            if (lane == 0) {
+            if (lane == 0 && a.shard) {
                 a.part[2 * wg] = sq;
                 a.part[2 * wg + 1] = s_sum[1];
                 if (wg == 0) {
@@ -2864,6 +2864,11 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
                     a.flags[0] = 0;
                     *a.eflag_prev = 0;
                 }
+            } else if (lane == 0) {                  // (single GPU: the deciding workgroup of this launch takes the decision)
+                st_coherent(&a.part[2 * wg], sq);
+                st_coherent(&a.part[2 * wg + 1], s_sum[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -3042,10 +3047,16 @@ __global__ __launch_bounds__(FZ_THREADS, 3) void trial_elim_kernel(FusedArgs a, 
 }
 
 // state <- [damping = 1 / radius, radius, down, run-ahead epoch 1], everything else and the four flag words zero
-__global__ __launch_bounds__(64) void control_init_kernel(double* __restrict__ st, int* __restrict__ flags, double radius, double down) {
+// ready16 != nullptr: the down-sweep's ready words are zeroed by the same launch (n16 16-byte items over the whole grid) -- the separate
+// fill launch in front of every run_pvgo cost ~2.5 us of the run
+__global__ __launch_bounds__(256) void control_init_kernel(double* __restrict__ st, int* __restrict__ flags, double radius, double down,
+                                                           uint4* __restrict__ ready16 = nullptr, unsigned n16 = 0) {
     const int t = threadIdx.x;
-    if (t < STATE_DOUBLES) st[t] = (t == 2 || t == STATE_HIST) ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : (t == 14 || t == 15) ? 1.0 : 0.0;     // [15]: first guess "radius kept"
-    if (t < 8) flags[t] = 0;
+    if (blockIdx.x == 0) {
+        if (t < STATE_DOUBLES) st[t] = (t == 2 || t == STATE_HIST) ? 1.0 / radius : t == 3 ? radius : t == 4 ? down : (t == 14 || t == 15) ? 1.0 : 0.0;     // [15]: first guess "radius kept"
+        if (t < 8) flags[t] = 0;
+    }
+    for (unsigned i = blockIdx.x * 256u + t; i < n16; i += gridDim.x * 256u) ready16[i] = uint4{0u, 0u, 0u, 0u};
 }
 
 __global__ __launch_bounds__(64) void control_begin_kernel(const double* __restrict__ loss_part, int nblk,
@@ -3524,6 +3535,20 @@ int enqueue_levels(const Workspace& w, const SolvePlan& sp, int lbegin, const Le
     }
     if (nev) *nev = ne;
     ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
+// state + flags + ready words of a run: one launch while the ready words fit a single pass of 64 workgroups (graphs up to ~20 000
+// nodes), the copy engine's fill + the one-wave kernel beyond
+static int enqueue_control_init(const Workspace& w, const islam_pvgo_params* prm, hipStream_t s) {
+    if (w.ready_bytes <= (1u << 20)) {
+        const unsigned n16 = (unsigned)(w.ready_bytes / 16);
+        hipLaunchKernelGGL(control_init_kernel, dim3(std::max(1u, std::min(64u, (n16 + 255u) / 256u))), dim3(256), 0, s, w.state, w.flags,
+                           prm->radius, prm->down, reinterpret_cast<uint4*>(w.ready), n16);
+    } else {
+        ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
+        hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down, (uint4*)nullptr, 0u);
+    }
     return ISLAM_OK;
 }
 
@@ -4143,11 +4168,13 @@ int run_chain_sharded_fused(const ShardSum& red, int world, int rank, double* no
     hs_all[15] = 0.0;
     hs_all[31] = 0.0;
     // product rows of other ranks' segments read as zero; the own rows of the exchange buffer are rewritten by every solve
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     if (world > 1)
         for (int l = 0; l < sp.nl; ++l) ISLAM_HIP_CHECK(hipMemsetAsync(w.lv[l].Dsep, 0, w.lv[l].prod_bytes, s));
     if (world > 1) ISLAM_HIP_CHECK(hipMemsetAsync(ex_own, 0, sizeof(double) * nex, s));
-    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
+    {
+        const int rc_init = enqueue_control_init(w, prm, s);
+        if (rc_init != ISLAM_OK) return rc_init;
+    }
     const TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
                       prm->max_steps, prm->patience, prm->decreasing};
     const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
@@ -4490,7 +4517,6 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
                           const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,
                           const islam_pvgo_reproj* reproj, const ReprojDev& rp, Workspace& w, hipStream_t s,
                           islam_pvgo_result* result, double* trace, int trace_cap) {
-    ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
     const int M = N - 1;
     // status blocks in pinned, device-visible host memory: the deciding wave of trial_lin_kernel writes one per trial
     // (two slots, alternating with the trial number), the host polls its sequence number (no stream synchronisation,
@@ -4506,7 +4532,10 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
     const double damping0 = 1.0 / prm->radius;               // TrustRegion: damping = 1/radius
     // device state and flags (flags[0] solver error, flags[2] ticket) initialised by a one-wave kernel: a host->device copy of a
     // stack array stalls the host for a staging round trip at the start of every run_pvgo
-    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
+    {
+        const int rc_init = enqueue_control_init(w, prm, s);
+        if (rc_init != ISLAM_OK) return rc_init;
+    }
     unsigned* ticket = reinterpret_cast<unsigned*>(w.flags + 2);
     TRParams tr{prm->high, prm->low, prm->up, prm->down, prm->factor, prm->rmin, prm->rmax, prm->reject,
                 prm->max_steps, prm->patience, prm->decreasing};
@@ -4594,7 +4623,23 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
             const Gate gate{w.state, ep};
             double* rep_slot = report + 16 * ((long long)seq & 1);
             int* eprev = prev_fused ? w.flags + 4 + ((long long)seq & 1) : eflag_none;
-            if (!more) {                     // nothing follows an accepted trial: the trial alone, no linearisation (lin_o = nullptr)
+            if (!more && !begin_pending) {   // nothing follows an accepted trial: the fused kernel's trial-only mode (no node blocks, no
+                FusedArgs fa{};              // elimination; 7 us against trial_lin_kernel's 10.6)
+                fa.nodes = c.cur_n; fa.vels = c.cur_v; fa.dx = w.dx; fa.poses = poses; fa.drots = drots; fa.dtrans = dtrans; fa.dvels = dvels;
+                fa.dts = dts; fa.lin = LIN[c.pb]; fa.N = N; fa.nodes_t = c.tri_n; fa.vels_t = c.tri_v; fa.part = w.part; fa.st = w.state;
+                fa.flags = w.flags; fa.ticket = ticket; fa.tr = tr; fa.report = rep_slot; fa.seq = seq; fa.W = W;
+                fa.lin_o = LIN[1 - c.pb]; fa.Hd_o = HD[1 - c.pb]; fa.Ho_o = HO[1 - c.pb]; fa.rhs_o = RH[1 - c.pb];
+                fa.dst = level_dst(w.lv[0], w.dx);
+                fa.m = sp.lv[0].m; fa.P = sp.lv[0].P; fa.nwg = fz_nwg;
+                fa.eflag = eflag_none;
+                fa.eflag_prev = eprev;
+                fa.Ms = M;
+                fa.trial_only = 1;
+                hipLaunchKernelGGL(trial_elim_kernel, dim3(xcd_grid(fz_nwg) + 1), dim3(FZ_THREADS), FZ_LDS_BYTES, s, fa, gate);
+                ISLAM_LAUNCH_CHECK();
+                return ISLAM_OK;
+            }
+            if (!more) {                     // (the run's first trial is also its last: the initial loss still has to be summed)
                 if (begin_pending) {
                     hipLaunchKernelGGL(control_begin_kernel, dim3(1), dim3(64), 0, s, w.loss_part, nlb, w.state, w.flags);
                     begin_pending = false;
@@ -4847,7 +4892,7 @@ int islam_pvgo_trial_elim_burst(const double* nodes, const double* vels, const d
     if (rc != ISLAM_OK) return rc;
     ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)trial_elim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES));
     ISLAM_HIP_CHECK(hipMemsetAsync(w.ready, 0, w.ready_bytes, s));
-    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down);
+    hipLaunchKernelGGL(control_init_kernel, dim3(1), dim3(64), 0, s, w.state, w.flags, prm->radius, prm->down, (uint4*)nullptr, 0u);
     const LinWeights W{prm->w[0], prm->w[1], prm->w[2], prm->w[3], prm->vmin, prm->vmax};
     const int nlb = (N + LB_NODES - 1) / LB_NODES;
     hipLaunchKernelGGL(linbuild_kernel, dim3(xcd_grid(nlb)), dim3(LB_THREADS), LB_DYN_BYTES, s, nodes, vels, poses, drots, dtrans, dvels, dts, N,
