@@ -8,6 +8,12 @@ import pytest
 MAXL = 6
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _built():
+    import __graft_entry__ as g
+    g.build()                          # (incremental: a no-op when the library is up to date)
+
+
 def _plan(N, seg=(0, 0)):
     from islam_amd._lib import lib
     L = lib()
