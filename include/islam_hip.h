@@ -38,6 +38,13 @@ extern "C" {
 const char* islam_last_error(void);
 int islam_abi_version(void);
 
+/* Measurement aid (no reference counterpart; bench.py's stereo_vio diagnostics): one wavefront runs `iters` dependent fp64 FMAs on
+ * `stream` and writes out3[0] = elapsed ticks of the constant-rate wall clock (islam_wall_clock_khz), out3[1] = elapsed shader
+ * cycles; shader MHz = out3[1] / out3[0] * wall kHz / 1e3.  Launched on a stream of its own it samples the clock the chip sustains
+ * while other streams keep it busy.  out3: 3 x int64 in device memory. */
+int islam_clock_probe(long long* out3, int iters, void* stream);
+int islam_wall_clock_khz(int device);
+
 /* ---------------------------------------------------------------- PWC-Net front-end kernels */
 
 /* 81-channel local correlation, forward.
@@ -312,7 +319,9 @@ int islam_scale_ls_depth(const float* depth, const float* flow, const float* pos
  * init_pos(3), init_rot(4), init_vel(3); motion_mode as imu_integrator.py:69-80.
  * max_frame_samples = max_i (seg[i+1]-seg[i]) (known on the host from rgb2imu_sync).
  * Outputs: world mode nframes+1 rows (row 0 = init), motion mode nframes rows.
- * scratch: at least islam_imu_scratch_bytes(S, nframes, dtype) bytes. */
+ * scratch: at least islam_imu_scratch_bytes(S, nframes, dtype) bytes.  Calls that may run CONCURRENTLY (different streams) must not share
+ * a scratch buffer: it holds the hand-off counter between the two workgroups of the world-row kernel.  If that hand-off ever times out
+ * (bounded wait), out_pos / out_vel are filled with NaN rather than left half-written. */
 size_t islam_imu_scratch_bytes(int64_t S, int nframes, int dtype);
 int islam_imu_preint(const void* dt, const void* gyro, const void* acc, const int64_t* seg, int nframes,
                      int64_t S, int max_frame_samples, const void* init_pos, const void* init_rot,
@@ -486,6 +495,10 @@ typedef int (*islam_allreduce_fn)(void* user, double* buf, size_t count, void* s
 int islam_dist_unique_id(void* out128);
 int islam_dist_comm_init(const void* id128, int world, int rank, void** comm);
 int islam_dist_comm_destroy(void* comm);
+/* What RCCL itself says about a communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): bench.py prints `ranks` as
+ * rccl_ranks_seen so that a multi-GPU record proves the collectives ran over that many ranks.  comm == NULL (world 1): 1, 0, the
+ * current device.  Any of the three outputs may be NULL. */
+int islam_dist_comm_info(void* comm, int* ranks, int* rank, int* device);
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world);
 int islam_pvgo_run_chain_sharded(void* comm, int world, int rank, double* nodes, double* vels, const double* poses, const double* drots,
                                  const double* dtrans, const double* dvels, const double* dts, int N, const islam_pvgo_params* prm,

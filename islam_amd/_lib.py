@@ -43,6 +43,8 @@ REPROJ_REC = 32         # ISLAM_REPROJ_REC
 SIGNATURES = {
     'islam_last_error': (ctypes.c_char_p, []),
     'islam_abi_version': (c_int, []),
+    'islam_clock_probe': (c_int, [c_void_p, c_int, c_void_p]),
+    'islam_wall_clock_khz': (c_int, [c_int]),
     'islam_corr81_scratch_bytes': (c_size_t, [c_int] * 4),
     'islam_corr81_fwd': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p]),
     'islam_corr81_bwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
@@ -126,6 +128,7 @@ SIGNATURES = {
     'islam_dist_unique_id': (c_int, [c_void_p]),
     'islam_dist_comm_init': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     'islam_dist_comm_destroy': (c_int, [c_void_p]),
+    'islam_dist_comm_info': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'islam_pvgo_sharded_scratch_bytes': (c_size_t, [c_int, c_int]),
     'islam_pvgo_run_chain_sharded': (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, ctypes.POINTER(PvgoParams),
                                              ctypes.POINTER(PvgoReproj), c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(PvgoResult),

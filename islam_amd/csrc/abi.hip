@@ -10,3 +10,32 @@ char* err_buf() {
 
 extern "C" const char* islam_last_error(void) { return islam::err_buf(); }
 extern "C" int islam_abi_version(void) { return 1; }
+
+// ---- measurement aid (bench.py): the shader clock the chip sustains RIGHT NOW.  One wavefront runs a dependent fp64 FMA chain and
+// reads both counters around it: wall_clock64() ticks at the constant hipDeviceAttributeWallClockRate, clock64() in shader cycles.
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long* out, int iters) {
+    const long long w0 = wall_clock64(), c0 = clock64();
+    double a = threadIdx.x * 1e-3 + 1.0;
+    const double b = 1.0000001;
+#pragma unroll 1
+    for (int i = 0; i < iters / 32; ++i) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a = fma(a, b, 1e-9);
+    }
+    const long long w1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) { out[0] = w1 - w0; out[1] = c1 - c0; out[2] = a > 0.0; }
+}
+}  // namespace
+
+extern "C" int islam_clock_probe(long long* out3, int iters, void* stream) {
+    if (!out3 || iters < 32) return islam::fail(ISLAM_EARG, "islam_clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, islam::as_stream(stream), out3, iters);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+extern "C" int islam_wall_clock_khz(int device) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess) return -1;
+    return khz;
+}

@@ -117,7 +117,7 @@ template <class T> __device__ __forceinline__ void stq(Q<T> q, T* p) { p[0] = q.
 template <class T>
 __global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ dt, const T* __restrict__ gyro,
                                                    const int64_t* __restrict__ seg, T* __restrict__ ir, int* __restrict__ zero_word) {
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;       // chain_world_kernel's published-rows counter
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) { zero_word[0] = 0; zero_word[1] = 0; }   // chain_world_kernel's published-rows counter + its gave-up flag
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* buf0 = reinterpret_cast<T*>(smem_raw);
     const int i = blockIdx.x;
@@ -208,9 +208,19 @@ __device__ __forceinline__ void publish_rows(int* ready, int rows) {
     __threadfence();
     __hip_atomic_store(ready, rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void await_rows(const int* ready, int rows) {
-    if ((threadIdx.x & 63) == 0)
-        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < rows) __builtin_amdgcn_s_sleep(4);
+// The wait is BOUNDED (as trial_elim_kernel's ticket wait is): if the producer workgroup never publishes -- it faulted, or another call
+// sharing this scratch re-zeroed the counter (islam_hip.h: concurrent calls need their own scratch) -- the waiting lane gives up after
+// ~2^22 sleeps (a few hundred ms), raises the sticky flag ready[1], and chain_world_kernel poisons the p / v rows with NaN instead of
+// hanging the stream without a diagnostic.
+constexpr int AWAIT_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ void await_rows(int* ready, int rows) {
+    if ((threadIdx.x & 63) == 0 && __hip_atomic_load(ready + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < rows) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > AWAIT_SPIN_LIMIT) { __hip_atomic_store(ready + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
     __threadfence();
 }
 
@@ -395,7 +405,7 @@ struct ChainLds {
 };
 // what the p / v chain needs to compute its frame terms itself (chain_world_kernel); ready == nullptr: they are read from `loc`
 template <class T>
-struct FrameSrc { const int* ready; const T* dt; const T* acc; const T* ir; T gravity; T* loc_out; };
+struct FrameSrc { int* ready; const T* dt; const T* acc; const T* ir; T gravity; T* loc_out; };
 
 template <class T>
 __device__ __forceinline__ void chain_pv_body(ChainLds<T>& L, const int64_t* __restrict__ seg, int nframes, const T* __restrict__ R0,
@@ -522,6 +532,13 @@ __device__ __forceinline__ void chain_pv_body(ChainLds<T>& L, const int64_t* __r
         __syncthreads();
     }
     copy_out(nchunk - 1, tid, 256);
+    if (fr.ready) {                                      // a wait gave up (await_rows): no silent garbage
+        __syncthreads();
+        if (__hip_atomic_load(fr.ready + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            const T nan = (T)__builtin_nan("");
+            for (int j = tid; j < 3 * (nframes + 1); j += 256) { out_pos[j] = nan; out_vel[j] = nan; }
+        }
+    }
 }
 
 // D: outputs.  world mode: sequential p/v chain (row 0 = init).  motion mode: every frame starts from p = v = 0.
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const int64_t* __restrict__
 // World rows in ONE launch of two workgroups: workgroup 0 walks the rotation chain (chain_rot_kernel's body) and publishes the rows of
 // R0 chunk by chunk; workgroup 1 turns them into the frames' terms (frame_kernel's arithmetic) and walks the p / v chain
 // (finish_kernel's body) a chunk or two behind -- the two serial chains of a 5000-frame trajectory overlap (236 us + 165 us one
-// after the other before).  Both workgroups are resident by construction (a grid of two).
+// after the other before).  A grid of two: both workgroups become resident (a busy XCD can only delay workgroup 0, and workgroup 1's wait is bounded).
 template <class T>
 __global__ __launch_bounds__(256) void chain_world_kernel(const int64_t* __restrict__ seg, int nframes, const T* __restrict__ ir,
                                                            const T* __restrict__ init_rot, T* __restrict__ R0, T* __restrict__ rot_copy,

@@ -215,6 +215,20 @@ int islam_dist_comm_destroy(void* comm) {
     return ISLAM_OK;
 }
 
+int islam_dist_comm_info(void* comm, int* ranks, int* rank, int* device) {
+    if (!comm) {                       // world 1 runs without a communicator
+        if (ranks) *ranks = 1;
+        if (rank) *rank = 0;
+        if (device) ISLAM_HIP_CHECK(hipGetDevice(device));
+        return ISLAM_OK;
+    }
+    int v = 0;
+    if (ranks) { ISLAM_NCCL_CHECK(ncclCommCount((ncclComm_t)comm, &v)); *ranks = v; }
+    if (rank) { ISLAM_NCCL_CHECK(ncclCommUserRank((ncclComm_t)comm, &v)); *rank = v; }
+    if (device) { ISLAM_NCCL_CHECK(ncclCommCuDevice((ncclComm_t)comm, &v)); *device = v; }
+    return ISLAM_OK;
+}
+
 size_t islam_pvgo_sharded_scratch_bytes(int N, int world) {
     const size_t n = (size_t)N + 2;
     size_t d = a256(LIN_C * n) + a256(n / 8 + 4) + 2 * a256(81 * n) + 2 * a256(9 * n) + 2 * a256(7 * n) + 2 * a256(3 * n) +

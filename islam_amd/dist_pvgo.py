@@ -279,6 +279,13 @@ class RcclComm:
             with torch.cuda.device(idx if idx is not None else torch.cuda.current_device()):
                 check(lib().islam_dist_comm_init(raw, self.world, self.rank, ctypes.byref(self.handle)))
 
+    def info(self):
+        """(ranks, rank, device) as RCCL reports them for this communicator (islam_dist_comm_info)."""
+        from ._lib import check, lib
+        n, r, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().islam_dist_comm_info(self.handle if self.handle else None, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)))
+        return n.value, r.value, d.value
+
     def close(self):
         from ._lib import check, lib
         if self.handle:

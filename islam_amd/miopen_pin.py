@@ -72,3 +72,25 @@ def use_pinned_db():
     os.environ['MIOPEN_USER_DB_PATH'] = dst
     _state['dir'] = dst
     return dst
+
+
+def searched_since_start():
+    """Did MIOpen ADD find records to this process's private copy of the pinned db?  It appends what a timing search finds, so a copy
+    that grew means at least one convolution shape was not served from the pinned set (another MIOpen build / device, or a shape the
+    set does not hold) and its kernel was picked by a search in this process -- not reproducible run to run.  Returns
+    {'pinned_db_in_use': bool, 'grew_bytes': int, 'new_records': int, 'new_files': [names]} (None when the pinned db is not in
+    use).  new_files: db files MIOpen created under ANOTHER key (device / version / build tag) -- the shipped set did not apply at all."""
+    d = _state['dir']
+    if d is None or os.environ.get('MIOPEN_USER_DB_PATH') != d:
+        return None
+    grew = recs = 0
+    new_files = sorted(f for f in os.listdir(d) if not os.path.exists(os.path.join(DB_DIR, f)))
+    for f in os.listdir(d):
+        if not f.endswith('.txt'):
+            continue
+        now = open(os.path.join(d, f), 'rb').read()
+        src = os.path.join(DB_DIR, f)
+        was = open(src, 'rb').read() if os.path.exists(src) else b''
+        grew += max(len(now) - len(was), 0)
+        recs += max(now.count(b'\n') - was.count(b'\n'), 0)
+    return {'pinned_db_in_use': True, 'grew_bytes': grew, 'new_records': recs, 'new_files': new_files}

@@ -400,6 +400,30 @@ HG_FUSED = _os.environ.get('ISLAM_HG_FUSED', '1') == '1'
 HG_FUSED_MAX_PIXELS = int(_os.environ.get('ISLAM_HG_FUSED_MAX_PIXELS', str(1 << 30)))
 
 
+def execution_description():
+    """What the frozen nets' execution copies run on, built from the switches above (bench.py prints it with the stereo_vio figure:
+    a hand-written literal there went stale when the stride-2 convolutions moved onto the HIP kernel)."""
+    on = lambda flag, a, b: a if flag else b
+    stereo = ['stereo net: bf16 NHWC execution copy']
+    if HIP_CONV_LEVEL >= 1:
+        stereo.append('stride-1 3x3%s convolutions on the HIP implicit-GEMM kernel conv_nhwc_kernel (BatchNorm statistics in the epilogue, '
+                      'BatchNorm + ReLU on load)' % on(HIP_CONV_LEVEL >= 2, ' and the hourglass 1x1', ''))
+    else:
+        stereo.append('all convolutions on MIOpen')
+    stereo.append(on(HIP_CONV_S2, 'stride-2 convolutions on islam_conv_nhwc_bf16_s2' + on(HIP_FIRST_LAYER, ' including the 3->32 first layer', ' (first layer on MIOpen)'),
+                     'stride-2 convolutions on MIOpen / CK'))
+    stereo.append(on(HG_FUSED, 'the 35 hourglass Residual modules as one launch each (islam_hg_residual_nhwc_bf16)', 'hourglass Residual modules as three launches'))
+    stereo.append(on(HIP_DECONV, 'decoder transposed convolutions on the convolution kernel', 'decoder transposed convolutions on MIOpen'))
+    stereo.append(on(UPSAMPLE_CAT, 'SPP up-samplings + concatenation as one launch', 'SPP up-samplings as separate launches'))
+    stereo.append('biased 1x1 / SPP 1x1 convolutions on MIOpen / CK')
+    flow = ['flow net: ' + on(FLOW_NHWC, 'DenseNet blocks / context network on the channels-last kernel through a bf16 mirror', 'DenseNet blocks on islam_conv3x3_mfma (fp32 NCHW)')]
+    flow.append(on(FLOW_PYR, 'pyramid levels 1-2 as one fused three-layer launch each', 'pyramid levels 1-2 layer by layer'))
+    flow.append(on(FLOW_S2_HIP, 'stride-2 layers of levels 3-6 on islam_conv3x3_mfma', 'stride-2 layers of levels 3-6 on MIOpen'))
+    flow.append(on(FLOW_HEAD_MIRROR, 'flow head + up-sampled features of a level as one convolution of the mirror', 'flow heads on islam_conv3x3_mfma'))
+    flow.append('81-channel correlation at four pixels per lane, warp + mask kernel')
+    return '; '.join(stereo) + ' | ' + '; '.join(flow) + on(FROZEN_FORK, ' | the two nets as parallel branches of one HIP graph', ' | the two nets one after the other')
+
+
 def _hip_conv_ok(conv, x, fused_1x1=False, strided=False):
     """strided: the caller can also run Conv2d(stride = 2) on the channels-last kernel (islam_conv_nhwc_bf16_s2)."""
     if HIP_CONV_LEVEL < 1 or not isinstance(conv, nn.Conv2d) or not isinstance(x, torch.Tensor):
@@ -1202,28 +1226,32 @@ class _PoseGraph:
             self.static_grads = torch.autograd.grad(self.static_y, self.params, self.static_gy, allow_unused=True)
         self.leaf = torch.zeros((), device=dev, requires_grad=True)
         self.zero = torch.zeros((), device=dev)
-        self.pending = False                             # a forward replay whose backward has not run yet
+        self.gen = 0                                     # serial number of the latest forward replay (see _PoseGraphFn)
         self.key = None
 
 
 class _PoseGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, leaf, pg):
-        # the backward graph reads the activations the LAST forward replay left in the graph's static buffers: a second forward
-        # before the pending backward would silently hand that backward the wrong activations
-        if pg.pending:
-            raise RuntimeError('graph_pose="accumulate": forward replayed while the previous forward still awaits its backward '
-                               '(run forwards that need no gradient under torch.no_grad() / TartanVO(..., need_grad=False))')
+        # the backward graph reads the activations the LAST forward replay left in the graph's static buffers.  A forward that never
+        # gets a backward (metrics pass, an exception between the VO forward and the gradient step) is harmless; what must not happen is
+        # forward A, forward B, backward of A -- A's activations are gone.  Every replay takes a generation number and the backward
+        # checks that its forward is still the latest one (the reference loop, train.py:212-283, has no such restriction because eager
+        # autograd keeps every forward's activations alive).
+        pg.gen += 1
+        ctx.gen = pg.gen
         pg.static_x.copy_(x)
         pg.fwd.replay()
         ctx.pg = pg
-        pg.pending = True
         return pg.static_y.detach().clone()
 
     @staticmethod
     def backward(ctx, gy):
         pg = ctx.pg
-        pg.pending = False
+        if ctx.gen != pg.gen:
+            raise RuntimeError('graph_pose="accumulate": backward of a forward whose activations a later forward replay has overwritten '
+                               '(forward #%d, latest #%d); run forwards that need no gradient under torch.no_grad() / '
+                               'TartanVO(..., need_grad=False), or back-propagate before the next forward' % (ctx.gen, pg.gen))
         pg.static_gy.copy_(gy)
         pg.bwd.replay()
         acc, new = [], []

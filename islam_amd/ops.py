@@ -955,3 +955,30 @@ class _VoLoss(torch.autograd.Function):
 
 def pvgo_vo_loss(nodes64, edges, poses):
     return _VoLoss.apply(nodes64, edges, poses)
+
+
+class ClockProbe:
+    """Shader clock the chip sustains while it is busy (islam_clock_probe): ``sample()`` queues a one-wavefront dependent-FMA kernel of
+    ~40 us on a stream of this object's own -- it runs beside whatever the other streams are doing -- and ``mhz()`` reads the samples
+    back (synchronises that stream only).  bench.py samples it before, during and after the stereo_vio measurement, so that a slow
+    run names its cause (a box that clocks lower under load vs. anything else)."""
+
+    def __init__(self, device, capacity=64, iters=20000):
+        from ._lib import lib
+        self.device, self.iters, self.n = torch.device(device), iters, 0
+        self.buf = torch.zeros(capacity, 3, dtype=torch.int64, device=self.device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.khz = lib().islam_wall_clock_khz(self.device.index or 0)
+
+    def sample(self):
+        from ._lib import check, lib, ptr, stream_ptr
+        if self.n >= self.buf.shape[0]:
+            return
+        with torch.cuda.stream(self.stream):
+            check(lib().islam_clock_probe(ptr(self.buf[self.n]), self.iters, stream_ptr(self.device)))
+        self.n += 1
+
+    def mhz(self):
+        self.stream.synchronize()
+        h = self.buf[:self.n].cpu().numpy().astype(float)
+        return [float(c / w * self.khz * 1e-3) for w, c, _ in h if w > 0]

@@ -329,6 +329,40 @@ def test_pose_head_graph_replay_trains_like_eager(cuda, mode):
     torch.cuda.synchronize()
 
 
+def test_pose_graph_forward_without_backward_is_harmless(cuda):
+    """graph_pose='accumulate' (nets._PoseGraphFn): a forward that never gets a backward (metrics pass, an exception between the VO
+    forward and the gradient step) does not block later forwards -- forward, forward, backward-of-the-SECOND gives the eager
+    gradients; only the backward of a forward whose activations a later replay overwrote raises (train.py:212-283 has no such
+    restriction: eager autograd keeps every forward's activations)."""
+    from islam_amd import nets
+    torch.manual_seed(11)
+    B = 2
+    va, vb = nets.VONet(fix_parts=('flow', 'stereo')), nets.VONet(fix_parts=('flow', 'stereo'))
+    vb.load_state_dict(va.state_dict())
+    for v in (va, vb):
+        v.flowPoseNet.to(cuda).train()
+    vb.graph_pose = 'accumulate'
+    wts = torch.arange(1, 7, device=cuda, dtype=torch.float32)
+    mk = lambda: (torch.randn(B, 2, 112, 160, device=cuda), torch.rand(B, 2, 112, 160, device=cuda))
+    (f1, i1), (f2, i2) = mk(), mk()
+    z = torch.zeros(B, 1, 112, 160, device=cuda)
+    _, _, p1 = vb(None, None, None, None, i1, frozen=(f1, z))            # never back-propagated
+    _, _, p2 = vb(None, None, None, None, i2, frozen=(f2, z))
+    (p2 * wts).sum().backward()
+    _, _, q2 = va(None, None, None, None, i2, frozen=(f2, z))
+    (q2 * wts).sum().backward()
+    torch.testing.assert_close(p2, q2, rtol=1e-3, atol=1e-5)
+    for a, b in zip(vb.flowPoseNet.parameters(), va.flowPoseNet.parameters()):
+        torch.testing.assert_close(a.grad, b.grad, rtol=5e-3, atol=2e-3 * float(b.grad.abs().max()) + 1e-8)
+    with pytest.raises(RuntimeError, match='overwritten'):
+        (p1 * wts).sum().backward()                                      # its activations are gone: must fail loudly, not silently
+    torch.cuda.synchronize()
+    del va, vb, p1, p2, q2
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def test_pose_head_fused_elementwise_tail(cuda):
     """VOFlowRes.set_fused_tail (islam_bias_act_f32_nhwc / _bwd): bias + ReLU (+ shortcut) behind every encoder convolution in one
     launch each way.  Same convolutions on the same inputs: the forward is the same sequence of fp32 additions (bit-equal pose), the

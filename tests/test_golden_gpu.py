@@ -54,26 +54,89 @@ BF16_OPERANDS = (8e-2, 3e-2, 1e-2)        # islam_conv3x3_mfma path: max, rms, |
 BF16_STEREO = (6e-2, 3e-2, 2.5e-2)        # bf16 execution copy of the stereo net: max, rms, |bias|
 
 
-def _within(got, ref, bounds, what='', flips=False):
-    """max / rms / bias of the error within ``bounds``.  flips=True (outputs behind PWC-Net's warp): the warp zeroes a feature pixel
-    when its validity mask drops below 0.9999 (PWCNet.py:195-206) -- a DISCONTINUITY of the reference network.  A rounding-level change
-    of the up-sampled flow can flip that decision for a pixel on the edge, and the 3x3 / dilated convolutions behind it spread the
-    difference over its neighbourhood: on the 128x192 vector one flipped pixel of the level-2 warp puts 7 of 1536 pixels of the
-    full-resolution flow above 5e-2 (max 1.08e-1) while rms and bias stay inside their bounds (scripts/debug/flow0_outliers.py; which
-    way the pixel falls depends on MIOpen's choice of fp32 kernels for the stride-2 pyramid layers, which differs between machines of
-    the pool).  So for those outputs the maximum may exceed its bound on at most 1 % of the pixels, and never 3x the bound; rms and
-    bias keep their bounds -- a wrong kernel moves those."""
+FLIP_RADIUS = 1          # a flipped mask pixel excuses its 3x3 neighbourhood (at the flipped level's resolution)
+
+
+class _WarpMaskRecorder:
+    """Records the validity mask of every warp of a PWCDCNet forward on the HIP path (islam_warp_mask: grid_sample(ones) >= 0.9999,
+    PWCNet.py:195-206) by wrapping nets.warp_fn: warp(ones) is non-zero exactly where the mask is 1.  Levels 5, 4, 3, 2 in call order."""
+
+    def __init__(self, monkeypatch):
+        from islam_amd import nets, ops
+        self.masks = []
+        inner = nets.warp_fn
+
+        def rec(x, flow, scale):
+            ones = torch.ones((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+            self.masks.append((ops.warp_mask(ones, flow.float().contiguous(), scale)[:, 0] > 0).cpu().numpy())
+            return inner(x, flow, scale)
+        monkeypatch.setattr(nets, 'warp_fn', rec)
+
+    def by_level(self):
+        assert len(self.masks) >= 4
+        return dict(zip((5, 4, 3, 2), self.masks[-4:]))
+
+
+def _ref_warp_masks(prefix):
+    """The reference run's masks of the same fixture (tests/golden/make_warp_mask_golden.py)."""
+    z = np.load(os.path.join(G, 'nets_warp_masks.npz'))
+    out = {}
+    for lvl in (5, 4, 3, 2):
+        shp = tuple(z['%s_level%d_shape' % (prefix, lvl)])
+        out[lvl] = np.unpackbits(z['%s_level%d' % (prefix, lvl)])[:int(np.prod(shp))].reshape(shp).astype(bool)
+    return out
+
+
+def _flip_region(ref_masks, got_masks, out_level, out_hw):
+    """(B, H, W) bool at the resolution of the output of pyramid level ``out_level``: the pixels a warp-mask decision that differs
+    between the reference run and this run may have moved.  A flip at level l >= out_level (the decoder runs coarse to fine: a warp at
+    level l feeds the flow of level l and of every finer level) excuses the 3x3 neighbourhood of the flipped pixel at level l's
+    resolution -- the footprint of that neighbourhood at the output's resolution."""
+    region = None
+    nflip = 0
+    for lvl in (5, 4, 3, 2):
+        if lvl < out_level:
+            continue
+        f = ref_masks[lvl] != got_masks[lvl]
+        nflip += int(f.sum())
+        r = FLIP_RADIUS
+        pad = np.pad(f, ((0, 0), (r, r), (r, r)))
+        d = np.zeros_like(f)
+        for dy in range(2 * r + 1):
+            for dx in range(2 * r + 1):
+                d |= pad[:, dy:dy + f.shape[1], dx:dx + f.shape[2]]
+        s = 2 ** (lvl - out_level)
+        d = np.repeat(np.repeat(d, s, axis=1), s, axis=2)
+        assert d.shape[1:] == tuple(out_hw), (d.shape, out_hw)
+        region = d if region is None else (region | d)
+    return region, nflip
+
+
+def _within(got, ref, bounds, what='', flip_region=None):
+    """max / rms / bias of the error within ``bounds``.  flip_region (outputs behind PWC-Net's warp; (B,H,W) bool from _flip_region):
+    the warp zeroes a feature pixel when its validity mask drops below 0.9999 (PWCNet.py:195-206) -- a DISCONTINUITY of the reference
+    network.  A rounding-level change of the up-sampled flow can flip that decision for a pixel on the edge (which way it falls depends
+    on the arithmetic in front of it), and the convolutions behind it spread the difference over its neighbourhood.  The maximum may
+    therefore exceed its bound ONLY on pixels inside the 3x3 neighbourhood of a pixel whose mask decision really differs between the
+    reference run and this run (and never 3x the bound there); everywhere else the plain bound holds -- a tile-border bug in a
+    convolution kernel cannot hide in this allowance.  rms and bias keep their bounds over the whole map."""
     mx, rms, bias = _stats(got, ref)
     print('%s: max %.3e rms %.3e bias %+.3e' % (what, mx, rms, bias))
     assert rms <= bounds[1] and abs(bias) <= bounds[2], (what, mx, rms, bias)
-    if mx > bounds[0] and flips:
-        r = np.asarray(ref, np.float64)
-        e = np.abs(got.detach().float().cpu().numpy().astype(np.float64) - r) / max(np.abs(r).max(), 1e-3)
-        frac = float((e > bounds[0]).mean())
-        print('%s: %.2f %% of the elements above %.1e' % (what, 100 * frac, bounds[0]))
-        assert frac <= 0.01 and mx <= 3 * bounds[0], (what, mx, frac)
-    else:
+    if flip_region is None:
         assert mx <= bounds[0], (what, mx, rms, bias)
+        return mx
+    region, nflip = flip_region
+    r = np.asarray(ref, np.float64)
+    e = np.abs(got.detach().float().cpu().numpy().astype(np.float64) - r) / max(np.abs(r).max(), 1e-3)
+    e = e.max(axis=1)                                                   # (B, H, W): worst channel of a pixel
+    outside = float(e[~region].max()) if (~region).any() else 0.0
+    inside = float(e[region].max()) if region.any() else 0.0
+    print('%s: %d flipped warp-mask pixels, %.2f %% of the map excused; max outside %.3e, inside %.3e' %
+          (what, nflip, 100.0 * region.mean(), outside, inside))
+    assert outside <= bounds[0], (what, 'outside the flipped neighbourhoods', outside, nflip)
+    assert inside <= 3 * bounds[0], (what, 'inside a flipped neighbourhood', inside, nflip)
+    assert region.mean() <= 0.02, (what, 'flipped neighbourhoods cover %.2f %% of the map' % (100.0 * region.mean()))
     return mx
 
 
@@ -121,15 +184,18 @@ def test_imu_denoiser_on_gpu_matches_reference(cuda):
 
 
 # ------------------------------------------------------------------------------------------ the paths the bench runs
-def test_flow_net_matrix_core_path_matches_reference(cuda):
+def test_flow_net_matrix_core_path_matches_reference(cuda, monkeypatch):
     """PWCDCNet.forward_mfma: islam_conv3x3_mfma (bf16 operands, fp32 accumulate), slice-written DenseNet blocks, batched
-    pyramid -- against the reference's fp32 outputs."""
+    pyramid -- against the reference's fp32 outputs; the max bound may be exceeded only next to a warp-mask pixel that really flipped."""
     from islam_amd import nets
     ref = _g('pwc')
     net = fill_state_dict(nets.PWCDCNet()).to(cuda).eval()
+    rec = _WarpMaskRecorder(monkeypatch)
     with torch.no_grad():
         flows, _ = net.forward_mfma(make_input('pwc').to(cuda))
-    errs = [_within(f, ref['flow%d' % i], BF16_OPERANDS, 'flow%d' % i, flips=True) for i, f in enumerate(flows)]
+    rm, gm = _ref_warp_masks('pwc'), rec.by_level()
+    errs = [_within(f, ref['flow%d' % i], BF16_OPERANDS, 'flow%d' % i, flip_region=_flip_region(rm, gm, 2 + i, f.shape[2:]))
+            for i, f in enumerate(flows)]
     assert max(errs) > 1e-5                  # it IS the reduced-precision path (the fp32 path sits at ~1e-6)
 
 
@@ -184,7 +250,7 @@ def test_whole_vonet_fp32_matches_reference(cuda):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph):
+def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph, monkeypatch):
     """What bench.py runs: flow net on the matrix-core convolution, stereo net through the bf16 execution copy, optionally
     replayed from a captured HIP graph (two replays: the second one must still be right, and BatchNorm running statistics
     keep moving)."""
@@ -194,11 +260,18 @@ def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph):
     vn.set_graph_frozen(graph)
     args = _vo_args(cuda)
     key = 'feature_extraction.firstconv.0.1.running_mean'
+    # the warp masks of THIS path, from an eager pass of the flow net with the recorder in place (a graph replay runs the same kernels on
+    # the same inputs: same masks), against the reference run's
+    rec = _WarpMaskRecorder(monkeypatch)
+    with torch.no_grad():
+        vn._run_frozen('flow', vn.flowNet, vn.flow_dtype, torch.cat([args[0], args[1]], 1))
+    region = _flip_region(_ref_warp_masks('vonet'), rec.by_level(), 2, ref['flow'].shape[2:])
+    monkeypatch.undo()
     for rep in range(2 if graph else 1):
         rm0 = vn.stereoNet.state_dict()[key].clone()
         with torch.no_grad():
             flow, disp, pose = vn(*args)
-        _within(flow, ref['flow'], BF16_OPERANDS, 'flow', flips=True)
+        _within(flow, ref['flow'], BF16_OPERANDS, 'flow', flip_region=region)
         _within(disp, ref['disp'], BF16_STEREO, 'disp')
         assert _relmax(pose, ref['pose']) <= 1e-2, rep     # pose head (fp32) fed with that flow (measured 7e-4)
         assert not torch.equal(vn.stereoNet.state_dict()[key], rm0)
