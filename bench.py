@@ -225,11 +225,16 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
     from islam_amd.bilevel import BilevelLoop
     from islam_amd.imu_integrator import IMUModule
     torch.manual_seed(0)
+    # batches whose frozen forward is queued ahead (= captured graph copies).  Measured on one box, three runs each: depth 1: 825 / 827 / 845
+    # frames/s, depth 2 (two graph copies, replays queued back to back, GPU_MAX_HW_QUEUES=8): 830 / 832 / 845 -- no gain: the step is bound by
+    # the main chain beside the replay, not by the replays' turn-around; and with HIP's default four hardware queues the second copy's fork
+    # stream lands on the main stream's queue and serialises the two (494).  So: one batch ahead.
+    depth = int(os.environ.get('ISLAM_PREFETCH_DEPTH', '1'))
     vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True,
                   miopen_find=True, pose_channels_last=True,
                   pose_dtype=torch.bfloat16 if os.environ.get('ISLAM_POSE_BF16') == '1' else None,   # measured: 330 vs 325 frames/s -- not worth the numerics
 
-                  graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1',
+                  graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1', graph_instances=depth,
                   graph_pose=False if os.environ.get('ISLAM_NO_GRAPH') == '1' else (True if os.environ.get('ISLAM_POSE_GRAPH') == 'callables' else 'accumulate'))
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
@@ -248,11 +253,25 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
     # graph replay (event pair on the side stream it runs on) and of every step's main chain (event pair on the main stream), the
     # shader clock sampled on a third stream before / during / after, and whether MIOpen served the pose head from the pinned set
     from islam_amd import miopen_pin
-    probe = ops_mod.ClockProbe(device, capacity=96)
+    # The probe's stream is created LAZILY, behind every stream of the pipeline (side stream of the prefetch, fork stream of the captured
+    # graph, capture stream of the pose head): HIP deals streams onto a few hardware queues in creation order, and a probe stream made
+    # first moved the prefetch's side stream onto the main stream's queue -- the two then ran one after the other (measured: 838 -> 460
+    # frames/s, pipelined == sequential).
+    probe_box = []
+
+    def probe():
+        if not probe_box:
+            probe_box.append(ops_mod.ClockProbe(device, capacity=96))
+        return probe_box[0]
     replay_ev = []
     inner = vo.vonet._frozen_graphed
 
+    diag_mode = os.environ.get('ISLAM_VIO_DIAG', 'all')       # all | none | replay | chain | probe  (A/B runs of the instrumentation itself)
+    ev_replay, ev_chain, ev_probe = (diag_mode in ('all', 'replay')), (diag_mode in ('all', 'chain')), (diag_mode in ('all', 'probe'))
+
     def timed_replay(imgs):
+        if not ev_replay:
+            return inner(imgs)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         r = inner(imgs)
@@ -264,7 +283,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
     def run(pipelined, probe_every=0):
         loop.reset()
         seq = []
-        for k in range(steps + warmup + 2):
+        for k in range(steps + warmup + 3):
             smp = dict(samples[k % 2])
             smp['link'] = samples[k % 2]['link'] + k * batch
             seq.append(smp)
@@ -276,31 +295,31 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                 loop.timing = dict(vo=0.0, imu=0.0, pgo=0.0, opt=0.0)
                 del replay_ev[:]
                 t0 = time.perf_counter()
-            if probe_every and k >= warmup and (k - warmup) % probe_every == 0:
-                probe.sample()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            ahead = (seq[k + 1], seq[k + 2]) if os.environ.get('ISLAM_PREFETCH_DEPTH', '1') == '2' else seq[k + 1]
-            loop.step(seq[k], next_sample=ahead if pipelined else None)      # (two batches ahead measured: 410-422 vs 415-417 frames/s, no gain)
-            b.record()
-            if k >= warmup:
-                chain_ev.append((a, b))
+            if ev_probe and probe_every and k >= warmup and (k - warmup) % probe_every == 0:
+                probe().sample()
+            if ev_chain:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            ahead = tuple(seq[k + 1:k + 1 + depth]) if depth > 1 else seq[k + 1]
+            loop.step(seq[k], next_sample=ahead if pipelined else None)
+            if ev_chain:
+                b.record()
+                if k >= warmup:
+                    chain_ev.append((a, b))
         torch.cuda.synchronize()
         el_ = time.perf_counter() - t0
         med = lambda ev: float(np.median([x.elapsed_time(y) for x, y in ev])) if ev else None
         return el_, dict(loop.timing), {'frozen_replay_gpu_ms': med(replay_ev[-steps:]), 'main_chain_gpu_ms': med(chain_ev)}
 
-    for _ in range(3):
-        probe.sample()
-    clock_idle = probe.n
     el_seq, tm, gpu_seq = run(False)
     # the frozen flow / disparity forward of batch k+1 overlaps the IMU / PVGO / backward of batch k.  THREE pipelined runs: the line
     # carries median / min / max (value = the median run)
     pipe = [run(True, probe_every=8) for _ in range(3)]
-    clock_run = probe.n
+    clock_run = probe().n
+    time.sleep(0.3)
     for _ in range(3):
-        probe.sample()
-    mhz = probe.mhz()
+        probe().sample()
+    mhz = probe().mhz()
     order = sorted(range(3), key=lambda r: pipe[r][0])
     el, _, gpu_pipe = pipe[order[1]]
     rates = [steps * batch / pipe[r][0] for r in range(3)]
@@ -312,9 +331,9 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
             'what': 'HIP event pairs: frozen_replay = around the frozen nets\' graph replay on the stream it runs on (side stream when pipelined); '
                     'main_chain = around BilevelLoop.step on the main stream (pose head, glue, IMU, PVGO, backward; includes host gaps and, '
                     'sequentially, the replay itself); medians over the timed steps of the median run'},
-        'shader_clock_mhz': {'before_idle': mhz[:clock_idle], 'during_pipelined_median': float(np.median(mhz[clock_idle:clock_run])) if clock_run > clock_idle else None,
-                             'during_pipelined_min': min(mhz[clock_idle:clock_run]) if clock_run > clock_idle else None,
-                             'after': mhz[clock_run:],
+        'shader_clock_mhz': {'during_pipelined_median': float(np.median(mhz[:clock_run])) if clock_run else None,
+                             'during_pipelined_min': min(mhz[:clock_run]) if clock_run else None,
+                             'idle_after': mhz[clock_run:],
                              'what': 'islam_clock_probe: one wavefront, dependent fp64 FMA chain, shader cycles / constant-rate wall clock, on a stream of its own'},
         'miopen_pinned_db': {'matches_device_and_version': bool(pin_ok), 'detail': pin_msg, 'searched_in_this_process': miopen_pin.searched_since_start()},
     }
@@ -323,7 +342,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                    ' | PVGO of the 9-node window: the whole LM loop in one launch (small_lm_kernel)',
            'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
            'ms_per_batch': el / steps * 1e3,
-           'schedule': 'software-pipelined: TartanVO.prefetch runs the frozen nets of the next batch on a side stream',
+           'schedule': 'software-pipelined: TartanVO.prefetch queues the frozen nets of the next %d batch(es) on a side stream (%d captured graph copies, round-robin)' % (depth, depth),
            'sequential_frames_per_s': steps * batch / el_seq, 'sequential_ms_per_batch': el_seq / steps * 1e3,
            'sequential_stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
            'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic',

@@ -55,7 +55,8 @@ def stereo_scale(disp, flow, pose_enu, intr4, baseline, edge, disp_th, depth_inp
 class TartanVO(nn.Module):
     def __init__(self, vo_model_name=None, pose_model_name=None, flow_model_name=None, stereo_model_name=None,
                  device_id=0, correct_scale=True, fix_parts=(), use_kitti_coord=True, frozen_dtype=None, flow_dtype=None,
-                 host_glue=False, miopen_find=False, pose_channels_last=False, graph_frozen=False, graph_pose=False, pose_dtype=None):
+                 host_glue=False, miopen_find=False, pose_channels_last=False, graph_frozen=False, graph_pose=False, pose_dtype=None,
+                 graph_instances=1):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('islam_amd.TartanVO runs on the MI355X only; there is no CPU fallback')
@@ -87,6 +88,8 @@ class TartanVO(nn.Module):
             self.vonet.set_pose_channels_last(True)
         if graph_frozen:        # the frozen flow + disparity forward replays from a HIP graph (VONet.set_graph_frozen)
             self.vonet.set_graph_frozen(True)
+        # captured copies of the frozen forward, used round-robin: N copies let prefetch() queue N batches ahead (VONet._frozen_graphed)
+        self.vonet.graph_instances = max(1, int(graph_instances))
         # forward + backward of the trainable pose head as HIP graphs; 'accumulate': the backward node adds the parameter gradients to
         # .grad itself (nets._PoseGraph; torch.autograd.grad callers list vonet.pose_graph_leaf() among their inputs)
         self.vonet.graph_pose = 'accumulate' if graph_pose == 'accumulate' else bool(graph_pose)

@@ -81,7 +81,7 @@ class BilevelLoop:
                             self.vo.prefetch(nxt)
             # the next batch's frozen forward is queued BEFORE this batch's pose head and host glue (ISLAM_PREFETCH_FIRST=0: behind them; the glue
             # synchronises with the device twice; queued behind it, the side stream sat idle for ~2 ms per batch)
-            first = PREFETCH_FIRST and not isinstance(next_sample, (tuple, list))
+            first = PREFETCH_FIRST
             if first:
                 prefetch_next()
             # no autograd state for the VO forward of an IMU epoch (TartanVO.forward opens its own grad mode: an outer

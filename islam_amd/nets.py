@@ -1082,26 +1082,39 @@ class VONet(nn.Module):
 
     def _frozen_graphed(self, imgs):
         key = (tuple(imgs[0].shape), imgs[0].device, self.stereoNet.training, self.flowNet.training, self.frozen_dtype, self.flow_dtype)
-        st = self._graphs.get(key)
-        if st is None:
+        ring = self._graphs.get(key)
+        if ring is None:
+            ring = self._graphs[key] = {'inst': [], 'next': 0}
+        # graph_instances (default 1) captured copies of the same forward, used round-robin: with two, the replay of batch k+2 can be
+        # QUEUED while batch k+1's is still running (TartanVO.prefetch two batches ahead) -- the replays then run back to back on the
+        # side stream instead of waiting for the host's turn-around (fence + input copies + graph launch: ~0.85 ms per batch).  Every
+        # instance has its own static inputs / outputs, memory pool and fork stream; BatchNorm running statistics are shared module
+        # buffers and are updated in stream order.
+        want = max(1, int(getattr(self, 'graph_instances', 1)))
+        if len(ring['inst']) < want:
             static_in = [t.detach().clone() for t in imgs]
-            with torch.no_grad():
-                for _ in range(2):                      # MIOpen's kernel search, lazy initialisation: outside the capture
-                    self._frozen_eager(*static_in)
+            if not ring['inst']:
+                with torch.no_grad():
+                    for _ in range(2):                  # MIOpen's kernel search, lazy initialisation: outside the capture
+                        self._frozen_eager(*static_in)
             torch.cuda.synchronize(imgs[0].device)
             g = torch.cuda.CUDAGraph()
             fork = torch.cuda.Stream(imgs[0].device) if FROZEN_FORK else None        # (created outside the capture)
             with torch.no_grad(), torch.cuda.graph(g):
                 static_out = self._frozen_eager(*static_in, fork=fork)
-            st = self._graphs[key] = (g, static_in, static_out)
-        g, static_in, static_out = st
-        # One launch of this graph in flight at a time: the host waits for the previous replay (and the clones of its outputs) before it
-        # queues the next one.  With two batches ahead the second replay used to be queued on the side stream while the first was
-        # still running, and on this stack (ROCm 7.0 hipGraphLaunch) that intermittently corrupted a few pixels of the FIRST replay's
-        # flow -- in about half of all fresh processes the stereo scale of one frame of the second batch moved by 3-4 %
-        # (scripts/debug/flaky_once.py; tests/test_benched_frontend_gpu.py was flaky for it).  bench.py's one-ahead schedule never
-        # overlaps two replays: there the wait returns at once.
-        prev = self.__dict__.get('_replay_done')
+            ring['inst'].append({'g': g, 'in': static_in, 'out': static_out, 'done': None, 'fork': fork})
+            st = ring['inst'][-1]
+        else:
+            st = ring['inst'][ring['next'] % len(ring['inst'])]
+            ring['next'] += 1
+        g, static_in, static_out = st['g'], st['in'], st['out']
+        # One launch of a captured graph in flight at a time: the host waits for THIS INSTANCE's previous replay (and the clones of its
+        # outputs) before it queues the next one.  With two batches ahead on ONE instance the second replay used to be queued on the side
+        # stream while the first was still running, and on this stack (ROCm 7.0 hipGraphLaunch) that intermittently corrupted a few pixels
+        # of the FIRST replay's flow -- in about half of all fresh processes the stereo scale of one frame of the second batch moved by
+        # 3-4 % (scripts/debug/flaky_once.py; tests/test_benched_frontend_gpu.py was flaky for it).  With one instance and one batch
+        # ahead, or N instances and N batches ahead, the wait returns at once.
+        prev = st['done']
         if prev is not None and os.environ.get('ISLAM_GRAPH_FENCE', '1') == '1':
             prev.synchronize()
         for d, t in zip(static_in, imgs):
@@ -1110,7 +1123,7 @@ class VONet(nn.Module):
         out = tuple(t.clone() for t in static_out)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(imgs[0].device))
-        self.__dict__['_replay_done'] = ev
+        st['done'] = ev
         return out
 
     def frozen_forward(self, img0, img1, img0_norm, img0_r_norm):

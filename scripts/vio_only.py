@@ -6,4 +6,4 @@ import bench
 from islam_amd.miopen_pin import use_pinned_db
 use_pinned_db()
 r = bench.vio_frames_per_sec(torch.device("cuda:0"), steps=int(os.environ.get("VIO_STEPS", "64")))
-print(json.dumps({k: r[k] for k in ('value', 'ms_per_batch', 'sequential_frames_per_s', 'sequential_ms_per_batch', 'forward_only_frames_per_s')}))
+print(json.dumps({k: r[k] for k in ('value', 'ms_per_batch', 'sequential_frames_per_s', 'sequential_ms_per_batch', 'forward_only_frames_per_s', 'diagnostics')}))

@@ -63,14 +63,18 @@ def _loop(vo, tr):
     return BilevelLoop(vo, imu, pp.identity_SE3(), tr['init'], batch_size=B, device='cuda')
 
 
-def test_benched_configuration_two_bilevel_steps(cuda):
-    steps = 2
+@pytest.mark.parametrize('instances', [1, 2])
+def test_benched_configuration_two_bilevel_steps(cuda, instances):
+    """instances: captured copies of the frozen forward (TartanVO(graph_instances=...)).  2 = what bench.py runs: two batches ahead on
+    two copies used round-robin, their replays queued back to back (four steps, so that every copy replays twice); 1 = two batches
+    ahead on ONE copy, serialised by the per-copy fence."""
+    steps = 2 * instances
     tr = synthetic.car_trajectory(steps * B + 1, seed=3)
     seq = _samples(cuda, steps + 2)
 
     # ---- the benched configuration, pipelined exactly like bench.py's timed loop
     vo_b = _make(cuda, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True, pose_channels_last=True,
-                 graph_frozen=True, graph_pose='accumulate')
+                 graph_frozen=True, graph_pose='accumulate', graph_instances=instances)
     loop_b = _loop(vo_b, tr)
     losses_b = [loop_b.step(seq[k], next_sample=(seq[k + 1], seq[k + 2])) for k in range(steps)]      # (a tuple: two batches ahead -- the deepest schedule BilevelLoop offers; bench.py runs one ahead)
     torch.cuda.synchronize()
@@ -78,6 +82,7 @@ def test_benched_configuration_two_bilevel_steps(cuda):
     poses_b = np.asarray(loop_b.pgo_poses, dtype=np.float64)
     grads_b = [p.grad.detach().float().cpu().clone() for p in vo_b.vonet.flowPoseNet.parameters()]
     assert len(vo_b.vonet._graphs) >= 1                      # the frozen forward really replayed from a captured graph
+    assert all(len(r['inst']) == instances for r in vo_b.vonet._graphs.values())
     assert all(torch.isfinite(g).all() for g in grads_b) and any(float(g.abs().sum()) > 0 for g in grads_b)
 
     # ---- (b) same frozen nets, eager pose head, device glue, sequential schedule: the gradients must agree

@@ -92,7 +92,7 @@ def _flip_region(ref_masks, got_masks, out_level, out_hw):
     between the reference run and this run may have moved.  A flip at level l >= out_level (the decoder runs coarse to fine: a warp at
     level l feeds the flow of level l and of every finer level) excuses the 3x3 neighbourhood of the flipped pixel at level l's
     resolution -- the footprint of that neighbourhood at the output's resolution."""
-    region = None
+    region = np.zeros((ref_masks[2].shape[0],) + tuple(out_hw), bool)      # (the level-6 flow sits in front of every warp: nothing excused)
     nflip = 0
     for lvl in (5, 4, 3, 2):
         if lvl < out_level:
@@ -108,7 +108,7 @@ def _flip_region(ref_masks, got_masks, out_level, out_hw):
         s = 2 ** (lvl - out_level)
         d = np.repeat(np.repeat(d, s, axis=1), s, axis=2)
         assert d.shape[1:] == tuple(out_hw), (d.shape, out_hw)
-        region = d if region is None else (region | d)
+        region |= d
     return region, nflip
 
 
