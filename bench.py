@@ -142,9 +142,21 @@ def trial_elim_burst(ops, prob, prm, N, device, launches=40):
     return float(us.value), list(info)
 
 
+def pvgo_source_sha16():
+    """sha256[:16] over the PVGO translation unit: pvgo.hip and the pvgo_*.inl parts it includes, in name order (what
+    scripts/make_traffic_json.py stamps the counter passes with)."""
+    import glob
+    import hashlib
+    d = os.path.join(ROOT, 'islam_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in [os.path.join(d, 'pvgo.hip')] + sorted(glob.glob(os.path.join(d, 'pvgo_*.inl'))):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (the latest profiles/traffic_r*.json), valid only for the kernel
-    source they were taken on: the file records sha256(pvgo.hip)[:16]; a different source -> no traffic figure (never a stale one)."""
+    source they were taken on: the file records pvgo_source_sha16() (pvgo.hip + its pvgo_*.inl parts); a different source -> no traffic figure (never a stale one)."""
     import glob
     import hashlib
     fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic_r[0-9]*.json')))
@@ -153,7 +165,7 @@ def committed_traffic():
     tpath = fs[-1]
     t = json.load(open(tpath))
     t['file'] = os.path.relpath(tpath, ROOT)
-    sha = hashlib.sha256(open(os.path.join(ROOT, 'islam_amd', 'csrc', 'pvgo.hip'), 'rb').read()).hexdigest()[:16]
+    sha = pvgo_source_sha16()
     if t.get('pvgo_hip_sha16') != sha:
         return {'stale': True, 'note': '%s was taken on pvgo.hip %s, this is %s: dropped' % (t['file'], t.get('pvgo_hip_sha16'), sha)}
     return t
@@ -321,11 +333,12 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
         probe().sample()
     mhz = probe().mhz()
     order = sorted(range(3), key=lambda r: pipe[r][0])
-    el, _, gpu_pipe = pipe[order[1]]
+    el, tm_pipe, gpu_pipe = pipe[order[1]]
     rates = [steps * batch / pipe[r][0] for r in range(3)]
     pin_ok, pin_msg = miopen_pin.check_pinned_db(device.index or 0, strict=False)
     diag = {
         'pipelined_runs_frames_per_s': {'median': float(np.median(rates)), 'min': min(rates), 'max': max(rates), 'runs': rates},
+        'pipelined_host_stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm_pipe.items()},
         'gpu_side_ms_per_step': {
             'pipelined': gpu_pipe, 'sequential': gpu_seq,
             'what': 'HIP event pairs: frozen_replay = around the frozen nets\' graph replay on the stream it runs on (side stream when pipelined); '

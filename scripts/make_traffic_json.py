@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'traffic_r04.json')
 S = json.load(open(os.path.join(src, 'summary.json')))
-sha = hashlib.sha256(open(os.path.join(ROOT, 'islam_amd', 'csrc', 'pvgo.hip'), 'rb').read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+import bench
+sha = bench.pvgo_source_sha16()          # pvgo.hip + the pvgo_*.inl parts it includes
 
 
 def pick(table, needle, grid=None):

@@ -24,7 +24,8 @@ def _device_disassembly(so):
     tmp = tempfile.mkdtemp(prefix='islam_isa_')
     try:
         fat = os.path.join(tmp, 'fat.bin')
-        subprocess.check_call(['objcopy', '--dump-section', '.hip_fatbin=' + fat, so])
+        # (objcopy rewrites its INPUT in place when no output file is named -- the loaded library would change under the process)
+        subprocess.check_call(['objcopy', '--dump-section', '.hip_fatbin=' + fat, so, os.path.join(tmp, 'copy.so')])
         blob = open(fat, 'rb').read()
         starts = [m.start() for m in re.finditer(re.escape(b'__CLANG_OFFLOAD_BUNDLE__'), blob)]
         out = []
