@@ -362,7 +362,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
            'diagnostics': diag}
     # roofline of the front end with EXECUTED matrix-core work (the reference-equivalent 466.4 GFLOP per frame above counts the
     # full-resolution tail the quarter-resolution evaluation skips) and the shader clock the chip sustains under this load: both from
-    # the committed hardware-counter pass over the frozen forward (scripts/frozen_pmc.sh -> profiles/r04/frozen_exec_summary_*.json)
+    # the committed hardware-counter pass over the frozen forward (scripts/frozen_pmc.sh -> profiles/r*/frozen_exec_summary_*.json, latest round)
     ex = committed_exec_summary()
     if ex:
         g = ex['executed_gflop_per_frame']
@@ -382,10 +382,10 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
 
 
 def committed_exec_summary():
-    """profiles/r04/frozen_exec_summary_*.json (latest): executed matrix-core GFLOP per frame and the shader clock of the frozen forward,
+    """profiles/r*/frozen_exec_summary_*.json (latest round): executed matrix-core GFLOP per frame and the shader clock of the frozen forward,
     from rocprofv3 PMC passes on the GPU box; None if no summary is committed."""
     import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04', 'frozen_exec_summary_*.json')))
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9]*', 'frozen_exec_summary_*.json')))
     if not fs:
         return None
     try:

@@ -1,4 +1,4 @@
-"""profiles/traffic_r04.json from a scripts/gpu_profile.sh run: HBM bytes per launch of the LM loop's kernels from the two rocprofv3
+"""profiles/traffic_r<NN>.json from a scripts/gpu_profile.sh run: HBM bytes per launch of the LM loop's kernels from the two rocprofv3
 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B requests at 64 B on
 gfx950 -> doubled; WRITE_SIZE as reported; KB = 1024 B), live dispatches only (gated no-op dispatches dropped), stamped with the
 hash of the kernel source they were taken on (bench.py refuses the figures for any other source).
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'traffic_r04.json')
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'traffic_r05.json')
 S = json.load(open(os.path.join(src, 'summary.json')))
 sys.path.insert(0, ROOT)
 import bench
