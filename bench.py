@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# HIP deals its streams onto this many hardware queues in creation order (default 4).  The software-pipelined stereo_vio step runs the
+# main chain, the prefetch stream and the fork streams of two captured graph copies: with four queues one fork stream shares the main
+# stream's queue and the two serialise (494 instead of 880 frames/s).  Read when the HIP runtime initialises: set before torch is imported.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -237,17 +242,20 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
     from islam_amd.bilevel import BilevelLoop
     from islam_amd.imu_integrator import IMUModule
     torch.manual_seed(0)
-    # batches whose frozen forward is queued ahead (= captured graph copies).  Measured on one box, three runs each: depth 1: 825 / 827 / 845
-    # frames/s, depth 2 (two graph copies, replays queued back to back, GPU_MAX_HW_QUEUES=8): 830 / 832 / 845 -- no gain: the step is bound by
-    # the main chain beside the replay, not by the replays' turn-around; and with HIP's default four hardware queues the second copy's fork
-    # stream lands on the main stream's queue and serialises the two (494).  So: one batch ahead.
-    depth = int(os.environ.get('ISLAM_PREFETCH_DEPTH', '1'))
+    # batches whose frozen forward is queued ahead (= captured graph copies).  With the main chain shortened by the fused pose algebra
+    # (islam_amd/glue.py) the step is bound by the replays: two copies, replays queued back to back, 884 / 885 against 849 / 874 frames/s
+    # with one batch ahead on one box (before the fused algebra: 830 / 832 against 825 / 827, no gain).  Two copies need the eight
+    # hardware queues set at the top of this file: with HIP's default four the second copy's fork stream shares the main stream's queue
+    # and the two serialise (494).  Should that happen anyway (the run below checks: pipelined rate < 1.3 x sequential), the
+    # measurement falls back to one batch ahead and says so.
+    depth = int(os.environ.get('ISLAM_PREFETCH_DEPTH', '2'))
     vo = TartanVO(correct_scale=False, fix_parts=("flow", "stereo"), use_kitti_coord=True, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True,
                   miopen_find=True, pose_channels_last=True,
                   pose_dtype=torch.bfloat16 if os.environ.get('ISLAM_POSE_BF16') == '1' else None,   # measured: 330 vs 325 frames/s -- not worth the numerics
 
                   graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1', graph_instances=depth,
                   graph_pose=False if os.environ.get('ISLAM_NO_GRAPH') == '1' else (True if os.environ.get('ISLAM_POSE_GRAPH') == 'callables' else 'accumulate'))
+    vo.fused_glue = os.environ.get('ISLAM_FUSED_GLUE', '1') == '1'      # the pose algebra behind the networks as one autograd node (islam_amd/glue.py)
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
         vo.vonet.stereoNet.conv_c13.bias.fill_(0.8)
@@ -292,7 +300,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
         return r
     vo.vonet._frozen_graphed = timed_replay
 
-    def run(pipelined, probe_every=0):
+    def run(pipelined, probe_every=0, depth=depth):
         loop.reset()
         seq = []
         for k in range(steps + warmup + 3):
@@ -326,7 +334,14 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
     el_seq, tm, gpu_seq = run(False)
     # the frozen flow / disparity forward of batch k+1 overlaps the IMU / PVGO / backward of batch k.  THREE pipelined runs: the line
     # carries median / min / max (value = the median run)
-    pipe = [run(True, probe_every=8) for _ in range(3)]
+    pipe = [run(True, probe_every=8)]
+    fallback = None
+    if depth > 1 and steps * batch / pipe[0][0] < 1.3 * (steps * batch / el_seq):
+        # the deeper schedule did not overlap (a stream of the second graph copy sharing the main stream's hardware queue?): one batch ahead
+        fallback = {'depth_%d_frames_per_s' % depth: steps * batch / pipe[0][0], 'now': 'one batch ahead'}
+        depth = 1
+        pipe = [run(True, probe_every=8, depth=1)]
+    pipe += [run(True, probe_every=8, depth=depth) for _ in range(2)]
     clock_run = probe().n
     time.sleep(0.3)
     for _ in range(3):
@@ -356,6 +371,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
            'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
            'ms_per_batch': el / steps * 1e3,
            'schedule': 'software-pipelined: TartanVO.prefetch queues the frozen nets of the next %d batch(es) on a side stream (%d captured graph copies, round-robin)' % (depth, depth),
+           'schedule_fallback': fallback,
            'sequential_frames_per_s': steps * batch / el_seq, 'sequential_ms_per_batch': el_seq / steps * 1e3,
            'sequential_stage_ms_per_batch': {k: v / steps * 1e3 for k, v in tm.items()},
            'forward_only_frames_per_s': steps * batch / tm['vo'], 'weights': 'random init', 'data': 'synthetic',

@@ -79,6 +79,7 @@ class TartanVO(nn.Module):
         # ~150 tiny tensor ops and as many autograd nodes) runs in float64 on the host instead of one device launch per op;
         # res['motion'] is still returned on the device, res['motion_host'] is the same LieTensor on the host
         self.host_glue = host_glue
+        self.fused_glue = True        # host_glue as ONE autograd node (islam_amd/glue.py); False: operator by operator (A/B runs, tests)
         for name, part in ((vo_model_name, self.vonet), (flow_model_name, self.vonet.flowNet),
                            (pose_model_name, self.vonet.flowPoseNet), (stereo_model_name, self.vonet.stereoNet)):
             if name is not None and name != '':
@@ -166,6 +167,18 @@ class TartanVO(nn.Module):
             precalc_flow = sample['flow'] if 'flow' in sample else None
 
             flow, disp, pose = self.vonet(img0, img1, img0_norm, img0_r_norm, intrinsic, frozen=frozen)
+            if self.host_glue and self.fused_glue and given_scale is None and not self.correct_scale and pose.is_cuda:
+                # the whole (B,6) -> (B,7) algebra below as ONE autograd node in vectorised numpy (islam_amd/glue.py): same arithmetic,
+                # same gradient conventions, two device reads instead of three, ~100 fewer autograd nodes on the step's main chain
+                from .glue import fused_pose_glue
+                flow, disp = flow.detach(), disp.detach()
+                flow = flow * 5 if precalc_flow is None else precalc_flow.cuda(dev)
+                disp = disp * (50 / 4)
+                th = torch.tensor([float(DISP_TH[d]) for d in sample['datatype']])
+                motion, scale, depth, mask, depth_mask = fused_pose_glue(pose, self.pose_std.double().cpu().numpy(), disp, flow, intrinsic_calib.float() / 4,
+                                                                         baseline.float(), edge_mask(img0), th, self.use_kitti_coord)
+                return {'flow': flow, 'disp': disp, 'mask': mask, 'depth': depth, 'depth_mask': depth_mask, 'baseline': baseline[0],
+                        'intrinsic': intrinsic_calib[0] / 4, 'motion_host': motion, 'motion': pp.SE3(motion.tensor().float().cuda(dev))}
             if self.host_glue:
                 pose = pose.double().cpu() * self.pose_std.double().cpu()
             else:

@@ -55,6 +55,17 @@ for base, runs in ((5001, 60), (300007, 3)):
         del prob
 t_shard = out['sharded_world1_us_per_lm_iter_N5001'] - out['fused_us_per_lm_iter']['5001']
 out['t_shard_us'] = t_shard
+print(json.dumps(out), file=sys.stderr, flush=True)          # (partial result, in case the RCCL part below takes the process down)
+table = {}
+for base in (5001, 300007):
+    t1 = out['fused_us_per_lm_iter'][str(base)]
+    rows = {}
+    for P in (2, 4, 8):
+        n = (base - 1) // P + 1
+        lo, hi = [out['fused_us_per_lm_iter'][str(n)] + t_shard + a for a in out['assumed_allreduce_us']]
+        rows[str(P)] = {'nodes_per_rank': n, 'predicted_us': [lo, hi], 'speedup_vs_1gpu': [t1 / hi, t1 / lo]}
+    table[str(base)] = {'one_gpu_us': t1, 'ranks': rows}
+out['predicted'] = table
 # RCCL at world 1 (a communicator of one: what the library call itself costs; no xGMI hop in it)
 try:
     import torch.distributed as dist
@@ -74,14 +85,6 @@ try:
     dist.destroy_process_group()
 except Exception as e:
     out['rccl_world1_allreduce_us'] = {'error': repr(e)[:200]}
-table = {}
-for base in (5001, 300007):
-    t1 = out['fused_us_per_lm_iter'][str(base)]
-    rows = {}
-    for P in (2, 4, 8):
-        n = (base - 1) // P + 1
-        lo, hi = [out['fused_us_per_lm_iter'][str(n)] + t_shard + a for a in out['assumed_allreduce_us']]
-        rows[str(P)] = {'nodes_per_rank': n, 'predicted_us': [lo, hi], 'speedup_vs_1gpu': [t1 / hi, t1 / lo]}
-    table[str(base)] = {'one_gpu_us': t1, 'ranks': rows}
-out['predicted'] = table
-print(json.dumps(out))
+print(json.dumps(out), flush=True)
+if len(sys.argv) > 1:
+    open(sys.argv[1], 'w').write(json.dumps(out, indent=1))

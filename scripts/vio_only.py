@@ -1,5 +1,6 @@
 """bench.py's stereo_vio measurement alone (full bilevel step at B=8, pipelined and sequential): A/B of front-end settings."""
 import json, os, sys
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # as bench.py: before the HIP runtime initialises
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

@@ -534,3 +534,42 @@ def test_flow_head_and_upsampled_features_from_the_mirror(cuda, H, W, up):
         assert torch.equal(buf[:, 4:6], upf) and bool((buf[:, :4] == 3.0).all()) and bool((buf[:, 6:] == 3.0).all())
     else:
         assert upf is None
+
+
+@pytest.mark.parametrize('kitti', [True, False])
+def test_fused_pose_glue_matches_the_operator_by_operator_path(cuda, kitti):
+    """islam_amd/glue.py: the (B,6) -> (B,7) algebra behind the networks (TartanVO.py:107-198 incl. the stereo scale's gradient,
+    dense_ba.py:88-176) as ONE autograd node in numpy against the same algebra run operator by operator on the LieTensor shim
+    (TartanVO(host_glue=True, fused_glue=False)): motions to 1e-12, the gradient w.r.t. the pose head's output to 1e-9 of its size --
+    for an arbitrary upstream gradient on all seven slots, through the frame change BilevelLoop applies (train.py:214-215)."""
+    from islam_amd import lietensor as pp, synthetic
+    from islam_amd.TartanVO import TartanVO
+    torch.manual_seed(5)
+    vo = TartanVO(correct_scale=False, fix_parts=('flow', 'stereo'), use_kitti_coord=kitti, host_glue=True)
+    smp = synthetic.stereo_batch(4, seed=21)
+    smp = {k: (v.to(cuda) if isinstance(v, torch.Tensor) and (k.startswith('img') or k == 'intrinsic') else v) for k, v in smp.items()}
+    B = 4
+    g = torch.Generator().manual_seed(2)
+    flow = (torch.randn(B, 2, 112, 160, generator=g) * 0.6).to(cuda)
+    disp = (0.6 + 0.4 * torch.rand(B, 1, 112, 160, generator=g)).to(cuda)           # x 12.5 -> 7.5 .. 12.5 px: above the KITTI threshold
+    pose0 = torch.tensor([[0.3, -0.2, 1.0, 0.02, -0.01, 0.03], [1.0, 0.1, 0.2, -0.05, 0.02, 0.01],
+                          [-0.4, 0.5, 0.8, 0.0, 0.0, 0.0], [0.1, 0.1, 0.9, 0.3, -0.2, 0.1]], device=cuda) / vo.pose_std      # (one row with a zero rotation)
+    T_IL = pp.SE3(torch.tensor([0.1, -0.05, 0.2, 0.0499792, 0.0, 0.0, 0.9987503], dtype=torch.float64))
+    w = torch.randn(B, 7, generator=g, dtype=torch.float64)
+
+    def run(fused):
+        vo.fused_glue = fused
+        pose = pose0.clone().requires_grad_(True)
+        vo.vonet.forward = lambda *a, **k: (flow, disp, pose)                 # the networks' outputs pinned: the glue alone is under test
+        res = vo(smp)
+        m = res['motion_host']
+        P = T_IL @ m @ T_IL.Inv()
+        (P.tensor() * w).sum().backward()
+        return m.tensor().detach().clone(), pose.grad.detach().double().cpu().clone(), {k: res[k] for k in ('mask', 'depth', 'depth_mask')}
+    m0, g0, r0 = run(False)
+    m1, g1, r1 = run(True)
+    assert float(g0.abs().max()) > 0
+    torch.testing.assert_close(m1, m0, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(g1, g0, rtol=1e-6, atol=1e-9 * float(g0.abs().max()))       # (the gradient returns to the device in fp32)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
