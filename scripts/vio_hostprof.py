@@ -51,5 +51,5 @@ el = time.perf_counter() - t0
 print('pipelined: %.2f ms per batch (with cProfile on); stage wall ms per batch: %s' % (el / steps * 1e3, {k: round(v / steps * 1e3, 2) for k, v in loop.timing.items()}))
 if os.environ.get('NOPROF') != '1':
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
+    pstats.Stats(pr, stream=s).sort_stats(os.environ.get('SORT', 'cumulative')).print_stats(45)
     print(s.getvalue()[:9000])
