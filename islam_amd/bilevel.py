@@ -140,7 +140,11 @@ class BilevelLoop:
         loss_bp = torch.cat((self.rot_w * rot_loss, self.trans_w * trans_loss))                # train.py:280
         # the value that is returned: read BEFORE the backward is enqueued -- a device-to-host read behind it would wait for the
         # whole backward pass, and the pipelined schedule wants the host back while the GPU still runs it
-        loss_value = float(loss_bp.detach().sum())
+        tl_h, rl_h = getattr(trans_loss, 'host', None), getattr(rot_loss, 'host', None)
+        if tl_h is not None and rl_h is not None:      # run_pvgo already brought the loss vectors to the host with the poses
+            loss_value = float(self.rot_w * rl_h.sum() + self.trans_w * tl_h.sum())
+        else:
+            loss_value = float(loss_bp.detach().sum())
         if loss_bp.requires_grad:
             self._accumulate_gradients(loss_bp)
         sync(); t4 = time.perf_counter()

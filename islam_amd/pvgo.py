@@ -87,8 +87,15 @@ def run_pvgo(init_nodes, init_vels, vo_motions, links, dts, imu_drots, imu_dtran
         raise ValueError("target must be 'vo' or 'imu'")
 
     an, av = ops.pvgo_align(nodes, vels, target0)
-    nodes_out = pp.SE3(an.to(out_dtype).cpu())
-    vels_out = av.to(out_dtype).cpu()
+    # ONE device -> host copy for everything the caller reads on the host: aligned poses, velocities and the two loss vectors (their
+    # host values ride along as ``.host`` on the returned loss tensors, so that a caller that only wants to report the loss does not
+    # pay another synchronising read: BilevelLoop.step)
+    E = trans_loss.shape[0]
+    host = torch.cat([an.reshape(-1), av.reshape(-1), trans_loss.detach().to(torch.float64).reshape(-1),
+                      rot_loss.detach().to(torch.float64).reshape(-1)]).cpu()
+    nodes_out = pp.SE3(host[:7 * N].view(N, 7).to(out_dtype))
+    vels_out = host[7 * N:10 * N].view(N, 3).to(out_dtype)
+    trans_loss.host, rot_loss.host = host[10 * N:10 * N + E], host[10 * N + E:10 * N + 2 * E]
     n1 = N - 1
     covs = {'vo_rot': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_rot': np.ones(n1) * loss_weight[2] ** 2,
             'vo_trans': np.ones(len(links)) * loss_weight[0] ** 2, 'imu_vel': np.ones(n1) * loss_weight[1] ** 2,
