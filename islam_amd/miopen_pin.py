@@ -84,7 +84,8 @@ def searched_since_start():
     if d is None or os.environ.get('MIOPEN_USER_DB_PATH') != d:
         return None
     grew = recs = 0
-    new_files = sorted(f for f in os.listdir(d) if not os.path.exists(os.path.join(DB_DIR, f)))
+    # ('<db>.time' is a stamp MIOpen keeps beside a db it has opened -- not a search result)
+    new_files = sorted(f for f in os.listdir(d) if not os.path.exists(os.path.join(DB_DIR, f)) and not f.endswith('.time'))
     for f in os.listdir(d):
         if not f.endswith('.txt'):
             continue

@@ -121,7 +121,7 @@ def test_product_fails_loudly_without_gpu():
         IMUModule(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5), device='cpu')
 
 
-@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json', 'bench_r03_final.json', 'bench_r04_final.json'])
+@pytest.mark.parametrize('name', ['bench_r01_final.json', 'bench_r02_final.json', 'bench_r03_final.json', 'bench_r04_final.json', 'bench_r05_final.json'])
 def test_committed_bench_line_follows_the_contract(name):
     """profiles/bench_rNN_final.json is the last `python bench.py` line of a round measured on the MI355X: one JSON object with
     the driver's keys, BASELINE.json's metric, a roofline object for the dominant kernel and a CPU baseline; from round 2 on
@@ -161,6 +161,18 @@ def test_committed_bench_line_follows_the_contract(name):
         assert d['reject_heavy']['value'] > 0 and d['reject_heavy']['damping_changes_per_run'] + d['reject_heavy']['rejected_trials_per_run'] > 0
         assert d['large_graph']['N'] == 300007 and d['large_graph']['scaling'] == 'strong' and d['large_graph']['value'] > 0
         assert 'MIOpen stride-2 flow' not in d['stereo_vio']['nets'] and 'islam_hg_residual_nhwc_bf16' in d['stereo_vio']['nets']
+    if 'r05' in name:                 # round 5: median-of-passes headline, counter traffic valid for the split source, self-explaining stereo_vio
+        tp = d['timed_passes']
+        assert tp['passes'] >= 5 and tp['passes'] * d['steps'] * d['ms_per_step'] >= 100.0 and tp['pass_ms']['min'] <= tp['pass_ms']['median'] <= tp['pass_ms']['max']
+        assert abs(tp['pass_ms']['median'] - d['steps'] * d['ms_per_step']) < 1e-6
+        assert d['roofline']['traffic'] is not None and 'pvgo.hip sha256' in d['roofline']['traffic_source']
+        assert 0.9 < d['roofline']['traffic'] / d['roofline']['algorithmic_bytes_per_launch'] < 1.1
+        assert 'extrapolated_iters_per_s_N5001' not in json.dumps(d['cpu_baseline'])
+        dg = d['stereo_vio']['diagnostics']
+        assert len(dg['pipelined_runs_frames_per_s']['runs']) == 3 and dg['pipelined_runs_frames_per_s']['median'] == d['stereo_vio']['value']
+        assert dg['gpu_side_ms_per_step']['pipelined']['frozen_replay_gpu_ms'] > 0 and dg['shader_clock_mhz']['during_pipelined_median'] > 1000
+        assert dg['miopen_pinned_db']['matches_device_and_version'] is True and set(dg['pipelined_host_stage_ms_per_batch']) == {'vo', 'imu', 'pgo', 'opt'}
+        assert d['stereo_vio']['schedule_fallback'] is None and 'conv_nhwc_kernel' in d['stereo_vio']['nets']
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
