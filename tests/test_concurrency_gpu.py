@@ -5,8 +5,8 @@ main chain, train.py:200-299 has no such concurrency).
 
 Why this test exists (round 5): with conv_nhwc_kernel looping on a side stream, the -O3 build of scale_partial_kernel returned a wrong
 mask / scale in ~45 % of its launches (16 consecutive pixels = lanes 48..63 of one wavefront read as masked out; inputs untouched, gone
-after a device synchronisation, never without the concurrent load, never in the -O1 build of the same source: scripts/debug/
-coherence_ops.py, coherence_alloc.py).  tests/test_benched_frontend_gpu.py saw it as a stereo scale 3-10 % off in some processes.
+after a device synchronisation, never without the concurrent load, never in the -O1 build of the same source: scripts/debug/scribble_probe.py,
+scripts/debug/coherence_ops.py; cause and fix: DESIGN.md section 4.4).  tests/test_benched_frontend_gpu.py saw it as a stereo scale 3-10 % off in some processes.
 Every op below is deterministic (fixed-order reductions), so equality with the unloaded result is exact."""
 import numpy as np
 import pytest
@@ -64,6 +64,13 @@ def _cases(cuda):
         world, motion, _ = ops.imu_preint_both(imu[0], imu[1], imu[2], seg_d, seg_h, init[0], init[1], init[2], tr['gravity'])
         return list(world) + list(motion)
     cases['imu_preint_both'] = imu_both
+    imu32 = [t.float() for t in imu]
+    init32 = [t.float() for t in init]
+
+    def imu_both_f32():           # the IMUModule's default dtype (imu_integrator.py:44); its -O3 kernels held op_sel packed-FP32 forms before the fix
+        world, motion, _ = ops.imu_preint_both(imu32[0], imu32[1], imu32[2], seg_d, seg_h, init32[0], init32[1], init32[2], tr['gravity'])
+        return list(world) + list(motion)
+    cases['imu_preint_both_f32'] = imu_both_f32
     prob, _ = chain_problem(9)
     pv = {k: t64(prob[k]) for k in ('init_nodes', 'init_vels', 'vo_motions', 'imu_drots', 'imu_dtrans', 'imu_dvels', 'dts')}
     prm = ops.pvgo_default_params((1, 0.1, 10, 0.1))
