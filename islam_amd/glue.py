@@ -83,60 +83,76 @@ def _row(g, M):
     return np.einsum('...i,...ij->...j', g, M)
 
 
+def glue_forward_np(p, use_kitti_coord, scale_fn):
+    """The forward in numpy.  p: (B,6) float64 = the pose head's output x pose_std; scale_fn(pose_enu (B,7)) -> sums (B,18) float64 of
+    islam_scale_ls at that pose (the one device call of the algebra; tests pass a stand-in).  Returns (motion (B,7), saved)."""
+    tau, phi = p[:, :3], p[:, 3:]
+    q = _so3_exp(phi)
+    T, Ti = _axes()
+    X0 = np.concatenate([tau, q], -1)
+    pose_enu = _mul(_mul(T, X0), Ti)                                           # tartan2kitti_pypose(pose): the scale is recovered in this frame
+    sums = scale_fn(pose_enu)
+    sv = np.float32(1.0 / sums[:, 0] * sums[:, 1]).astype(np.float64)          # = the kernel's scale (scale_final_kernel's arithmetic)
+    n, ntau = _normalize(tau)
+    X = np.concatenate([n * sv[:, None], q], -1)
+    M = _mul(_mul(T, X), Ti) if use_kitti_coord else X
+    return M, (tau, phi, n, ntau, sv, pose_enu, sums)
+
+
+def glue_backward_np(g6, saved, intr4, use_kitti_coord):
+    """Gradient w.r.t. p (B,6) given the left-tangent gradient g6 (B,6) of the motion; conventions in the module docstring."""
+    tau, phi, n, ntau, sv, pose_enu, sums = saved
+    T, Ti = _axes()
+    AdT = _adj(T)
+    gX = _row(g6, AdT) if use_kitti_coord else g6                             # M = (T X) T^-1
+    Jl = _so3_Jl(phi)
+    g_trans = gX[:, :3]
+    g_phi = _row(gX[:, 3:6], Jl)
+    g_s = (n * g_trans).sum(-1)                                               # trans = n * s
+    g_tau = _normalize_bwd(g_trans * sv[:, None], n, ntau)
+    # ---- the scale's own dependence on the pose (TartanVO.stereo_scale): s = Mw / MM with M linear in a = K t^ and w linear in R
+    fx, fy, cx, cy = intr4[:, 0], intr4[:, 1], intr4[:, 2], intr4[:, 3]
+    MM = sums[:, 0]
+    dMw_da = np.stack([-sums[:, 2], -sums[:, 3], sums[:, 4]], -1)
+    dMM_da = np.stack([-2 * sums[:, 5], -2 * sums[:, 6], 2 * sums[:, 7]], -1)
+    ga = (dMw_da - sv[:, None] * dMM_da) / MM[:, None]
+    GR = np.stack([fx[:, None] * sums[:, 8:11], fy[:, None] * sums[:, 11:14], sums[:, 14:17]], 1) / MM[:, None, None]
+    Tinv = _inv(pose_enu)
+    tn, nt = _normalize(Tinv[:, :3])
+    g_a = g_s[:, None] * ga
+    g_tn = np.stack([fx * g_a[:, 0], fy * g_a[:, 1], cx * g_a[:, 0] + cy * g_a[:, 1] + g_a[:, 2]], -1)
+    g_t = _normalize_bwd(g_tn, tn, nt)
+    R = pp._qmat_np(Tinv[:, 3:])                                               # column j = R e_j
+    g_cols = g_s[:, None, None] * GR
+    gR = np.zeros_like(g_t)
+    for j in range(3):
+        gR -= _row(g_cols[:, :, j], pp._skew_np(R[:, :, j]))
+    g_enu = -_row(np.concatenate([g_t, gR], -1), _adj(Tinv))                  # Tinv = pose_enu^-1
+    gX0 = _row(g_enu, AdT)                                                    # pose_enu = (T X0) T^-1
+    g_tau = g_tau + gX0[:, :3]
+    g_phi = g_phi + _row(gX0[:, 3:6], Jl)
+    return np.concatenate([g_tau, g_phi], -1)
+
+
 class _FusedPoseGlue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pose, std, disp, flow, intr4, baseline, edge, th, use_kitti_coord):
         dev = pose.device
         p = pose.detach().double().cpu().numpy() * std                       # (B,6), the one read of the network output
-        tau, phi = p[:, :3], p[:, 3:]
-        q = _so3_exp(phi)
-        T, Ti = _axes()
-        X0 = np.concatenate([tau, q], -1)
-        pose_enu = _mul(_mul(T, X0), Ti)                                       # tartan2kitti_pypose(pose): the scale is recovered in this frame
-        s, z, mask, dmask, sums = ops.scale_ls(disp, flow, torch.from_numpy(pose_enu).to(dev), intr4, baseline, edge, th)
-        sums = sums.cpu().numpy()                                              # (B,18) float64: the second (and last) read
-        sv = np.float32(1.0 / sums[:, 0] * sums[:, 1]).astype(np.float64)      # = s (scale_final_kernel's arithmetic), without another copy
-        n, ntau = _normalize(tau)
-        X = np.concatenate([n * sv[:, None], q], -1)
-        M = _mul(_mul(T, X), Ti) if use_kitti_coord else X
-        ctx.saved = (std, tau, phi, n, ntau, sv, pose_enu, sums, intr4.detach().double().cpu().numpy(), bool(use_kitti_coord), dev, pose.dtype)
-        ctx.mark_non_differentiable(s, z, mask, dmask)
-        return torch.from_numpy(M), s, z, mask, dmask
+        out = {}
+
+        def scale_fn(pose_enu):
+            out['s'], out['z'], out['mask'], out['dmask'], sums = ops.scale_ls(disp, flow, torch.from_numpy(pose_enu).to(dev), intr4, baseline, edge, th)
+            return sums.cpu().numpy()                                          # (B,18) float64: the second (and last) read
+        M, saved = glue_forward_np(p, use_kitti_coord, scale_fn)
+        ctx.saved = (std, saved, intr4.detach().double().cpu().numpy(), bool(use_kitti_coord), dev, pose.dtype)
+        ctx.mark_non_differentiable(out['s'], out['z'], out['mask'], out['dmask'])
+        return torch.from_numpy(M), out['s'], out['z'], out['mask'], out['dmask']
 
     @staticmethod
     def backward(ctx, g, *_unused):
-        std, tau, phi, n, ntau, sv, pose_enu, sums, intr4, kitti, dev, dtype = ctx.saved
-        T, Ti = _axes()
-        AdT = _adj(T)
-        g6 = g.detach().double().cpu().numpy()[:, :6]
-        gX = _row(g6, AdT) if kitti else g6                                   # M = (T X) T^-1
-        Jl = _so3_Jl(phi)
-        g_trans = gX[:, :3]
-        g_phi = _row(gX[:, 3:6], Jl)
-        g_s = (n * g_trans).sum(-1)                                           # trans = n * s
-        g_tau = _normalize_bwd(g_trans * sv[:, None], n, ntau)
-        # ---- the scale's own dependence on the pose (TartanVO.stereo_scale): s = Mw / MM with M linear in a = K t^ and w linear in R
-        fx, fy, cx, cy = intr4[:, 0], intr4[:, 1], intr4[:, 2], intr4[:, 3]
-        MM = sums[:, 0]
-        dMw_da = np.stack([-sums[:, 2], -sums[:, 3], sums[:, 4]], -1)
-        dMM_da = np.stack([-2 * sums[:, 5], -2 * sums[:, 6], 2 * sums[:, 7]], -1)
-        ga = (dMw_da - sv[:, None] * dMM_da) / MM[:, None]
-        GR = np.stack([fx[:, None] * sums[:, 8:11], fy[:, None] * sums[:, 11:14], sums[:, 14:17]], 1) / MM[:, None, None]
-        Tinv = _inv(pose_enu)
-        tn, nt = _normalize(Tinv[:, :3])
-        g_a = g_s[:, None] * ga
-        g_tn = np.stack([fx * g_a[:, 0], fy * g_a[:, 1], cx * g_a[:, 0] + cy * g_a[:, 1] + g_a[:, 2]], -1)
-        g_t = _normalize_bwd(g_tn, tn, nt)
-        R = pp._qmat_np(Tinv[:, 3:])                                           # column j = R e_j
-        g_cols = g_s[:, None, None] * GR
-        gR = np.zeros_like(g_t)
-        for j in range(3):
-            gR -= _row(g_cols[:, :, j], pp._skew_np(R[:, :, j]))
-        g_enu = -_row(np.concatenate([g_t, gR], -1), _adj(Tinv))              # Tinv = pose_enu^-1
-        gX0 = _row(g_enu, AdT)                                                # pose_enu = (T X0) T^-1
-        g_tau = g_tau + gX0[:, :3]
-        g_phi = g_phi + _row(gX0[:, 3:6], Jl)
-        gp = np.concatenate([g_tau, g_phi], -1) * std
+        std, saved, intr4, kitti, dev, dtype = ctx.saved
+        gp = glue_backward_np(g.detach().double().cpu().numpy()[:, :6], saved, intr4, kitti) * std
         return (torch.from_numpy(gp).to(dev, dtype),) + (None,) * 8
 
 

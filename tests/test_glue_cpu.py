@@ -223,3 +223,50 @@ def test_host_lm_control_follows_ieee_division_at_an_exactly_converged_point():
         # the oracle's update takes J.D and R; a one-row system with (JD)^T (2R + JD) = q:  JD = 1, R = (q - 1) / 2
         tr.update(last, loss, np.array([1.0]), np.array([(q - 1.0) / 2.0]))
         assert ctl.damping == tr.pg['damping'], (last, loss, q)
+
+
+@pytest.mark.parametrize('kitti', [True, False])
+def test_fused_pose_glue_math_against_the_lietensor_operators(kitti):
+    """islam_amd/glue.py (the numpy core of the fused pose algebra, TartanVO.py:107-198 + the scale gradient of dense_ba.py:88-176) against
+    the same algebra written with the LieTensor shim's operators and differentiated by autograd -- on the CPU, with a stand-in for the one
+    device call (islam_scale_ls: any positive-definite sums will do; the algebra only consumes them).  The GPU test
+    tests/test_frontend_gpu.py::test_fused_pose_glue_matches_the_operator_by_operator_path holds the two product paths against each
+    other with the real kernel."""
+    import numpy as np
+    import torch
+    from islam_amd import glue, lietensor as pp
+    from islam_amd.transformation import cvtSE3_pypose, tartan2kitti_pypose
+    rng = np.random.default_rng(4)
+    B = 5
+    p0 = np.concatenate([rng.normal(0, 0.5, (B, 3)), rng.normal(0, 0.2, (B, 3))], 1)
+    p0[2, 3:] = 0.0                                                    # a zero rotation: the Taylor branches
+    sums = rng.normal(0, 1.0, (B, 18))
+    sums[:, 0] = rng.uniform(2.0, 5.0, B)                              # MM > 0
+    sums[:, 1] = rng.uniform(0.5, 3.0, B)
+    intr4 = np.tile(np.array([[180.0, 175.0, 80.0, 56.0]]), (B, 1))
+    w = rng.normal(size=(B, 7))
+    # ---- the fused core
+    M, saved = glue.glue_forward_np(p0, kitti, lambda pose_enu: sums)
+    # ---- operator by operator (TartanVO.forward's host_glue branch + TartanVO.stereo_scale's re-attachment), autograd through the shim
+    p = torch.tensor(p0, requires_grad=True)
+    pose_enu = tartan2kitti_pypose(p)
+    st = torch.tensor(sums)
+    sv = torch.tensor(np.float32(1.0 / sums[:, 0] * sums[:, 1]).astype(np.float64))
+    fx, fy, cx, cy = torch.tensor(intr4).unbind(-1)
+    MM = st[:, 0]
+    ga = (torch.stack([-st[:, 2], -st[:, 3], st[:, 4]], -1) - sv[:, None] * torch.stack([-2 * st[:, 5], -2 * st[:, 6], 2 * st[:, 7]], -1)) / MM[:, None]
+    GR = torch.stack([fx[:, None] * st[:, 8:11], fy[:, None] * st[:, 11:14], st[:, 14:17]], 1) / MM[:, None, None]
+    Tinv = pose_enu.Inv()
+    tn = torch.nn.functional.normalize(Tinv.translation(), dim=-1)
+    a = torch.stack([fx * tn[:, 0] + cx * tn[:, 2], fy * tn[:, 1] + cy * tn[:, 2], tn[:, 2]], -1)
+    R = Tinv.rotation()
+    eye = torch.eye(3, dtype=torch.float64)
+    cols = torch.stack([R.Act(eye[j].expand(B, 3)) for j in range(3)], -1)
+    sur = (ga * a).sum(-1) + (GR * cols).sum((-1, -2))
+    scale = sv + (sur - sur.detach())
+    pose = torch.cat([torch.nn.functional.normalize(p[:, :3], dim=1) * scale.view(-1, 1), p[:, 3:]], dim=1)
+    motion = tartan2kitti_pypose(pose) if kitti else cvtSE3_pypose(pose)
+    (motion.tensor() * torch.tensor(w)).sum().backward()
+    np.testing.assert_allclose(M, motion.tensor().detach().numpy(), rtol=1e-13, atol=1e-13)
+    got = glue.glue_backward_np(w[:, :6], saved, intr4, kitti)
+    np.testing.assert_allclose(got, p.grad.numpy(), rtol=1e-9, atol=1e-11 * np.abs(p.grad.numpy()).max())
