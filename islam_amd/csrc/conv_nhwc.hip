@@ -29,6 +29,7 @@
 
 #include "../../include/islam_hip.h"
 #include "common.h"
+#include "conv_ws.h"
 
 // scripts/conv_probe.sh builds two experiment variants of this file (never the product library): ISLAM_CONV_PROBE=1 skips the
 // multiply phase (what the staging pipeline costs on its own), =2 skips fetch + staging (what the multiply phase costs on its own)
@@ -513,6 +514,8 @@ int islam_conv_probe_read(long long* out) {
 }
 #endif
 
+int islam_conv_ws_mode(int mode) { return conv_ws_set_mode(mode); }
+
 size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     return (size_t)ksize * ksize * CoutP * CinP;
@@ -560,17 +563,19 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
     // instead of two, but twice the barriers) -- measured 10-20 % slower on every shape of the stereo net, kept for A/B runs
     static const bool kc16 = [] { const char* e = std::getenv("ISLAM_CONV_KC"); return e && e[0] == '1'; }();
     int rc;
+    const bool ws = !bias && !res && !relu && !in_relu && conv_ws_applies(Cin, Cout, ksize, B, H, W);      // weight-stationary persistent kernel (conv_ws.hip)
 #define ISLAM_CONV_LAUNCH(TN_, KS_, ROWS_)                                                                                              \
     (kc16 ? launch<TN_, KS_, ROWS_, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s) \
           : launch<TN_, KS_, ROWS_, 32>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s))
-    if (conv_r4(Cin, Cout, ksize, B, H, W))
+    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    else if (conv_r4(Cin, Cout, ksize, B, H, W))
         rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
     else if (ksize == 3) rc = wide ? ISLAM_CONV_LAUNCH(64, 3, 2) : ISLAM_CONV_LAUNCH(32, 3, 4);
     else rc = wide ? ISLAM_CONV_LAUNCH(64, 1, 2) : ISLAM_CONV_LAUNCH(32, 1, 4);
 #undef ISLAM_CONV_LAUNCH
     if (rc != ISLAM_OK) return rc;
     if (stats) {
-        const int nblk = tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));      // workgroups along x of the launch above
+        const int nblk = ws ? conv_ws_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));      // rows of partial sums the launch above wrote
         hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout,
                            stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
@@ -595,6 +600,8 @@ int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const 
     const Slices sl{Cin, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 1, W, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const bool wide = Cout > 32;
+    if (!bias && !relu && !in_relu && conv_ws_applies(Cin, Cout, ksize, B, H, W))
+        return conv_ws_launch(x, wpacked, in_affine, y, nullptr, B, H, W, Cout, CoutP, Cin, 0, ytot, yoff, s);
     if (conv_r4(Cin, Cout, ksize, B, H, W)) return launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
     if (ksize == 3) return wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl)
                                 : launch<32, 3, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
@@ -668,13 +675,15 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
     const bool wide = Cout > 32;
     const int ir = in_relu ? 1 : 0;
     int rc;
-    if (conv_r4(Cin, Cout, ksize, B, H, W)) rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
+    const bool ws = (!ir || in_affine) && conv_ws_applies(Cin, Cout, ksize, B, H, W);
+    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    else if (conv_r4(Cin, Cout, ksize, B, H, W)) rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
                                    : launch<32, 3, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else rc = wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
                    : launch<32, 1, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     if (rc != ISLAM_OK) return rc;
-    const int nblk = tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
+    const int nblk = ws ? conv_ws_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
     hipLaunchKernelGGL(fold_finalize_kernel, dim3(RED_BLOCKS), dim3(FF_THREADS), 0, s, stats, nblk, Cout,
                        stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout, (double)B * H * W, weight, bias, running_mean,
                        running_var, num_batches_tracked, momentum, eps, scale_shift, counter);

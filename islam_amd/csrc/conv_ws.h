@@ -1,0 +1,16 @@
+// Internal interface between conv_nhwc.hip (the C-ABI entry points of the channels-last convolutions) and conv_ws.hip (the
+// weight-stationary 128 -> 128 3x3 kernel they dispatch to).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace islam {
+
+int conv_ws_set_mode(int mode);                           // returns the previous mode; out-of-range: query only
+bool conv_ws_applies(int Cin, int Cout, int ksize, int B, int H, int W);
+int conv_ws_blocks(int B, int H, int W);                 // workgroups of the launch = rows of per-workgroup BatchNorm partial sums it writes
+// raw bf16 output (no bias / residual / ReLU), optional BatchNorm + ReLU of the input on load, optional per-workgroup partial sums;
+// x: channels [xoff, xoff + 128) of a (B,H,W,xs) tensor, y: channels [yoff, yoff + 128) of a (B,H,W,ys) tensor
+int conv_ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
+                   int Cout, int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s);
+
+}  // namespace islam
