@@ -125,46 +125,6 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
 #ifdef ISLAM_WS_STAMPS
     const long long begin_ = wall_clock64();
 #endif
-    // ---- the wave's weights: output channels 32 wave + li (A operand rows), taps x k-slices, for the whole launch.  A lane's operand is 16
-    // bytes of a 256-byte weight row, so direct loads touch 32 cache lines per instruction for a quarter of each (8-10 us for the 72
-    // loads with every workgroup of the chip asking the L2 for the same lines); instead the workgroup copies two taps at a time
-    // (2 x 128 rows x 256 bytes, consecutive lanes = consecutive 16 bytes) into LDS rows of PS elements and every lane picks its operands
-    // from there with the conflict-free pattern of the B operand reads.
-    bf16x8 wr[9 * NK];
-    {
-        unsigned short* wl = lds + HALO;                           // second halo buffer + output tile: 90 KB, two taps need 68 KB
-        static_assert(2 * TN * PS <= HALO + TW * ROWS * TS, "two taps of weights fit behind the first halo buffer");
-        u32x4 wv[2][2 * TN * OPP / THREADS];                       // the pieces of round r + 1 are requested before round r is copied
-        auto request = [&](auto rr) {
-            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;      // 16-byte pieces per thread
-            static_for<0, NP>([&](auto nn) {
-                constexpr int n = decltype(nn)::value;
-                const int pc = tid + n * THREADS, tl_ = pc / (TN * OPP), row = (pc / OPP) % TN, o = pc % OPP;
-                wv[r & 1][n] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((2 * r + tl_) * CoutP + row)) * CIN + 8 * o);
-            });
-        };
-        request(ic<0>{});
-        static_for<0, 5>([&](auto rr) {
-            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;
-            if constexpr (r + 1 < 5) request(ic<r + 1>{});
-            if constexpr (r > 0) __syncthreads();                  // the previous round's operand reads are done
-            static_for<0, NP>([&](auto nn) {
-                constexpr int n = decltype(nn)::value;
-                const int pc = tid + n * THREADS, tl_ = pc / (TN * OPP), row = (pc / OPP) % TN, o = pc % OPP;
-                *reinterpret_cast<u32x4*>(wl + (tl_ * TN + row) * PS + 8 * o) = wv[r & 1][n];
-            });
-            __syncthreads();
-            static_for<0, ntap * NK>([&](auto ii) {
-                constexpr int i = decltype(ii)::value, tl_ = i / NK, ks = i % NK;
-                wr[(2 * r + tl_) * NK + ks] = *reinterpret_cast<const bf16x8*>(wl + (tl_ * TN + 32 * wave + li) * PS + 16 * ks + 8 * kg);
-            });
-        });
-        __syncthreads();                                           // (the region becomes the halo buffer / output tile)
-    }
-#ifdef ISLAM_WS_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long weights_ = wall_clock64();
-#endif
     const int oct = tid & (OPP - 1), prow = tid >> 4;             // the thread's channel octet (the same for all its items), first halo pixel
     if constexpr (AFFINE) reinterpret_cast<float*>(lds + L_AFF)[tid] = in_affine[tid];      // [scale(128) | shift(128)]
     f32x4 s0 = {1, 1, 1, 1}, s1 = s0, h0 = {0, 0, 0, 0}, h1 = h0;
@@ -309,13 +269,59 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
 
     unsigned short* bufc = lds;                                    // the halo tile being multiplied / the one being filled
     unsigned short* bufn = lds + HALO;
-    __syncthreads();                                               // (the BatchNorm table)
-    load_affine();
+    // the first tile: all 13 items are requested BEFORE the weights (nothing else needs registers yet) and staged behind them
+    u32x4 first[NIN];
     fetch_tile(t0);
-    static_for<0, NPRE>([&](auto kk) { fetch(kk); });
-    static_for<0, NPRE>([&](auto kk) { stage(kk, bufc); });
-    static_for<NPRE, NIN>([&](auto kk) { fetch(kk); });
-    static_for<NPRE, NIN>([&](auto kk) { stage(kk, bufc); });
+    static_for<0, NIN>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        fetch(kk);
+        first[k] = pre[k % NPRE];
+    });
+    // ---- the wave's weights: output channels 32 wave + li (A operand rows), taps x k-slices, for the whole launch.  A lane's operand is 16
+    // bytes of a 256-byte weight row, so direct loads touch 32 cache lines per instruction for a quarter of each (8-10 us for the 72
+    // loads with every workgroup of the chip asking the L2 for the same lines); instead the workgroup copies two taps at a time
+    // (2 x 128 rows x 256 bytes, consecutive lanes = consecutive 16 bytes) into LDS rows of PS elements and every lane picks its operands
+    // from there with the conflict-free pattern of the B operand reads.
+    bf16x8 wr[9 * NK];
+    {
+        unsigned short* wl = lds + HALO;                           // second halo buffer + output tile: 90 KB, two taps need 68 KB
+        static_assert(2 * TN * PS <= HALO + TW * ROWS * TS, "two taps of weights fit behind the first halo buffer");
+        u32x4 wv[2][2 * TN * OPP / THREADS];                       // the pieces of round r + 1 are requested before round r is copied
+        auto request = [&](auto rr) {
+            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;      // 16-byte pieces per thread
+            static_for<0, NP>([&](auto nn) {
+                constexpr int n = decltype(nn)::value;
+                const int pc = tid + n * THREADS, tl_ = pc / (TN * OPP), row = (pc / OPP) % TN, o = pc % OPP;
+                wv[r & 1][n] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((2 * r + tl_) * CoutP + row)) * CIN + 8 * o);
+            });
+        };
+        request(ic<0>{});
+        static_for<0, 5>([&](auto rr) {
+            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;
+            if constexpr (r + 1 < 5) request(ic<r + 1>{});
+            if constexpr (r > 0) __syncthreads();                  // the previous round's operand reads are done
+            static_for<0, NP>([&](auto nn) {
+                constexpr int n = decltype(nn)::value;
+                const int pc = tid + n * THREADS, tl_ = pc / (TN * OPP), row = (pc / OPP) % TN, o = pc % OPP;
+                *reinterpret_cast<u32x4*>(wl + (tl_ * TN + row) * PS + 8 * o) = wv[r & 1][n];
+            });
+            __syncthreads();
+            static_for<0, ntap * NK>([&](auto ii) {
+                constexpr int i = decltype(ii)::value, tl_ = i / NK, ks = i % NK;
+                wr[(2 * r + tl_) * NK + ks] = *reinterpret_cast<const bf16x8*>(wl + (tl_ * TN + 32 * wave + li) * PS + 16 * ks + 8 * kg);
+            });
+        });
+        __syncthreads();                                           // (the region becomes the halo buffer / output tile)
+    }
+#ifdef ISLAM_WS_STAMPS
+    const long long weights_ = wall_clock64();
+#endif
+    load_affine();                                                 // (the weight rounds' barriers have published the BatchNorm table)
+    static_for<0, NIN>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        pre[k % NPRE] = first[k];
+        stage(kk, bufc);
+    });
     __syncthreads();
     fetch_tile(t0 + 1);                                            // (past the range: everything masked)
     static_for<0, NPRE>([&](auto kk) { fetch(kk); });
