@@ -230,10 +230,11 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
                             int H, int W, int Cout, int ksize, int in_relu, const float* weight, const float* bias, float* running_mean,
                             float* running_var, long long* num_batches_tracked, double momentum, double eps, float* scale_shift,
                             int* counter, void* stream);
-/* Which kernel serves the 128 -> 128 3x3 layers (Network/PSM/submodule.py:66-155 feature_extraction layer3 / layer4, eleven per forward)
- * behind islam_conv_nhwc_bf16 / _into / _bn: 0 = the tile kernel, 1 (default; ISLAM_CONV_WS presets it) = the weight-stationary persistent
- * kernel of csrc/conv_ws.hip when the layer has at least 1024 tiles of 32 x 4 pixels, 2 = the weight-stationary kernel on every such
- * layer (tests, A/B runs).  Same results contract either way.  Returns the previous mode; any other argument only queries. */
+/* Which kernel serves the 128 -> 128 and the 32 -> 32 3x3 layers (Network/PSM/submodule.py:66-155 feature_extraction: layer3 / layer4,
+ * eleven per forward; firstconv / layer1, eight per forward) behind islam_conv_nhwc_bf16 / _into / _bn: 0 = the tile kernel, 1 (default;
+ * ISLAM_CONV_WS presets it) = the persistent kernels of csrc/conv_ws.hip (weights in the register file, 32 x 4-pixel tiles) and
+ * csrc/conv_ws32.hip (32 x 16-pixel tiles) when the image is whole tiles and has at least 1024 of them, 2 = the persistent kernels on
+ * every whole-tile layer (tests, A/B runs).  Bit-identical outputs either way.  Returns the previous mode; any other argument only queries. */
 int islam_conv_ws_mode(int mode);
 /* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),
  * :237-292 the blocks) on the channels-last kernel.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) MIRROR of the block's

@@ -564,10 +564,12 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
     static const bool kc16 = [] { const char* e = std::getenv("ISLAM_CONV_KC"); return e && e[0] == '1'; }();
     int rc;
     const bool ws = !bias && !res && !relu && !in_relu && conv_ws_applies(Cin, Cout, ksize, B, H, W);      // weight-stationary persistent kernel (conv_ws.hip)
+    const bool ws32 = !bias && !res && !relu && !in_relu && conv_ws32_applies(Cin, Cout, ksize, B, H, W);  // persistent 32 -> 32 kernel (conv_ws32.hip)
 #define ISLAM_CONV_LAUNCH(TN_, KS_, ROWS_)                                                                                              \
     (kc16 ? launch<TN_, KS_, ROWS_, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s) \
           : launch<TN_, KS_, ROWS_, 32>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s))
     if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    else if (ws32) rc = conv_ws32_launch(x, wpacked, in_affine, y, stats, B, H, W, CoutP, Cin, 0, Cout, 0, s);
     else if (conv_r4(Cin, Cout, ksize, B, H, W))
         rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
     else if (ksize == 3) rc = wide ? ISLAM_CONV_LAUNCH(64, 3, 2) : ISLAM_CONV_LAUNCH(32, 3, 4);
@@ -575,7 +577,7 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 #undef ISLAM_CONV_LAUNCH
     if (rc != ISLAM_OK) return rc;
     if (stats) {
-        const int nblk = ws ? conv_ws_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));      // rows of partial sums the launch above wrote
+        const int nblk = ws ? conv_ws_blocks(B, H, W) : ws32 ? conv_ws32_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));      // rows of partial sums the launch above wrote
         hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout,
                            stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout);
         ISLAM_LAUNCH_CHECK();
@@ -602,6 +604,8 @@ int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const 
     const bool wide = Cout > 32;
     if (!bias && !relu && !in_relu && conv_ws_applies(Cin, Cout, ksize, B, H, W))
         return conv_ws_launch(x, wpacked, in_affine, y, nullptr, B, H, W, Cout, CoutP, Cin, 0, ytot, yoff, s);
+    if (!bias && !relu && !in_relu && conv_ws32_applies(Cin, Cout, ksize, B, H, W))
+        return conv_ws32_launch(x, wpacked, in_affine, y, nullptr, B, H, W, CoutP, Cin, 0, ytot, yoff, s);
     if (conv_r4(Cin, Cout, ksize, B, H, W)) return launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
     if (ksize == 3) return wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl)
                                 : launch<32, 3, 4, 32>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
@@ -676,14 +680,16 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
     const int ir = in_relu ? 1 : 0;
     int rc;
     const bool ws = (!ir || in_affine) && conv_ws_applies(Cin, Cout, ksize, B, H, W);
+    const bool ws32 = (!ir || in_affine) && conv_ws32_applies(Cin, Cout, ksize, B, H, W);
     if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    else if (ws32) rc = conv_ws32_launch(x, wpacked, in_affine, y, stats, B, H, W, CoutP, Cin, 0, Cout, 0, s);
     else if (conv_r4(Cin, Cout, ksize, B, H, W)) rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
                                    : launch<32, 3, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else rc = wide ? launch<64, 1, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)
                    : launch<32, 1, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     if (rc != ISLAM_OK) return rc;
-    const int nblk = ws ? conv_ws_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
+    const int nblk = ws ? conv_ws_blocks(B, H, W) : ws32 ? conv_ws32_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
     hipLaunchKernelGGL(fold_finalize_kernel, dim3(RED_BLOCKS), dim3(FF_THREADS), 0, s, stats, nblk, Cout,
                        stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout, (double)B * H * W, weight, bias, running_mean,
                        running_var, num_batches_tracked, momentum, eps, scale_shift, counter);

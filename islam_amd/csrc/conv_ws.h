@@ -1,5 +1,5 @@
 // Internal interface between conv_nhwc.hip (the C-ABI entry points of the channels-last convolutions) and conv_ws.hip (the
-// weight-stationary 128 -> 128 3x3 kernel they dispatch to).
+// weight-stationary 128 -> 128 kernel) and conv_ws32.hip (the persistent 32 -> 32 kernel) they dispatch to.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,5 +12,11 @@ int conv_ws_blocks(int B, int H, int W);                 // workgroups of the la
 // x: channels [xoff, xoff + 128) of a (B,H,W,xs) tensor, y: channels [yoff, yoff + 128) of a (B,H,W,ys) tensor
 int conv_ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
                    int Cout, int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s);
+
+// conv_ws32.hip: the persistent 32 -> 32 3x3 kernel (same contract; whole tiles of 32 x 16 pixels)
+bool conv_ws32_applies(int Cin, int Cout, int ksize, int B, int H, int W);
+int conv_ws32_blocks(int B, int H, int W);
+int conv_ws32_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
+                     int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s);
 
 }  // namespace islam

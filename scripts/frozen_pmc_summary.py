@@ -19,7 +19,7 @@ def load(sub):
 
 
 def fam(name, grid):
-    m = re.search(r'(conv_nhwc_kernel|conv3x3_ws_kernel|conv3x3_mfma_kernel|pyr_level_kernel|hg_residual_kernel|hg_residual64_kernel|corr81_fwd4_kernel|corr81_fwd_kernel|warp_mask_kernel|'
+    m = re.search(r'(conv_nhwc_kernel|conv3x3_ws32_kernel|conv3x3_ws_kernel|conv3x3_mfma_kernel|pyr_level_kernel|hg_residual_kernel|hg_residual64_kernel|corr81_fwd4_kernel|corr81_fwd_kernel|warp_mask_kernel|'
                   r'resize_bilinear\w*|bn_apply_kernel|maxpool2\w*|nchw_to_nhwc_kernel|deconv4x4s2_to2_kernel)(<[^>]*>)?', name)
     if not m:
         return None

@@ -372,58 +372,61 @@ def ws_mode():
     lib().islam_conv_ws_mode(prev)
 
 
-@pytest.mark.parametrize('B,H,W', [(1, 4, 32), (2, 8, 64), (3, 12, 96), (5, 20, 160), (9, 112, 160)])
-def test_weight_stationary_kernel_matches_the_tile_kernel_bit_for_bit(cuda, ws_mode, B, H, W):
-    """csrc/conv_ws.hip (one workgroup per CU walks a range of 32 x 4-pixel tiles with its weights in registers) behind the three entry
-    points that dispatch to it: the same bf16 outputs as conv_nhwc_kernel -- same operands, same accumulation order -- with and without
-    the producer's BatchNorm + ReLU on load, from one tile (one workgroup) to nine tiles per workgroup; its per-workgroup BatchNorm
-    partial sums fold to the sums over the stored output; the same [scale | shift] and running statistics through the one-launch
-    fold + finalize up to the summation order of the partial sums; a channel slice of a wider tensor as destination."""
+@pytest.mark.parametrize('C,B,H,W', [(128, 1, 4, 32), (128, 2, 8, 64), (128, 3, 12, 96), (128, 5, 20, 160), (128, 9, 112, 160),
+                                     (32, 1, 16, 32), (32, 2, 32, 64), (32, 3, 48, 96), (32, 5, 224, 320)])
+def test_persistent_kernels_match_the_tile_kernel_bit_for_bit(cuda, ws_mode, C, B, H, W):
+    """csrc/conv_ws.hip (128 -> 128: one workgroup per CU walks a range of 32 x 4-pixel tiles with its weights in the register file) and
+    csrc/conv_ws32.hip (32 -> 32: two persistent workgroups per CU, 32 x 16-pixel tiles, the next tile's halo requested a tile ahead)
+    behind the three entry points that dispatch to them: the same bf16 outputs as conv_nhwc_kernel -- same operands, same accumulation
+    order -- with and without the producer's BatchNorm + ReLU on load, from one tile (one workgroup) to several tiles per workgroup;
+    the per-workgroup BatchNorm partial sums fold to the sums over the stored output; the same [scale | shift] and running statistics
+    through the one-launch fold + finalize up to the summation order of the partial sums; a channel slice of a wider tensor as
+    destination."""
     from islam_amd import ops
-    x, w = _mk(B, 128, H, W, 128, 3, seed=H + B)
+    x, w = _mk(B, C, H, W, C, 3, seed=H + B)
     wp = ops.pack_conv_nhwc_weight(w)
     g = torch.Generator().manual_seed(6)
-    aff = torch.cat((torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3)).to(cuda)
+    aff = torch.cat((torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3)).to(cuda)
     ref = F.conv2d(x.float(), w.float(), None, 1, 1)
     for in_affine in (None, aff):
         ws_mode(0)
-        y0, f0 = ops.conv_nhwc(x, wp, 128, 3, in_affine=in_affine, stats=True)
+        y0, f0 = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
         ws_mode(2)
-        y2, f2 = ops.conv_nhwc(x, wp, 128, 3, in_affine=in_affine, stats=True)
+        y2, f2 = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
         assert torch.equal(y0, y2)
         if in_affine is None:
             assert float((y2.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
-        s = f2.view(256, 2, 128).double().sum(0)
+        s = f2.view(256, 2, C).double().sum(0)
         want = torch.stack([y2.double().sum((0, 2, 3)), (y2.double() ** 2).sum((0, 2, 3))])
         np.testing.assert_allclose(s.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-3)
-        _, f2b = ops.conv_nhwc(x, wp, 128, 3, in_affine=in_affine, stats=True)
+        _, f2b = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
         assert torch.equal(f2, f2b)                                           # fixed-order sums
-        bn0, bn2 = torch.nn.BatchNorm2d(128).to(cuda).train(), torch.nn.BatchNorm2d(128).to(cuda).train()
+        bn0, bn2 = torch.nn.BatchNorm2d(C).to(cuda).train(), torch.nn.BatchNorm2d(C).to(cuda).train()
         ws_mode(0)
-        _, ss0 = ops.conv_nhwc_bn(x, wp, 128, 3, bn0, in_affine=in_affine)
+        _, ss0 = ops.conv_nhwc_bn(x, wp, C, 3, bn0, in_affine=in_affine)
         ws_mode(2)
-        y2b, ss2 = ops.conv_nhwc_bn(x, wp, 128, 3, bn2, in_affine=in_affine)
+        y2b, ss2 = ops.conv_nhwc_bn(x, wp, C, 3, bn2, in_affine=in_affine)
         assert torch.equal(y2b, y2)
         torch.testing.assert_close(ss2, ss0, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(bn2.running_var, bn0.running_var, rtol=1e-5, atol=1e-7)
-        out = torch.full((B, 200, H, W), 7.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
-        ops.conv_nhwc_into(x, wp, 128, 3, out, 64, in_affine=in_affine)
-        assert torch.equal(out[:, 64:192], y2) and bool((out[:, :64] == 7.0).all()) and bool((out[:, 192:] == 7.0).all())
+        out = torch.full((B, C + 72, H, W), 7.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
+        ops.conv_nhwc_into(x, wp, C, 3, out, 64, in_affine=in_affine)
+        assert torch.equal(out[:, 64:64 + C], y2) and bool((out[:, :64] == 7.0).all()) and bool((out[:, 64 + C:] == 7.0).all())
     assert all(int(t[0].abs().sum()) == 0 for t in ops._BN_COUNTERS.values())
 
 
-def test_weight_stationary_kernel_serves_whole_tile_layers_only(cuda, ws_mode):
-    """Images that are not a multiple of 32 x 4 pixels, and epilogues the kernel does not have (bias, residual, ReLU), stay on the tile
-    kernel whatever the mode says: same results with the mode on and off."""
+def test_persistent_kernels_serve_whole_tile_layers_only(cuda, ws_mode):
+    """Images that are not whole tiles (32 x 4 pixels at 128 channels, 32 x 16 at 32), and epilogues the kernels do not have (bias,
+    residual, ReLU), stay on the tile kernel whatever the mode says: same results with the mode on and off."""
     from islam_amd import ops
     ws_mode(2)
-    for (B, H, W) in [(2, 24, 40), (1, 33, 47), (1, 6, 32)]:
-        x, w = _mk(B, 128, H, W, 128, 3, seed=W)
+    for (C, B, H, W) in [(128, 2, 24, 40), (128, 1, 33, 47), (128, 1, 6, 32), (32, 2, 24, 64), (32, 1, 16, 40)]:
+        x, w = _mk(B, C, H, W, C, 3, seed=W)
         wp = ops.pack_conv_nhwc_weight(w)
         ws_mode(2)
-        y2 = ops.conv_nhwc(x, wp, 128, 3)
+        y2 = ops.conv_nhwc(x, wp, C, 3)
         ws_mode(0)
-        assert torch.equal(y2, ops.conv_nhwc(x, wp, 128, 3))
+        assert torch.equal(y2, ops.conv_nhwc(x, wp, C, 3))
     x, w = _mk(2, 128, 8, 64, 128, 3, seed=1)
     wp = ops.pack_conv_nhwc_weight(w)
     bias = torch.randn(128).to(cuda)
