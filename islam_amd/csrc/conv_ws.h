@@ -6,6 +6,8 @@
 namespace islam {
 
 int conv_ws_set_mode(int mode);                           // returns the previous mode; out-of-range: query only
+int conv_ws_spare_cus();
+int conv_ws_balanced(long long ntiles, int slots);      // smallest launch whose longest tile range is as short as with `slots` workgroups
 bool conv_ws_applies(int Cin, int Cout, int ksize, int B, int H, int W);
 int conv_ws_blocks(int B, int H, int W);                 // workgroups of the launch = rows of per-workgroup BatchNorm partial sums it writes
 // raw bf16 output (no bias / residual / ReLU), optional BatchNorm + ReLU of the input on load, optional per-workgroup partial sums;

@@ -434,9 +434,24 @@ bool conv_ws_applies(int Cin, int Cout, int ksize, int B, int H, int W) {
 
 // one workgroup per CU, and never more than the callers' room for per-workgroup partial sums (islam_conv_nhwc_stat_blocks: one row per
 // 32 x 8-pixel tile of the tile kernel)
+int conv_ws_balanced(long long ntiles, int slots);
+int conv_ws_spare_cus() {                                  // ISLAM_CONV_WS_SPARE: CUs a launch leaves to kernels of other streams (A/B runs)
+    static const int n = [] { const char* e = std::getenv("ISLAM_CONV_WS_SPARE"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 128 ? 128 : v); }();
+    return n;
+}
 int conv_ws_blocks(int B, int H, int W) {
     const long long rows = (long long)B * ((H + 2 * ROWS - 1) / (2 * ROWS)) * ((W + TW - 1) / TW);
-    return (int)(rows < 256 ? rows : 256);
+    const int cus = 256 - conv_ws_spare_cus();
+    const int cap = (int)(rows < cus ? rows : cus);
+    return conv_ws_balanced((long long)B * ((H + ROWS - 1) / ROWS) * ((W + TW - 1) / TW), cap);
+}
+// ... and no more than the makespan needs: with `slots` workgroups the longest range has ceil(ntiles / slots) tiles; the smallest launch
+// with ranges no longer than that leaves the other CUs to the kernels of concurrent streams (2240 tiles: 249 workgroups of 9 instead of
+// 256 of 8-9) at no cost to this one
+int conv_ws_balanced(long long ntiles, int slots) {
+    if (ntiles <= slots) return (int)ntiles;
+    const long long per = (ntiles + slots - 1) / slots;
+    return (int)((ntiles + per - 1) / per);
 }
 
 int conv_ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,

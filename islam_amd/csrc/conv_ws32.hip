@@ -216,7 +216,8 @@ bool conv_ws32_applies(int Cin, int Cout, int ksize, int B, int H, int W) {
 // two workgroups per CU, and never more than the callers' room for per-workgroup partial sums (one row per 32 x 16-pixel tile)
 int conv_ws32_blocks(int B, int H, int W) {
     const long long ntiles = (long long)B * (H / TH) * (W / TW);
-    return (int)(ntiles < 512 ? ntiles : 512);
+    const int slots = 2 * (256 - conv_ws_spare_cus());
+    return conv_ws_balanced(ntiles, slots);                        // (2240 tiles: 448 workgroups of 5, a quarter of the slots stay free)
 }
 
 int conv_ws32_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
