@@ -199,14 +199,26 @@ def test_flow_net_matrix_core_path_matches_reference(cuda, monkeypatch):
     assert max(errs) > 1e-5                  # it IS the reduced-precision path (the fp32 path sits at ~1e-6)
 
 
-@pytest.mark.parametrize('direct_cat', [True, False])
-def test_stereo_net_bf16_execution_copy_matches_reference(cuda, monkeypatch, direct_cat):
+@pytest.fixture
+def conv_ws_mode():
+    """islam_conv_ws_mode for the duration of a test (restored afterwards)."""
+    from islam_amd._lib import lib
+    prev = lib().islam_conv_ws_mode(-1)
+    yield lambda m: lib().islam_conv_ws_mode(m)
+    lib().islam_conv_ws_mode(prev)
+
+
+@pytest.mark.parametrize('direct_cat,persistent', [(True, True), (False, True), (True, False)])
+def test_stereo_net_bf16_execution_copy_matches_reference(cuda, monkeypatch, conv_ws_mode, direct_cat, persistent):
     """The frozen stereo net as the bench runs it: bf16 channels-last execution copy in train mode, BatchNorm on
     islam_bn_train_nhwc_bf16 (batch statistics + running-stat update), islam_resize_bilinear_nhwc_bf16,
     islam_bias_act_add_nhwc_bf16 -- against the reference's fp32 train-mode forward.  direct_cat: the feature extractor writes
-    conv_c0's input in place (left images first in the batch: the default) / dense features in the reference's interleaved order."""
+    conv_c0's input in place (left images first in the batch: the default) / dense features in the reference's interleaved order.
+    persistent: the eleven 128 -> 128 and eight 32 -> 32 3x3 layers on csrc/conv_ws.hip / conv_ws32.hip (the default at this size) or
+    on the tile kernel like every other layer."""
     from islam_amd import nets
     monkeypatch.setattr(nets, 'STEREO_DIRECT_CAT', direct_cat)
+    conv_ws_mode(1 if persistent else 0)
     ref = _g('stereo')
     vn = nets.VONet(fix_parts=('flow', 'stereo'))
     fill_state_dict(vn.stereoNet)
@@ -322,3 +334,4 @@ def test_tartanvo_forward_matches_reference_nets_and_oracle_glue(cuda, tmp_path)
         np.testing.assert_allclose(motion, o['motion'], rtol=2e-3, atol=2e-5)
         assert res['motion'].requires_grad
         del vo
+
