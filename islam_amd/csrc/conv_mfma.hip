@@ -403,6 +403,80 @@ __global__ __launch_bounds__(256) void upsample_cat_nhwc_bf16_kernel(UpCatArgs a
     y[i] = o;
 }
 
+// The same, laid out for the one call the nets make (352 channel groups... 44 per pixel, 50 M output groups): at one thread per group the
+// kernel above is bound by its index arithmetic, not by memory (three runtime divisions, a seven-step select of the piece and 64-bit
+// addresses per 16 bytes: 416 us for 1.06 GB = 2.5 TB/s).  Here the grid is (groups of a row, output row, image): the row's vertical taps
+// and weights are uniform, the piece of a channel group comes out of a 16-byte table entry in LDS built once per workgroup, one
+// division per thread, 32-bit offsets.  Same arithmetic per sample (the `mix` expression is the one above, character for character).
+constexpr int UPCAT_ROWS = 4;
+struct UpCatEntry { const uint4* src; int c8, cg; };              // the piece (or the tail: c8 < 0, -c8 channel groups) and the group within it
+__global__ __launch_bounds__(256) void upsample_cat_rows_kernel(UpCatArgs a, uint4* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
+                                                                float sh, float sw, int align, int yC8, int B) {
+    __shared__ UpCatEntry tab[256];
+    // XCD-aware order (workgroup i runs on XCD i % 8): XCD x takes the contiguous range [x Q, (x + 1) Q) of the (image, row block, column
+    // block) items, so the row blocks that read the same source rows sit behind the same L2 (in plain order every XCD fetched every
+    // source row: 2.2 x the algorithmic reads from HBM)
+    const int gx = (Wo * yC8 + 255) / 256, gy = (Ho + UPCAT_ROWS - 1) / UPCAT_ROWS, nwork = gx * gy * B;
+    const int Q = (nwork + 7) / 8, L = (blockIdx.x & 7) * Q + (blockIdx.x >> 3);
+    if (L >= nwork || (int)(blockIdx.x >> 3) >= Q) return;
+    const int bx = L % gx, by = (L / gx) % gy, b = L / (gx * gy);
+    if ((int)threadIdx.x < yC8) {
+        const int cgo = threadIdx.x;
+        UpCatEntry e;
+        if (cgo >= a.first8[a.n]) { e.src = a.tail; e.c8 = -a.tail8; e.cg = cgo - a.first8[a.n]; }
+        else {
+            const uint4* sp = a.src[0];
+            int C8 = a.c8[0], f8 = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                if (q < a.n && cgo >= a.first8[q]) { sp = a.src[q]; C8 = a.c8[q]; f8 = a.first8[q]; }
+            e.src = sp; e.c8 = C8; e.cg = cgo - f8;
+        }
+        tab[cgo] = e;
+    }
+    __syncthreads();
+    const unsigned item = bx * 256u + threadIdx.x;
+    if (item >= (unsigned)(Wo * yC8)) return;
+    const unsigned ox = item / (unsigned)yC8, cgo = item - ox * (unsigned)yC8;
+    const UpCatEntry e = tab[cgo];
+    // UPCAT_ROWS consecutive output rows per workgroup: a 2x up-sampling reads every source row from about four output rows, and rows
+    // handled by different workgroups (different CUs) fetch it from the L2 each time -- 64 bytes of L2 traffic per 16 bytes of output
+    // made the kernel L2-bound; back to back in one workgroup the repeats hit the CU's L1
+    for (int oy = by * UPCAT_ROWS; oy < min(Ho, (by + 1) * UPCAT_ROWS); ++oy) {
+        const unsigned opix = (unsigned)((b * Ho + oy) * Wo) + ox;
+        if (e.c8 < 0) {                                  // the tail: a copy
+            y[(size_t)opix * yC8 + cgo] = e.src[(size_t)opix * (unsigned)(-e.c8) + e.cg];
+            continue;
+        }
+        float fy, fx;
+        if (align) {
+            fy = sh * oy;
+            fx = sw * (int)ox;
+        } else {
+            fy = fmaxf(sh * (oy + 0.5f) - 0.5f, 0.0f);
+            fx = fmaxf(sw * ((int)ox + 0.5f) - 0.5f, 0.0f);
+        }
+        const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const unsigned C8 = e.c8, r0 = (unsigned)((b * Hi + y0) * Wi), r1 = (unsigned)((b * Hi + y1) * Wi);
+        const uint4* base = e.src + e.cg;
+        const uint4 p00 = base[(r0 + x0) * C8], p01 = base[(r0 + x1) * C8];
+        const uint4 p10 = base[(r1 + x0) * C8], p11 = base[(r1 + x1) * C8];
+        auto mix = [&](unsigned va, unsigned vb, unsigned vc, unsigned vd) {
+            const float lo = hy * (hx * bf16_lo(va) + lx * bf16_lo(vb)) + ly * (hx * bf16_lo(vc) + lx * bf16_lo(vd));
+            const float hi = hy * (hx * bf16_hi(va) + lx * bf16_hi(vb)) + ly * (hx * bf16_hi(vc) + lx * bf16_hi(vd));
+            return pack_bf16(lo, hi);
+        };
+        uint4 o;
+        o.x = mix(p00.x, p01.x, p10.x, p11.x);
+        o.y = mix(p00.y, p01.y, p10.y, p11.y);
+        o.z = mix(p00.z, p01.z, p10.z, p11.z);
+        o.w = mix(p00.w, p01.w, p10.w, p11.w);
+        y[(size_t)opix * yC8 + cgo] = o;
+    }
+}
+
 // The stereo pair as the feature extractor's batch: x (B, H, W, 2c) channels-last bf16 holds the left image in channels [0, c) and the
 // right one in [c, 2c) (Network/StereoNet7.py:95-97 runs both through one feature extractor); y (2B, H, W, 8): image b = left image b,
 // image B + b = right image b, channels [c, 8) zero -- the 8-channel input islam_conv_nhwc_bf16_s2 stages for the 3 -> 32 first layer
@@ -541,8 +615,17 @@ extern "C" int islam_upsample_cat_nhwc_bf16(const uint16_t* const* srcs, const i
         sw = (float)Wi / (float)Wo;
     }
     const long long total = (long long)B * Ho * Wo * yC8;
-    hipLaunchKernelGGL(upsample_cat_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       reinterpret_cast<uint4*>(y), Hi, Wi, Ho, Wo, sh, sw, align_corners, total, yC8);
+    int maxc8 = std::max(a.tail8, 1);
+    for (int k = 0; k < n; ++k) maxc8 = std::max(maxc8, a.c8[k]);
+    static const bool rows_off = [] { const char* e = std::getenv("ISLAM_UPCAT_ROWS"); return e && e[0] == '0'; }();      // (A/B runs)
+    if (!rows_off && yC8 <= 256 && Ho <= 65535 && B <= 65535 && total < (1LL << 31) && (long long)B * std::max(Hi, Ho) * std::max(Wi, Wo) * maxc8 < (1LL << 31)) {
+        const long long nwork = (((long long)Wo * yC8 + 255) / 256) * ((Ho + UPCAT_ROWS - 1) / UPCAT_ROWS) * B;
+        dim3 grid((unsigned)(8 * ((nwork + 7) / 8)));
+        hipLaunchKernelGGL(upsample_cat_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, reinterpret_cast<uint4*>(y), Hi, Wi, Ho, Wo, sh, sw,
+                           align_corners, yC8, B);
+    } else
+        hipLaunchKernelGGL(upsample_cat_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                           reinterpret_cast<uint4*>(y), Hi, Wi, Ho, Wo, sh, sw, align_corners, total, yC8);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
