@@ -230,8 +230,8 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
                             int H, int W, int Cout, int ksize, int in_relu, const float* weight, const float* bias, float* running_mean,
                             float* running_var, long long* num_batches_tracked, double momentum, double eps, float* scale_shift,
                             int* counter, void* stream);
-/* Which kernel serves the 128 -> 128 and the 32 -> 32 3x3 layers (Network/PSM/submodule.py:66-155 feature_extraction: layer3 / layer4,
- * eleven per forward; firstconv / layer1, eight per forward) behind islam_conv_nhwc_bf16 / _into / _bn: 0 = the tile kernel, 1 (default;
+/* Which kernel serves the 128 -> 128, 64 -> 128 and 32 -> 32 3x3 layers (Network/PSM/submodule.py:66-155 feature_extraction: layer3 /
+ * layer4, twelve per forward; firstconv / layer1, eight per forward) behind islam_conv_nhwc_bf16 / _into / _bn: 0 = the tile kernel, 1 (default;
  * ISLAM_CONV_WS presets it) = the persistent kernels of csrc/conv_ws.hip (weights in the register file, 32 x 4-pixel tiles) and
  * csrc/conv_ws32.hip (32 x 16-pixel tiles) when the image is whole tiles and has at least 1024 of them, 2 = the persistent kernels on
  * every whole-tile layer (tests, A/B runs).  Bit-identical outputs either way.  Returns the previous mode; any other argument only queries. */

@@ -568,7 +568,7 @@ int islam_conv_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float
 #define ISLAM_CONV_LAUNCH(TN_, KS_, ROWS_)                                                                                              \
     (kc16 ? launch<TN_, KS_, ROWS_, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s) \
           : launch<TN_, KS_, ROWS_, 32>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s))
-    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, Cin, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
     else if (ws32) rc = conv_ws32_launch(x, wpacked, in_affine, y, stats, B, H, W, CoutP, Cin, 0, Cout, 0, s);
     else if (conv_r4(Cin, Cout, ksize, B, H, W))
         rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, res, y, stats, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s);
@@ -603,7 +603,7 @@ int islam_conv_nhwc_bf16_into(const uint16_t* x, const uint16_t* wpacked, const 
     hipStream_t s = (hipStream_t)stream;
     const bool wide = Cout > 32;
     if (!bias && !relu && !in_relu && conv_ws_applies(Cin, Cout, ksize, B, H, W))
-        return conv_ws_launch(x, wpacked, in_affine, y, nullptr, B, H, W, Cout, CoutP, Cin, 0, ytot, yoff, s);
+        return conv_ws_launch(x, wpacked, in_affine, y, nullptr, B, Cin, H, W, Cout, CoutP, Cin, 0, ytot, yoff, s);
     if (!bias && !relu && !in_relu && conv_ws32_applies(Cin, Cout, ksize, B, H, W))
         return conv_ws32_launch(x, wpacked, in_affine, y, nullptr, B, H, W, CoutP, Cin, 0, ytot, yoff, s);
     if (conv_r4(Cin, Cout, ksize, B, H, W)) return launch<64, 3, 4, 16>(x, wpacked, in_affine, bias, nullptr, y, nullptr, B, Cin, CinP, H, W, Cout, CoutP, relu, in_relu, s, sl);
@@ -681,7 +681,7 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
     int rc;
     const bool ws = (!ir || in_affine) && conv_ws_applies(Cin, Cout, ksize, B, H, W);
     const bool ws32 = (!ir || in_affine) && conv_ws32_applies(Cin, Cout, ksize, B, H, W);
-    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
+    if (ws) rc = conv_ws_launch(x, wpacked, in_affine, y, stats, B, Cin, H, W, Cout, CoutP, Cin, 0, Cout, 0, s);
     else if (ws32) rc = conv_ws32_launch(x, wpacked, in_affine, y, stats, B, H, W, CoutP, Cin, 0, Cout, 0, s);
     else if (conv_r4(Cin, Cout, ksize, B, H, W)) rc = launch<64, 3, 4, 16>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     else if (ksize == 3) rc = wide ? launch<64, 3, 2, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s)

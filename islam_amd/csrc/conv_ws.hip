@@ -1,7 +1,7 @@
-// conv_ws.hip -- weight-STATIONARY 3x3 stride-1 convolution, 128 -> 128 channels, bf16 channels-last, for the 128-channel residual
+// conv_ws.hip -- weight-STATIONARY 3x3 stride-1 convolution, 128 (or 64) -> 128 channels, bf16 channels-last, for the 128-channel residual
 // blocks of the frozen stereo network's feature extractor (Network/PSM/submodule.py:10-13 `convbn`, :24-43 BasicBlock, :66-155
-// feature_extraction layer3 / layer4 -- eleven such convolutions per forward at 112 x 160 x 16 images, the largest share of the
-// frozen nets' kernel time).  Same arithmetic contract as conv_nhwc.hip's conv_nhwc_kernel (bf16 operands, fp32 accumulation in the
+// feature_extraction layer3 / layer4 -- eleven 128 -> 128 convolutions per forward at 112 x 160 x 16 images, the largest share of the
+// frozen nets' kernel time, and the 64 -> 128 one that opens layer3).  Same arithmetic contract as conv_nhwc.hip's conv_nhwc_kernel (bf16 operands, fp32 accumulation in the
 // same order, output rounded to nearest even, the PREVIOUS BatchNorm + ReLU applied while the input is staged, THIS layer's BatchNorm
 // partial sums from the epilogue): the outputs are bit-identical to that kernel's.  Different machine mapping:
 //   * conv_nhwc_kernel re-stages the weight taps (9 x 64 x 32 bf16 = 63 % of its LDS staging traffic) for every 32 x 8-pixel tile and
@@ -61,30 +61,45 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {            // ReLU of pa
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, t), z));
 }
 
-constexpr int CIN = 128, TN = 128, ROWS = 4, TW = 32, THREADS = 256;
+constexpr int TN = 128, ROWS = 4, TW = 32, THREADS = 256;
 constexpr int IH = ROWS + 2, IW = TW + 2, NPIX = IH * IW;          // 6 x 34 halo pixels
-constexpr int PS = CIN + 8;                                        // LDS pixel stride (elements): 272 bytes = 68 banks, conflict-free 16-byte reads
-constexpr int OPP = CIN / 8;                                       // 16-byte octets per pixel
-constexpr int NIN = (NPIX * OPP + THREADS - 1) / THREADS;          // 13 staging items per thread
-constexpr int NPRE = 7;                                            // 16-byte registers they go through: item k and item k + 7 share one
-constexpr int HALO = NPIX * PS;                                    // elements of one halo buffer
 constexpr int TS = TN + 8, OCT = TN / 8, PPT = TW * ROWS * OCT / THREADS;      // output staging tile: [128 pixels][TS]; 8 items per thread
-constexpr int NK = CIN / 16;                                       // k-slices of one MFMA (16 input channels)
-constexpr int NSTEP = 3 * NK, SLOTS = 12;                          // (k-slice, horizontal tap) steps of 12 MFMAs
-// LDS (elements of 2 bytes): two halo buffers | output staging tile | [scale | shift] of the input's BatchNorm (2 x 128 floats) | 16 bytes
-constexpr int L_TL = 2 * HALO, L_AFF = L_TL + TW * ROWS * TS, L_DUMMY = L_AFF + 4 * CIN;
-constexpr size_t LDS_BYTES = (size_t)(L_DUMMY + 8) * sizeof(unsigned short);
-static_assert((size_t)THREADS * 17 * sizeof(float) <= (size_t)2 * HALO * sizeof(unsigned short), "the final reduction reuses the halo buffers");
+constexpr int SLOTS = 12;                                          // MFMAs of a (k-slice, horizontal tap) step
+// Everything that depends on the number of input channels (128: the residual blocks of layer3 / layer4; 64: layer3's first convolution)
+template <int CIN_>
+struct Cfg {
+    static constexpr int CIN = CIN_;
+    static constexpr int PS = CIN + 8;                             // LDS pixel stride (elements): 272 / 144 bytes, conflict-free 16-byte reads
+    static constexpr int OPP = CIN / 8;                            // 16-byte octets per pixel
+    static constexpr int PPI = THREADS / OPP;                      // halo pixels one round of staging items covers (16 / 32)
+    static constexpr int NIN = (NPIX * OPP + THREADS - 1) / THREADS;       // staging items per thread (13 / 7)
+    static constexpr int NPRE = (NIN + 1) / 2;                     // 16-byte registers they go through: item k and item k + NPRE share one (7 / 4)
+    static constexpr int NB = NIN - NPRE;                          // items of the second batch
+    static constexpr int HALO = NPIX * PS;                         // elements of one halo buffer
+    static constexpr int NK = CIN / 16;                            // k-slices of one MFMA (16 input channels)
+    static constexpr int NSTEP = 3 * NK;                           // (k-slice, horizontal tap) steps of 12 MFMAs
+    static constexpr int NW = 9 * NK, NWA = NW < 64 ? NW : 64;     // weight operands of a wave; those that live in AGPRs
+    // LDS (elements of 2 bytes): two halo buffers | output staging tile | [scale | shift] of the input's BatchNorm (2 x CIN floats) | 16 bytes
+    static constexpr int L_TL = 2 * HALO, L_AFF = L_TL + TW * ROWS * TS, L_DUMMY = L_AFF + 4 * CIN;
+    static constexpr size_t LDS_BYTES = (size_t)(L_DUMMY + 8) * sizeof(unsigned short);
+    // the weights enter through LDS, TPR taps per round, behind the first halo buffer
+    static constexpr int TPR = (HALO + TW * ROWS * TS) / (TN * PS), NROUND = (9 + TPR - 1) / TPR;
+    // what rides where in a tile's multiply phase (see `ride`): first batch staged at steps [0, NPRE), store phase of the previous tile
+    // in the five steps behind it, second batch at [BS0, BS0 + NB) together with the requests of the tile after the next
+    static constexpr int ST0 = NPRE, BS0 = NPRE + 5;
+    static_assert(BS0 + NB <= NSTEP && NPRE - NB <= NB && 7 * PPT + 1 <= 5 * SLOTS, "the riders fit the multiply phase");
+    static_assert((size_t)THREADS * 17 * sizeof(float) <= (size_t)2 * HALO * sizeof(unsigned short), "the final reduction reuses the halo buffers");
+    static_assert((TPR * TN * OPP) % THREADS == 0 && ((9 - (NROUND - 1) * TPR) * TN * OPP) % THREADS == 0, "whole 16-byte pieces per thread and round");
+};
 
-// One MFMA with the weight operand taken straight from where it lives.  The 72 weight operands of a wave are 288 registers: the first
-// NWA = 64 of them fill the 256 AGPRs, the rest sit in VGPRs beside the accumulators.  Written as inline assembly because the register
+// One MFMA with the weight operand taken straight from where it lives.  At 128 input channels the 72 weight operands of a wave are 288
+// registers: the first NWA = 64 of them fill the 256 AGPRs, the rest sit in VGPRs beside the accumulators (64 channels: 36, all in AGPRs).  Written as inline assembly because the register
 // allocator otherwise treats the AGPRs as spill space for VGPR-class values and copies every operand back (v_accvgpr_read / _mov, four per
 // MFMA operand, ~300 VALU-class instructions per tile).  FIRST: the accumulator starts from zero.  The compiler does not know these are
 // MFMAs: the hazard it would guard (MFMA result -> VALU read) is covered by the s_nop in front of the epilogue; source registers are only
 // ever rewritten by LDS reads that return long after the MFMA has read them.
-constexpr int NWA = 64;
-template <int J, bool FIRST>
-__device__ __forceinline__ void mma(f32x16& acc, const bf16x8 (&wr)[9 * NK], const bf16x8& b) {
+template <int J, bool FIRST, int NWA, int NW>
+__device__ __forceinline__ void mma(f32x16& acc, const bf16x8 (&wr)[NW], const bf16x8& b) {
     if constexpr (J < NWA) {
         if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(wr[J]), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wr[J]), "v"(b));
@@ -109,11 +124,14 @@ namespace {
 #define WSTAMP(j) do { } while (0)
 #endif
 
-template <bool AFFINE>
+template <int CIN, bool AFFINE>
 __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                                 const float* __restrict__ in_affine, unsigned short* __restrict__ y,
                                                                 float* __restrict__ partial, int H, int W, int tiles_x, int tiles_y, int ntiles,
                                                                 int xs, int xoff, int ys, int yoff, int Cout, int CoutP) {
+    using K = Cfg<CIN>;
+    constexpr int PS = K::PS, OPP = K::OPP, PPI = K::PPI, NIN = K::NIN, NPRE = K::NPRE, NB = K::NB, HALO = K::HALO, NK = K::NK, NSTEP = K::NSTEP;
+    constexpr int L_TL = K::L_TL, L_AFF = K::L_AFF, L_DUMMY = K::L_DUMMY, ST0 = K::ST0, BS0 = K::BS0;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     unsigned short* tl = lds + L_TL;                               // output staging tile
     const float* afl = reinterpret_cast<const float*>(lds + L_AFF);
@@ -125,8 +143,8 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
 #ifdef ISLAM_WS_STAMPS
     const long long begin_ = wall_clock64();
 #endif
-    const int oct = tid & (OPP - 1), prow = tid >> 4;             // the thread's channel octet (the same for all its items), first halo pixel
-    if constexpr (AFFINE) reinterpret_cast<float*>(lds + L_AFF)[tid] = in_affine[tid];      // [scale(128) | shift(128)]
+    const int oct = tid & (OPP - 1), prow = tid / OPP;            // the thread's channel octet (the same for all its items), first halo pixel
+    if constexpr (AFFINE) { if (tid < 2 * CIN) reinterpret_cast<float*>(lds + L_AFF)[tid] = in_affine[tid]; }      // [scale(CIN) | shift(CIN)]
     f32x4 s0 = {1, 1, 1, 1}, s1 = s0, h0 = {0, 0, 0, 0}, h1 = h0;
     auto load_affine = [&]() {                                     // (reloaded where a staging block starts: the 16 registers are free in between)
         if constexpr (AFFINE) {
@@ -136,24 +154,25 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
         }
     };
 
-    // ---- staging: item k of a thread = halo pixel prow + 16 k, channel octet oct.  Requests (global -> registers) and the staging proper
+    // ---- staging: item k of a thread = halo pixel prow + PPI k, channel octet oct.  Requests (global -> registers) and the staging proper
     // (normalise, zero-pad, registers -> LDS) are separate micro-operations so that they can ride in the MFMA slots; everything about
     // an item that does not depend on the tile is computed once: its byte offset from the tile's first halo pixel and its bit in the
     // masks of the halo's top / bottom row and left / right column (whole tiles only: these are the only pixels that can lie outside).
     unsigned relb[NIN], m_pix = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
     static_for<0, NIN>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        const int pix = prow + 16 * k, yy = pix / IW, xx = pix - yy * IW;
+        const int pix = prow + PPI * k, yy = pix / IW, xx = pix - yy * IW;
         relb[k] = (unsigned)(((yy * W + xx) * xs + 8 * oct) * 2);
         m_pix |= (unsigned)(pix < NPIX) << k;
         m_top |= (unsigned)(yy == 0) << k; m_bot |= (unsigned)(yy == IH - 1) << k;
         m_left |= (unsigned)(xx == 0) << k; m_right |= (unsigned)(xx == IW - 1) << k;
     });
     const unsigned safeb = (unsigned)(((W + 1) * xs + 8 * oct) * 2);      // the tile's first interior pixel: what masked items read
-    const unsigned lds_st = (unsigned)((prow * PS + 8 * oct) * 2), tl_ld = (unsigned)((prow * TS + 8 * oct) * 2);
-    const unsigned g_st = (unsigned)((prow * ys + 8 * oct) * 2);
+    const unsigned lds_st = (unsigned)((prow * PS + 8 * oct) * 2);
+    // (the OUTPUT tile has 128 channels whatever the input has: store item j of a thread = pixel tid / 16 + 16 j, channel octet tid % 16)
+    const unsigned tl_ld = (unsigned)(((tid / OCT) * TS + 8 * (tid & (OCT - 1))) * 2), g_st = (unsigned)(((tid / OCT) * ys + 8 * (tid & (OCT - 1))) * 2);
     u32x4 pre[NPRE];
-    unsigned okmask = 0;
+    unsigned okmask = 0, oknext = 0;                                // validity bits of the tile being staged / of the tile requested last
     float tf[4] = {0, 0, 0, 0};
     const char* fbase = nullptr;                                   // first halo pixel of the tile being requested (uniform; may lie outside the tensor)
     auto fetch_tile = [&](int t) {
@@ -161,11 +180,11 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
         const int ty = tc % tiles_y, q = tc / tiles_y, tx = q % tiles_x, b = q / tiles_x;
         fbase = reinterpret_cast<const char*>(x + xoff) + ((long long)((b * H + ty * ROWS - 1) * W + tx * TW - 1) * xs) * 2;
         const unsigned out = (ty == 0 ? m_top : 0u) | (ty == tiles_y - 1 ? m_bot : 0u) | (tx == 0 ? m_left : 0u) | (tx == tiles_x - 1 ? m_right : 0u);
-        okmask = t < t1 ? (m_pix & ~out) : 0u;
+        oknext = t < t1 ? (m_pix & ~out) : 0u;
     };
-    auto fetch = [&](auto kk) {                                    // request of item k
+    auto fetch = [&](auto kk, unsigned mask) {                     // request of item k
         constexpr int k = decltype(kk)::value;
-        const unsigned off = ((okmask >> k) & 1u) ? relb[k] : safeb;
+        const unsigned off = ((mask >> k) & 1u) ? relb[k] : safeb;
         pre[k % NPRE] = *reinterpret_cast<const u32x4*>(fbase + off);
     };
     // staging of item k in nine parts: 0-2 normalise dwords x, y (two independent chains side by side), 3-5 dwords z, w, 6-7 zero padding, 8 write
@@ -193,15 +212,15 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
             const bool ok = (okmask >> k) & 1u;
             v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
         } else {
-            char* d = reinterpret_cast<char*>(dst) + lds_st + k * 16 * PS * 2;
-            if constexpr (k == NIN - 1) d = ((m_pix >> k) & 1u) ? d : reinterpret_cast<char*>(lds + L_DUMMY);      // (the last item of 12 threads in 16 only)
+            char* d = reinterpret_cast<char*>(dst) + lds_st + k * PPI * PS * 2;
+            if constexpr (k == NIN - 1) d = ((m_pix >> k) & 1u) ? d : reinterpret_cast<char*>(lds + L_DUMMY);      // (the last item: not every thread has one)
             *reinterpret_cast<u32x4*>(d) = v;
         }
     };
     auto stage = [&](auto kk, unsigned short* dst) { static_for<0, 9>([&](auto pp) { stage_part(kk, pp, dst); }); };
 
-    // ---- store phase of a finished tile, item j of a thread = pixel prow + 16 j of the 32 x 4 tile (row j / 2, column prow + 16 (j % 2)),
-    // channel octet oct: read the bf16 tile from LDS (16 bytes), add to the thread's BatchNorm sums (of the stored, rounded values), store
+    // ---- store phase of a finished tile, item j of a thread = pixel tid / 16 + 16 j of the 32 x 4 tile (row j / 2, column tid / 16 + 16 (j % 2)),
+    // channel octet tid % 16: read the bf16 tile from LDS (16 bytes), add to the thread's BatchNorm sums (of the stored, rounded values), store
     // 16 bytes (16 lanes = one pixel's 256 bytes)
     float sm[8], sq[8];
 #pragma unroll
@@ -238,67 +257,66 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
         }
     };
 
-    // ---- what rides in slot (step i, MFMA m) of tile t's multiply phase:
-    //   steps 0-6    staging of the A items 0-6 of tile t + 1 (requested during tile t - 1), then the request of B item k + 7
-    //   steps 7-11   store phase of tile t - 1 (57 micro-operations)
-    //   steps 13-18  staging of the B items 7-12 of tile t + 1
-    //   steps 19-20  requests of the A items of tile t + 2
+    // ---- what rides in slot (step i, MFMA m) of tile t's multiply phase (128 input channels: 24 steps, 13 items; 64: 12 steps, 7 items):
+    //   steps [0, NPRE)          staging of the A items of tile t + 1 (requested during tile t - 1); slot 10: the request of B item i + NPRE
+    //   steps [NPRE, NPRE + 5)   store phase of tile t - 1 (57 micro-operations)
+    //   steps [BS0, BS0 + NB)    staging of the B items of tile t + 1; slot 9 of the first: the coordinates of tile t + 2; slot 10: the
+    //                            request of its A item i - BS0 into the register the B item has just left; slot 11: its other A items
     auto ride = [&](auto ii, auto mm, auto has_prev, int t, unsigned short* bufn) {
         constexpr int i = decltype(ii)::value, m = decltype(mm)::value;
         constexpr bool HAS_PREV = decltype(has_prev)::value;
         if constexpr (i < NPRE) {
             if constexpr (i == 0 && m == 0) load_affine();
             if constexpr (m < 9) stage_part(ic<i>{}, mm, bufn);
-            else if constexpr (m == 10 && i + NPRE < NIN) fetch(ic<i + NPRE>{});
-        } else if constexpr (i < 12) {
+            else if constexpr (m == 10 && i + NPRE < NIN) fetch(ic<i + NPRE>{}, okmask);
+        } else if constexpr (i < BS0) {
             if constexpr (HAS_PREV) {
-                constexpr int e = (i - NPRE) * SLOTS + m;          // 0: first LDS read; then 7 parts per item
+                constexpr int e = (i - ST0) * SLOTS + m;           // 0: first LDS read; then 7 parts per item
                 if constexpr (e == 0) { store_tile(t - 1); store_part(ic<0>{}, ic<0>{}); }
                 else if constexpr (e <= 7 * PPT) store_part(ic<(e - 1) / 7>{}, ic<(e - 1) % 7 + 1>{});
             }
-        } else if constexpr (i == 12) {
-            if constexpr (m == 11) load_affine();
-        } else if constexpr (i < 13 + NIN - NPRE) {
-            if constexpr (m < 9) stage_part(ic<i - 13 + NPRE>{}, mm, bufn);
-        } else if constexpr (i < 21) {
-            constexpr int e = (i - 19) * SLOTS + m;               // every other slot: the tile's coordinates, then one request each
-            if constexpr (e == 0) fetch_tile(t + 2);
-            else if constexpr (e % 2 == 0 && e / 2 <= NPRE) fetch(ic<e / 2 - 1>{});
+            if constexpr (i == BS0 - 1 && m == 11) load_affine();
+        } else if constexpr (i < BS0 + NB) {
+            if constexpr (m < 9) stage_part(ic<i - BS0 + NPRE>{}, mm, bufn);
+            else if constexpr (m == 9) { if constexpr (i == BS0) fetch_tile(t + 2); }
+            else if constexpr (m == 10) fetch(ic<i - BS0>{}, oknext);
+            else if constexpr (NB + (i - BS0) < NPRE) fetch(ic<NB + (i - BS0)>{}, oknext);
         }
     };
 
     unsigned short* bufc = lds;                                    // the halo tile being multiplied / the one being filled
     unsigned short* bufn = lds + HALO;
-    // the first tile: all 13 items are requested BEFORE the weights (nothing else needs registers yet) and staged behind them
+    // the first tile: all its items are requested BEFORE the weights (nothing else needs registers yet) and staged behind them
     u32x4 first[NIN];
     fetch_tile(t0);
+    okmask = oknext;
     static_for<0, NIN>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        fetch(kk);
+        fetch(kk, okmask);
         first[k] = pre[k % NPRE];
     });
     // ---- the wave's weights: output channels 32 wave + li (A operand rows), taps x k-slices, for the whole launch.  A lane's operand is 16
-    // bytes of a 256-byte weight row, so direct loads touch 32 cache lines per instruction for a quarter of each (8-10 us for the 72
-    // loads with every workgroup of the chip asking the L2 for the same lines); instead the workgroup copies two taps at a time
-    // (2 x 128 rows x 256 bytes, consecutive lanes = consecutive 16 bytes) into LDS rows of PS elements and every lane picks its operands
-    // from there with the conflict-free pattern of the B operand reads.
-    bf16x8 wr[9 * NK];
+    // bytes of a weight row, so direct loads touch 32 cache lines per instruction for a fraction of each (8-10 us for the 72 loads at 128
+    // channels, with every workgroup of the chip asking the L2 for the same lines); instead the workgroup copies TPR taps at a time
+    // (TPR x 128 rows, consecutive lanes = consecutive 16 bytes) into LDS rows of PS elements and every lane picks its operands from
+    // there with the conflict-free pattern of the B operand reads.
+    bf16x8 wr[K::NW];
     {
-        unsigned short* wl = lds + HALO;                           // second halo buffer + output tile: 90 KB, two taps need 68 KB
-        static_assert(2 * TN * PS <= HALO + TW * ROWS * TS, "two taps of weights fit behind the first halo buffer");
-        u32x4 wv[2][2 * TN * OPP / THREADS];                       // the pieces of round r + 1 are requested before round r is copied
+        constexpr int TPR = K::TPR, NROUND = K::NROUND;
+        unsigned short* wl = lds + HALO;                           // second halo buffer + output tile
+        u32x4 wv[2][TPR * TN * OPP / THREADS];                     // the pieces of round r + 1 are requested before round r is copied
         auto request = [&](auto rr) {
-            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;      // 16-byte pieces per thread
+            constexpr int r = decltype(rr)::value, ntap = r + 1 < NROUND ? TPR : 9 - r * TPR, NP = ntap * TN * OPP / THREADS;      // 16-byte pieces per thread
             static_for<0, NP>([&](auto nn) {
                 constexpr int n = decltype(nn)::value;
                 const int pc = tid + n * THREADS, tl_ = pc / (TN * OPP), row = (pc / OPP) % TN, o = pc % OPP;
-                wv[r & 1][n] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((2 * r + tl_) * CoutP + row)) * CIN + 8 * o);
+                wv[r & 1][n] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((TPR * r + tl_) * CoutP + row)) * CIN + 8 * o);
             });
         };
         request(ic<0>{});
-        static_for<0, 5>([&](auto rr) {
-            constexpr int r = decltype(rr)::value, ntap = r < 4 ? 2 : 1, NP = ntap * TN * OPP / THREADS;
-            if constexpr (r + 1 < 5) request(ic<r + 1>{});
+        static_for<0, NROUND>([&](auto rr) {
+            constexpr int r = decltype(rr)::value, ntap = r + 1 < NROUND ? TPR : 9 - r * TPR, NP = ntap * TN * OPP / THREADS;
+            if constexpr (r + 1 < NROUND) request(ic<r + 1>{});
             if constexpr (r > 0) __syncthreads();                  // the previous round's operand reads are done
             static_for<0, NP>([&](auto nn) {
                 constexpr int n = decltype(nn)::value;
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
             __syncthreads();
             static_for<0, ntap * NK>([&](auto ii) {
                 constexpr int i = decltype(ii)::value, tl_ = i / NK, ks = i % NK;
-                wr[(2 * r + tl_) * NK + ks] = *reinterpret_cast<const bf16x8*>(wl + (tl_ * TN + 32 * wave + li) * PS + 16 * ks + 8 * kg);
+                wr[(TPR * r + tl_) * NK + ks] = *reinterpret_cast<const bf16x8*>(wl + (tl_ * TN + 32 * wave + li) * PS + 16 * ks + 8 * kg);
             });
         });
         __syncthreads();                                           // (the region becomes the halo buffer / output tile)
@@ -324,7 +342,8 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
     });
     __syncthreads();
     fetch_tile(t0 + 1);                                            // (past the range: everything masked)
-    static_for<0, NPRE>([&](auto kk) { fetch(kk); });
+    okmask = oknext;
+    static_for<0, NPRE>([&](auto kk) { fetch(kk, okmask); });
 
 #ifdef ISLAM_WS_STAMPS
     const bool stamp = wgl == 3 && tid == 0;
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
             constexpr int ks1 = (i + 1) / 3, s1n = (i + 1) % 3;
             static_for<0, SLOTS>([&](auto mm) {
                 constexpr int m = decltype(mm)::value, q = MQ[m], r = MR[m];
-                mma<(r * 3 + s) * NK + ks, (i == 0 && r == 0)>(acc[q - r], wr, bf[q]);
+                mma<(r * 3 + s) * NK + ks, (i == 0 && r == 0), K::NWA, K::NW>(acc[q - r], wr, bf[q]);
                 if constexpr (MLAST[m] && i + 1 < NSTEP) bf[q] = *reinterpret_cast<const bf16x8*>(bb + (q * IW + s1n) * PS + 16 * ks1);
                 ride(ii, mm, has_prev, t, bufn);
                 __builtin_amdgcn_sched_barrier(0);                 // the order written here is the order issued
@@ -368,6 +387,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv3x3_ws_kernel(const unsigned s
         __syncthreads();
         WSTAMP(3);
         unsigned short* tmp = bufc; bufc = bufn; bufn = tmp;
+        okmask = oknext;                                           // the tile requested during this one is staged during the next
     };
     if (t0 < t1) tile(t0, std::false_type{});
     for (int t = t0 + 1; t < t1; ++t) tile(t, std::true_type{});
@@ -428,7 +448,7 @@ namespace islam {
 // whole tiles only (no predication in the riding store phase): the image is a multiple of 32 x 4 pixels
 bool conv_ws_applies(int Cin, int Cout, int ksize, int B, int H, int W) {
     const int mode = ws_mode();
-    if (!mode || ksize != 3 || Cin != CIN || Cout != TN || (H % ROWS) || (W % TW)) return false;
+    if (!mode || ksize != 3 || (Cin != 128 && Cin != 64) || Cout != TN || (H % ROWS) || (W % TW)) return false;
     return mode == 2 || (long long)B * (H / ROWS) * (W / TW) >= 1024;
 }
 
@@ -454,26 +474,33 @@ int conv_ws_balanced(long long ntiles, int slots) {
     return (int)((ntiles + per - 1) / per);
 }
 
-int conv_ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
-                   int Cout, int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s) {
+template <int CIN>
+static int ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int H, int W,
+                     int Cout, int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s) {
     int dev = 0;
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<CIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<CIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev] = true;
     }
     const int tiles_x = W / TW, tiles_y = H / ROWS, ntiles = tiles_x * tiles_y * B;
     const int G = conv_ws_blocks(B, H, W);
     if (in_affine)
-        hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3(G), dim3(THREADS), LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x, tiles_y, ntiles,
-                           xs, xoff, ys, yoff, Cout, CoutP);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<CIN, true>), dim3(G), dim3(THREADS), Cfg<CIN>::LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x,
+                           tiles_y, ntiles, xs, xoff, ys, yoff, Cout, CoutP);
     else
-        hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3(G), dim3(THREADS), LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x, tiles_y, ntiles,
-                           xs, xoff, ys, yoff, Cout, CoutP);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<CIN, false>), dim3(G), dim3(THREADS), Cfg<CIN>::LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x,
+                           tiles_y, ntiles, xs, xoff, ys, yoff, Cout, CoutP);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
+}
+
+int conv_ws_launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, unsigned short* y, float* partial, int B, int Cin, int H,
+                   int W, int Cout, int CoutP, int xs, int xoff, int ys, int yoff, hipStream_t s) {
+    return Cin == 64 ? ws_launch<64>(x, wp, in_affine, y, partial, B, H, W, Cout, CoutP, xs, xoff, ys, yoff, s)
+                     : ws_launch<128>(x, wp, in_affine, y, partial, B, H, W, Cout, CoutP, xs, xoff, ys, yoff, s);
 }
 
 }  // namespace islam

@@ -410,7 +410,7 @@ def execution_description():
                       'BatchNorm + ReLU on load)' % on(HIP_CONV_LEVEL >= 2, ' and the hourglass 1x1', ''))
         from ._lib import lib
         if lib().islam_conv_ws_mode(-1) > 0:
-            stereo.append('the eleven 128->128 3x3 layers on the weight-stationary persistent kernel conv3x3_ws_kernel (weights in the register file), '
+            stereo.append('the twelve 3x3 layers with 128 output channels of layer3 / layer4 on the weight-stationary persistent kernel conv3x3_ws_kernel (weights in the register file), '
                           'the eight 32->32 ones on the persistent kernel conv3x3_ws32_kernel')
     else:
         stereo.append('all convolutions on MIOpen')

@@ -372,10 +372,11 @@ def ws_mode():
     lib().islam_conv_ws_mode(prev)
 
 
-@pytest.mark.parametrize('C,B,H,W', [(128, 1, 4, 32), (128, 2, 8, 64), (128, 3, 12, 96), (128, 5, 20, 160), (128, 9, 112, 160),
-                                     (32, 1, 16, 32), (32, 2, 32, 64), (32, 3, 48, 96), (32, 5, 224, 320)])
-def test_persistent_kernels_match_the_tile_kernel_bit_for_bit(cuda, ws_mode, C, B, H, W):
-    """csrc/conv_ws.hip (128 -> 128: one workgroup per CU walks a range of 32 x 4-pixel tiles with its weights in the register file) and
+@pytest.mark.parametrize('C,CO,B,H,W', [(128, 128, 1, 4, 32), (128, 128, 2, 8, 64), (128, 128, 3, 12, 96), (128, 128, 5, 20, 160), (128, 128, 9, 112, 160),
+                                        (64, 128, 1, 4, 32), (64, 128, 2, 8, 64), (64, 128, 3, 12, 96), (64, 128, 9, 112, 160),
+                                        (32, 32, 1, 16, 32), (32, 32, 2, 32, 64), (32, 32, 3, 48, 96), (32, 32, 5, 224, 320)])
+def test_persistent_kernels_match_the_tile_kernel_bit_for_bit(cuda, ws_mode, C, CO, B, H, W):
+    """csrc/conv_ws.hip (128 -> 128 and 64 -> 128: one workgroup per CU walks a range of 32 x 4-pixel tiles with its weights in the register file) and
     csrc/conv_ws32.hip (32 -> 32: two persistent workgroups per CU, 32 x 16-pixel tiles, the next tile's halo requested a tile ahead)
     behind the three entry points that dispatch to them: the same bf16 outputs as conv_nhwc_kernel -- same operands, same accumulation
     order -- with and without the producer's BatchNorm + ReLU on load, from one tile (one workgroup) to several tiles per workgroup;
@@ -383,35 +384,35 @@ def test_persistent_kernels_match_the_tile_kernel_bit_for_bit(cuda, ws_mode, C, 
     through the one-launch fold + finalize up to the summation order of the partial sums; a channel slice of a wider tensor as
     destination."""
     from islam_amd import ops
-    x, w = _mk(B, C, H, W, C, 3, seed=H + B)
+    x, w = _mk(B, C, H, W, CO, 3, seed=H + B)
     wp = ops.pack_conv_nhwc_weight(w)
     g = torch.Generator().manual_seed(6)
     aff = torch.cat((torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3)).to(cuda)
     ref = F.conv2d(x.float(), w.float(), None, 1, 1)
     for in_affine in (None, aff):
         ws_mode(0)
-        y0, f0 = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
+        y0, f0 = ops.conv_nhwc(x, wp, CO, 3, in_affine=in_affine, stats=True)
         ws_mode(2)
-        y2, f2 = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
+        y2, f2 = ops.conv_nhwc(x, wp, CO, 3, in_affine=in_affine, stats=True)
         assert torch.equal(y0, y2)
         if in_affine is None:
             assert float((y2.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
-        s = f2.view(256, 2, C).double().sum(0)
+        s = f2.view(256, 2, CO).double().sum(0)
         want = torch.stack([y2.double().sum((0, 2, 3)), (y2.double() ** 2).sum((0, 2, 3))])
         np.testing.assert_allclose(s.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-3)
-        _, f2b = ops.conv_nhwc(x, wp, C, 3, in_affine=in_affine, stats=True)
+        _, f2b = ops.conv_nhwc(x, wp, CO, 3, in_affine=in_affine, stats=True)
         assert torch.equal(f2, f2b)                                           # fixed-order sums
-        bn0, bn2 = torch.nn.BatchNorm2d(C).to(cuda).train(), torch.nn.BatchNorm2d(C).to(cuda).train()
+        bn0, bn2 = torch.nn.BatchNorm2d(CO).to(cuda).train(), torch.nn.BatchNorm2d(CO).to(cuda).train()
         ws_mode(0)
-        _, ss0 = ops.conv_nhwc_bn(x, wp, C, 3, bn0, in_affine=in_affine)
+        _, ss0 = ops.conv_nhwc_bn(x, wp, CO, 3, bn0, in_affine=in_affine)
         ws_mode(2)
-        y2b, ss2 = ops.conv_nhwc_bn(x, wp, C, 3, bn2, in_affine=in_affine)
+        y2b, ss2 = ops.conv_nhwc_bn(x, wp, CO, 3, bn2, in_affine=in_affine)
         assert torch.equal(y2b, y2)
         torch.testing.assert_close(ss2, ss0, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(bn2.running_var, bn0.running_var, rtol=1e-5, atol=1e-7)
-        out = torch.full((B, C + 72, H, W), 7.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
-        ops.conv_nhwc_into(x, wp, C, 3, out, 64, in_affine=in_affine)
-        assert torch.equal(out[:, 64:64 + C], y2) and bool((out[:, :64] == 7.0).all()) and bool((out[:, 64 + C:] == 7.0).all())
+        out = torch.full((B, CO + 72, H, W), 7.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
+        ops.conv_nhwc_into(x, wp, CO, 3, out, 64, in_affine=in_affine)
+        assert torch.equal(out[:, 64:64 + CO], y2) and bool((out[:, :64] == 7.0).all()) and bool((out[:, 64 + CO:] == 7.0).all())
     assert all(int(t[0].abs().sum()) == 0 for t in ops._BN_COUNTERS.values())
 
 
