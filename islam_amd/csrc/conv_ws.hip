@@ -1,9 +1,10 @@
-// conv_ws.hip -- weight-STATIONARY 3x3 stride-1 convolution, 128 (or 64) -> 128 channels, bf16 channels-last, for the 128-channel residual
-// blocks of the frozen stereo network's feature extractor (Network/PSM/submodule.py:10-13 `convbn`, :24-43 BasicBlock, :66-155
+// conv_ws.hip -- weight-STATIONARY 3x3 stride-1 convolution, 128 (or 64) -> 128 channels, bf16 channels-last, for the 128-channel
+// residual blocks of the frozen stereo network's feature extractor (Network/PSM/submodule.py:10-13 `convbn`, :24-43 BasicBlock, :66-155
 // feature_extraction layer3 / layer4 -- eleven 128 -> 128 convolutions per forward at 112 x 160 x 16 images, the largest share of the
-// frozen nets' kernel time, and the 64 -> 128 one that opens layer3).  Same arithmetic contract as conv_nhwc.hip's conv_nhwc_kernel (bf16 operands, fp32 accumulation in the
-// same order, output rounded to nearest even, the PREVIOUS BatchNorm + ReLU applied while the input is staged, THIS layer's BatchNorm
-// partial sums from the epilogue): the outputs are bit-identical to that kernel's.  Different machine mapping:
+// frozen nets' kernel time, and the 64 -> 128 one that opens layer3).  Same arithmetic contract as conv_nhwc.hip's conv_nhwc_kernel
+// (bf16 operands, fp32 accumulation in the same order, output rounded to nearest even, the PREVIOUS BatchNorm + ReLU applied while the
+// input is staged, THIS layer's BatchNorm partial sums from the epilogue): the outputs are bit-identical to that kernel's.  Different
+// machine mapping (numbers for 128 input channels; Cfg<64> halves the weights, the steps per tile and the staging items):
 //   * conv_nhwc_kernel re-stages the weight taps (9 x 64 x 32 bf16 = 63 % of its LDS staging traffic) for every 32 x 8-pixel tile and
 //     every 32-channel chunk, reads 0.83 LDS operands per MFMA, and lives 25 us per workgroup of which 6.5 us are set-up and epilogue;
 //   * here ONE workgroup per CU (4 waves, one per SIMD) owns the gfx950 register file: wave w keeps the weights of output channels
