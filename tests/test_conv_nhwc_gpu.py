@@ -437,3 +437,32 @@ def test_persistent_kernels_serve_whole_tile_layers_only(cuda, ws_mode):
     ws_mode(0)
     want = [ops.conv_nhwc(x, wp, 128, 3, relu=True), ops.conv_nhwc(x, wp, 128, 3, bias=bias, res=res), ops.conv_nhwc(x, wp, 128, 3, in_relu=True)]
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_persistent_kernels_on_random_whole_tile_shapes(cuda, ws_mode):
+    """Seeded sweep over shapes the fixed cases do not hit (odd tile counts per workgroup, one image row of tiles, many images of one tile,
+    destinations with a channel offset): persistent kernel == tile kernel, bit for bit, and the folded statistics are the sums over the output."""
+    from islam_amd import ops
+    rng = np.random.default_rng(11)
+    for case in range(14):
+        C, CO, th = [(128, 128, 4), (64, 128, 4), (32, 32, 16)][case % 3]
+        B = int(rng.integers(1, 7))
+        H = th * int(rng.integers(1, 9 if th == 4 else 4))
+        W = 32 * int(rng.integers(1, 5))
+        x, w = _mk(B, C, H, W, CO, 3, seed=100 + case)
+        wp = ops.pack_conv_nhwc_weight(w)
+        aff = None
+        if rng.integers(0, 2):
+            aff = torch.tensor(np.concatenate([rng.uniform(0.5, 1.5, C), rng.normal(0, 0.3, C)]), dtype=torch.float32, device=cuda)
+        ws_mode(0)
+        y0, f0 = ops.conv_nhwc(x, wp, CO, 3, in_affine=aff, stats=True)
+        ws_mode(2)
+        y2, f2 = ops.conv_nhwc(x, wp, CO, 3, in_affine=aff, stats=True)
+        assert torch.equal(y0, y2), (C, CO, B, H, W)
+        s = f2.view(256, 2, CO).double().sum(0)
+        want = torch.stack([y2.double().sum((0, 2, 3)), (y2.double() ** 2).sum((0, 2, 3))])
+        np.testing.assert_allclose(s.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-3)
+        yoff = 8 * int(rng.integers(0, 5))
+        out = torch.full((B, CO + 40, H, W), 3.0, dtype=torch.bfloat16, device=cuda).contiguous(memory_format=CL)
+        ops.conv_nhwc_into(x, wp, CO, 3, out, yoff, in_affine=aff)
+        assert torch.equal(out[:, yoff:yoff + CO], y2) and bool((out[:, :yoff] == 3.0).all()) and bool((out[:, yoff + CO:] == 3.0).all())
