@@ -16,10 +16,10 @@
 // -- the rounding points of the layer-by-layer path.  GEMM view as in conv_nhwc.hip: M = output channels (A = weights), N = pixels
 // (B = activations, [pixel][channel] rows in LDS), v_mfma_f32_32x32x16_bf16; a wave owns one 32-pixel N tile (two tile rows) in
 // phases 2 / 3 and one or two of the six N tiles of the 180-pixel patch in phase 1, with all M tiles of the layer.
-// WEIGHTS never pass through registers: the host packs every K step's operand image (rows of 32 channels + 16 bytes of
-// padding = the conflict-free 80-byte LDS row stride) contiguously, and the waves copy stage s + 1 into the other half of a
-// double buffer with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs, no ds_write) while stage s is
-// multiplied; one workgroup barrier per stage.
+// WEIGHTS never pass through LDS: the host packs them as MFMA A fragments in consumption order (1 KiB = one fragment of all 64 lanes)
+// and every wave loads the fragments of the output-channel tiles it owns straight from L2 through a small register ring (details in
+// front of the kernels below; a first version that streamed weight stages through LDS by LDS-DMA was bound by the DMA round trip per
+// stage and is gone).  Only the raw input patch arrives by LDS-DMA.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
