@@ -44,6 +44,10 @@ int islam_abi_version(void);
  * while other streams keep it busy.  out3: 3 x int64 in device memory. */
 int islam_clock_probe(long long* out3, int iters, void* stream);
 int islam_wall_clock_khz(int device);
+/* Measurement aid (no reference counterpart; bench.py's roofline.latency_model, SURVEY 8(d) "t >= n_launch * t_launch + depth * t_block"):
+ * `n` back-to-back launches of a kernel that does nothing (grid x block threads) on `stream` between one pair of events;
+ * *us_per_launch = the period of a kernel in a chain of dependent launches on this platform.  Synchronises the stream. */
+int islam_launch_cost_probe(int grid, int block, int n, float* us_per_launch, void* stream);
 
 /* ---------------------------------------------------------------- PWC-Net front-end kernels */
 
@@ -236,6 +240,10 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
  * csrc/conv_ws32.hip (32 x 16-pixel tiles) when the image is whole tiles and has at least 1024 of them, 2 = the persistent kernels on
  * every whole-tile layer (tests, A/B runs).  Bit-identical outputs either way.  Returns the previous mode; any other argument only queries. */
 int islam_conv_ws_mode(int mode);
+/* Launches of the two persistent kernels since the library was loaded (host-side counters; a launch recorded into a HIP graph counts once,
+ * at capture): out2[0] = conv3x3_ws_kernel (conv_ws.hip), out2[1] = conv3x3_ws32_kernel (conv_ws32.hip).  The parity tests of the stereo
+ * feature extractor (Network/PSM/submodule.py:66-155) use it to prove which kernel produced the output they compare. */
+int islam_conv_ws_launch_counts(long long* out2);
 /* 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),
  * :237-292 the blocks) on the channels-last kernel.  x: bf16 channels [xoff, xoff + Cin) of a (B,H,W,xtot) MIRROR of the block's
  * concatenation buffer; the result goes as fp32 NCHW into channels [coff, coff + Cout) of y32 (B,ytot,H,W) -- what correlation /

@@ -45,6 +45,7 @@ SIGNATURES = {
     'islam_abi_version': (c_int, []),
     'islam_clock_probe': (c_int, [c_void_p, c_int, c_void_p]),
     'islam_wall_clock_khz': (c_int, [c_int]),
+    'islam_launch_cost_probe': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     'islam_corr81_scratch_bytes': (c_size_t, [c_int] * 4),
     'islam_corr81_fwd': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p]),
     'islam_corr81_bwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     'islam_conv_nhwc_bf16': (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     'islam_conv_nhwc_s2_stats_floats': (c_size_t, [c_int] * 4),
     'islam_conv_ws_mode': (c_int, [c_int]),
+    'islam_conv_ws_launch_counts': (c_int, [c_void_p]),
     'islam_conv_nhwc_bf16_s2': (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
     'islam_conv_nhwc_bf16_into': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'islam_conv_nhwc_bf16_bn': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p] * 5 + [c_double, c_double] + [c_void_p] * 3),

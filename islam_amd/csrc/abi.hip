@@ -34,6 +34,37 @@ extern "C" int islam_clock_probe(long long* out3, int iters, void* stream) {
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
+// ---- measurement aid (bench.py, roofline.latency_model): what ONE kernel in a chain of dependent launches costs on this platform whatever
+// it does -- `n` launches of a kernel that does nothing, back to back on `stream` between one pair of events.  Synchronises the stream.
+namespace {
+struct ProbePad { double pad[40]; };                     // (a kernel-argument block the size the LM kernels pass)
+__global__ void launch_cost_kernel(double* p, ProbePad b) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && b.pad[0] == 12345.0) p[0] = 1.0;
+}
+}  // namespace
+extern "C" int islam_launch_cost_probe(int grid, int block, int n, float* us_per_launch, void* stream) {
+    if (grid < 1 || block < 1 || block > 1024 || n < 1 || !us_per_launch) return islam::fail(ISLAM_EARG, "islam_launch_cost_probe: bad argument");
+    hipStream_t s = islam::as_stream(stream);
+    double* p = nullptr;
+    ISLAM_HIP_CHECK(hipMalloc(&p, 64));
+    hipEvent_t e0, e1;
+    ISLAM_HIP_CHECK(hipEventCreate(&e0));
+    ISLAM_HIP_CHECK(hipEventCreate(&e1));
+    ProbePad b{};
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(launch_cost_kernel, dim3(grid), dim3(block), 0, s, p, b);
+    ISLAM_HIP_CHECK(hipStreamSynchronize(s));
+    ISLAM_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(launch_cost_kernel, dim3(grid), dim3(block), 0, s, p, b);
+    ISLAM_HIP_CHECK(hipEventRecord(e1, s));
+    ISLAM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    ISLAM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(p);
+    *us_per_launch = ms * 1e3f / n;
+    return ISLAM_OK;
+}
 extern "C" int islam_wall_clock_khz(int device) {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess) return -1;

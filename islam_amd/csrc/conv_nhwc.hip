@@ -515,6 +515,7 @@ int islam_conv_probe_read(long long* out) {
 #endif
 
 int islam_conv_ws_mode(int mode) { return conv_ws_set_mode(mode); }
+int islam_conv_ws_launch_counts(long long* out2) { if (!out2) return ISLAM_EARG; conv_ws_read_counts(out2); return ISLAM_OK; }
 
 size_t islam_conv_nhwc_packed_elems(int Cin, int Cout, int ksize) {
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;

@@ -7,6 +7,8 @@ namespace islam {
 
 int conv_ws_set_mode(int mode);                           // returns the previous mode; out-of-range: query only
 int conv_ws_spare_cus();
+void conv_ws_count_launch(int which);                    // 0: conv3x3_ws_kernel, 1: conv3x3_ws32_kernel (host-side launch counters: islam_conv_ws_launch_counts)
+void conv_ws_read_counts(long long out[2]);
 int conv_ws_balanced(long long ntiles, int slots);      // smallest launch whose longest tile range is as short as with `slots` workgroups
 bool conv_ws_applies(int Cin, int Cout, int ksize, int B, int H, int W);
 int conv_ws_blocks(int B, int H, int W);                 // workgroups of the launch = rows of per-workgroup BatchNorm partial sums it writes

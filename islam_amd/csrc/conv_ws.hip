@@ -102,10 +102,10 @@ struct Cfg {
 template <int J, bool FIRST, int NWA, int NW>
 __device__ __forceinline__ void mma(f32x16& acc, const bf16x8 (&wr)[NW], const bf16x8& b) {
     if constexpr (J < NWA) {
-        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(wr[J]), "v"(b));
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wr[J]), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wr[J]), "v"(b));
     } else {
-        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(wr[J]), "v"(b));
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wr[J]), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wr[J]), "v"(b));
     }
 }
@@ -432,6 +432,9 @@ static int ws_mode() {
     }
     return m;
 }
+static std::atomic<long long> g_launches[2];
+void conv_ws_count_launch(int which) { g_launches[which & 1].fetch_add(1, std::memory_order_relaxed); }
+void conv_ws_read_counts(long long out[2]) { out[0] = g_launches[0].load(std::memory_order_relaxed); out[1] = g_launches[1].load(std::memory_order_relaxed); }
 int conv_ws_set_mode(int mode) {
     const int prev = ws_mode();
     if (mode >= 0 && mode <= 2) g_mode.store(mode, std::memory_order_relaxed);
@@ -495,6 +498,7 @@ static int ws_launch(const unsigned short* x, const unsigned short* wp, const fl
         hipLaunchKernelGGL((conv3x3_ws_kernel<CIN, false>), dim3(G), dim3(THREADS), Cfg<CIN>::LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x,
                            tiles_y, ntiles, xs, xoff, ys, yoff, Cout, CoutP);
     ISLAM_LAUNCH_CHECK();
+    conv_ws_count_launch(0);
     return ISLAM_OK;
 }
 

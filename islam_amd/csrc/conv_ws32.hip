@@ -239,6 +239,7 @@ int conv_ws32_launch(const unsigned short* x, const unsigned short* wp, const fl
         hipLaunchKernelGGL(conv3x3_ws32_kernel<false>, dim3(G), dim3(THREADS), LDS_BYTES, s, x, wp, in_affine, y, partial, H, W, tiles_x, tiles_y, ntiles,
                            xs, xoff, ys, yoff, CoutP);
     ISLAM_LAUNCH_CHECK();
+    conv_ws_count_launch(1);
     return ISLAM_OK;
 }
 

@@ -208,17 +208,28 @@ def conv_ws_mode():
     lib().islam_conv_ws_mode(prev)
 
 
+def _ws_launches():
+    """(launches of conv3x3_ws_kernel, of conv3x3_ws32_kernel) so far: islam_conv_ws_launch_counts."""
+    import ctypes
+    from islam_amd._lib import lib
+    c = (ctypes.c_longlong * 2)()
+    assert lib().islam_conv_ws_launch_counts(ctypes.cast(c, ctypes.c_void_p)) == 0
+    return int(c[0]), int(c[1])
+
+
 @pytest.mark.parametrize('direct_cat,persistent', [(True, True), (False, True), (True, False)])
 def test_stereo_net_bf16_execution_copy_matches_reference(cuda, monkeypatch, conv_ws_mode, direct_cat, persistent):
     """The frozen stereo net as the bench runs it: bf16 channels-last execution copy in train mode, BatchNorm on
     islam_bn_train_nhwc_bf16 (batch statistics + running-stat update), islam_resize_bilinear_nhwc_bf16,
     islam_bias_act_add_nhwc_bf16 -- against the reference's fp32 train-mode forward.  direct_cat: the feature extractor writes
     conv_c0's input in place (left images first in the batch: the default) / dense features in the reference's interleaved order.
-    persistent: the eleven 128 -> 128 and eight 32 -> 32 3x3 layers on csrc/conv_ws.hip / conv_ws32.hip (the default at this size) or
-    on the tile kernel like every other layer."""
+    persistent: the 64 -> 128, the eleven 128 -> 128 and the eight 32 -> 32 3x3 layers on csrc/conv_ws.hip / conv_ws32.hip (FORCED with
+    islam_conv_ws_mode(2): the fixture's 2x256x256 input has 128 tiles per layer, below the 1024 at which the default mode 1 engages them;
+    the launch counters prove the two kernels produced what is compared) or on the tile kernel like every other layer (mode 0)."""
     from islam_amd import nets
     monkeypatch.setattr(nets, 'STEREO_DIRECT_CAT', direct_cat)
-    conv_ws_mode(1 if persistent else 0)
+    conv_ws_mode(2 if persistent else 0)
+    ws0 = _ws_launches()
     ref = _g('stereo')
     vn = nets.VONet(fix_parts=('flow', 'stereo'))
     fill_state_dict(vn.stereoNet)
@@ -230,6 +241,10 @@ def test_stereo_net_bf16_execution_copy_matches_reference(cuda, monkeypatch, con
     with torch.no_grad():
         out = vn._run_frozen('stereo', vn.stereoNet, vn.frozen_dtype, x)[0]
     assert out.dtype == torch.bfloat16
+    ws1 = _ws_launches()
+    # Network/PSM/submodule.py:66-155: layer3 = 64 -> 128 + 5 x 128 -> 128, layer4 = 6 x 128 -> 128 (twelve launches
+    # of conv3x3_ws_kernel); firstconv's two 32 -> 32 + layer1's six (eight launches of conv3x3_ws32_kernel)
+    assert (ws1[0] - ws0[0], ws1[1] - ws0[1]) == ((12, 8) if persistent else (0, 0)), (ws0, ws1)
     ex = vn._exec['stereo'].module()
     assert ex.feature_extraction.firstconv[0][0].weight.dtype == torch.bfloat16         # the reduced-precision copy ran
     _within(out, ref['disp'], BF16_STEREO, 'disp (bf16 execution copy)')
@@ -262,10 +277,13 @@ def test_whole_vonet_fp32_matches_reference(cuda):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph, monkeypatch):
+def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph, monkeypatch, conv_ws_mode):
     """What bench.py runs: flow net on the matrix-core convolution, stereo net through the bf16 execution copy, optionally
     replayed from a captured HIP graph (two replays: the second one must still be right, and BatchNorm running statistics
-    keep moving)."""
+    keep moving).  The persistent convolution kernels bench.py's B = 8 engages by size are forced here (islam_conv_ws_mode(2): B = 1 is
+    280 tiles per layer) and the launch counters prove they ran."""
+    conv_ws_mode(2)
+    ws0 = _ws_launches()
     ref = _g('vonet')
     vn = _vonet(cuda)
     vn.set_frozen_dtype(torch.bfloat16, torch.bfloat16)
@@ -287,6 +305,8 @@ def test_whole_vonet_reduced_precision_paths_match_reference(cuda, graph, monkey
         _within(disp, ref['disp'], BF16_STEREO, 'disp')
         assert _relmax(pose, ref['pose']) <= 1e-2, rep     # pose head (fp32) fed with that flow (measured 7e-4)
         assert not torch.equal(vn.stereoNet.state_dict()[key], rm0)
+    ws1 = _ws_launches()
+    assert ws1[0] - ws0[0] >= 12 and ws1[1] - ws0[1] >= 8, (ws0, ws1)      # (a graph records each launch once, at capture)
     if graph:
         assert len(vn._graphs) == 1
         torch.cuda.synchronize()

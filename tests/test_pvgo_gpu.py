@@ -318,6 +318,28 @@ def test_block_tridiagonal_solver_random_sizes_and_segment_lengths(cuda):
         assert np.abs(dx - ref).max() <= 1e-9 * np.abs(ref).max(), (case, N, seg)
 
 
+def test_rejecting_bench_configuration_matches_oracle(cuda):
+    """bench.py's `reject_heavy` leg: the N = 5001 graph from its dead-reckoning start under TrustRegion(radius=1e8).  The first
+    optimizer.step rejects its trial four times (damping 2e-8 -> 8e-8 -> 6.4e-7 -> 1.02e-5) before it accepts: same accept / reject
+    sequence, dampings, losses and final iterate as the oracle (pvgo.py:168-180 with radius 1e8 instead of 1e4)."""
+    from islam_amd import ops
+    prob, _ = chain_problem(5001)
+    out = opvgo.run_pvgo(**prob, loss_weight=LW, mode='banded', return_optimizer=True, radius=1e8)
+    opt = out[5]
+    rej = ''.join(str(int(not t[2])) for t in opt.trace)
+    assert rej == '11110000000000', 'the oracle problem changed: %s' % rej
+    nodes, vels, poses, drots, dtrans, dvels, dts = _dev(prob, cuda)
+    res, trace = ops.pvgo_run_chain(nodes, vels, poses, drots, dtrans, dvels, dts, ops.pvgo_default_params(LW, radius=1e8), trace_cap=256)
+    ot = np.array([(l, d, float(a)) for l, d, a in opt.trace])
+    assert res.trials == len(ot)
+    np.testing.assert_array_equal(trace[:, 2], ot[:, 2])
+    np.testing.assert_allclose(trace[:, 1], ot[:, 1], rtol=1e-12)
+    np.testing.assert_allclose(trace[:, 0], ot[:, 0], rtol=1e-6)
+    err = se3_log_err(nodes.cpu().numpy(), opt.nodes)
+    ref = np.maximum(np.linalg.norm(lie.se3_log(opt.nodes), axis=-1), 1e-6)
+    assert (err / ref).max() < 1e-4                    # north_star's bound on the SE(3) log
+
+
 @pytest.mark.parametrize('F,seed,sig', [(1000, 3, 0.8), (5001, 5, 0.5), (5001, 6, 1.5), (777, 9, 3.0)])
 def test_fused_loop_equals_the_launch_per_stage_loop_on_reject_heavy_graphs(cuda, F, seed, sig, monkeypatch):
     """islam_pvgo_run_chain's two loops on problems that make LM reject trials and change its damping at full size: the fused loop
