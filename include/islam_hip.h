@@ -183,6 +183,28 @@ long long islam_bias_act_bwd_scratch_floats(long long pixels, int C);
 int islam_bias_act_bwd_f32_nhwc(const float* gy, const float* y, float* gx, float* gbias, float* scratch, unsigned* ticket,
                                 long long pixels, int C, int relu, void* stream);
 
+/* The trainable pose head, whole: VOFlowRes.forward_ (Network/VOFlowNet.py:185-194) over the feature embedding of config 1 (:110-157: three
+ * plain convolutions, five stages of BasicBlocks :20-39 of 3/4/6/7/3 blocks at 64/128/128/256/256 channels, first block of a stage with
+ * stride 2 and a 1x1 stride-2 convolution on its shortcut) and the two Linear heads (:84-92), and its backward (what
+ * train.py:280-283's loss.backward() runs through this module) -- each ONE call that enqueues hand-written fp32 kernels (exact-fp32
+ * matrix-core implicit GEMMs, csrc/pose_head.hip) on `stream`: no MIOpen / CK / ATen launch, deterministic summation orders.
+ *   x        (B,H,W,4) fp32 channels-last: [flow(2), intrinsic layer(2)] (Network/VONet.py:36); B <= 16; the input's 1/64-size feature map must
+ *            have 6 pixels (448x640 images: H = 112, W = 160)
+ *   params   the module's 120 parameters in state_dict order (feat_net.0.0.weight, feat_net.0.0.bias, ..., voflow_rot.2.bias), device pointers;
+ *            convolution weights in channels_last memory ([Cout][ky][kx][Cin]), everything else contiguous
+ *   out6     (B,6) = cat(trans, rot)
+ *   workspace  islam_pose_head_workspace_bytes(B,H,W) bytes (0: unsupported shape); holds every activation of the forward -- the backward
+ *            reads what the LAST forward on this workspace left there -- plus gradient ping-pong buffers and split-K scratch.  Must be
+ *            zero-filled once before its first use (ticket words; every launch leaves them zero).
+ * backward: grads[i] receives (accumulate = 0) or is incremented by (accumulate = 1) the gradient of parameter i, same layouts as params;
+ * grad_out6 (B,6).  No gradient w.r.t. x is produced (the reference detaches the flow in front of the head's consumers only when the flow
+ * net is frozen, TartanVO.py:109; a trainable flow net takes the eager autograd path in islam_amd/nets.py). */
+size_t islam_pose_head_workspace_bytes(int B, int H, int W);
+int islam_pose_head_forward(const float* x, const float* const* params, float* out6, void* workspace, size_t workspace_bytes, int B, int H,
+                            int W, void* stream);
+int islam_pose_head_backward(const float* x, const float* const* params, float* const* grads, const float* grad_out6, void* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int accumulate, void* stream);
+
 /* Train-mode BatchNorm2d (+ ReLU, + residual add) on a channels-last bf16 tensor -- the BatchNorm layers of the "frozen"
  * stereo feature extractor, which the reference still runs with batch statistics (TartanVO.py:90-91; Network/PSM/
  * submodule.py:10-43):  y = act(bf16(x*scale[c] + shift[c]) [+ res]), scale = weight*rsqrt(var_biased + eps),

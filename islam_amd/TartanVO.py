@@ -93,7 +93,7 @@ class TartanVO(nn.Module):
         self.vonet.graph_instances = max(1, int(graph_instances))
         # forward + backward of the trainable pose head as HIP graphs; 'accumulate': the backward node adds the parameter gradients to
         # .grad itself (nets._PoseGraph; torch.autograd.grad callers list vonet.pose_graph_leaf() among their inputs)
-        self.vonet.graph_pose = 'accumulate' if graph_pose == 'accumulate' else bool(graph_pose)
+        self.vonet.graph_pose = graph_pose if graph_pose in ('accumulate', 'hip') else bool(graph_pose)
         self.vonet.pose_dtype = pose_dtype           # bf16 autocast for the trainable pose head (fp32 master weights)
 
     def load_model(self, model, modelname):

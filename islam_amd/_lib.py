@@ -75,6 +75,9 @@ SIGNATURES = {
     'islam_bias_act_f32_nhwc': (c_int, [c_void_p] * 4 + [ctypes.c_longlong, c_int, c_int, c_void_p]),
     'islam_bias_act_bwd_scratch_floats': (ctypes.c_longlong, [ctypes.c_longlong, c_int]),
     'islam_bias_act_bwd_f32_nhwc': (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_int, c_int, c_void_p]),
+    'islam_pose_head_workspace_bytes': (c_size_t, [c_int] * 3),
+    'islam_pose_head_forward': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 3 + [c_void_p]),
+    'islam_pose_head_backward': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [c_void_p]),
     'islam_bn_scratch_floats': (c_size_t, [c_int]),
     'islam_bn_train_nhwc_bf16': (c_int, [c_void_p] * 8 + [c_double, c_double, c_int, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
     'islam_conv_nhwc_packed_elems': (c_size_t, [c_int] * 3),

@@ -985,7 +985,27 @@ class VOFlowRes(nn.Module):
             if isinstance(m, _PoseBlock):
                 m.fused_tail = bool(on)
 
+    def set_hip_head(self, on=True, graphs=False):
+        """Forward and backward of the WHOLE module on the hand-written fp32 kernels of csrc/pose_head.hip (islam_amd/pose_head.py): one C
+        call each way instead of ~110 / ~430 third-party launches (CK / MIOpen convolutions, ATen elementwise, zero-fills).  Serves fp32
+        channels-last (B,4,H,W) device inputs that carry no gradient; anything else takes the modules below.  graphs: the two calls
+        replay from captured HIP graphs.  Same parameters and state dict; the backward node adds the parameter gradients to .grad itself
+        and hangs on ``self.hip_head().leaf`` (see pose_head.py)."""
+        self.use_hip_head, self.hip_graphs = bool(on), bool(graphs)
+        self.__dict__.pop('_hip_head', None)
+
+    def hip_head(self):
+        hh = self.__dict__.get('_hip_head')
+        if hh is None:
+            from . import pose_head
+            hh = self.__dict__['_hip_head'] = pose_head.PoseHeadHip(self, graphs=getattr(self, 'hip_graphs', False))
+        return hh
+
     def forward(self, x, extrinsic=None):
+        if getattr(self, 'use_hip_head', False) and not (torch.is_grad_enabled() and x.requires_grad):
+            from . import pose_head
+            if pose_head.supported_input(x):
+                return self.hip_head()(x)
         if getattr(self, 'fused_tail', False) and _fused_tail_ok(x):
             for i, m in enumerate(self.feat_net):
                 x = _conv_relu_fused(m, x) if i < 3 else m(x)
@@ -1161,7 +1181,13 @@ class VONet(nn.Module):
         x = torch.cat([flow, intrinsic], 1)
         if self.pose_channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        if self.graph_pose == 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled() and x.is_cuda and not x.requires_grad:
+        if self.graph_pose == 'hip' and x.is_cuda and not x.requires_grad:
+            # the whole head -- forward now, backward when the loss is back-propagated -- on the kernels of csrc/pose_head.hip, each way one
+            # HIP graph replay; the backward node adds the parameter gradients to .grad itself (pose_graph_leaf() as for 'accumulate')
+            if not getattr(self.flowPoseNet, 'use_hip_head', False):
+                self.flowPoseNet.set_hip_head(True, graphs=True)
+            pose = self.flowPoseNet(x)
+        elif self.graph_pose == 'accumulate' and self.flowPoseNet.training and torch.is_grad_enabled() and x.is_cuda and not x.requires_grad:
             # forward and backward as two HIP graphs whose backward node adds the parameter gradients to .grad itself (_PoseGraph).
             # Only for an input that carries no gradient (frozen flow net: the reference detaches flow behind the pose head,
             # TartanVO.py:109, so with a TRAINABLE flow net the pose loss must reach it -- that case takes the eager branch below).
@@ -1195,6 +1221,9 @@ class VONet(nn.Module):
         """The zero-dimensional leaf that keeps the graphed pose head's backward node alive (graph_pose='accumulate'): callers of
         torch.autograd.grad(loss, inputs) list it among ``inputs`` or the engine prunes the node and the head gets no gradient.
         None while no graph has been captured."""
+        if self.graph_pose == 'hip':
+            hh = self.flowPoseNet.__dict__.get('_hip_head')
+            return None if hh is None else hh.leaf
         pg = self.__dict__.get('_pose_graph')
         return None if pg is None else pg.leaf
 
