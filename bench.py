@@ -316,7 +316,7 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
                   pose_dtype=torch.bfloat16 if os.environ.get('ISLAM_POSE_BF16') == '1' else None,   # measured: 330 vs 325 frames/s -- not worth the numerics
 
                   graph_frozen=os.environ.get('ISLAM_NO_GRAPH') != '1', graph_instances=depth,
-                  graph_pose=False if os.environ.get('ISLAM_NO_GRAPH') == '1' else (True if os.environ.get('ISLAM_POSE_GRAPH') == 'callables' else 'accumulate'))
+                  graph_pose=False if os.environ.get('ISLAM_NO_GRAPH') == '1' else {'callables': True, 'accumulate': 'accumulate'}.get(os.environ.get('ISLAM_POSE_GRAPH'), 'hip'))
     vo.fused_glue = os.environ.get('ISLAM_FUSED_GLUE', '1') == '1'      # the pose algebra behind the networks as one autograd node (islam_amd/glue.py)
     with torch.no_grad():      # random weights predict garbage disparity: pin the stereo head to 10 px so the scale mask is non-empty
         vo.vonet.stereoNet.conv_c13.weight.zero_()
@@ -428,8 +428,9 @@ def vio_frames_per_sec(device, batch=8, steps=64, warmup=3):   # (16 timed steps
         'miopen_pinned_db': {'matches_device_and_version': bool(pin_ok), 'detail': pin_msg, 'searched_in_this_process': miopen_pin.searched_since_start()},
     }
     out = {'value': steps * batch / el, 'unit': 'frames/s', 'batch': batch, 'image': '448x640 stereo',
-           'nets': nets_mod.execution_description() + ' | pose head fp32 (trainable, MIOpen with a pinned solution set; forward / backward as HIP graphs)'
-                   ' | PVGO of the 9-node window: the whole LM loop in one launch (small_lm_kernel)',
+           'nets': nets_mod.execution_description() + (' | pose head fp32 (trainable): forward and backward on the hand-written exact-fp32 matrix-core kernels of csrc/pose_head.hip, each a HIP graph'
+                              if vo.vonet.graph_pose == 'hip' else ' | pose head fp32 (trainable, MIOpen with a pinned solution set; forward / backward as HIP graphs)')
+                   + ' | PVGO of the 9-node window: the whole LM loop in one launch (small_lm_kernel)',
            'gflop_per_frame': 466.4, 'tflops': 466.4e-3 * steps * batch / el, 'mfma_frac': 466.4e-3 * steps * batch / el / 2500.0,
            'ms_per_batch': el / steps * 1e3,
            'schedule': 'software-pipelined: TartanVO.prefetch queues the frozen nets of the next %d batch(es) on a side stream (%d captured graph copies, round-robin)' % (depth, depth),

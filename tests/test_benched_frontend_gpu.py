@@ -74,7 +74,7 @@ def test_benched_configuration_two_bilevel_steps(cuda, instances):
 
     # ---- the benched configuration, pipelined exactly like bench.py's timed loop
     vo_b = _make(cuda, frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True, pose_channels_last=True,
-                 graph_frozen=True, graph_pose='accumulate', graph_instances=instances)
+                 graph_frozen=True, graph_pose='hip', graph_instances=instances)
     loop_b = _loop(vo_b, tr)
     losses_b = [loop_b.step(seq[k], next_sample=(seq[k + 1], seq[k + 2])) for k in range(steps)]      # (a tuple: two batches ahead -- the deepest schedule BilevelLoop offers; bench.py runs one ahead)
     torch.cuda.synchronize()

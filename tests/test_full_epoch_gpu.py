@@ -64,7 +64,7 @@ def test_whole_kitti04_length_epoch_with_the_real_nets(cuda, tmp_path):
 
     # ---- the benched configuration over the whole sequence, pipelined one batch ahead like bench.py
     vo_b = _make(frozen_dtype=torch.bfloat16, flow_dtype=torch.bfloat16, host_glue=True, pose_channels_last=True,
-                 graph_frozen=True, graph_pose='accumulate')
+                 graph_frozen=True, graph_pose='hip')
     imu = IMUModule(tr['accels'], tr['gyros'], tr['imu_dts'], np.zeros(3), np.zeros(3), tr['init'], tr['gravity'],
                     tr['rgb2imu_sync'], device='cuda', denoise_model_name=None, denoise_accel=True, denoise_gyro=False)
     loop = BilevelLoop(vo_b, imu, pp.identity_SE3(), tr['init'], loss_weight=LW, batch_size=B, device='cuda')
