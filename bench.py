@@ -779,6 +779,31 @@ def main():
                 raise                    # world > 1: the other ranks are inside collectives this rank left -- fail the job, do not hang it
             large = {'error': repr(e)[:300]}
 
+    # ---- N > 1 (and the 1-GPU self-test of that path): what a SCALE record is checked against, line by line
+    # (profiles/r05/scaling_model_r05.json: t(P) = t_fused(N / P) + t_shard + t_allreduce).  Every rank times the FUSED single-GPU loop on
+    # a chain of its own stretch's length (N / P nodes, same generator): t_fused(N / P) measured where the sharded run ran.
+    if dist is not None:
+        n_loc = (N - 1) // world + 1
+        prob_l, _ = build_problem(device, n_loc)
+        ws_l = ops.pvgo_workspace(n_loc, device)
+        st_l = [(prob_l['init_nodes'].clone(), prob_l['init_vels'].clone()) for _ in range(6)]
+        tr_l = 0
+        for i, (n_, v_) in enumerate(st_l):
+            if i == 1:
+                torch.cuda.synchronize()
+                t_l = time.perf_counter()
+            r_l, _ = ops.pvgo_run_chain(n_, v_, prob_l['vo'], prob_l['drots'], prob_l['dtrans'], prob_l['dvels'], prob_l['dts'], prm, workspace=ws_l)
+            if i >= 1:
+                tr_l += r_l.trials
+        torch.cuda.synchronize()
+        t_loc = torch.tensor([(time.perf_counter() - t_l) / max(tr_l, 1) * 1e6], dtype=torch.float64, device=device)
+        t_all = [torch.zeros_like(t_loc) for _ in range(world)]
+        dist.all_gather(t_all, t_loc)
+        sharded_info['nodes_per_rank'] = n_loc
+        sharded_info['t_fused_us_per_lm_iter_per_rank'] = [float(t.item()) for t in t_all]
+        sharded_info['t_fused_what'] = 'the fused single-GPU LM loop on a chain of N / P nodes, timed on every rank (5 runs): the first term of the scaling model'
+        del prob_l, ws_l, st_l
+
     # ---- N > 1 only: the same graph solved independently on every GPU (one trajectory per GPU, SURVEY 8(e) row 4: no
     # data-path collective), reported NEXT to the headline sharded-graph figure, never instead of it
     replicas = None

@@ -74,16 +74,20 @@ class BilevelLoop:
         if motions is None:
             # a VO forward inside an IMU epoch (first epoch, or a short slice of last epoch's motions) must not leave gradients
             # on the pose head: the next 'vo' epoch's optimizer.step() would apply them (the IMU epoch never zeroes them)
-            def prefetch_next():
-                if next_sample is not None and hasattr(self.vo, 'prefetch'):
-                    for nxt in (next_sample if isinstance(next_sample, (tuple, list)) else (next_sample,)):
-                        if nxt is not None:
-                            self.vo.prefetch(nxt)
+            ahead = [n for n in (next_sample if isinstance(next_sample, (tuple, list)) else (next_sample,)) if n is not None] \
+                if next_sample is not None and hasattr(self.vo, 'prefetch') else []
+
+            def prefetch_next(batches):
+                for nxt in batches:
+                    self.vo.prefetch(nxt)
             # the next batch's frozen forward is queued BEFORE this batch's pose head and host glue (ISLAM_PREFETCH_FIRST=0: behind them; the glue
-            # synchronises with the device twice; queued behind it, the side stream sat idle for ~2 ms per batch)
+            # synchronises with the device twice; queued behind it, the side stream sat idle for ~2 ms per batch) -- but no more batches
+            # than there are captured graph copies: a replay on a copy whose previous replay is still running makes the HOST wait
+            # (VONet._frozen_graphed's per-copy fence) before anything of this batch's main chain is enqueued; the rest goes behind the forward
             first = PREFETCH_FIRST
+            n_first = len(ahead) if not first else min(len(ahead), max(1, int(getattr(getattr(self.vo, 'vonet', None), 'graph_instances', 1))))
             if first:
-                prefetch_next()
+                prefetch_next(ahead[:n_first])
             # no autograd state for the VO forward of an IMU epoch (TartanVO.forward opens its own grad mode: an outer
             # torch.set_grad_enabled would not reach it)
             if self.__dict__.get('_vo_takes_need_grad') is None:
@@ -95,8 +99,7 @@ class BilevelLoop:
             else:                                                  # a VO front-end without the flag (stand-ins in tests)
                 with torch.set_grad_enabled(target == 'vo'):
                     res = self.vo(sample)
-            if not first:
-                prefetch_next()
+            prefetch_next(ahead if not first else ahead[n_first:])
             motions = res.get('motion_host', res['motion'])      # TartanVO(host_glue=True): the same motions, on the host
             T_IL = self.T_IL.to(motions.device).to(motions.dtype)
             motions = T_IL @ motions @ T_IL.Inv()                                               # train.py:214-215

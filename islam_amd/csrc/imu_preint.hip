@@ -210,15 +210,16 @@ __device__ __forceinline__ void publish_rows(int* ready, int rows) {
 }
 // The wait is BOUNDED (as trial_elim_kernel's ticket wait is): if the producer workgroup never publishes -- it faulted, or another call
 // sharing this scratch re-zeroed the counter (islam_hip.h: concurrent calls need their own scratch) -- the waiting lane gives up after
-// ~2^22 sleeps (a few hundred ms), raises the sticky flag ready[1], and chain_world_kernel poisons the p / v rows with NaN instead of
-// hanging the stream without a diagnostic.
-constexpr int AWAIT_SPIN_LIMIT = 1 << 22;
+// AWAIT_LIMIT_TICKS of the constant-rate 100 MHz wall clock (0.5 s whatever the shader clock and however many persistent kernels of
+// other streams compete for the producer's CU), raises the sticky flag ready[1], and chain_world_kernel poisons the p / v rows with
+// NaN instead of hanging the stream without a diagnostic.
+constexpr long long AWAIT_LIMIT_TICKS = 50000000LL;
 __device__ __forceinline__ void await_rows(int* ready, int rows) {
     if ((threadIdx.x & 63) == 0 && __hip_atomic_load(ready + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        int spins = 0;
+        const long long t0 = wall_clock64();
         while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < rows) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > AWAIT_SPIN_LIMIT) { __hip_atomic_store(ready + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (wall_clock64() - t0 > AWAIT_LIMIT_TICKS) { __hip_atomic_store(ready + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
     __threadfence();
