@@ -762,7 +762,11 @@ constexpr size_t lds_bytes(int nw) {
 // Cross-workgroup split of K: only when the tiles alone leave most of the chip idle -- a split costs a write-through round trip, an
 // atomic and a read-back across XCDs (~5 us, scripts/debug/pose_head_stamps.py) on top of the launch.
 int pick_split(int ntiles, int nchunk) {
-    if (ntiles >= 128 || nchunk < 4) return 1;
+    // (A/B knob) ISLAM_POSE_SPLIT_BIG=k: layers with 128 .. 400 tiles and >= 8 chunks split k ways, so that every CU holds two or more
+    // workgroups of equal length instead of one long one (or two on some CUs, one on others)
+    static const int big = [] { const char* e = std::getenv("ISLAM_POSE_SPLIT_BIG"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    if (ntiles >= 128) return (ntiles <= 400 && nchunk >= 8) ? big : 1;
+    if (nchunk < 4) return 1;
     int ks = 1;
     while (ks < nchunk / 2 && ntiles * ks < 192) ++ks;
     return ks;

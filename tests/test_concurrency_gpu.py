@@ -1,5 +1,5 @@
 """Kernels of the bilevel step's MAIN CHAIN (scale recovery, edge mask, IMU pre-integration, the 9-node PVGO window, pose-head tail,
-VO loss, correlation / warp) must give bit-identical results while another stream keeps the chip busy with the frozen nets' convolution
+VO loss, correlation / warp, the hand-written pose head's forward + backward) must give bit-identical results while another stream keeps the chip busy with the frozen nets' convolution
 kernel -- the situation of the software-pipelined schedule (TartanVO.prefetch: the next batch's frozen forward runs beside this batch's
 main chain, train.py:200-299 has no such concurrency).
 
@@ -93,6 +93,20 @@ def _cases(cuda):
     xb = rn(B, 64, 28, 40).contiguous(memory_format=torch.channels_last)
     bias = rn(64)
     cases['bias_act'] = lambda: ops.bias_act(xb, bias, None, True)
+    # the trainable pose head on csrc/pose_head.hip (forward + backward: what the main chain runs since round 6 instead of MIOpen / CK):
+    # fixed summation orders, so the pose AND every parameter gradient are bit-stable
+    from islam_amd import nets, pose_head
+    torch.manual_seed(0)
+    head_net = nets.VOFlowRes().to(cuda).to(memory_format=torch.channels_last)
+    head = pose_head.PoseHeadHip(head_net)
+    hx = rn(B, 4, H, W).contiguous(memory_format=torch.channels_last)
+    hg = rn(B, 6)
+
+    def pose_fwd_bwd():
+        y = head.forward_raw(hx)
+        head._c_backward(head.x_saved, hg)
+        return [y, head.gflat]
+    cases['pose_head_fwd_bwd'] = pose_fwd_bwd
     return cases
 
 
