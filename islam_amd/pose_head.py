@@ -80,7 +80,7 @@ class PoseHeadHip:
             offs.append(total)
             total += (p.numel() + 63) // 64 * 64
         if getattr(self, 'gflat', None) is None or self.gflat.numel() != total or self.gflat.device != dev:
-            self.gflat = torch.empty(total, dtype=torch.float32, device=dev)
+            self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)       # (zeros: the alignment gaps between the views are never written)
             self.acc_flat = None
         self._offs, self._total = offs, total
         self.gviews = self._views(self.gflat)
