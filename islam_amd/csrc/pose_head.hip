@@ -65,6 +65,7 @@ struct ConvArgs {
     int rows;              // GEMM rows: FWD B*Hout*Wout, DGRAD B*Hin*Win, WGRAD Cout
     int nchunk_main, nchunk;     // FWD / DGRAD: K chunks of the 3x3 part / in total.  WGRAD: pixel chunks
     int ntile_main;        // WGRAD: tiles of the 3x3 weights (the rest belong to w2)
+    unsigned mg_hw, mg_w, mg_n8;        // ceil(2^32 / d) for d = (rows' H*W, W) and the padded tile count: n / d = umulhi(n, magic) for n, d < 2^16
     int zin, zin2, zg, zg2;             // offset (floats) of the workspace's 4 KB zero region from in / in2 / g / g2: where invalid pieces are read from
     float* partial; unsigned* ticket;   // cross-workgroup split (gridDim.y > 1)
     int stamp_slot;                     // ISLAM_POSE_STAMPS builds (scripts/debug/pose_head_stamps.py): which row of the phase-clock table this launch writes
@@ -78,6 +79,10 @@ namespace {
 #else
 #define PSTAMP(j) do { } while (0)
 #endif
+
+// n / d for n * d < 2^32 with mg = ceil(2^32 / d): one multiply instead of the ~40-instruction integer division sequence (the row decode
+// of a workgroup's set-up and of every weight-gradient chunk was 4-6 of them per thread)
+__device__ __forceinline__ int fdiv(int n, unsigned mg) { return (int)__umulhi((unsigned)n, mg); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return float4{0.f, 0.f, 0.f, 0.f}; }
@@ -130,17 +135,17 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int x, c
         ds_tile = tl >= a.ntile_main;
         if (ds_tile) tl -= a.ntile_main;
         const int nci = ds_tile ? a.Cin2 / 32 : (a.Cin == 4 ? 2 : a.Cin / 32);      // (first convolution: 36 = 9 taps x 4 channels in two column tiles)
-        const int ci_t = tl % nci;
-        tl /= nci;
-        const int nco = a.Cout / 32;
-        const int co_t = tl % nco;
-        tap_w = tl / nco;
+        const int lci = 31 - __clz(nci), nco = a.Cout / 32, lco = 31 - __clz(nco);      // (channel counts are powers of two)
+        const int ci_t = tl & (nci - 1);
+        tl >>= lci;
+        const int co_t = tl & (nco - 1);
+        tap_w = tl >> lco;
         row0 = co_t * 32;
         col0 = ci_t * 32;
     } else {
         const int ncol = (MODE == MODE_FWD ? a.Cout : a.Cin) / 32;
-        col0 = (tile % ncol) * 32;
-        row0 = (tile / ncol) * 32;
+        col0 = (tile & (ncol - 1)) * 32;
+        row0 = (tile >> (31 - __clz(ncol))) * 32;
     }
 
     // ---- the pixel rows this thread stages (FWD / DGRAD), decoded ONCE: the pixel index its taps are offsets from and a 9-bit mask of the
@@ -161,7 +166,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int x, c
         for (int j = 0; j < NP; ++j) {
             const int m = row0 + srow + (T / 32) * j;
             if (m < a.rows) {
-                const int b = m / (H * W), r = m - b * (H * W), y = r / W, x = r - y * W;
+                const int b = fdiv(m, a.mg_hw), r = m - b * (H * W), y = fdiv(r, a.mg_w), x = r - y * W;
                 if constexpr (MODE == MODE_FWD) {
                     const int yb = y * a.stride - 1, xb = x * a.stride - 1;
                     p0[j] = (b * a.Hin + yb) * a.Win + xb;
@@ -255,7 +260,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs& a, const int x, c
                 const bool okm = live && m < npx;
                 ra[j] = ld4(a.g + (okm ? m * a.Cout + row0 + rnq : a.zg + zsp));
                 const int mm = okm ? m : 0;
-                const int b = mm / (a.Hout * a.Wout), r = mm - b * (a.Hout * a.Wout), oy = r / a.Wout, ox = r - oy * a.Wout;
+                const int b = fdiv(mm, a.mg_hw), r = mm - b * (a.Hout * a.Wout), oy = fdiv(r, a.mg_w), ox = r - oy * a.Wout;
                 const int iy = oy * a.stride - 1 + ky, ix = ox * a.stride - 1 + kx;
                 const bool okb = okm && tap < 9 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
                 const int o_main = okb ? ((b * a.Hin + iy) * a.Win + ix) * a.Cin + (first ? 0 : col0 + rnq) : (first ? 0 : a.zin + zsp);
@@ -457,8 +462,8 @@ template <int MODE, int NW, bool HAS_DS>
 __global__ __launch_bounds__(64 * NW, 1) void conv_gemm_kernel(const ConvArgs a, const int ntiles, const int KS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // max(2 * BUF, NW * 1056 + NW * 64) floats; 16-byte fragments need the alignment
     __shared__ int s_last;
-    const int n8 = (ntiles + 7) & ~7;
-    conv_gemm_body<MODE, NW, HAS_DS>(a, blockIdx.x % n8, ntiles, blockIdx.x / n8, KS, lds, s_last);
+    const int n8 = (ntiles + 7) & ~7, z = fdiv(blockIdx.x, a.mg_n8);
+    conv_gemm_body<MODE, NW, HAS_DS>(a, blockIdx.x - z * n8, ntiles, z, KS, lds, s_last);
 }
 
 // A data gradient and a weight gradient that read the SAME output gradient, in one launch (the backward of a convolution is this pair;
@@ -471,10 +476,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bwd_pair_kernel(const ConvArg
     __shared__ int s_last;
     const int n8d = (ntiles_d + 7) & ~7, n1 = n8d * KS_d;
     if ((int)blockIdx.x < n1) {
-        conv_gemm_body<MODE_DGRAD, NW, HAS_DS>(ad, blockIdx.x % n8d, ntiles_d, blockIdx.x / n8d, KS_d, lds, s_last);
+        const int z = fdiv(blockIdx.x, ad.mg_n8);
+        conv_gemm_body<MODE_DGRAD, NW, HAS_DS>(ad, blockIdx.x - z * n8d, ntiles_d, z, KS_d, lds, s_last);
     } else {
-        const int id = blockIdx.x - n1, n8w = (ntiles_w + 7) & ~7;
-        conv_gemm_body<MODE_WGRAD, NW, false>(aw, id % n8w, ntiles_w, id / n8w, KS_w, lds, s_last);
+        const int id = blockIdx.x - n1, n8w = (ntiles_w + 7) & ~7, z = fdiv(id, aw.mg_n8);
+        conv_gemm_body<MODE_WGRAD, NW, false>(aw, id - z * n8w, ntiles_w, z, KS_w, lds, s_last);
     }
 }
 
@@ -803,6 +809,13 @@ int prepare(ConvArgs a, int kdim, int kdim2, float* partial, size_t partial_floa
     if (ntiles > N_TICKETS) KS = 1;
     a.partial = partial;
     a.ticket = ticket;
+    {
+        auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+        const int H = MODE == MODE_DGRAD ? a.Hin : a.Hout, W = MODE == MODE_DGRAD ? a.Win : a.Wout, n8 = (ntiles + 7) & ~7;
+        // (n / d == umulhi(n, ceil(2^32 / d)) for n * d < 2^32)
+        if ((long long)a.B * H * W * H * W >= (1ll << 32) || (long long)n8 * KS * n8 >= (1ll << 32)) return fail(ISLAM_EARG, "pose head: %d x %d x %d pixels exceed the row decode", a.B, H, W);
+        a.mg_hw = magic(H * W); a.mg_w = magic(W); a.mg_n8 = magic(n8);
+    }
     out.a = a; out.ntiles = ntiles; out.KS = KS;
     return ISLAM_OK;
 }

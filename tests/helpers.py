@@ -129,3 +129,27 @@ def imu_preint_torch(dt, gyro, acc, seg, init_pos, init_rot, init_vel, gravity, 
         if not motion_mode:
             lp, lv = sp, sv
     return torch.stack(P), torch.stack(R), torch.stack(V)
+
+
+def spawn_ranks(worker, nprocs, *args, retries=1):
+    """torch.multiprocessing.spawn(worker, args=(nprocs, port, *args)) on a free 127.0.0.1 port.  The workers open their gloo group with a
+    3-minute timeout (GLOO_TIMEOUT_S below), so a peer that never arrives fails the attempt in minutes instead of gloo's default 30 --
+    seen once in round 6: the whole `-m gpu` run sat 35 minutes in one spawn test that passes in 4 s alone and in the next full run --
+    and the attempt is repeated once on a fresh port."""
+    import socket
+    import torch.multiprocessing as mp
+    last = None
+    for attempt in range(retries + 1):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        try:
+            mp.spawn(worker, args=(nprocs, port) + tuple(args), nprocs=nprocs, join=True)
+            return
+        except Exception as e:          # pragma: no cover (transient)
+            last = e
+    raise last
+
+
+GLOO_TIMEOUT_S = 180

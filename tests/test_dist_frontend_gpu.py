@@ -38,7 +38,9 @@ def _sample(B, H=256, W=256):
 def _worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    from tests.helpers import GLOO_TIMEOUT_S
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
     torch.cuda.set_device(0)
     from islam_amd import nets
     from islam_amd.dist_train import FrameParallelVO, ShardedBatchNorm2d
@@ -58,11 +60,8 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_frame_parallel_stereo_copy_uses_global_batch_statistics(cuda, tmp_path):
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from tests.helpers import spawn_ranks
+    spawn_ranks(_worker, 2, str(tmp_path))
     outs = [torch.load(os.path.join(str(tmp_path), 'f%d.pt' % r)) for r in range(2)]
     torch.manual_seed(0)
     vo = _StereoFrontEnd().cuda().train()

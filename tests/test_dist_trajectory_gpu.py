@@ -39,7 +39,9 @@ def _loop(vo, traj):
 def _worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    from tests.helpers import GLOO_TIMEOUT_S
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GLOO_TIMEOUT_S))
     torch.cuda.set_device(0)
     from islam_amd.dist_train import TrajectoryParallel, allreduce_gradients
     vo = _make()
@@ -58,11 +60,8 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_trajectory_parallel_bilevel_loop_with_real_nets(cuda, tmp_path):
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from tests.helpers import spawn_ranks
+    spawn_ranks(_worker, 2, str(tmp_path))
     outs = [torch.load(os.path.join(str(tmp_path), 't%d.pt' % r)) for r in range(2)]
     assert outs[0]['buckets'] == 1                                       # 60.5 MB of pose-head gradients: one collective
     assert all(np.isfinite(o['loss']) for o in outs)
