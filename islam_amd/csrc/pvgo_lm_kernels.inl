@@ -285,6 +285,11 @@ struct SmallArgs {
     double* trace;                                      // pinned host rows (trial loss, damping, accepted) or nullptr
     int trace_cap;
     double marker;
+    // two-level solve (m0 > 0): the window as two segments of m0 nodes around a separator, eliminated by two wavefronts side by side,
+    // then the 1- or 2-node root (bt_top_kernel's scheme inside this workgroup): 4 + 1 dependent node steps each way instead of 9
+    LevelSrc src1;
+    LevelDst dst1;
+    int m0, P0, n1;
 };
 
 __global__ __launch_bounds__(LB_THREADS) void small_lm_kernel(SmallArgs a) {
@@ -303,7 +308,23 @@ __global__ __launch_bounds__(LB_THREADS) void small_lm_kernel(SmallArgs a) {
     double *cur_n = a.nodes, *cur_v = a.vels, *tri_n = a.nodes_t, *tri_v = a.vels_t;
     for (;;) {
         // ---- damped solve on buffer pb (bt_top_kernel with one level: the diagonal is damped in place, cumulatively over retries)
-        if (wave == 0) {
+        if (a.m0 > 0) {
+            if (wave < a.P0) {
+                LevelSrc src{};
+                src.level0 = 1; src.Hd = a.HD[pb]; src.Ho = a.HO[pb]; src.rhs0 = a.RH[pb]; src.state = a.st; src.damping_override = 0.0;
+                eliminate_segment(src, a.dst, N, a.m0, wave, a.flags, lane, lds_solve + wave * LDS_PER_WAVE);
+            }
+            __syncthreads();                                     // the two segments' products are visible to the workgroup
+            if (wave == 0) {
+                eliminate_segment(a.src1, a.dst1, a.n1, a.n1, 0, a.flags, lane, lds_solve);
+                double xn[9], xL[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) { xn[q] = 0.0; xL[q] = 0.0; }
+                backsub_segment(a.dst1.fac, a.dst1.inv, a.dst1.x, 0, a.n1, lane, xn, xL);
+            }
+            __syncthreads();
+            if (wave < a.P0) backsub_level_segment(a.dst.fac, a.dst.inv, a.dst1.x, a.dx, N, a.m0, wave, lane);
+        } else if (wave == 0) {
             LevelSrc src{};
             src.level0 = 1; src.Hd = a.HD[pb]; src.Ho = a.HO[pb]; src.rhs0 = a.RH[pb]; src.state = a.st; src.damping_override = 0.0;
             eliminate_segment(src, a.dst, N, N, 0, a.flags, lane, lds_solve);

@@ -243,7 +243,7 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
     // launch-per-stage loop is faster -- N = 65 takes 190 us per run there)
     constexpr int SMALL_MAX_N = 16;
     if (!no_small && !reproj && N <= SMALL_MAX_N) {
-        constexpr int SMALL_LDS = LB_DYN_BYTES + LDS_PER_WAVE * (int)sizeof(double);
+        constexpr int SMALL_LDS = LB_DYN_BYTES + 2 * LDS_PER_WAVE * (int)sizeof(double);
         static bool small_attr_set[64] = {};
         int dev_i = 0;
         ISLAM_HIP_CHECK(hipGetDevice(&dev_i));
@@ -265,6 +265,18 @@ static int run_chain_impl(double* nodes, double* vels, const double* poses, cons
         sa.loss_part = w.loss_part; sa.st = w.state; sa.flags = w.flags; sa.tr = tr; sa.W = W;
         sa.dst = level_dst(w.lv[0], w.dx);
         sa.report = report; sa.trace = trace_dev; sa.trace_cap = std::min(trace_cap, TRACE_ROWS); sa.marker = 7.0;
+        {
+            // two segments around a separator (ISLAM_SMALL_LM_ONE_SEGMENT=1: the one-segment sweep of rounds 3-5, A/B runs)
+            const bool one = [] { const char* e = std::getenv("ISLAM_SMALL_LM_ONE_SEGMENT"); return e && e[0] == '1'; }();
+            const int m0 = (!one && N >= 3) ? (N - 1) / 2 : 0;
+            sa.m0 = m0;
+            if (m0 > 0) {
+                sa.P0 = (N + m0) / (m0 + 1);
+                sa.n1 = N / (m0 + 1);
+                sa.src1 = level_src_from(w.lv[0], sa.P0);
+                sa.dst1 = level_dst(w.lv[1], w.lv[1].x);
+            }
+        }
         hipLaunchKernelGGL(small_lm_kernel, dim3(1), dim3(LB_THREADS), SMALL_LDS, s, sa);
         ISLAM_LAUNCH_CHECK();
         {
