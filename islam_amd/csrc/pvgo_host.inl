@@ -162,6 +162,13 @@ static int next_serial() {
 }
 
 static void launch_tw(const LevelSrc& src, const LevelDst& dst, int n, int m, int* flags, int seg0, int nseg, Gate gate, hipStream_t s) {
+    // level 0 of a graph with >= 3072 segments (four rounds of resident workgroups) runs on the two-wave kernel: N = 300 007, 37 504
+    // segments: 1266 -> 1205 us per LM iteration.  (ISLAM_PVGO_L0_TW2 = that threshold; 0: never)
+    static const int tw2_from = [] { const char* e = std::getenv("ISLAM_PVGO_L0_TW2"); return e ? std::atoi(e) : 3072; }();
+    if (src.level0 && tw2_from > 0 && nseg >= tw2_from) {
+        hipLaunchKernelGGL(bt_eliminate_tw2_kernel, dim3(xcd_grid(nseg)), dim3(128), 0, s, src, dst, n, m, flags, seg0, nseg, gate);
+        return;
+    }
     if (src.level0) hipLaunchKernelGGL(bt_eliminate_tw_kernel<1>, dim3(xcd_grid(nseg)), dim3(192), 0, s, src, dst, n, m, flags, seg0, nseg, gate);
     else hipLaunchKernelGGL(bt_eliminate_tw_kernel<0>, dim3(xcd_grid(nseg)), dim3(192), 0, s, src, dst, n, m, flags, seg0, nseg, gate);
 }

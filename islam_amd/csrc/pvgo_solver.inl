@@ -1022,6 +1022,16 @@ __global__ __launch_bounds__(192, L0 ? 3 : 2) void bt_eliminate_tw_kernel(LevelS
     eliminate_twisted3<L0>(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
 }
 
+// Level 0 of a LARGE graph (far more segments than the chip holds at once, launch_tw): two wavefronts per segment, no helper -- a
+// workgroup is 128 threads and 2/3 of the LDS, so half again as many segments are in flight per CU; what the helper took off the
+// sweeping waves' critical path matters less than residency once a level runs in dozens of rounds.  Same factor layout.
+__global__ __launch_bounds__(128, 3) void bt_eliminate_tw2_kernel(LevelSrc src, LevelDst dst, int n, int m, int* flags, int seg0, int nseg, Gate gate) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_TWISTED];
+    const int p = xcd_index(blockIdx.x, nseg);
+    if (p < 0) return;
+    eliminate_twisted<1>(src, dst, n, m, p + seg0, flags, threadIdx.x >> 6, threadIdx.x & 63, lds, gate);
+}
+
 #ifdef ISLAM_PROBE
 extern "C" int islam_probe_read(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_probe_buf), sizeof(long long) * 1024) == hipSuccess ? 0 : -2;
