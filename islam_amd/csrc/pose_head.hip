@@ -86,10 +86,6 @@ __device__ __forceinline__ int fdiv(int n, unsigned mg) { return (int)__umulhi((
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return float4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ float4 mask4(float4 v, float4 a) {
-    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
-    return v;
-}
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -758,6 +754,12 @@ bool make_plan(int B, int H, int W, Plan& p) {
     return true;
 }
 
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
+
 template <int MODE>
 constexpr size_t lds_bytes(int nw) {
     const int a_floats = (MODE == MODE_WGRAD) ? KC * 32 : 32 * LDK, b_floats = (MODE == MODE_FWD) ? 32 * LDK : KC * 32;
@@ -778,7 +780,9 @@ int pick_split(int ntiles, int nchunk) {
     return ks;
 }
 
+#ifdef ISLAM_POSE_STAMPS
 static int g_stamp_slot = 0;
+#endif
 
 inline bool pow2(int v) { return v > 0 && !(v & (v - 1)); }
 
@@ -787,7 +791,9 @@ struct Prepared { ConvArgs a; int ntiles, KS; };
 // fills the decomposition fields of `a`; kdim / kdim2: channels per tap of the K axis (FWD: Cin / Cin2, DGRAD: Cout / Cout of the shortcut)
 template <int MODE>
 int prepare(ConvArgs a, int kdim, int kdim2, float* partial, size_t partial_floats, unsigned* ticket, Prepared& out) {
+#ifdef ISLAM_POSE_STAMPS
     a.stamp_slot = g_stamp_slot++;
+#endif
     int ntiles;
     if constexpr (MODE == MODE_WGRAD) {
         const int npx = a.B * a.Hout * a.Wout;
@@ -830,10 +836,11 @@ int waves_per_wg() {
 template <int MODE, int NW, bool HAS_DS>
 int launch_single_ds(const Prepared& p, hipStream_t s) {
     constexpr size_t lds = lds_bytes<MODE>(NW);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // per device: the attribute lives in the device's code object
+    const int dev = current_device();
+    if (!attr_set[dev]) {
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_kernel<MODE, NW, HAS_DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, NW, HAS_DS>), dim3(((p.ntiles + 7) & ~7) * p.KS), dim3(64 * NW), lds, s, p.a, p.ntiles, p.KS);
     ISLAM_LAUNCH_CHECK();
@@ -858,10 +865,11 @@ int launch_conv(const ConvArgs& a, int kdim, int kdim2, hipStream_t s, float* pa
 template <int NW, bool HAS_DS>
 int launch_pair_ds(const Prepared& d, const Prepared& w, hipStream_t s) {
     constexpr size_t lds = lds_bytes<MODE_DGRAD>(NW) > lds_bytes<MODE_WGRAD>(NW) ? lds_bytes<MODE_DGRAD>(NW) : lds_bytes<MODE_WGRAD>(NW);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
         ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_bwd_pair_kernel<NW, HAS_DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int grid = ((d.ntiles + 7) & ~7) * d.KS + ((w.ntiles + 7) & ~7) * w.KS;
     hipLaunchKernelGGL((conv_bwd_pair_kernel<NW, HAS_DS>), dim3(grid), dim3(64 * NW), lds, s, d.a, d.ntiles, d.KS, w.a, w.ntiles, w.KS);
@@ -1001,10 +1009,11 @@ int islam_pose_head_forward(const float* x, const float* const* params, float* o
     float* h1 = ws + p.a_h1;
     float* h2 = ws + p.a_h2;
     {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};
+        const int dev = current_device();
+        if (!attr_set[dev]) {
             ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)fc1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FC_MAXB * FC_IN * sizeof(float))));
-            attr_set = true;
+            attr_set[dev] = true;
         }
     }
     hipLaunchKernelGGL(fc1_fwd_kernel, dim3(2 * FC_H1 / 4), dim3(TS), (size_t)B * FC_IN * sizeof(float), s, cur, params[108], params[109], params[114],
