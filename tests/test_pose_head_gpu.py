@@ -50,11 +50,19 @@ def test_forward_matches_the_reference_generated_vector(cuda):
     assert float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()) <= 2e-5      # (the fixture itself is an fp32 run)
 
 
-@pytest.mark.parametrize('B,seed', [(2, None), (8, 5), (3, 7)])
-def test_forward_and_all_gradients_match_float64_autograd(cuda, B, seed):
+@pytest.mark.parametrize('B,seed,H,W', [(2, None, 112, 160), (8, 5, 112, 160), (3, 7, 112, 160), (1, 11, 112, 160), (12, 17, 112, 160),
+                                        (2, 12, 96, 160), (2, 14, 100, 132)])
+def test_forward_and_all_gradients_match_float64_autograd(cuda, B, seed, H, W):
+    """B = 8 at 112 x 160 is the benched shape; 96 x 160 and 100 x 132 reach the 2 x 3 feature map through other (odd) intermediate sizes:
+    48-24-12-6-3-2 rows, 50-25-13-7-4-2 rows x 66-33-17-9-5-3 columns.  Seeds are fixed and the kernels deterministic, so the figures are the
+    same on every box (measured: forward 4e-8 .. 1e-7, gradients 7e-7 .. 1e-6).  What a float64 reference CANNOT hold an fp32 run to is a
+    pre-activation within rounding of zero: the two disagree on that ReLU's mask and one term of a gradient sum appears or disappears --
+    at B = 16 (57 M activations in the first layers) three of four seeds have such an element and single tensors move by 1e-3 .. 7e-3
+    (scripts/debug/pose_head_b16_errors.py; round 5 chased the same effect in MIOpen's atomics).  The upper end of the served range is
+    therefore held by the flip-tolerant test below."""
     net, head, ref = _head(cuda, seed, scale_last=1.0 if seed is not None else 1e-3)
     g = torch.Generator().manual_seed(100 + B)
-    x = torch.randn(B, 4, 112, 160, generator=g)
+    x = torch.randn(B, 4, H, W, generator=g)
     gy = torch.randn(B, 6, generator=g)
     yr = ref(x.double())
     yr.backward(gy.double())
@@ -77,6 +85,25 @@ def test_forward_and_all_gradients_match_float64_autograd(cuda, B, seed):
     y2.backward(gy.to(cuda))
     for p, f in zip(net.parameters(), first):
         assert torch.equal(p.grad, f + f)
+
+
+def test_largest_batch_against_float64_up_to_relu_flips(cuda):
+    """B = 16, the largest batch the entry points serve: forward 1e-5; gradients 1e-4 for all but the few tensors a ReLU flip reaches (see
+    the docstring above: three of four seeds have one at this size) -- at most 8 of the 120 may exceed 1e-4 and none 2e-2.  A wrong
+    kernel (a mis-indexed tile, a lost K chunk at the larger tile counts / other split factors of this batch) moves every tensor."""
+    net, head, ref = _head(cuda, 13)
+    g = torch.Generator().manual_seed(116)
+    x = torch.randn(16, 4, 112, 160, generator=g)
+    gy = torch.randn(16, 6, generator=g)
+    yr = ref(x.double())
+    yr.backward(gy.double())
+    y = head(x.to(cuda).contiguous(memory_format=torch.channels_last))
+    assert _rel(y, yr) <= 1e-5
+    y.backward(gy.to(cuda))
+    errs = sorted((_rel(p.grad, pr.grad), name) for (name, p), pr in zip(net.named_parameters(), ref.parameters()))
+    assert errs[-1][0] <= 2e-2, errs[-4:]
+    assert sum(e > 1e-4 for e, _ in errs) <= 8, errs[-10:]
+    assert errs[len(errs) // 2][0] <= 5e-6, errs[len(errs) // 2]               # the typical tensor is at fp32 round-off
 
 
 def test_graph_replay_equals_direct_calls(cuda):
