@@ -249,9 +249,10 @@ int islam_conv_nhwc_bf16_s2(const uint16_t* x, const uint16_t* wpacked, const fl
                             void* stream);
 
 /* `convbn` in training mode up to the BatchNorm's [scale | shift] (Network/PSM/submodule.py:10-13): islam_conv_nhwc_bf16 with `stats`
- * followed by islam_bn_finalize in two launches instead of three, bit for bit the same results (y raw convolution output, scale_shift
- * 2*Cout floats, running statistics updated like nn.BatchNorm2d; count = B*H*W).  counter: one int of device memory that is zero
- * before the call and is left zero; calls that may run concurrently on different streams must not share it. */
+ * followed by islam_bn_finalize as one call, bit for bit the same results (y raw convolution output, scale_shift 2*Cout floats, running
+ * statistics updated like nn.BatchNorm2d; count = B*H*W).  Two launches behind the persistent kernels (their few rows of partial sums go
+ * straight into the finalize), three behind the tile kernel.  counter: one int of device memory that is zero before the call and is left
+ * zero (used by the ticketed variant only, ISLAM_BN_FINALIZE=1); calls that may run concurrently on different streams must not share it. */
 int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const float* in_affine, uint16_t* y, float* stats, int B, int Cin,
                             int H, int W, int Cout, int ksize, int in_relu, const float* weight, const float* bias, float* running_mean,
                             float* running_var, long long* num_batches_tracked, double momentum, double eps, float* scale_shift,

@@ -478,6 +478,66 @@ __global__ __launch_bounds__(FF_THREADS) void fold_finalize_kernel(const float* 
     }
 }
 
+// The persistent kernels write ONE row of partial sums per workgroup -- 249 rows (conv3x3_ws_kernel) or 448 (conv3x3_ws32_kernel) at the
+// benched size, where the tile kernel writes 2240-4480: folding them to RED_BLOCKS rows costs a launch (~5 us on the critical path of
+// the replay, 20 such layers per forward) to move 100-250 KB.  This is bn_finalize_kernel reading the UNFOLDED rows: the value of folded
+// row b is formed on the fly exactly as partial_fold_kernel forms it (0.0f + row b + row b + 256, in float; rows past nblk do not
+// exist = the zeros the fold would have written), then the same slices, the same groups of four, the same order: the same bits.
+// nblk <= NF * RED_BLOCKS.
+template <int NF>
+__global__ __launch_bounds__(FF_THREADS) void finalize_rows_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   long long* __restrict__ num_batches, double momentum, double eps,
+                                                                   float* __restrict__ scale_shift) {
+    __shared__ double ls[FF_THREADS], lq[FF_THREADS];
+    const int nsl = FF_THREADS / C, c = threadIdx.x % C, sl = threadIdx.x / C, C2 = 2 * C;
+    auto row = [&](int b, int which) {                  // folded[b][which][c]
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const int r = b + k * RED_BLOCKS;
+            const float t = partial[(size_t)min(r, nblk - 1) * C2 + which * C + c];      // (always a load, then a select: a branch per
+            v += r < nblk ? t : 0.0f;                                                    //  row would serialise the eight loads of a group)
+        }
+        return v;
+    };
+    double s = 0.0, q = 0.0;
+    if (sl < nsl) {
+        const int per = (RED_BLOCKS + nsl - 1) / nsl, b0 = sl * per, b1 = min(RED_BLOCKS, b0 + per);
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            const float s0 = row(b, 0), q0 = row(b, 1), s1 = row(b + 1, 0), q1 = row(b + 1, 1);
+            const float s2 = row(b + 2, 0), q2 = row(b + 2, 1), s3 = row(b + 3, 0), q3 = row(b + 3, 1);
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; b < b1; ++b) {
+            s += (double)row(b, 0);
+            q += (double)row(b, 1);
+        }
+    }
+    ls[threadIdx.x] = s;
+    lq[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        s = 0.0;
+        q = 0.0;
+        for (int k = 0; k < nsl; ++k) { s += ls[k * C + c]; q += lq[k * C + c]; }
+        const double mean = s / count;
+        const double var = fmax(q / count - mean * mean, 0.0);
+        const double sc = (double)weight[c] / sqrt(var + eps);
+        scale_shift[c] = (float)sc;
+        scale_shift[C + c] = (float)((double)bias[c] - mean * sc);
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    }
+    if (threadIdx.x == 0 && num_batches) *num_batches += 1;
+}
+
 template <int TN, int KS, int ROWS, int KC, bool FLOW = false, int S = 1>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
@@ -691,8 +751,29 @@ int islam_conv_nhwc_bf16_bn(const uint16_t* x, const uint16_t* wpacked, const fl
                    : launch<32, 1, 4, 32>(x, wpacked, in_affine, nullptr, nullptr, y, stats, B, Cin, CinP, H, W, Cout, CoutP, 0, ir, s);
     if (rc != ISLAM_OK) return rc;
     const int nblk = ws ? conv_ws_blocks(B, H, W) : ws32 ? conv_ws32_blocks(B, H, W) : tiles_of(B, H, W, tile_h(Cout, Cin, ksize, B, H, W));
+    // how the statistics get from the per-workgroup rows to [scale | shift]: 0 = fold, then finalize (two launches); 1 = both in one launch
+    // with a ticket (fold_finalize_kernel: measured no faster than two launches, kept for A/B runs); default = the persistent kernels' few
+    // rows straight into the finalize (one launch, no fold), everything else as 0
+    static const int how = [] { const char* e = std::getenv("ISLAM_BN_FINALIZE"); return e ? std::atoi(e) : 2; }();
+    float* folded = stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout;
+    if (how != 1) {
+        const double count = (double)B * H * W;
+        if (how == 2 && nblk <= RED_BLOCKS)
+            hipLaunchKernelGGL(finalize_rows_kernel<1>, dim3(1), dim3(FF_THREADS), 0, s, stats, nblk, Cout, count, weight, bias, running_mean, running_var,
+                               num_batches_tracked, momentum, eps, scale_shift);
+        else if (how == 2 && nblk <= 2 * RED_BLOCKS)
+            hipLaunchKernelGGL(finalize_rows_kernel<2>, dim3(1), dim3(FF_THREADS), 0, s, stats, nblk, Cout, count, weight, bias, running_mean, running_var,
+                               num_batches_tracked, momentum, eps, scale_shift);
+        else {
+            hipLaunchKernelGGL(partial_fold_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, stats, nblk, 2 * Cout, folded);
+            hipLaunchKernelGGL(finalize_rows_kernel<1>, dim3(1), dim3(FF_THREADS), 0, s, folded, RED_BLOCKS, Cout, count, weight, bias, running_mean,
+                               running_var, num_batches_tracked, momentum, eps, scale_shift);
+        }
+        ISLAM_LAUNCH_CHECK();
+        return ISLAM_OK;
+    }
     hipLaunchKernelGGL(fold_finalize_kernel, dim3(RED_BLOCKS), dim3(FF_THREADS), 0, s, stats, nblk, Cout,
-                       stats + (size_t)islam_conv_nhwc_stat_blocks(B, H, W, Cout) * 2 * Cout, (double)B * H * W, weight, bias, running_mean,
+                       folded, (double)B * H * W, weight, bias, running_mean,
                        running_var, num_batches_tracked, momentum, eps, scale_shift, counter);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;

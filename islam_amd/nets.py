@@ -386,9 +386,13 @@ FROZEN_FORK = _os.environ.get('ISLAM_FROZEN_FORK', '1') == '1'
 HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 # hourglass Residual modules as one launch each (0: three convolution launches, for A/B runs); only for maps of at most
 # ISLAM_HG_FUSED_MAX_PIXELS pixels per image
-# 1: the convolution's batch statistics folded AND finalized by one launch (islam_conv_nhwc_bf16_bn, same bits) instead of partial_fold +
-# bn_finalize.  Measured on the stereo net's graph replay in alternating runs: 6.80 / 6.80 ms with it, 6.76 / 6.75 ms without -- the 45 saved
-# launches are not on the replay's critical path and the ticketed 256 x 1024-thread launch costs what the two small ones do: default off.
+# 1: stride-1 convbn layers through islam_conv_nhwc_bf16_bn -- convolution + [scale | shift] of its train-mode BatchNorm in one C call, same
+# bits as convolution(stats) + partial_fold + bn_finalize.  Behind the persistent kernels (20 of the stereo net's 29 such layers at the
+# benched size: one row of partial sums per workgroup) the finalize launch reads the rows directly, no fold launch; layers on the tile
+# kernel keep fold + finalize (ISLAM_BN_FINALIZE=1: the round-4 variant, fold + finalize in one ticketed launch).  Default off: neither
+# moves the replay -- round 4: 6.80 / 6.80 ms per stereo replay with the ticketed launch, 6.76 / 6.75 without; round 6, 20 launches fewer
+# per forward: 8.02 / 7.99 ms per replay of both nets against 7.96 / 7.98 (profiles/r06/bn_finalize_ab_r06.txt).  Launches of a few
+# microseconds on one branch of the replay are filled by the other branch's kernels; what the replay costs is its large kernels.
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'

@@ -16,15 +16,18 @@ lo, hi = seg[0], seg[-1]
 win = rows[lo:hi]
 nsteps = len(seg) - 1
 qcount = collections.Counter(r['Queue_Id'] for r in win)
-mainq = qcount.most_common(1)[0][0]
+mainq = rows[lm[0]]['Queue_Id']                 # the queue small_lm_kernel runs on (the replay's stereo branch has MORE launches since the pose head went to ~100)
 print('window: %d launches over %d steps; queues %s; main chain = queue %s' % (len(win), nsteps, dict(qcount), mainq))
 agg = collections.defaultdict(lambda: [0, 0])
+third = collections.Counter()
 for r in win:
     if r['Queue_Id'] != mainq: continue
     n = r['Kernel_Name']
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'^void ', '', n)
     n = re.sub(r'<.*', '', n)[:70]
     agg[n][0] += 1; agg[n][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    if re.search(r'miopen|Miopen|MIOpen|^_ZN2ck|ck::|Cijk_|rocblas|naive_conv|igemm|gridwise', r['Kernel_Name']): third[n] += 1
+print('third-party (MIOpen / CK / rocBLAS / Tensile) kernels on the main chain: %d launches %s' % (sum(third.values()), dict(third)))
 tot = sum(v[1] for v in agg.values())
 print('main-chain kernels: %.2f ms per step in %.0f launches per step' % (tot / nsteps / 1e6, sum(v[0] for v in agg.values()) / nsteps))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
