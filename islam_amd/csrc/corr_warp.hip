@@ -142,33 +142,57 @@ __global__ __launch_bounds__(NT) void corr81_fwd_kernel(const float* __restrict_
     }
 }
 
-// Four pixels per lane (same arithmetic, same argument meaning as corr81_fwd_kernel above, which stays for
-// W % 4 != 0).  The one-pixel-pair form issues per channel and lane six 8-byte LDS reads for 18 FMAs and stages its tiles with
-// 4-byte global loads and LDS writes: it is bound by instruction issue (LDS + vector-memory requests), 72 us for the level-2 call
-// (83 MB: 0.14 of the HBM roof).  Here a workgroup owns a 32 x 8 pixel tile, a lane four horizontally adjacent pixels x nine
-// horizontal displacements of its wave's vertical displacement (36 accumulators): per channel ONE 16-byte read of f1 and three of
-// the f2 halo row feed 36 FMAs; tiles are staged with 16-byte global loads / LDS writes, results leave as 16-byte stores
-// (128-byte row segments of a displacement plane).  Needs W % 4 == 0 and 16-byte aligned tensors.
-constexpr int TW4 = 32, TH4 = 8, F2W4 = TW4 + 8, F2H4 = TH4 + 8;
-constexpr int Q2 = (CC * F2H4 * (F2W4 / 4) + NT - 1) / NT;     // float4 items of the f2 halo tile per thread (2560 / 576 -> 5)
-constexpr int Q1 = (CC * TH4 * (TW4 / 4) + NT - 1) / NT;       // float4 items of the f1 tile per thread (1024 / 576 -> 2)
+// Four pixels per lane (same arithmetic, same argument meaning as corr81_fwd_kernel above, which stays for W % 4 != 0).  The
+// one-pixel-pair form issues per channel and lane six 8-byte LDS reads for 18 FMAs and stages its tiles with 4-byte global loads and
+// LDS writes: it is bound by instruction issue (LDS + vector-memory requests), 72 us for the level-2 call (83 MB: 0.14 of the HBM
+// roof).  Here a lane owns four horizontally adjacent pixels x nine horizontal displacements of ONE vertical displacement (36
+// accumulators): per channel one 16-byte read of f1 and three of the f2 halo row feed 36 FMAs; tiles are staged with 16-byte global
+// loads / LDS writes, results leave as 16-byte stores (128-byte row segments of a displacement plane).  Needs W % 4 == 0 and 16-byte
+// aligned tensors.
+//
+// Work layout (round 6).  The unit of work is a SLOT: 8 lanes = one 32-pixel tile row of one vertical displacement.  A workgroup owns
+// a 32 x 7 pixel tile = 9 x 7 = 63 slots on 8 waves (the 64th slot idles): two waves on every SIMD, and at <= 128 registers two such
+// workgroups per CU.  Rounds 3-5 ran a 32 x 8 tile on NINE waves (one per vertical displacement, 72 slots): phase clocks
+// (scripts/debug/corr_stamps.py) showed the multiply phase to be what the call costs -- with global loads AND stores compiled out
+// the level-2 call still took 35 of its 36 us -- and one SIMD carrying three of the nine waves: the others waited 2-3 us per tile at
+// the next barrier, and 560 tiles on 256 one-workgroup CUs meant three rounds for 2.2 tiles' worth of work.  Measured on one box,
+// level 2 (B = 8, C = 32, 112 x 160): 35.5 us -> 30.4 (7 rows, 8 waves, one workgroup per CU) -> 24.9 (two per CU: no spills, see
+// `fetch`) = 0.29 -> 0.42 of the HBM roof.  Measured and dropped on the way: requesting channel c + 1's LDS operands before channel c
+// is multiplied (+16 registers; 2-3 us SLOWER in every configuration: the phase is bound by issue, not by LDS latency), storing a
+// tile's results behind the next tile's first commit (slower), 3 x 128 / 3 x 256 workgroups (same / slower).  H = 7, 14, 28, 56, 112
+// (every PWC level of a 448-row image) are whole tiles.
+constexpr int TW4 = 32, TH4 = 7, F2W4 = TW4 + 8, F2H4 = TH4 + 8;
+constexpr int NT4 = 512;                                         // 8 waves = 64 slots of 8 lanes; 63 of them = 9 displacements x 7 rows
+constexpr int Q2 = (CC * F2H4 * (F2W4 / 4) + NT4 - 1) / NT4;   // float4 items of the f2 halo tile per thread (2400 / 512 -> 5)
+constexpr int Q1 = (CC * TH4 * (TW4 / 4) + NT4 - 1) / NT4;     // float4 items of the f1 tile per thread (896 / 512 -> 2)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Persistent form: the launch has one workgroup per CU (122 VGPRs x 9 waves: a CU holds one), workgroup i walks the logical tiles
-// i', i' + G', ... of ITS XCD's contiguous range (workgroup i runs on XCD i % 8: the 32 tiles the CUs of an XCD work on at a time are
-// neighbours -- 6 tile rows of one image -- so their halos come out of that XCD's L2 instead of being fetched once per XCD), and the
-// first chunk of the NEXT tile is requested before the 81 result planes of the current one are stored.  As independent workgroups
-// the level-2 call (560 tiles on 256 CUs) ran in three rounds of ~13 us of latencies each (first fetch, two barriers per chunk,
-// store tail): 39 us.
-__global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+#ifdef ISLAM_CORR_STAMPS               // scripts/debug/corr_stamps.sh: event clocks of workgroup 0's wave 0 (never in the product build)
+}  // namespace
+__device__ long long islam_corr_stamps_buf[64];
+__device__ int islam_corr_dbg;            // 1: no stores, 2: no global loads (what the other half costs on its own)
+namespace {
+#define CSTAMP() do { __builtin_amdgcn_sched_barrier(0); if (stamp && st_n < 62) st_ev[st_n++] = wall_clock64() - st_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CSTAMP() do { } while (0)
+#endif
+
+// Persistent form: the launch has two workgroups per CU, workgroup i walks the logical tiles i', i' + G', ... of ITS XCD's contiguous
+// range (workgroup i runs on XCD i % 8: the tiles the CUs of an XCD work on at a time are neighbours -- a few tile rows of one image --
+// so their halos come out of that XCD's L2 instead of being fetched once per XCD), and the first chunk of the NEXT tile is requested
+// before the 81 result planes of the current one are stored.
+__global__ __launch_bounds__(NT4, 4) void corr81_fwd4_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           float* __restrict__ out, float* __restrict__ part, int B, int C,
                                                           int H, int W, int nslice, int cps, int otot, int ooff, float slope,
                                                           int ntx, int nty, int ntiles) {
     __shared__ __attribute__((aligned(16))) float s1[CC * TH4 * TW4];
     __shared__ __attribute__((aligned(16))) float s2[CC * F2H4 * F2W4];
-    const int tid = threadIdx.x, lane = tid & 63, dyi = tid >> 6;        // 9 waves = 9 vertical displacements
-    const int tx = lane & 7, ty = lane >> 3;                              // pixels 4 tx ... 4 tx + 3 of tile row ty
+    const int tid = threadIdx.x;
+    // slot = 8 lanes = one tile row of ONE vertical displacement (pixels 4 tx ... 4 tx + 3 per lane): 9 x 7 = 63 of the 64 slots work,
+    // the last one repeats slot 62 and stores nothing
+    const int slot = tid >> 3, tx = tid & 7, uu = min(slot, 9 * TH4 - 1), dyi = uu / TH4, ty = uu - dyi * TH4;
+    const bool live = slot < 9 * TH4;
     const size_t plane = (size_t)H * W;
     // XCD x owns the logical tiles [x Q, (x + 1) Q); its workgroups (blockIdx.x >> 3 = 0 .. G8 - 1) take every G8-th of them
     const int Q = (ntiles + 7) / 8, G8 = (gridDim.x + 7) / 8, xcd = blockIdx.x & 7;
@@ -190,34 +214,47 @@ __global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict
     v4f r2[Q2], r1[Q1];                          // (native vectors: arrays of HIP's float4 struct are copied by memcpy and end up in scratch)
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](const Tile& T, int cb, int nc) {
-        const float* f1b = f1 + (size_t)T.b * C * plane;
-        const float* f2b = f2 + (size_t)T.b * C * plane;
+        // (uniform 64-bit base of the chunk + a 32-bit offset per lane: seven 64-bit addresses held across the multiply phase were what
+        //  pushed the kernel past the 128 registers that let two workgroups share a CU)
+        const float* f1b = f1 + ((size_t)T.b * C + cb) * plane;
+        const float* f2b = f2 + ((size_t)T.b * C + cb) * plane;
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                 // (opaque: the item decode below is recomputed per fetch, ~100 VALU instructions, instead of being
+                                                     //  hoisted out of the tile loop into ~30 registers that then spill)
 #pragma unroll
         for (int q = 0; q < Q2; ++q) {
-            const int i = tid + q * NT;
+            const int i = tv + q * NT4;
             const int c = i / (F2H4 * (F2W4 / 4)), rem = i - c * (F2H4 * (F2W4 / 4));
             const int ly = rem / (F2W4 / 4), lx = 4 * (rem - ly * (F2W4 / 4));
             const int gy = T.y0 - 4 + ly, gx = T.x0 - 4 + lx;
+#ifdef ISLAM_CORR_STAMPS
+            const bool ok = !(islam_corr_dbg & 2) && c < nc && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#else
             const bool ok = c < nc && gy >= 0 && gy < H && gx >= 0 && gx < W;          // (c < nc <= CC also bounds i)
-            r2[q] = ok ? *reinterpret_cast<const v4f*>(f2b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
+#endif
+            r2[q] = ok ? *reinterpret_cast<const v4f*>(f2b + (unsigned)(c * (int)plane + gy * W + gx)) : zero4;
         }
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
-            const int i = tid + q * NT;
+            const int i = tv + q * NT4;
             const int c = i / (TH4 * (TW4 / 4)), rem = i - c * (TH4 * (TW4 / 4));
             const int ly = rem / (TW4 / 4), lx = 4 * (rem - ly * (TW4 / 4));
             const int gy = T.y0 + ly, gx = T.x0 + lx;
+#ifdef ISLAM_CORR_STAMPS
+            const bool ok = !(islam_corr_dbg & 2) && c < nc && gy < H && gx < W;
+#else
             const bool ok = c < nc && gy < H && gx < W;
-            r1[q] = ok ? *reinterpret_cast<const v4f*>(f1b + (size_t)(cb + c) * plane + gy * W + gx) : zero4;
+#endif
+            r1[q] = ok ? *reinterpret_cast<const v4f*>(f1b + (unsigned)(c * (int)plane + gy * W + gx)) : zero4;
         }
     };
     auto commit = [&]() {                        // item i lives at float4 slot i of its tile: both tiles are dense [c][row][col] arrays
 #pragma unroll
         for (int q = 0; q < Q2; ++q)
-            if (tid + q * NT < CC * F2H4 * (F2W4 / 4)) *reinterpret_cast<v4f*>(&s2[4 * (tid + q * NT)]) = r2[q];
+            if (tid + q * NT4 < CC * F2H4 * (F2W4 / 4)) *reinterpret_cast<v4f*>(&s2[4 * (tid + q * NT4)]) = r2[q];
 #pragma unroll
         for (int q = 0; q < Q1; ++q)
-            if (tid + q * NT < CC * TH4 * (TW4 / 4)) *reinterpret_cast<v4f*>(&s1[4 * (tid + q * NT)]) = r1[q];
+            if (tid + q * NT4 < CC * TH4 * (TW4 / 4)) *reinterpret_cast<v4f*>(&s1[4 * (tid + q * NT4)]) = r1[q];
     };
 
     // [measured on one box, level-2 call, as independent workgroups: 72.5 us for the one-pixel-pair kernel, 39.1 us for this lane
@@ -225,56 +262,94 @@ __global__ __launch_bounds__(NT) void corr81_fwd4_kernel(const float* __restrict
     //  on another box); the 36 FMAs as 16 v_pk_fma_f32 + 4 v_fma_f32: 39.1 us, no change -- the kernel is not VALU-bound]
     int t = xcd * Q + (blockIdx.x >> 3);
     if (t >= t_end) return;
+#ifdef ISLAM_CORR_STAMPS
+    const int dbg = islam_corr_dbg;
+    const bool stamp = blockIdx.x == 0 && tid == 0;
+    long long st_ev[62];
+    int st_n = 0;
+    const long long st_t0 = wall_clock64();
+#endif
     Tile T = tile_of(t);
     fetch(T, T.c_begin, min(CC, T.c_end - T.c_begin));
-    for (;;) {
-        const int tn = t + G8;
-        const bool more = tn < t_end;
-        Tile Tn = T;
-        if (more) Tn = tile_of(tn);
-        float acc[4][9];
+    CSTAMP();                                        // 0: first fetch issued
+    float acc[4][9];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
-        for (int cb = T.c_begin; cb < T.c_end; cb += CC) {
-            const int nc = min(CC, T.c_end - cb);
-            __syncthreads();                         // previous chunk fully consumed
-            commit();
-            __syncthreads();
-            if (cb + CC < T.c_end) fetch(T, cb + CC, min(CC, T.c_end - cb - CC));      // in flight while this chunk is consumed
-            else if (more) fetch(Tn, Tn.c_begin, min(CC, Tn.c_end - Tn.c_begin));      // ... and across the tile boundary
-            for (int c = 0; c < nc; ++c) {
-                const v4f a = *reinterpret_cast<const v4f*>(&s1[(c * TH4 + ty) * TW4 + 4 * tx]);
-                const float* row = &s2[(c * F2H4 + ty + dyi) * F2W4 + 4 * tx];
-                float r[12];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const v4f v = *reinterpret_cast<const v4f*>(row + 4 * q);
-                    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-                }
-                const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int dx = 0; dx < 9; ++dx) acc[p][dx] = fmaf(av[p], r[p + dx], acc[p][dx]);
-            }
-        }
-        const int gy = T.y0 + ty, gx = T.x0 + 4 * tx;
-        if (gy < H && gx < W) {
+        for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
+    // the 9 x 16-byte stores of a finished tile; they zero the accumulators behind them
+    auto store = [&](const Tile& S) {
+        const int gy = S.y0 + ty, gx = S.x0 + 4 * tx;
+#ifdef ISLAM_CORR_STAMPS
+        if (live && gy < H && gx < W && (!(dbg & 1) || acc[0][0] == 12345.678f)) {
+#else
+        if (live && gy < H && gx < W) {
+#endif
             const float sc = nslice == 1 ? 1.0f / (float)C : 1.0f;          // the mean over channels (correlation.py:97-99)
-            float* ob = (nslice == 1 ? out + ((size_t)T.b * otot + ooff + (size_t)dyi * 9) * plane
-                                     : part + (size_t)T.slice * B * 81 * plane + ((size_t)T.b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
+            float* ob = (nslice == 1 ? out + ((size_t)S.b * otot + ooff + (size_t)dyi * 9) * plane
+                                     : part + (size_t)S.slice * B * 81 * plane + ((size_t)S.b * 81 + (size_t)dyi * 9) * plane) + (size_t)gy * W + gx;
             const float sl = nslice == 1 ? slope : 1.0f;
             auto act = [&](float v) { return v > 0.0f ? v : v * sl; };
 #pragma unroll
             for (int dx = 0; dx < 9; ++dx)
                 *reinterpret_cast<v4f*>(ob + (size_t)dx * plane) = v4f{act(acc[0][dx] * sc), act(acc[1][dx] * sc), act(acc[2][dx] * sc), act(acc[3][dx] * sc)};
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[p][i] = 0.f;
+    };
+    for (;;) {
+        const int tn = t + G8;
+        const bool more = tn < t_end;
+        Tile Tn = T;
+        if (more) Tn = tile_of(tn);
+        for (int cb = T.c_begin; cb < T.c_end; cb += CC) {
+            const int nc = min(CC, T.c_end - cb);
+            __syncthreads();                         // previous chunk fully consumed
+            CSTAMP();                                // per chunk: barrier 1 passed
+            commit();
+            CSTAMP();                                //            loads arrived, LDS writes issued
+            __syncthreads();
+            CSTAMP();                                //            barrier 2 passed
+            if (cb + CC < T.c_end) fetch(T, cb + CC, min(CC, T.c_end - cb - CC));      // in flight while this chunk is consumed
+            else if (more) fetch(Tn, Tn.c_begin, min(CC, Tn.c_end - Tn.c_begin));      // ... and across the tile boundary
+            CSTAMP();                                //            next fetch issued
+            const float* p1 = &s1[ty * TW4 + 4 * tx];
+            const float* p2 = &s2[(ty + dyi) * F2W4 + 4 * tx];
+            struct Ops { v4f a, v0, v1, v2; };
+            auto ld = [&](int c) {
+                Ops o;
+                o.a = *reinterpret_cast<const v4f*>(p1 + c * (TH4 * TW4));
+                o.v0 = *reinterpret_cast<const v4f*>(p2 + c * (F2H4 * F2W4));
+                o.v1 = *reinterpret_cast<const v4f*>(p2 + c * (F2H4 * F2W4) + 4);
+                o.v2 = *reinterpret_cast<const v4f*>(p2 + c * (F2H4 * F2W4) + 8);
+                return o;
+            };
+            auto mac = [&](const Ops& o) {
+                const float r[12] = {o.v0.x, o.v0.y, o.v0.z, o.v0.w, o.v1.x, o.v1.y, o.v1.z, o.v1.w, o.v2.x, o.v2.y, o.v2.z, o.v2.w};
+                const float av[4] = {o.a.x, o.a.y, o.a.z, o.a.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int dx = 0; dx < 9; ++dx) acc[p][dx] = fmaf(av[p], r[p + dx], acc[p][dx]);
+            };
+            for (int c = 0; c < nc; ++c) mac(ld(c));
+            CSTAMP();                                //            multiplied
+        }
+        store(T);
+        CSTAMP();                                    // per tile: stores issued
         if (!more) break;
         t = tn;
         T = Tn;
     }
+#ifdef ISLAM_CORR_STAMPS
+    if (stamp) {
+        islam_corr_stamps_buf[0] = st_n;
+        for (int q = 0; q < st_n; ++q) islam_corr_stamps_buf[1 + q] = st_ev[q];
+        islam_corr_stamps_buf[63] = wall_clock64() - st_t0;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void corr81_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
@@ -734,6 +809,13 @@ static void launch_head_up(const float* x, const float* w, const float* bias, fl
                            wf, bf, flow);
 }
 
+#ifdef ISLAM_CORR_STAMPS
+extern "C" int islam_corr_dbg_set(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(islam_corr_dbg), &v, sizeof(int)) == hipSuccess ? 0 : 1; }
+extern "C" int islam_corr_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(islam_corr_stamps_buf), sizeof(long long) * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" {
 
 // which kernel, how many channel slices (small pyramid levels: too few tiles for 256 CUs), channels per slice -- ONE place, so that
@@ -745,8 +827,9 @@ static void corr81_plan(int B, int C, int H, int W, bool* fwd4, int* nslice, int
     const int tiles = ((W + TW - 1) / TW) * ((H + th - 1) / th) * B;
     const int chunks = (C + CC - 1) / CC;
     // workgroups wanted before the channels are split into slices (partial sums + a reduce pass: 4 x the output traffic of the level-3
-    // call).  The four-pixel kernel holds one workgroup per CU: past ~256 of them slicing only adds traffic -- B = 8, level 3 (C 64, 56 x 80)
-    // 39.3 -> 22.5 us, level 4 (C 96, 28 x 40) 29.1 -> 21.4 us with 256 instead of 1024; the small-map kernel keeps 1024 (16.3 -> 18.6 us
+    // call).  Past ~256 workgroups of the four-pixel kernel slicing only adds traffic -- B = 8, level 3 (C 64, 56 x 80) 39.3 -> 22.5 us,
+    // level 4 (C 96, 28 x 40) 29.1 -> 21.4 us with 256 instead of 1024 (round 4, one workgroup per CU); with the 7-row tiles and two
+    // workgroups per CU of round 6: 19.1 / 18.7 us at 128 or 256, 30.8 / 23.0 us at 512; the small-map kernel keeps 1024 (16.3 -> 18.6 us
     // at 128).  ISLAM_CORR_SLICE_TARGET overrides both (A/B runs).
     static const int forced = [] { const char* e = std::getenv("ISLAM_CORR_SLICE_TARGET"); return e && std::atoi(e) > 0 ? std::atoi(e) : 0; }();
     const int target = forced ? forced : (*fwd4 ? 256 : 1024);
@@ -777,12 +860,13 @@ static int corr81_launch(const float* f1, const float* f2, float* out, int otot,
         static const int cus = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+            n *= 2;                                                      // two workgroups of 8 waves per CU
             const char* e = std::getenv("ISLAM_CORR4_WGS");              // (A/B runs: workgroups of the launch)
             if (e && std::atoi(e) > 0) n = std::atoi(e);
             return n / 8 * 8;
         }();
         const int grid4 = std::max(8, std::min(cus, (ntiles + 7) / 8 * 8));
-        hipLaunchKernelGGL(corr81_fwd4_kernel, dim3(grid4), dim3(NT), 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps,
+        hipLaunchKernelGGL(corr81_fwd4_kernel, dim3(grid4), dim3(NT4), 0, as_stream(stream), f1, f2, out, (float*)scratch, B, C, H, W, nslice, cps,
                            otot, ooff, slope, ntx, nty, ntiles);
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * nslice), block(16, 4, 9);
