@@ -436,11 +436,14 @@ __global__ __launch_bounds__(256) void warp_mask_kernel(const float* __restrict_
 #pragma clang fp contract(off)
     const int ngrp = (C + WCH - 1) / WCH;
     const int b = blockIdx.z / ngrp, c0 = (blockIdx.z % ngrp) * WCH;
-    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
+    // pixels in row-major order, 256 per workgroup: with 64 x 4-pixel blocks a 160-pixel row left a sixth of the lanes idle and the
+    // level-2 call (B = 8) had 1344 workgroups for the 1280 a chip holds at once at this kernel's ~100 registers -- a second round for
+    // 5 % of the work; 1120 workgroups fit one
+    const int pidx = blockIdx.x * 256 + threadIdx.x;
+    if (pidx >= H * W) return;
+    const int py = pidx / W, px = pidx - py * W;
     const size_t plane = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
+    const size_t pix = (size_t)pidx;
     const float fx = flow[((size_t)b * 2 + 0) * plane + pix] * scale;
     const float fy = flow[((size_t)b * 2 + 1) * plane + pix] * scale;
     const float vx = (float)px + fx, vy = (float)py + fy;
@@ -905,7 +908,8 @@ int islam_corr81_bwd(const float* f1, const float* f2, const float* gout, float*
 
 int islam_warp_mask(const float* x, const float* flow, float scale, float* out, int B, int C, int H, int W, void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return fail(ISLAM_EARG, "islam_warp_mask: bad shape (%d,%d,%d,%d)", B, C, H, W);
-    dim3 grid((W + 63) / 64, (H + 3) / 4, B * ((C + WCH - 1) / WCH)), block(256);
+    if ((long long)H * W >= (1LL << 31) - 256) return fail(ISLAM_EARG, "islam_warp_mask: image too large (%dx%d)", H, W);
+    dim3 grid((unsigned)(((long long)H * W + 255) / 256), 1, B * ((C + WCH - 1) / WCH)), block(256);
     hipLaunchKernelGGL(warp_mask_kernel, grid, block, 0, as_stream(stream), x, flow, scale, out, C, H, W);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;

@@ -10,9 +10,12 @@ pytestmark = pytest.mark.gpu
 # the five (C,H,W) shapes PWC-Net calls the correlation with at 448x640 + ragged edge cases
 PWC_SHAPES = [(196, 7, 10), (128, 14, 20), (96, 28, 40), (64, 56, 80), (32, 112, 160)]
 EDGE_SHAPES = [(1, 1, 1), (3, 5, 7), (17, 9, 33), (33, 4, 65), (5, 13, 31)]
+# the four-pixel kernel (W % 4 == 0, H W >= 1024) away from its whole 32 x 7 tiles: last band of 3 / 1 / 2 rows, partial tile columns,
+# a channel count that is not a whole chunk
+RAGGED4_SHAPES = [(20, 45, 64), (8, 36, 36), (16, 100, 132), (40, 30, 44)]
 
 
-@pytest.mark.parametrize('C,H,W', PWC_SHAPES + EDGE_SHAPES)
+@pytest.mark.parametrize('C,H,W', PWC_SHAPES + EDGE_SHAPES + RAGGED4_SHAPES)
 def test_corr81_forward(cuda, C, H, W):
     from islam_amd import ops
     B = 2
