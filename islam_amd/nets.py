@@ -415,7 +415,9 @@ def execution_description():
         from ._lib import lib
         if lib().islam_conv_ws_mode(-1) > 0:
             stereo.append('the twelve 3x3 layers with 128 output channels of layer3 / layer4 on the weight-stationary persistent kernel conv3x3_ws_kernel (weights in the register file), '
-                          'the eight 32->32 ones on the persistent kernel conv3x3_ws32_kernel')
+                          'the eight 32->32 ones on the persistent kernel conv3x3_ws32_kernel'
+                          + (' (layers whose image is whole tiles and has >= 1024 of them, as at the benched size; the tile kernel otherwise)'
+                             if lib().islam_conv_ws_mode(-1) == 1 else ' (every layer whose image is whole tiles)'))
     else:
         stereo.append('all convolutions on MIOpen')
     stereo.append(on(HIP_CONV_S2, 'stride-2 convolutions on islam_conv_nhwc_bf16_s2' + on(HIP_FIRST_LAYER, ' including the 3->32 first layer', ' (first layer on MIOpen)'),
