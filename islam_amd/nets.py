@@ -394,6 +394,9 @@ HIP_DECONV = _os.environ.get('ISLAM_HIP_DECONV', '1') == '1'
 # per forward: 8.02 / 7.99 ms per replay of both nets against 7.96 / 7.98 (profiles/r06/bn_finalize_ab_r06.txt).  Launches of a few
 # microseconds on one branch of the replay are filled by the other branch's kernels; what the replay costs is its large kernels.
 BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
+# 1x1 stride-1 convbn layers (layer3's 64 -> 128 downsample, the four SPP branch convolutions) on the channels-last kernel with the batch
+# statistics from its epilogue instead of CK + a statistics pass over the output (0: as through round 5)
+CONV1X1_BN = os.environ.get('ISLAM_CONV1X1_BN', '1') == '1'
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
 HIP_FIRST_LAYER = os.environ.get('ISLAM_HIP_FIRST_LAYER', '1') != '0'   # the 3 -> 32 stride-2 first layer of the stereo net on the channels-last kernel
@@ -411,7 +414,7 @@ def execution_description():
     stereo = ['stereo net: bf16 NHWC execution copy']
     if HIP_CONV_LEVEL >= 1:
         stereo.append('stride-1 3x3%s convolutions on the HIP implicit-GEMM kernel conv_nhwc_kernel (BatchNorm statistics in the epilogue, '
-                      'BatchNorm + ReLU on load)' % on(HIP_CONV_LEVEL >= 2, ' and the hourglass 1x1', ''))
+                      'BatchNorm + ReLU on load)' % on(HIP_CONV_LEVEL >= 2, on(CONV1X1_BN, ', the hourglass 1x1 and the 1x1 convbn', ' and the hourglass 1x1'), ''))
         from ._lib import lib
         if lib().islam_conv_ws_mode(-1) > 0:
             stereo.append('the twelve 3x3 layers with 128 output channels of layer3 / layer4 on the weight-stationary persistent kernel conv3x3_ws_kernel (weights in the register file), '
@@ -425,7 +428,8 @@ def execution_description():
     stereo.append(on(HG_FUSED, 'the 35 hourglass Residual modules as one launch each (islam_hg_residual_nhwc_bf16)', 'hourglass Residual modules as three launches'))
     stereo.append(on(HIP_DECONV, 'decoder transposed convolutions on the convolution kernel', 'decoder transposed convolutions on MIOpen'))
     stereo.append(on(UPSAMPLE_CAT, 'SPP up-samplings + concatenation as one launch', 'SPP up-samplings as separate launches'))
-    stereo.append('biased 1x1 / SPP 1x1 convolutions on MIOpen / CK')
+    stereo.append(on(CONV1X1_BN and HIP_CONV_LEVEL >= 2, 'biased convolutions of the 384 / 512-channel levels, the second SPP and the one-channel output convolution on MIOpen / CK',
+                     'biased 1x1 / SPP 1x1 convolutions on MIOpen / CK'))
     flow = ['flow net: ' + on(FLOW_NHWC, 'DenseNet blocks / context network on the channels-last kernel through a bf16 mirror', 'DenseNet blocks on islam_conv3x3_mfma (fp32 NCHW)')]
     flow.append(on(FLOW_PYR, 'pyramid levels 1-2 as one fused three-layer launch each', 'pyramid levels 1-2 layer by layer'))
     flow.append(on(FLOW_S2_HIP, 'stride-2 layers of levels 3-6 on islam_conv3x3_mfma', 'stride-2 layers of levels 3-6 on MIOpen'))
@@ -483,7 +487,7 @@ def _cbn(convbn, x, relu=False, res=None, defer=False):
     conv, bn = convbn[0], convbn[1]
     plain_bn = type(bn) is nn.BatchNorm2d and bn.training and bn.weight.dtype == torch.float32
     xin = x.raw if isinstance(x, _Pending) else x
-    if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin, strided=True):
+    if plain_bn and bn.num_features <= 256 and _hip_conv_ok(conv, xin, fused_1x1=CONV1X1_BN, strided=True):
         if conv.stride == (2, 2):     # layer2's first block (submodule.py:76-85): stride-2 3x3 convbn and its stride-2 1x1 downsample
             y, folded = ops.conv_nhwc_s2(xin, _packed_nhwc(conv), conv.out_channels, conv.kernel_size[0],
                                          in_affine=x.affine if isinstance(x, _Pending) else None, stats=True)
