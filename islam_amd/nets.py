@@ -428,7 +428,7 @@ def execution_description():
     stereo.append(on(HG_FUSED, 'the 35 hourglass Residual modules as one launch each (islam_hg_residual_nhwc_bf16)', 'hourglass Residual modules as three launches'))
     stereo.append(on(HIP_DECONV, 'decoder transposed convolutions on the convolution kernel', 'decoder transposed convolutions on MIOpen'))
     stereo.append(on(UPSAMPLE_CAT, 'SPP up-samplings + concatenation as one launch', 'SPP up-samplings as separate launches'))
-    stereo.append(on(CONV1X1_BN and HIP_CONV_LEVEL >= 2, 'biased convolutions of the 384 / 512-channel levels, the second SPP and the one-channel output convolution on MIOpen / CK',
+    stereo.append(on(CONV1X1_BN and HIP_CONV_LEVEL >= 2, 'biased convolutions of the 384 / 512-channel levels, the second SPP and the two output convolutions (conv_c12, the one-channel conv_c13) on MIOpen / CK',
                      'biased 1x1 / SPP 1x1 convolutions on MIOpen / CK'))
     flow = ['flow net: ' + on(FLOW_NHWC, 'DenseNet blocks / context network on the channels-last kernel through a bf16 mirror', 'DenseNet blocks on islam_conv3x3_mfma (fp32 NCHW)')]
     flow.append(on(FLOW_PYR, 'pyramid levels 1-2 as one fused three-layer launch each', 'pyramid levels 1-2 layer by layer'))
