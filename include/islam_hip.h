@@ -145,6 +145,9 @@ int islam_upsample_cat_nhwc_bf16(const uint16_t* const* srcs, const int* chans, 
  * y (2B, H, W, 8): images [0, B) left, [B, 2B) right, channels [C2/2, 8) zero -- the input of the 3 -> 32 stride-2 first layer
  * (Network/PSM/submodule.py:63) on islam_conv_nhwc_bf16_s2 with its weights zero-padded to 8 input channels. */
 int islam_stack_pair_pad8_nhwc_bf16(const uint16_t* x, uint16_t* y, int B, int C2, int H, int W, void* stream);
+/* The same stacked batch AND the concatenated pair from the two fp32 NCHW images (B,c,H,W), c <= 4, in one pass: x6 (B,H,W,2c) bf16 =
+ * torch.cat((left, right), 1).to(bfloat16) channels-last (Network/VONet.py:31-34), xs (2B,H,W,8) as above.  Round-to-nearest-even. */
+int islam_stereo_pair_prepare_f32(const float* left, const float* right, uint16_t* x6, uint16_t* xs, int B, int c, int H, int W, void* stream);
 /* y = add + resize(x) in one pass (hourglass.py:60-69 `up1 + up2(low3)`): the up-sampled value is rounded to bf16 before the add,
  * like the two separate ops.  add, y: (B,Ho,Wo,C). */
 int islam_resize_bilinear_add_nhwc_bf16(const uint16_t* x, const uint16_t* add, uint16_t* y, int B, int C, int Hi, int Wi, int Ho, int Wo,

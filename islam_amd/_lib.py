@@ -70,6 +70,7 @@ SIGNATURES = {
     'islam_avgpool_nhwc_bf16': (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     'islam_resize_bilinear_nhwc_bf16_into': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'islam_stack_pair_pad8_nhwc_bf16': (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    'islam_stereo_pair_prepare_f32': (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     'islam_upsample_cat_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     'islam_bias_act_add_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p]),
     'islam_bias_act_f32_nhwc': (c_int, [c_void_p] * 4 + [ctypes.c_longlong, c_int, c_int, c_void_p]),

@@ -507,6 +507,53 @@ extern "C" int islam_stack_pair_pad8_nhwc_bf16(const uint16_t* x, uint16_t* y, i
     return ISLAM_OK;
 }
 
+// The stereo pair as it arrives -- two fp32 NCHW tensors (B, c, H, W), c <= 4 (Network/VONet.py:31-34: torch.cat((img0_norm, img0_r_norm), 1)
+// feeds the stereo net) -- straight to the two bf16 channels-last tensors the execution copy reads: x6 (B, H, W, 2c) = the concatenated
+// pair (what half_image_into_kernel samples for conv_c0's input) and xs (2B, H, W, 8) = islam_stack_pair_pad8_nhwc_bf16's stacked,
+// zero-padded batch.  One pass (reads 2 x 4 c bytes, writes 4 c + 32 bytes per pixel) instead of torch.cat + a bf16 cast + a layout copy +
+// the stacking kernel (four passes, 84 us per batch at B = 8, 448 x 640).  Same values: round-to-nearest-even like Tensor.to(bfloat16).
+__global__ __launch_bounds__(256) void stereo_pair_prepare_kernel(const float* __restrict__ left, const float* __restrict__ right, unsigned* __restrict__ x6,
+                                                                  uint4* __restrict__ xs, int B, int c, long long HW, long long total) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const long long b = p / HW, q = p - b * HW;
+    float l[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < c) {
+            l[k] = left[(b * c + k) * HW + q];
+            r[k] = right[(b * c + k) * HW + q];
+        }
+    xs[p] = make_uint4(pack_bf16(l[0], l[1]), pack_bf16(l[2], l[3]), 0u, 0u);
+    xs[(long long)B * HW + p] = make_uint4(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]), 0u, 0u);
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                    // (v[k] = l[k], v[c + k] = r[k] with compile-time register indices)
+                if (j == k) v[j] = l[k];
+                if (j == c + k) v[j] = r[k];
+            }
+        }
+    unsigned* o = x6 + p * c;                                // 2c bf16 = c dwords per pixel
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < c) o[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
+}
+
+extern "C" int islam_stereo_pair_prepare_f32(const float* left, const float* right, uint16_t* x6, uint16_t* xs, int B, int c, int H, int W, void* stream) {
+    if (!left || !right || !x6 || !xs || B < 1 || c < 1 || c > 4 || H < 1 || W < 1)
+        return fail(ISLAM_EARG, "islam_stereo_pair_prepare_f32: bad argument (B=%d, c=%d, %dx%d)", B, c, H, W);
+    const long long HW = (long long)H * W, total = (long long)B * HW;
+    hipLaunchKernelGGL(stereo_pair_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, left, right,
+                       reinterpret_cast<unsigned*>(x6), reinterpret_cast<uint4*>(xs), B, c, HW, total);
+    ISLAM_LAUNCH_CHECK();
+    return ISLAM_OK;
+}
+
 // 2x2 / stride-2 max pooling (floor mode), optionally of relu(x): relu and max commute
 __global__ __launch_bounds__(256) void maxpool2_nhwc_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int C8, int Hi, int Wi,
                                                                  int Ho, int Wo, int relu, long long total) {

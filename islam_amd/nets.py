@@ -397,6 +397,8 @@ BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 # 1x1 stride-1 convbn layers (layer3's 64 -> 128 downsample, the four SPP branch convolutions) on the channels-last kernel with the batch
 # statistics from its epilogue instead of CK + a statistics pass over the output (0: as through round 5)
 CONV1X1_BN = os.environ.get('ISLAM_CONV1X1_BN', '1') == '1'
+# the stereo pair from its two fp32 images to the execution copy's bf16 inputs in one kernel (0: torch.cat + cast + layout copy + stacking)
+STEREO_PAIR_PREPARE = os.environ.get('ISLAM_STEREO_PAIR_PREPARE', '1') == '1'
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
 HIP_FIRST_LAYER = os.environ.get('ISLAM_HIP_FIRST_LAYER', '1') != '0'   # the 3 -> 32 stride-2 first layer of the stereo net on the channels-last kernel
@@ -810,7 +812,9 @@ class StereoNet7(nn.Module):
             return direct['buf'], [(0, B, 0), (B, B, cf)]
         stacked = STEREO_DIRECT_CAT and x.dtype == torch.bfloat16
         if stacked and HIP_FIRST_LAYER and HIP_CONV_S2 and C2 // 2 < 8 and x.is_contiguous(memory_format=torch.channels_last):
-            xs = ops.stack_pair_pad8(x)                      # [left images; right images], three channels padded to eight
+            xs = getattr(x, '_islam_stacked', None)          # (VONet._run_frozen_stereo_pair: built together with x from the fp32 pair)
+            if xs is None or tuple(xs.shape) != (2 * B, 8, H, W):
+                xs = ops.stack_pair_pad8(x)                  # [left images; right images], three channels padded to eight
         else:
             xs = torch.cat((x[:, :C2 // 2], x[:, C2 // 2:]), 0) if stacked else x.reshape(B * 2, C2 // 2, H, W)
         f2 = self.feature_extraction(xs, into=into if stacked else None)      # left / right images stacked along the batch
@@ -1078,6 +1082,21 @@ class VONet(nn.Module):
         xin = x.to(dtype).contiguous(memory_format=torch.channels_last)
         return ex.module()(xin, quarter=True) if quarter else ex.module()(xin)
 
+    def _run_frozen_stereo_pair(self, left, right, quarter=True):
+        """_run_frozen('stereo', ..., torch.cat((left, right), 1)) with the concatenation, the bf16 cast, the channels-last copy and the
+        stacking of the pair done by ONE kernel (ops.stereo_pair_prepare) when the execution copy takes the stacked batch anyway."""
+        dtype, master = self.frozen_dtype, self.stereoNet
+        if (STEREO_PAIR_PREPARE and dtype == torch.bfloat16 and not any(p.requires_grad for p in master.parameters()) and left.is_cuda
+                and left.dtype == torch.float32 and right.dtype == torch.float32 and left.shape == right.shape and left.shape[1] <= 3
+                and left.is_contiguous() and right.is_contiguous() and STEREO_DIRECT_CAT and HIP_FIRST_LAYER and HIP_CONV_S2):
+            ex = self._exec.get('stereo')
+            if ex is None or ex.dtype != dtype:
+                ex = self._exec['stereo'] = _HalfExec(master, dtype)
+            x6, xs = ops.stereo_pair_prepare(left, right)
+            x6._islam_stacked = xs
+            return ex.module()(x6, quarter=True) if quarter else ex.module()(x6)
+        return self._run_frozen('stereo', master, dtype, torch.cat((left, right), 1), quarter=quarter)
+
     def set_graph_frozen(self, on=True):
         """Replay the frozen flow + disparity forward (~750 launches) from a captured HIP graph instead of enqueueing it
         launch by launch: same kernels and results, the host is free during the replay.  Graphs are keyed by input shape and
@@ -1176,14 +1195,14 @@ class VONet(nn.Module):
             cur = torch.cuda.current_stream(img0.device)
             fork.wait_stream(cur)
             with torch.cuda.stream(fork):
-                disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1), quarter=True)[0]
+                disp = self._run_frozen_stereo_pair(img0_norm, img0_r_norm, quarter=True)[0]
                 disp = disp.float().contiguous()
             flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0].float().contiguous()
             cur.wait_stream(fork)
             return flow, disp
         flow = self._run_frozen('flow', self.flowNet, self.flow_dtype, torch.cat([img0, img1], 1))[0][0]
         # Network/VONet.py:33-34 keeps disp[..., ::4, ::4] (nearest, scale 1/4): only those pixels are computed (StereoNet7.forward)
-        disp = self._run_frozen('stereo', self.stereoNet, self.frozen_dtype, torch.cat((img0_norm, img0_r_norm), 1), quarter=True)[0]
+        disp = self._run_frozen_stereo_pair(img0_norm, img0_r_norm, quarter=True)[0]
         return flow.float().contiguous(), disp.float().contiguous()
 
     def forward(self, img0, img1, img0_norm, img0_r_norm, intrinsic, frozen=None):

@@ -504,6 +504,19 @@ def stack_pair_pad8(x):
     return y
 
 
+def stereo_pair_prepare(left, right):
+    """The stereo pair (two fp32 (B,c,H,W) tensors, c <= 4) as the frozen stereo net's execution copy reads it, in one pass
+    (islam_stereo_pair_prepare_f32): (x6, xs) with x6 = torch.cat((left, right), 1).to(bfloat16) channels-last and xs = stack_pair_pad8(x6)."""
+    require_cuda(left, right)
+    B, c, H, W = left.shape
+    assert left.dtype == torch.float32 and right.dtype == torch.float32 and left.shape == right.shape and c <= 4
+    assert left.is_contiguous() and right.is_contiguous()
+    x6 = torch.empty((B, 2 * c, H, W), dtype=torch.bfloat16, device=left.device, memory_format=torch.channels_last)
+    xs = torch.empty((2 * B, 8, H, W), dtype=torch.bfloat16, device=left.device, memory_format=torch.channels_last)
+    check(lib().islam_stereo_pair_prepare_f32(ptr(left), ptr(right), ptr(x6), ptr(xs), B, c, H, W, stream_ptr(left.device)))
+    return x6, xs
+
+
 def upsample_cat(pieces, size, tail=None, align_corners=False):
     """torch.cat([F.interpolate(p, size, mode='bilinear') for p in pieces] + [tail], 1) for channels-last bf16 pieces of one shape
     (B, C_k, Hi, Wi), C_k multiples of 8, at most 8 of them; tail: (B, C_t, *size) or None.  One launch

@@ -103,3 +103,22 @@ def test_stereo_pair_stacked_and_padded_to_eight_channels(cuda, B, C2, H, W):
     want[:B, :c] = x[:, :c]
     want[B:, :c] = x[:, c:]
     assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, want)
+
+
+@pytest.mark.parametrize('B,c,H,W', [(2, 3, 10, 14), (1, 1, 5, 3), (3, 4, 4, 6), (8, 3, 64, 96)])
+def test_stereo_pair_prepared_from_the_fp32_images_in_one_pass(cuda, B, c, H, W):
+    """islam_stereo_pair_prepare_f32 == torch.cat((left, right), 1).to(bfloat16) channels-last + islam_stack_pair_pad8_nhwc_bf16, bit for
+    bit (Network/VONet.py:31-34 feeds the concatenated pair to the stereo net; values that round differently to nearest even / by
+    truncation are in the sample)."""
+    from islam_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(7 + B)
+    left = torch.randn(B, c, H, W, device=cuda, generator=g)
+    right = torch.randn(B, c, H, W, device=cuda, generator=g) * 3.0
+    left.view(-1)[:4] = torch.tensor([1.00390625, 1.01171875, -0.0, float('inf')], device=cuda)      # ties, signed zero, infinity
+    x6, xs = ops.stereo_pair_prepare(left, right)
+    want6 = torch.cat((left, right), 1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert x6.shape == want6.shape and x6.is_contiguous(memory_format=torch.channels_last) and torch.equal(x6.view(torch.int16), want6.view(torch.int16))
+    wants = torch.zeros(2 * B, 8, H, W, dtype=torch.bfloat16, device=cuda)
+    wants[:B, :c] = want6[:, :c]
+    wants[B:, :c] = want6[:, c:]
+    assert xs.is_contiguous(memory_format=torch.channels_last) and torch.equal(xs.view(torch.int16), wants.contiguous(memory_format=torch.channels_last).view(torch.int16))
