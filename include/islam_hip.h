@@ -291,6 +291,13 @@ int islam_conv_nhwc_flow(const uint16_t* x, int xtot, int xoff, int Cin, const u
 size_t islam_deconv_nhwc_packed_elems(int Cin, int Cout);
 int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, const float* bias, uint16_t* y, int ytot, int yoff, int B, int Cin,
                                 int H, int W, int Cout, int relu, void* stream);
+/* The transposed convolution above / islam_conv_nhwc_bf16_s2 (kernel size 2) on torch.cat((x1, x2), 1) of two dense channels-last tensors
+ * read where they lie (Network/StereoNet7.py:121-138: the decoder concatenates the previous stage's result with a skip tensor in front of
+ * every transposed convolution): C1 a multiple of 32 (16 for _s2_cat), C2 of 8, wpacked as for Cin = C1 + C2; bit-identical. */
+int islam_deconv4x4s2_nhwc_bf16_cat(const uint16_t* x1, int C1, const uint16_t* x2, int C2, const uint16_t* wpacked, const float* bias, uint16_t* y,
+                                    int ytot, int yoff, int B, int H, int W, int Cout, int relu, void* stream);
+int islam_conv_nhwc_bf16_s2_cat(const uint16_t* x1, int C1, const uint16_t* x2, int C2, const uint16_t* wpacked, const float* bias, uint16_t* y, int B,
+                                int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int relu, void* stream);
 /* One Residual module of the stereo net's hourglass stacks in ONE launch -- Network/PSM/hourglass.py:28-52 (`Residual.forward`),
  * instantiated by Network/PSM/hourglass.py:53-77 / Network/StereoNet7.py:56-90:
  *   y = conv3(relu(conv2(relu(conv1(relu(x)))))) + res ;  conv1 1x1 Cin -> h, conv2 3x3 h -> h (padding 1), conv3 1x1 h -> Cout,

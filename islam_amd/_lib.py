@@ -84,6 +84,8 @@ SIGNATURES = {
     'islam_conv_nhwc_packed_elems': (c_size_t, [c_int] * 3),
     'islam_deconv_nhwc_packed_elems': (c_size_t, [c_int] * 2),
     'islam_deconv4x4s2_nhwc_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    'islam_deconv4x4s2_nhwc_bf16_cat': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'islam_conv_nhwc_bf16_s2_cat': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'islam_conv_nhwc_stat_blocks': (c_int, [c_int] * 4),
     'islam_conv_nhwc_stats_floats': (c_size_t, [c_int] * 4),
     'islam_conv_nhwc_bf16': (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),

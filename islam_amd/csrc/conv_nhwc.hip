@@ -105,14 +105,19 @@ __device__ __forceinline__ unsigned relu2(unsigned t) {
 // on B * 4 "images" (d = 2 decodes the class like a dilation sub-grid): the INPUT is the dense image with its origin shifted by
 // (a, c), the OUTPUT is the sub-grid (a::2, c::2) of the (2H, 2W) result, the weights are the class's slice of the packed array.
 struct Slices { int xs, xoff, ys, yoff; float* y32; int ytot, coff; float slope; int d, Wf; int tc; int Hi, Wi; };      // (Hi, Wi: the input's size when it differs from the output's -- stride 2)
+// TWO (template): the input is the concatenation of TWO dense tensors along the channels -- channels [0, split) from x (xs = split), channels
+// [split, Cin) from x2 (pixel stride xs2) -- read where they lie: the decoder's torch.cat((hourglass output, skip tensor), 1) in front of
+// every transposed convolution (Network/StereoNet7.py:121-138) is never materialised.  split is a multiple of the chunk size KC, so a chunk
+// comes from one tensor.
+struct Src2 { const unsigned short* x2; int xs2, split; };
 
-template <int TN, int KS, int ROWS, int KC, bool FLOW, int S = 1>
+template <int TN, int KS, int ROWS, int KC, bool FLOW, int S = 1, bool TWO = false>
 __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv_nhwc_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ in_affine, const float* __restrict__ bias,
                                                              const unsigned short* __restrict__ res, unsigned short* __restrict__ y,
                                                              float* __restrict__ partial, int Cin, int CinP, int H, int W, int Cout,
                                                              int CoutP, int relu, int tiles_x, int tiles, int in_relu, Slices sl, int nimg,
-                                                             int nblk_n) {
+                                                             int nblk_n, Src2 s2) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     // (S = 2: Conv2d(stride = 2, padding = KS / 2) -- Network/PSM/submodule.py:76-85 layer2's first block and its 1x1 downsample, the
     //  quarter-resolution tail of StereoNet7: output pixel (y, x) reads input rows 2 y - P ... 2 y - P + KS - 1; the halo tile covers
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
     const size_t out_img0 = tcm ? ((size_t)(bb * 2 * H + sga)) * (2 * W) + sgc : img0;
     if (tcm) wp += (size_t)(sga * 2 + sgc) * TAPS * CoutP * CinP;
     const unsigned short* xb = x + in_img0 * sl.xs + sl.xoff;
+    [[maybe_unused]] const unsigned short* xb2 = TWO ? s2.x2 + in_img0 * s2.xs2 : nullptr;
 
     f32x16 acc[NT][ROWS];
 #pragma unroll
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
             const int yy = pix / IW, xx = pix - yy * IW;
             const int gy = ho0 * S - P + oy + yy, gx = wo0 * S - P + ox + xx;
             loff[k] = pix * PS + coct;
-            if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) goff[k] = (gy * iWf + gx) * idil * sl.xs + coct;
+            if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) goff[k] = TWO ? (gy * iWf + gx) * idil : (gy * iWf + gx) * idil * sl.xs + coct;      // (TWO: the pixel index)
         }
     });
     int woff[NWT], wlds[NWT];
@@ -204,6 +210,12 @@ __global__ __launch_bounds__(THREADS, (ROWS == 4 && TN == 64) ? 2 : 1) void conv
         }
         static_for<0, NIN>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
+            if constexpr (TWO) {
+                const bool second = c0 >= s2.split;                     // (uniform: the chunk lies in one tensor)
+                const unsigned short* base = second ? xb2 : xb;
+                const int xsc = second ? s2.xs2 : sl.xs, cc = (second ? c0 - s2.split : c0) + coct;
+                pre[k] = *reinterpret_cast<const u32x4*>(base + ((cok && goff[k] >= 0) ? (size_t)goff[k] * xsc + cc : (size_t)0));
+            } else
             pre[k] = *reinterpret_cast<const u32x4*>(xb + ((cok && goff[k] >= 0) ? (size_t)goff[k] + c0 : (size_t)0));   // masked: any valid address
         });
         static_for<0, NWT>([&](auto kk) {
@@ -538,10 +550,10 @@ __global__ __launch_bounds__(FF_THREADS) void finalize_rows_kernel(const float* 
     if (threadIdx.x == 0 && num_batches) *num_batches += 1;
 }
 
-template <int TN, int KS, int ROWS, int KC, bool FLOW = false, int S = 1>
+template <int TN, int KS, int ROWS, int KC, bool FLOW = false, int S = 1, bool TWO = false>
 int launch(const unsigned short* x, const unsigned short* wp, const float* in_affine, const float* bias, const unsigned short* res,
            unsigned short* y, float* partial, int B, int Cin, int CinP, int H, int W, int Cout, int CoutP, int relu, int in_relu, hipStream_t s,
-           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0, 0, 0, 0}) {
+           Slices sl = Slices{0, 0, 0, 0, nullptr, 0, 0, 0.0f, 1, 0, 0, 0, 0}, Src2 s2 = Src2{nullptr, 0, 0}) {
     if (sl.xs == 0) { sl.xs = Cin; sl.ys = Cout; }           // dense tensors
     if (sl.Wf == 0) sl.Wf = W;
     constexpr int TH = 4 * ROWS, P = KS / 2, NPIX = ((TH - 1) * S + 1 + 2 * P) * ((TW - 1) * S + 1 + 2 * P), TAPS = KS * KS, PS = KC + 8;
@@ -552,14 +564,14 @@ int launch(const unsigned short* x, const unsigned short* wp, const float* in_af
     ISLAM_HIP_CHECK(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ISLAM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[dev] = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int nblk_n = (Cout + TN - 1) / TN, nwork = tiles_x * tiles_y * B * nblk_n;      // TH = tile_h(Cout): TN = 64 <=> Cout > 32
     dim3 grid(nblk_n > 1 ? 8 * ((nwork + 7) / 8) : nwork);
-    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP,
-                       H, W, Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu, sl, B, nblk_n);
+    hipLaunchKernelGGL((conv_nhwc_kernel<TN, KS, ROWS, KC, FLOW, S, TWO>), grid, dim3(THREADS), lds, s, x, wp, in_affine, bias, res, y, partial, Cin, CinP,
+                       H, W, Cout, CoutP, relu, tiles_x, tiles_x * tiles_y, in_relu, sl, B, nblk_n, s2);
     ISLAM_LAUNCH_CHECK();
     return ISLAM_OK;
 }
@@ -802,6 +814,44 @@ int islam_deconv4x4s2_nhwc_bf16(const uint16_t* x, const uint16_t* wpacked, cons
     hipStream_t s = (hipStream_t)stream;
     return Cout > 32 ? launch<64, 2, 2, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl)
                      : launch<32, 2, 4, 32>(x, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl);
+}
+
+// The same with the input given as TWO dense tensors x1 (B,H,W,C1), x2 (B,H,W,C2) whose channel concatenation torch.cat((x1, x2), 1) is
+// what the layer convolves (Network/StereoNet7.py:121-138: every transposed convolution of the decoder reads a concatenation of the
+// previous stage's result and a skip tensor): the concatenation is never written.  C1 a multiple of 32 (whole chunks), C2 of 8; wpacked as
+// for Cin = C1 + C2.  Bit-identical to islam_deconv4x4s2_nhwc_bf16 on the concatenated tensor.
+int islam_deconv4x4s2_nhwc_bf16_cat(const uint16_t* x1, int C1, const uint16_t* x2, int C2, const uint16_t* wpacked, const float* bias, uint16_t* y,
+                                    int ytot, int yoff, int B, int H, int W, int Cout, int relu, void* stream) {
+    const int Cin = C1 + C2;
+    if (!x1 || !x2 || B < 1 || H < 1 || W < 1 || C1 < 32 || (C1 & 31) || C2 < 8 || (C2 & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16_cat: bad shape (C1=%d must be a multiple of 32, C2=%d and Cout=%d of 8)", C1, C2, Cout);
+    if ((ytot & 7) || (yoff & 7) || yoff < 0 || yoff + Cout > ytot) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16_cat: output slice %d+%d of %d", yoff, Cout, ytot);
+    if ((size_t)B * 4 * H * W * std::max(Cin, ytot) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_deconv4x4s2_nhwc_bf16_cat: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{C1, 0, ytot, yoff, nullptr, 0, 0, 0.0f, 2, W, 1, 0, 0};
+    const Src2 s2{x2, C2, C1};
+    hipStream_t s = (hipStream_t)stream;
+    return Cout > 32 ? launch<64, 2, 2, 32, false, 1, true>(x1, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl, s2)
+                     : launch<32, 2, 4, 32, false, 1, true>(x1, wpacked, nullptr, bias, nullptr, y, nullptr, B * 4, Cin, CinP, H, W, Cout, CoutP, relu & 1, 0, s, sl, s2);
+}
+
+// islam_conv_nhwc_bf16_s2 (kernel size 2: the quarter-resolution tail of the stereo net, Network/StereoNet7.py:88-90 through
+// islam_amd/nets.py::_deconv_c11_quarter) on the concatenation of two dense tensors, as above.  C1 a multiple of 16.  No statistics.
+int islam_conv_nhwc_bf16_s2_cat(const uint16_t* x1, int C1, const uint16_t* x2, int C2, const uint16_t* wpacked, const float* bias, uint16_t* y, int B,
+                                int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int relu, void* stream) {
+    const int Cin = C1 + C2;
+    if (!x1 || !x2 || B < 1 || Hi < 1 || Wi < 1 || C1 < 16 || (C1 & 15) || C2 < 8 || (C2 & 7) || Cout < 8 || (Cout & 7))
+        return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2_cat: bad shape (C1=%d must be a multiple of 16, C2=%d and Cout=%d of 8)", C1, C2, Cout);
+    if (ksize != 2) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2_cat: kernel size %d (2)", ksize);
+    const int Hmax = Hi / 2 + 1, Wmax = Wi / 2 + 1;                  // padding ksize / 2 = 1: (Hi + 2 - 2) / 2 + 1
+    if (Ho < 1 || Wo < 1 || Ho > Hmax || Wo > Wmax) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2_cat: output %dx%d of at most %dx%d", Ho, Wo, Hmax, Wmax);
+    if ((size_t)B * Hi * Wi * std::max(Cin, Cout) >= ((size_t)1 << 31)) return fail(ISLAM_EARG, "islam_conv_nhwc_bf16_s2_cat: tensor too large for 32-bit offsets");
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    const Slices sl{C1, 0, Cout, 0, nullptr, 0, 0, 0.0f, 1, Wo, 0, Hi, Wi};
+    const Src2 s2{x2, C2, C1};
+    hipStream_t s = (hipStream_t)stream;
+    return Cout > 32 ? launch<64, 2, 2, 16, false, 2, true>(x1, wpacked, nullptr, bias, nullptr, y, nullptr, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu & 1, (relu >> 1) & 1, s, sl, s2)
+                     : launch<32, 2, 2, 16, false, 2, true>(x1, wpacked, nullptr, bias, nullptr, y, nullptr, B, Cin, CinP, Ho, Wo, Cout, CoutP, relu & 1, (relu >> 1) & 1, s, sl, s2);
 }
 
 // 3x3 stride-1 convolution of the flow net's DenseNet blocks (Network/PWC/PWCNet.py:16-20 `conv()` = Conv2d + LeakyReLU(0.1),

@@ -399,6 +399,29 @@ BN_FOLD_FINALIZE = os.environ.get('ISLAM_BN_FOLD_FINALIZE', '0') == '1'
 CONV1X1_BN = os.environ.get('ISLAM_CONV1X1_BN', '1') == '1'
 # the stereo pair from its two fp32 images to the execution copy's bf16 inputs in one kernel (0: torch.cat + cast + layout copy + stacking)
 STEREO_PAIR_PREPARE = os.environ.get('ISLAM_STEREO_PAIR_PREPARE', '1') == '1'
+# the stereo decoder's torch.cat((previous stage, skip tensor), 1) in front of every transposed convolution (StereoNet7.py:121-138) kept as a
+# PAIR of dense tensors that the consumer reads where they lie (islam_deconv4x4s2_nhwc_bf16_cat / islam_conv_nhwc_bf16_s2_cat) instead of a
+# concatenation buffer the skip tensor is copied into.  Bit-identical, 0.3 GB less traffic per forward at B = 8 (five copies, 79 us when run
+# alone) -- and no faster where it counts: replay 7.872 / 7.876 ms with the pairs against 7.873 / 7.907 without (alternating runs): the
+# copies are HBM-bound and ride beside the other branch's matrix-core kernels.  Default off.
+CAT_PAIRS = os.environ.get('ISLAM_CAT_PAIRS', '0') == '1'
+
+
+class _Cat:
+    """torch.cat((a, b), 1) of two dense channels-last bf16 tensors that has not been written: a consumer that can reads the two halves
+    (ops.deconv_nhwc / ops.conv_nhwc_s2 with x2=), any other calls materialize()."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def materialize(self):
+        return torch.cat((self.a, self.b), 1)
+
+    def readable(self, cin, mult):
+        a, b = self.a, self.b
+        return (a.shape[1] + b.shape[1] == cin and a.shape[1] % mult == 0 and ops.fusable_nhwc_bf16(a, a.shape[1])
+                and ops.fusable_nhwc_bf16(b, b.shape[1]) and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:])
+
 # stride-2 convolutions of the frozen stereo net (layer2's first block, the quarter-resolution tail) on islam_conv_nhwc_bf16_s2; 0: MIOpen / CK
 HIP_CONV_S2 = os.environ.get('ISLAM_HIP_CONV_S2', '1') != '0'
 HIP_FIRST_LAYER = os.environ.get('ISLAM_HIP_FIRST_LAYER', '1') != '0'   # the 3 -> 32 stride-2 first layer of the stereo net on the channels-last kernel
@@ -728,9 +751,10 @@ class Hourglass(nn.Module):
         self.low3 = _HGResidual(nf, nf)
         self.up2 = nn.Upsample(scale_factor=2, mode='bilinear')
 
-    def forward(self, x, cat_with=None):
+    def forward(self, x, cat_with=None, pair=False):
         """cat_with: a tensor the caller concatenates behind the result (torch.cat((hourglass(x), cat_with), 1)); on the bf16
-        channels-last path the result is written straight into its half of that concatenation, which is returned."""
+        channels-last path the result is written straight into its half of that concatenation, which is returned -- or, with ``pair``,
+        the concatenation is returned as a _Cat of the dense result and cat_with (no buffer, no copy of cat_with)."""
         u = self.up1(x)
         fused = ops.fusable_nhwc_bf16(u, u.shape[1])
         low = self.low3(self.low2(ops.maxpool2(u) if fused else self.pool1(u)))
@@ -738,6 +762,8 @@ class Hourglass(nn.Module):
         # pooling, and the up-sampling with the addition of u in the same pass
         if fused and ops.fusable_nhwc_bf16(low, low.shape[1]) and (low.shape[2] * 2, low.shape[3] * 2) == tuple(u.shape[2:]):
             if cat_with is not None and ops.fusable_nhwc_bf16(cat_with, cat_with.shape[1]) and cat_with.shape[2:] == u.shape[2:]:
+                if pair:
+                    return _Cat(ops.resize_bilinear_add(low, u), cat_with)
                 c = u.shape[1]
                 out = torch.empty((u.shape[0], c + cat_with.shape[1], u.shape[2], u.shape[3]), dtype=u.dtype, device=u.device,
                                   memory_format=torch.channels_last)
@@ -860,13 +886,13 @@ class StereoNet7(nn.Module):
         x = act(self.conv_c6_2(relu_pool(self.conv_c6(cat4))))                # 1/64, 512
         x = self._deconv_act(self.deconv_c7_2, x, cat4)
         x = self._deconv_act(self.deconv_c7, x, cat3)
-        x = self.conv_c8(self._deconv_act(self.deconv_c8, x), cat_with=cat2)     # = torch.cat((conv_c8(...), cat2), 1), StereoNet7.py:129-138
-        x = self.conv_c9(self._deconv_act(self.deconv_c9, x), cat_with=cat1)
-        x = self.conv_c10(self._deconv_act(self.deconv_c10, x), cat_with=cat0)
+        x = self.conv_c8(self._deconv_act(self.deconv_c8, x), cat_with=cat2, pair=CAT_PAIRS)     # = torch.cat((conv_c8(...), cat2), 1), StereoNet7.py:129-138
+        x = self.conv_c9(self._deconv_act(self.deconv_c9, x), cat_with=cat1, pair=CAT_PAIRS)
+        x = self.conv_c10(self._deconv_act(self.deconv_c10, x), cat_with=cat0, pair=CAT_PAIRS)
         if quarter:
             x = self._deconv_c11_quarter(x, act)
         else:
-            x = act(self.deconv_c11(x))
+            x = act(self.deconv_c11(x.materialize() if isinstance(x, _Cat) else x))
         return self.conv_c13(act(self.conv_c12(x))), None
 
     def _deconv_act(self, dc, x, skip=None):
@@ -876,7 +902,13 @@ class StereoNet7(nn.Module):
         bf16 backward-data kernels whose output was then activated and copied by torch.cat)."""
         act = self.actfun
         co, ci = dc.out_channels, dc.in_channels
-        if (HIP_DECONV and act is F.relu and ops.fusable_nhwc_bf16(x, ci) and dc.weight.dtype == torch.bfloat16 and co % 8 == 0
+        x2 = None
+        if isinstance(x, _Cat):                              # the previous stage's pair: read where its halves lie, if this layer can
+            if HIP_DECONV and act is F.relu and x.readable(ci, 32):
+                x, x2 = x.a, x.b
+            else:
+                x = x.materialize()
+        if (HIP_DECONV and act is F.relu and (x2 is not None or ops.fusable_nhwc_bf16(x, ci)) and dc.weight.dtype == torch.bfloat16 and co % 8 == 0
                 and dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1) and dc.output_padding == (0, 0)
                 and dc.groups == 1 and dc.dilation == (1, 1)
                 and (skip is None or (ops.fusable_nhwc_bf16(skip, skip.shape[1]) and tuple(skip.shape[2:]) == (2 * x.shape[2], 2 * x.shape[3])))):
@@ -885,11 +917,15 @@ class StereoNet7(nn.Module):
             if hit is None or hit[0] != key:
                 hit = dc.__dict__['_nhwc_deconv'] = (key, ops.pack_deconv_nhwc_weight(dc.weight), dc.bias.detach().float().contiguous())
             out = None
+            if skip is not None and CAT_PAIRS:
+                return _Cat(ops.deconv_nhwc(x, hit[1], hit[2], co, relu=True, x2=x2), skip)
             if skip is not None:
                 out = torch.empty((x.shape[0], co + skip.shape[1], 2 * x.shape[2], 2 * x.shape[3]), dtype=x.dtype, device=x.device,
                                   memory_format=torch.channels_last)
                 out[:, co:].copy_(skip)
-            return ops.deconv_nhwc(x, hit[1], hit[2], co, out=out, yoff=0, relu=True)
+            return ops.deconv_nhwc(x, hit[1], hit[2], co, out=out, yoff=0, relu=True, x2=x2)
+        if x2 is not None:
+            x = torch.cat((x, x2), 1)
         y = act(dc(x))
         return y if skip is None else torch.cat((y, skip), 1)
 
@@ -898,6 +934,12 @@ class StereoNet7(nn.Module):
         (ox+1-kx)/2] W[i, o, ky, kx] over the taps where the division is exact; for oy = 4y: ky = 1 -> row 2y, ky = 3 -> row 2y-1.
         That is a 2x2 convolution with stride 2 and one row / column of zero padding in front: K[o, i, a, b] = W[i, o, 3-2a, 3-2b]."""
         dc = self.deconv_c11
+        x2 = None
+        if isinstance(x, _Cat):
+            if HIP_CONV_S2 and HIP_CONV_LEVEL >= 1 and act is F.relu and dc.bias is not None and x.readable(dc.in_channels, 16):
+                x, x2 = x.a, x.b
+            else:
+                x = x.materialize()
         key = (dc.weight._version, dc.weight.data_ptr())
         hit = self.__dict__.get('_c11q')
         if hit is None or hit[0] != key:
@@ -907,13 +949,15 @@ class StereoNet7(nn.Module):
             hit = self.__dict__['_c11q'] = (key, K)
         h, w = x.shape[2] // 2, x.shape[3] // 2
         co, ci = hit[1].shape[0], hit[1].shape[1]
-        if (HIP_CONV_S2 and HIP_CONV_LEVEL >= 1 and act is F.relu and ops.fusable_nhwc_bf16(x, ci) and hit[1].dtype == torch.bfloat16
+        if (HIP_CONV_S2 and HIP_CONV_LEVEL >= 1 and act is F.relu and (x2 is not None or ops.fusable_nhwc_bf16(x, ci)) and hit[1].dtype == torch.bfloat16
                 and ci % 8 == 0 and co % 8 == 0 and dc.bias is not None):
             # the 2x2 stride-2 convolution, its bias, the ReLU and the crop to (h, w) in one launch of the channels-last kernel
             pk = self.__dict__.get('_c11q_packed')
             if pk is None or pk[0] != key:
                 pk = self.__dict__['_c11q_packed'] = (key, ops.pack_conv_nhwc_weight(hit[1]), dc.bias.detach().float().contiguous())
-            return ops.conv_nhwc_s2(x, pk[1], co, 2, bias=pk[2], relu=True, out_hw=(h, w))
+            return ops.conv_nhwc_s2(x, pk[1], co, 2, bias=pk[2], relu=True, out_hw=(h, w), x2=x2)
+        if x2 is not None:
+            x = torch.cat((x, x2), 1)
         y = F.conv2d(x, hit[1], dc.bias, stride=2, padding=1)[:, :, :h, :w]
         return y if act is None else act(y)
 

@@ -299,15 +299,22 @@ def conv_nhwc(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=
     return y
 
 
-def conv_nhwc_s2(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False, in_relu=False, out_hw=None):
+def conv_nhwc_s2(x, packed, cout, ksize, in_affine=None, bias=None, res=None, relu=False, stats=False, in_relu=False, out_hw=None, x2=None):
     """conv_nhwc at stride 2 with padding ksize // 2 (islam_conv_nhwc_bf16_s2; ksize 1, 2 or 3).  out_hw: fewer output rows / columns than
-    the convolution has (the quarter-resolution tail keeps (H/2, W/2) of (H/2 + 1, W/2 + 1))."""
-    require_cuda(x, packed)
+    the convolution has (the quarter-resolution tail keeps (H/2, W/2) of (H/2 + 1, W/2 + 1)).  x2 (ksize 2, bias / ReLU only): the input is
+    torch.cat((x, x2), 1) read from the two tensors where they lie (islam_conv_nhwc_bf16_s2_cat; x.shape[1] % 16 == 0)."""
+    require_cuda(x, packed, x2)
     B, Cin, H, W = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
     P = ksize // 2
     Ho, Wo = ((H + 2 * P - ksize) // 2 + 1, (W + 2 * P - ksize) // 2 + 1) if out_hw is None else out_hw
     y = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if x2 is not None:
+        assert in_affine is None and res is None and not stats and ksize == 2
+        assert x2.dtype == torch.bfloat16 and x2.is_contiguous(memory_format=torch.channels_last) and x2.shape[0] == B and tuple(x2.shape[2:]) == (H, W)
+        check(lib().islam_conv_nhwc_bf16_s2_cat(ptr(x), Cin, ptr(x2), int(x2.shape[1]), ptr(packed), ptr(bias), ptr(y), B, H, W, int(cout), Ho, Wo,
+                                                int(ksize), int(bool(relu)) | (2 if in_relu else 0), stream_ptr(x.device)))
+        return y
     st = None
     if stats:
         st = torch.empty(lib().islam_conv_nhwc_s2_stats_floats(B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
@@ -429,16 +436,22 @@ def pack_deconv_nhwc_weight(w):
     return p.contiguous()
 
 
-def deconv_nhwc(x, packed, bias32, cout, out=None, yoff=0, relu=False):
+def deconv_nhwc(x, packed, bias32, cout, out=None, yoff=0, relu=False, x2=None):
     """act(ConvTranspose2d(k=4, s=2, p=1)(x) + bias) of a channels-last bf16 tensor on islam_deconv4x4s2_nhwc_bf16, written into
-    channels [yoff, yoff + cout) of ``out`` (B, ytot, 2H, 2W) channels_last bf16 (allocated dense when None)."""
-    require_cuda(x, packed)
+    channels [yoff, yoff + cout) of ``out`` (B, ytot, 2H, 2W) channels_last bf16 (allocated dense when None).  x2: the layer's input is
+    torch.cat((x, x2), 1), read from the two tensors where they lie (islam_deconv4x4s2_nhwc_bf16_cat; x.shape[1] % 32 == 0)."""
+    require_cuda(x, packed, x2)
     B, Cin, H, W = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and bias32.dtype == torch.float32
     if out is None:
         out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
     assert out.shape[0] == B and tuple(out.shape[2:]) == (2 * H, 2 * W)
+    if x2 is not None:
+        assert x2.dtype == torch.bfloat16 and x2.is_contiguous(memory_format=torch.channels_last) and x2.shape[0] == B and tuple(x2.shape[2:]) == (H, W)
+        check(lib().islam_deconv4x4s2_nhwc_bf16_cat(ptr(x), Cin, ptr(x2), int(x2.shape[1]), ptr(packed), ptr(bias32), ptr(out), int(out.shape[1]),
+                                                    int(yoff), B, H, W, int(cout), int(bool(relu)), stream_ptr(x.device)))
+        return out
     check(lib().islam_deconv4x4s2_nhwc_bf16(ptr(x), ptr(packed), ptr(bias32), ptr(out), int(out.shape[1]), int(yoff), B, Cin, H, W, int(cout),
                                             int(bool(relu)), stream_ptr(x.device)))
     return out

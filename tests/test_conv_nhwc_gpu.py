@@ -233,6 +233,44 @@ def test_transposed_convolution_on_the_parity_classes(cuda, B, Cin, H, W, Cout, 
         assert bool((y[:, Cout:] == 7.0).all())                      # the rest of the concatenation buffer is left alone
 
 
+@pytest.mark.parametrize('B,C1,C2,H,W,Cout', [(2, 512, 384, 7, 10, 320), (1, 320, 256, 14, 20, 192), (2, 192, 192, 28, 40, 128), (1, 128, 128, 37, 45, 64),
+                                              (3, 64, 8, 9, 20, 32), (1, 32, 24, 5, 3, 72)])
+def test_transposed_convolution_of_a_concatenation_read_from_its_two_tensors(cuda, B, C1, C2, H, W, Cout):
+    """islam_deconv4x4s2_nhwc_bf16_cat(x1, x2) == islam_deconv4x4s2_nhwc_bf16(torch.cat((x1, x2), 1)), bit for bit: the decoder's
+    concatenations (Network/StereoNet7.py:121-138) are read where their halves lie; the benched decoder's four shapes and two small ones."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C1 + C2)
+    x1 = torch.randn(B, C1, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=CL)
+    x2 = torch.randn(B, C2, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=CL)
+    w = (torch.randn(C1 + C2, Cout, 4, 4, generator=g) / ((C1 + C2) * 4) ** 0.5).cuda().to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).cuda()
+    wp = ops.pack_deconv_nhwc_weight(w)
+    want = ops.deconv_nhwc(torch.cat((x1, x2), 1).contiguous(memory_format=CL), wp, bias, Cout, relu=True)
+    got = ops.deconv_nhwc(x1, wp, bias, Cout, relu=True, x2=x2)
+    assert torch.equal(got, want)
+    out = torch.full((B, Cout + 16, 2 * H, 2 * W), 7.0, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=CL)
+    ops.deconv_nhwc(x1, wp, bias, Cout, out=out, yoff=8, relu=False, x2=x2)
+    assert torch.equal(out[:, 8:8 + Cout], ops.deconv_nhwc(torch.cat((x1, x2), 1).contiguous(memory_format=CL), wp, bias, Cout, relu=False))
+    assert bool((out[:, :8] == 7.0).all()) and bool((out[:, 8 + Cout:] == 7.0).all())
+
+
+@pytest.mark.parametrize('B,C1,C2,H,W,Cout', [(2, 64, 64, 64, 96, 64), (1, 64, 64, 37, 70, 64), (2, 16, 8, 10, 12, 32), (1, 48, 40, 9, 7, 72)])
+def test_stride2_convolution_of_a_concatenation_read_from_its_two_tensors(cuda, B, C1, C2, H, W, Cout):
+    """islam_conv_nhwc_bf16_s2_cat == islam_conv_nhwc_bf16_s2 on the concatenated tensor, bit for bit (kernel size 2, bias, ReLU, cropped
+    output: the quarter-resolution tail StereoNet7._deconv_c11_quarter runs)."""
+    from islam_amd import ops
+    g = torch.Generator().manual_seed(C1 * 3 + C2)
+    x1 = torch.randn(B, C1, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=CL)
+    x2 = torch.randn(B, C2, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=CL)
+    w = (torch.randn(Cout, C1 + C2, 2, 2, generator=g) / ((C1 + C2) * 4) ** 0.5).cuda().to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).cuda()
+    wp = ops.pack_conv_nhwc_weight(w)
+    hw = (H // 2, W // 2)
+    want = ops.conv_nhwc_s2(torch.cat((x1, x2), 1).contiguous(memory_format=CL), wp, Cout, 2, bias=bias, relu=True, out_hw=hw)
+    got = ops.conv_nhwc_s2(x1, wp, Cout, 2, bias=bias, relu=True, out_hw=hw, x2=x2)
+    assert torch.equal(got, want)
+
+
 def test_stereo_decoder_on_the_transposed_convolution_kernel(cuda):
     """StereoNet7._deconv_act on the bf16 channels-last execution copy: HIP path == torch path (MIOpen + ReLU + torch.cat) within bf16
     rounding, for a plain output and for one written into its concatenation."""
@@ -242,13 +280,20 @@ def test_stereo_decoder_on_the_transposed_convolution_kernel(cuda):
     x = torch.randn(2, 896, 14, 20, device='cuda').to(torch.bfloat16).contiguous(memory_format=CL)
     skip = torch.randn(2, 256, 28, 40, device='cuda').to(torch.bfloat16).contiguous(memory_format=CL)
     with torch.no_grad():
-        got = net._deconv_act(net.deconv_c7, x, skip)
-        old = nets.HIP_DECONV
-        nets.HIP_DECONV = False
+        old, oldp = nets.HIP_DECONV, nets.CAT_PAIRS
+        nets.CAT_PAIRS = True
         try:
+            pair = net._deconv_act(net.deconv_c7, x, skip)      # (ISLAM_CAT_PAIRS=1: the concatenation as a pair of dense tensors, nets._Cat)
+            assert isinstance(pair, nets._Cat) and pair.b is skip and pair.readable(576, 32)
+            nxt = net._deconv_act(net.deconv_c8, pair)          # ... which the next transposed convolution reads where they lie
+            nets.CAT_PAIRS = False
+            got = net._deconv_act(net.deconv_c7, x, skip)       # the concatenation buffer
+            assert torch.equal(got, pair.materialize())
+            assert torch.equal(net._deconv_act(net.deconv_c8, got), nxt)
+            nets.HIP_DECONV = False
             ref = net._deconv_act(net.deconv_c7, x, skip)
         finally:
-            nets.HIP_DECONV = old
+            nets.HIP_DECONV, nets.CAT_PAIRS = old, oldp
         ref32 = torch.cat((F.relu(F.conv_transpose2d(x.float(), net.deconv_c7.weight.float(), net.deconv_c7.bias.float(), stride=2, padding=1)),
                            skip.float()), 1)
     assert got.shape == ref.shape == ref32.shape and got.is_contiguous(memory_format=CL)
