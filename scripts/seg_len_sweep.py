@@ -10,7 +10,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300007
 dev = torch.device('cuda:0')
 prob, _ = bench.build_problem(dev, N - 1)
 args = [prob[k] for k in ('init_nodes', 'init_vels', 'vo', 'drots', 'dtrans', 'dvels', 'dts')]
-for seg in [(0, 0), (8, 8), (10, 10)]:
+for seg in [(0, 0), (4, 4), (5, 5), (6, 6), (7, 7), (8, 8), (7, 5), (6, 5), (10, 10)]:
     prm = ops.pvgo_default_params(bench.LOSS_WEIGHT, radius=1e4, seg_len=seg)
     best, res = 1e9, None
     for rep in range(4):
